@@ -1,0 +1,149 @@
+/*
+ * sparsefusion_hip.h -- C ABI of libsparsefusion_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the score-distillation hot path of zhizdev/sparsefusion
+ * (SURVEY.md section 8(b)).  Plain pointers and sizes only: no torch types.
+ * Every pointer is a DEVICE pointer unless its name starts with `h_`.
+ * `stream` is a hipStream_t passed as void* (NULL = the null stream); all work
+ * is enqueued on it and nothing synchronises.  Callee never allocates: every
+ * output is caller-allocated and mutated in place (reference ownership rule,
+ * external/gridencoder/grid.py:42-47, raymarching/raymarching.py:42-45).
+ *
+ * Return value: 0 on success, non-zero SF_ERR_* on failure; sf_last_error()
+ * returns a thread-local message (the Python wrappers raise RuntimeError with
+ * it, mirroring TORCH_CHECK / std::runtime_error in the reference bindings).
+ */
+#ifndef SPARSEFUSION_HIP_H
+#define SPARSEFUSION_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_OK 0
+#define SF_ERR_INVALID 1   /* bad argument (unsupported C / D / shape)        */
+#define SF_ERR_LAUNCH 2    /* hipLaunch / hipGetLastError reported an error   */
+
+const char* sf_last_error(void);
+int sf_abi_version(void);
+
+/* ------------------------------------------------------------------------ */
+/* _gridencoder  (external/gridencoder/src/bindings.cpp:6-7)                 */
+/* ------------------------------------------------------------------------ */
+
+/* Replaces grid_encode_forward (gridencoder.cu:424-447, kernel_grid :75-223).
+ * inputs [B,D] f32 in [0,1]; embeddings [rows,C] f32; offsets [L+1] i32;
+ * outputs [L,B,C] f32 (level-major, as the reference); dy_dx [B,L*D*C] or NULL.
+ * S = log2(per_level_scale), H = base resolution, gridtype 0=hash 1=tiled.
+ * h_offsets: host copy of offsets (L+1 ints) -- needed to launch without a
+ * device->host sync; pass NULL to let the library read it back (syncs). */
+int sf_grid_encode_forward(const float* inputs, const float* embeddings,
+                           const int32_t* offsets, float* outputs,
+                           uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                           float S, uint32_t H, float* dy_dx,
+                           uint32_t gridtype, int align_corners,
+                           const int32_t* h_offsets, void* stream);
+
+/* Replaces grid_encode_backward (gridencoder.cu:449-479, kernel_grid_backward
+ * :226-313, kernel_input_backward :316-342).  grad [L,B,C]; grad_embeddings
+ * [rows,C] must be zero-initialised by the caller (grid.py:72); dy_dx /
+ * grad_inputs may be NULL together. */
+int sf_grid_encode_backward(const float* grad, const float* inputs,
+                            const float* embeddings, const int32_t* offsets,
+                            float* grad_embeddings,
+                            uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                            float S, uint32_t H, const float* dy_dx,
+                            float* grad_inputs, uint32_t gridtype,
+                            int align_corners, const int32_t* h_offsets,
+                            void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* _raymarching  (raymarching/src/bindings.cpp:7-18)                         */
+/* ------------------------------------------------------------------------ */
+
+/* Replaces near_far_from_aabb (raymarching.cu:91-156). rays_o/d [N,3],
+ * aabb [6], nears/fars [N]; all f32. */
+int sf_near_far_from_aabb(const float* rays_o, const float* rays_d,
+                          const float* aabb, uint32_t N, float min_near,
+                          float* nears, float* fars, void* stream);
+
+/* Replaces morton3D / morton3D_invert (raymarching.cu:214-254). coords [N,3]
+ * i32, indices [N] i32. Bit-exact integer work. */
+int sf_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, void* stream);
+int sf_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, void* stream);
+
+/* Replaces packbits (raymarching.cu:267-289). grid [N*8] f32 -> bitfield [N] u8,
+ * bit i of byte n set iff grid[n*8+i] > density_thresh. */
+int sf_packbits(const float* grid, uint32_t N, float density_thresh,
+                uint8_t* bitfield, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Fused NGP render (external/nerf/renderer_df.py:310-468 `run`,             */
+/* network_grid.py:69-88 `common_forward`) -- see DESIGN.md section 3.       */
+/* ------------------------------------------------------------------------ */
+
+/* Field parameters: tiled grid table + 32-64-64-4 MLP (network_grid.py:50-52). */
+typedef struct {
+  const float* embeddings;   /* [rows, 2]                                   */
+  const int32_t* h_offsets;  /* host, [L+1]                                 */
+  uint32_t L;                /* 16                                          */
+  float S;                   /* log2(per_level_scale)                       */
+  uint32_t H;                /* base resolution                             */
+  uint32_t gridtype;         /* 0 hash, 1 tiled                             */
+  const float* w0; const float* b0;   /* [64,32],[64]  sigma_net.net.0     */
+  const float* w1; const float* b1;   /* [64,64],[64]  sigma_net.net.1     */
+  const float* w2; const float* b2;   /* [4,64],[4]    sigma_net.net.2     */
+  float bound;               /* scene bound (inputs mapped (x+b)/(2b))      */
+} sf_ngp_field;
+
+/* Gradient outputs of the field (all caller-zeroed, accumulated with atomics) */
+typedef struct {
+  float* g_embeddings;
+  float* g_w0; float* g_b0;
+  float* g_w1; float* g_b1;
+  float* g_w2; float* g_b2;
+} sf_ngp_field_grad;
+
+/* sigma/albedo at arbitrary points (NeRFNetwork.density, network_grid.py:200).
+ * xyz [P,3] in [-bound,bound] -> sigma [P], albedo [P,3]. */
+int sf_ngp_density(const sf_ngp_field* f, const float* xyz, uint32_t P,
+                   float* sigma, float* albedo, void* stream);
+
+/* Full training/eval render of N rays with T coarse + T fine samples (T<=64).
+ * lin [T] = linspace(0,1,T); u_coarse [N,T] in [0,1) or NULL (perturb=False);
+ * u_fine: uniforms for the inverse-CDF draw, row n at u_fine + n*u_fine_row_stride
+ * ([N,T] with stride T for training, or one [T] row linspace(.5/T,1-.5/T,T) with
+ * stride 0 for det=True).  Saved for backward: z_sorted [N,2T], sigma_s [N,2T],
+ * rgb_s [N,2T,3], nears/fars [N].  Outputs image [N,3], depth [N], weights_sum [N].
+ * bg_color: scalar background.  workspace: sf_ngp_render_workspace_bytes(N,T). */
+int sf_ngp_render_forward(const sf_ngp_field* f, const float* rays_o,
+                          const float* rays_d, const float* aabb, uint32_t N,
+                          uint32_t T, float min_near, const float* lin,
+                          const float* u_coarse, const float* u_fine,
+                          uint32_t u_fine_row_stride, float bg_color, float* nears,
+                          float* fars, float* z_sorted, float* sigma_s,
+                          float* rgb_s, float* image, float* depth,
+                          float* weights_sum, float* workspace,
+                          uint64_t workspace_bytes, void* stream);
+
+/* Backward of sf_ngp_render_forward w.r.t. the field parameters given
+ * grad_image [N,3] and grad_weights_sum [N] or NULL (depth carries no gradient
+ * in the reference losses).  Gradients are ACCUMULATED into caller-zeroed buffers. */
+int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_grad* g,
+                           const float* rays_o, const float* rays_d,
+                           const float* aabb, uint32_t N, uint32_t T,
+                           const float* nears, const float* fars,
+                           const float* z_sorted, const float* sigma_s,
+                           const float* rgb_s, float bg_color,
+                           const float* grad_image, const float* grad_weights_sum,
+                           float* workspace, uint64_t workspace_bytes,
+                           void* stream);
+
+uint64_t sf_ngp_render_workspace_bytes(uint32_t N, uint32_t T);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARSEFUSION_HIP_H */

@@ -1,0 +1,97 @@
+"""ctypes binding of libsparsefusion_hip.so (C ABI declared in include/sparsefusion_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing, or a tensor
+is not on a GPU, the wrappers raise.  torch is used only for device memory and
+streams (``tensor.data_ptr()``, ``torch.cuda.current_stream().cuda_stream``).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsparsefusion_hip.so")
+
+_lib = None
+
+c_f32p = C.c_void_p   # device pointers travel as integers
+c_i32p = C.c_void_p
+u32 = C.c_uint32
+u64 = C.c_uint64
+
+
+class SfNgpField(C.Structure):
+    _fields_ = [("embeddings", C.c_void_p), ("h_offsets", C.c_void_p), ("L", u32), ("S", C.c_float),
+                ("H", u32), ("gridtype", u32),
+                ("w0", C.c_void_p), ("b0", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
+                ("w2", C.c_void_p), ("b2", C.c_void_p), ("bound", C.c_float)]
+
+
+class SfNgpFieldGrad(C.Structure):
+    _fields_ = [("g_embeddings", C.c_void_p), ("g_w0", C.c_void_p), ("g_b0", C.c_void_p),
+                ("g_w1", C.c_void_p), ("g_b1", C.c_void_p), ("g_w2", C.c_void_p), ("g_b2", C.c_void_p)]
+
+
+class SfOp(C.Structure):
+    _fields_ = [("type", C.c_int32), ("flags", C.c_int32), ("p", C.c_void_p * 8),
+                ("i", C.c_int32 * 16), ("f", C.c_float * 4)]
+
+
+# name -> (restype, argtypes); mirrors include/sparsefusion_hip.h one to one.
+SIGNATURES = {
+    "sf_last_error": (C.c_char_p, []),
+    "sf_abi_version": (C.c_int, []),
+    "sf_grid_encode_forward": (C.c_int, [c_f32p, c_f32p, c_i32p, c_f32p, u32, u32, u32, u32, C.c_float, u32,
+                                         c_f32p, u32, C.c_int, C.c_void_p, C.c_void_p]),
+    "sf_grid_encode_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, u32, u32, u32, u32, C.c_float,
+                                          u32, c_f32p, c_f32p, u32, C.c_int, C.c_void_p, C.c_void_p]),
+    "sf_near_far_from_aabb": (C.c_int, [c_f32p, c_f32p, c_f32p, u32, C.c_float, c_f32p, c_f32p, C.c_void_p]),
+    "sf_morton3D": (C.c_int, [c_i32p, u32, c_i32p, C.c_void_p]),
+    "sf_morton3D_invert": (C.c_int, [c_i32p, u32, c_i32p, C.c_void_p]),
+    "sf_packbits": (C.c_int, [c_f32p, u32, C.c_float, C.c_void_p, C.c_void_p]),
+    "sf_ngp_density": (C.c_int, [C.POINTER(SfNgpField), c_f32p, u32, c_f32p, c_f32p, C.c_void_p]),
+    "sf_ngp_render_forward": (C.c_int, [C.POINTER(SfNgpField), c_f32p, c_f32p, c_f32p, u32, u32, C.c_float,
+                                        c_f32p, c_f32p, c_f32p, u32, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p,
+                                        c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, u64, C.c_void_p]),
+    "sf_ngp_render_backward": (C.c_int, [C.POINTER(SfNgpField), C.POINTER(SfNgpFieldGrad), c_f32p, c_f32p,
+                                         c_f32p, u32, u32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                         C.c_float, c_f32p, c_f32p, c_f32p, u64, C.c_void_p]),
+    "sf_ngp_render_workspace_bytes": (u64, [u32, u32]),
+}
+
+
+def lib():
+    """Load the HIP library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m sparsefusion_amd.build` "
+                "(there is no CPU fallback for the sparsefusion_amd hot path)")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().sf_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what}: {msg}" if what else msg)
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("sparsefusion_amd: tensor must live on a HIP device (no CPU path)")
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

@@ -1,0 +1,68 @@
+"""Build recipe for libsparsefusion_hip.so (gfx950) and the CPU oracle.
+
+`python -m sparsefusion_amd.build` compiles every HIP source under csrc/ with
+hipcc --offload-arch=gfx950 into ONE shared library that lives in-tree (so it
+travels to the GPU box with the repo snapshot).  hipcc cross-compiles without
+a GPU.  Objects are cached by source mtime.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libsparsefusion_hip.so")
+OBJ_DIR = os.path.join(HERE, "_obj")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
+         "-Wall", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include")]
+
+
+def _sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps_mtime():
+    m = 0.0
+    for d in (CSRC, os.path.join(ROOT, "include")):
+        for f in os.listdir(d):
+            if f.endswith(".h"):
+                m = max(m, os.path.getmtime(os.path.join(d, f)))
+    return m
+
+
+def _compile(src, hdr_m, verbose):
+    obj = os.path.join(OBJ_DIR, src[:-4] + ".o")
+    sp = os.path.join(CSRC, src)
+    if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(sp), hdr_m):
+        return obj, False
+    cmd = [HIPCC] + FLAGS + ["-c", sp, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return obj, True
+
+
+def build(verbose=True, force=False):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdr_m = _deps_mtime()
+    if force:
+        for f in os.listdir(OBJ_DIR):
+            os.remove(os.path.join(OBJ_DIR, f))
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        res = list(ex.map(lambda s: _compile(s, hdr_m, verbose), _sources()))
+    objs = [o for o, _ in res]
+    if any(c for _, c in res) or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

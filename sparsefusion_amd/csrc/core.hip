@@ -1,0 +1,7 @@
+// Error reporting + ABI version for libsparsefusion_hip.so.
+#include "sf_common.h"
+
+thread_local char sf_err_buf[512] = {0};
+
+extern "C" const char* sf_last_error(void) { return sf_err_buf; }
+extern "C" int sf_abi_version(void) { return 1; }

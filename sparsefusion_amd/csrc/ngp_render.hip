@@ -1,0 +1,470 @@
+// Fused Instant-NGP volume render for gfx950 (forward + backward w.r.t. field parameters).
+//
+// What it replaces: NeRFRenderer.run (external/nerf/renderer_df.py:310-468) driving
+// NeRFNetwork.common_forward (external/nerf/network_grid.py:77-88) three times per render plus
+// ~40 unfused torch elementwise/sort/gather/cumprod kernels.  MI355X-first restructuring:
+//   * the field is evaluated ONCE per sample (128/ray instead of the reference's 256: its third
+//     pass re-evaluates the same points; value-identical, and the gradient of one evaluation
+//     with both upstream grads equals the sum of the reference's two paths);
+//   * encode + MLP + activations are one kernel, MLP weights live in LDS and are read as
+//     broadcasts; nothing but sigma/rgb per sample is written to HBM;
+//   * sampling (inverse-CDF), merge-sort and alpha compositing are per-ray kernels whose
+//     per-thread scratch columns live in LDS ([k][lane] layout: bank-conflict free);
+//   * backward RECOMPUTES the field forward instead of saving activations (VALU is cheap, HBM is
+//     not); MLP weight gradients are formed per 256-point tile as LDS-staged outer-product
+//     sums, one atomic flush per workgroup; table gradients use fp32 L2 atomics.
+// Per-thread math lives in ngp_device.h (also compiled for the host by tests/hostemu).
+//
+// Layouts (row-major): z_c,sig_c [N,T]; rgb_c [N,T,3]; z_f,sig_f,rgb_f same; z_sorted,sigma_s
+// [N,2T]; rgb_s [N,2T,3]; image [N,3]; depth, weights_sum, nears, fars [N].
+
+#include "sf_common.h"
+#include "ngp_device.h"
+
+struct GridLevels;  // gridencoder.hip
+int sf_fill_levels(GridLevels* lv, const int32_t* offsets_dev, const int32_t* h_offsets, uint32_t L, float S,
+                   uint32_t H, hipStream_t st);
+
+struct FieldPtrs {
+  const float* table;
+  const float* w0; const float* b0; const float* w1; const float* b1; const float* w2; const float* b2;
+  float bound;
+};
+
+__device__ __forceinline__ void load_weights_lds(float* W, const FieldPtrs& f) {
+  for (int i = threadIdx.x; i < NGP_HID * NGP_FEAT; i += blockDim.x) W[NGP_W0 + i] = f.w0[i];
+  for (int i = threadIdx.x; i < NGP_HID * NGP_HID; i += blockDim.x) W[NGP_W1 + i] = f.w1[i];
+  for (int i = threadIdx.x; i < NGP_OUT * NGP_HID; i += blockDim.x) W[NGP_W2 + i] = f.w2[i];
+  for (int i = threadIdx.x; i < NGP_HID; i += blockDim.x) { W[NGP_B0 + i] = f.b0[i]; W[NGP_B1 + i] = f.b1[i]; }
+  if (threadIdx.x < NGP_OUT) W[NGP_B2 + threadIdx.x] = f.b2[threadIdx.x];
+}
+
+// mode 0: z from stratified coarse rule (writes z_out); mode 1: z read from z_in; mode 2: xyz given.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_ngp_field(
+    FieldPtrs f, NgpLevels lv, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    const float* __restrict__ aabb, const float* __restrict__ nears, const float* __restrict__ fars,
+    const float* __restrict__ lin, const float* __restrict__ u, const float* __restrict__ z_in,
+    const float* __restrict__ xyz_in, uint32_t P, uint32_t T, float* __restrict__ z_out,
+    float* __restrict__ sigma, float* __restrict__ rgb) {
+  __shared__ __attribute__((aligned(16))) float W[NGP_WTOTAL];
+  load_weights_lds(W, f);
+  __syncthreads();
+  float box[6];
+  if (MODE != 2) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) box[i] = aabb[i];
+  }
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+    // Memory clobber: stops LLVM from hoisting the 6.5k loop-invariant LDS weight reads out of the
+    // grid-stride loop (which would pin them in 512 registers and spill).
+    asm volatile("" ::: "memory");
+    float x[3];
+    if (MODE == 2) {
+      x[0] = xyz_in[p * 3 + 0]; x[1] = xyz_in[p * 3 + 1]; x[2] = xyz_in[p * 3 + 2];
+    } else {
+      const uint32_t n = p / T, k = p - n * T;
+      float z;
+      if (MODE == 0) {
+        z = ngp_coarse_z(nears[n], fars[n], lin[k], u ? u[p] : -1.0f, T);
+        z_out[p] = z;
+      } else {
+        z = z_in[p];
+      }
+      const float o[3] = {rays_o[n * 3], rays_o[n * 3 + 1], rays_o[n * 3 + 2]};
+      const float d[3] = {rays_d[n * 3], rays_d[n * 3 + 1], rays_d[n * 3 + 2]};
+      ngp_point(o, d, z, box, x);
+    }
+    float x01[3];
+    const bool inside = ngp_unit(x, f.bound, x01);
+    float feat[NGP_FEAT], h1[NGP_HID], h2[NGP_HID], out[NGP_OUT];
+    ngp_encode(lv, f.table, x01, inside, feat);
+    ngp_mlp_forward(W, feat, h1, h2, out);
+    sigma[p] = expf(out[0] + ngp_blob(x));
+    rgb[p * 3 + 0] = ngp_sigmoid(out[1]);
+    rgb[p * 3 + 1] = ngp_sigmoid(out[2]);
+    rgb[p * 3 + 2] = ngp_sigmoid(out[3]);
+  }
+}
+
+// thread per ray; dynamic LDS = 2 * T * 64 floats (cdf, bins columns)
+__global__ __launch_bounds__(64) void k_ngp_sample_fine(
+    const float* __restrict__ z_c, const float* __restrict__ sig_c, const float* __restrict__ u,
+    uint32_t u_row_stride, const float* __restrict__ nears, const float* __restrict__ fars, uint32_t N,
+    uint32_t T, float* __restrict__ z_f) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const uint32_t n = blockIdx.x * 64 + threadIdx.x;
+  if (n >= N) return;
+  SfCol cdf{smem + threadIdx.x, 64};
+  SfCol bins{smem + (size_t)T * 64 + threadIdx.x, 64};
+  ngp_sample_fine(z_c + (size_t)n * T, sig_c + (size_t)n * T, u + (size_t)n * u_row_stride, nears[n], fars[n], T,
+                  cdf, bins, z_f + (size_t)n * T);
+}
+
+__global__ __launch_bounds__(64) void k_ngp_composite(
+    const float* __restrict__ z_c, const float* __restrict__ sig_c, const float* __restrict__ rgb_c,
+    const float* __restrict__ z_f, const float* __restrict__ sig_f, const float* __restrict__ rgb_f,
+    const float* __restrict__ nears, const float* __restrict__ fars, uint32_t N, uint32_t T, float bg,
+    float* __restrict__ z_s, float* __restrict__ sig_s, float* __restrict__ rgb_s, float* __restrict__ image,
+    float* __restrict__ depth, float* __restrict__ weights_sum) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const uint32_t n = blockIdx.x * 64 + threadIdx.x;
+  if (n >= N) return;
+  SfCol key{smem + threadIdx.x, 64};
+  SfCol ord{smem + (size_t)T * 64 + threadIdx.x, 64};
+  NgpRayOut r;
+  ngp_merge_composite(z_c + (size_t)n * T, sig_c + (size_t)n * T, rgb_c + (size_t)n * T * 3, z_f + (size_t)n * T,
+                      sig_f + (size_t)n * T, rgb_f + (size_t)n * T * 3, nears[n], fars[n], T, bg, key, ord,
+                      z_s + (size_t)n * 2 * T, sig_s + (size_t)n * 2 * T, rgb_s + (size_t)n * 6 * T, r);
+  image[n * 3 + 0] = r.image[0]; image[n * 3 + 1] = r.image[1]; image[n * 3 + 2] = r.image[2];
+  depth[n] = r.depth;
+  weights_sum[n] = r.weights_sum;
+}
+
+__global__ __launch_bounds__(64) void k_ngp_composite_bwd(
+    const float* __restrict__ z_s, const float* __restrict__ sig_s, const float* __restrict__ rgb_s,
+    const float* __restrict__ nears, const float* __restrict__ fars, uint32_t N, uint32_t T, float bg,
+    const float* __restrict__ g_image, const float* __restrict__ g_ws, float* __restrict__ dsig,
+    float* __restrict__ drgb) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const uint32_t n = blockIdx.x * 64 + threadIdx.x;
+  if (n >= N) return;
+  SfCol tr{smem + threadIdx.x, 64};
+  SfCol wt{smem + (size_t)2 * T * 64 + threadIdx.x, 64};
+  const float gI[3] = {g_image[n * 3], g_image[n * 3 + 1], g_image[n * 3 + 2]};
+  const float gW = g_ws ? g_ws[n] : 0.0f;
+  ngp_composite_backward(z_s + (size_t)n * 2 * T, sig_s + (size_t)n * 2 * T, rgb_s + (size_t)n * 6 * T, nears[n],
+                         fars[n], T, bg, gI, gW, tr, wt, dsig + (size_t)n * 2 * T, drgb + (size_t)n * 6 * T);
+}
+
+// ---------------------------------------------------------------------------
+// Field backward.  256 threads = 256 points per tile; LDS: W + two [256][66] staging arrays.
+// Per-point vectors (h1, h2, dh2, dh1) live in the thread's own LDS row; matrix-vector products
+// run as 16-output chunks (rolled outer loop) so the kernel stays well under 256 VGPRs.
+// ---------------------------------------------------------------------------
+#define BW_S 66   // row stride (floats): 8-byte aligned rows, ds_read_b64 conflict-free, cols 64,65 spare
+struct FieldGrad { float* g_table; float* g_w0; float* g_b0; float* g_w1; float* g_b1; float* g_w2; float* g_b2; };
+
+// out_row[j] = act(bias[j] + sum_k Wm[j*K + k] * in[k]),  j < 64, in[] in registers
+template <int K, bool RELU>
+__device__ __forceinline__ void bw_matvec(const float* __restrict__ Wm, const float* __restrict__ bias,
+                                          const float (&in)[K], float* __restrict__ out_row) {
+#pragma unroll 1
+  for (int jc = 0; jc < NGP_HID; jc += 16) {
+    float a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = bias[jc + i];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a[i] = fmaf(Wm[(jc + i) * K + k], in[k], a[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) out_row[jc + i] = RELU ? fmaxf(a[i], 0.0f) : a[i];
+  }
+}
+
+// out[k] = sum_j Wm[j*K + k] * in_row[j]  (transposed product; in_row in LDS, K outputs in chunks of 16)
+template <int K>
+__device__ __forceinline__ void bw_matvec_t(const float* __restrict__ Wm, const float* __restrict__ in_row,
+                                            float (&out)[K]) {
+#pragma unroll
+  for (int k = 0; k < K; ++k) out[k] = 0.0f;
+#pragma unroll 1
+  for (int j = 0; j < NGP_HID; j += 4) {
+    const float d0 = in_row[j], d1 = in_row[j + 1], d2 = in_row[j + 2], d3 = in_row[j + 3];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      out[k] = fmaf(Wm[(j + 0) * K + k], d0, out[k]);
+      out[k] = fmaf(Wm[(j + 1) * K + k], d1, out[k]);
+      out[k] = fmaf(Wm[(j + 2) * K + k], d2, out[k]);
+      out[k] = fmaf(Wm[(j + 3) * K + k], d3, out[k]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ngp_field_bwd(
+    FieldPtrs f, FieldGrad g, NgpLevels lv, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+    const float* __restrict__ aabb, const float* __restrict__ z_s, const float* __restrict__ dsig,
+    const float* __restrict__ drgb, uint32_t P, uint32_t T2) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* W = smem;                                   // NGP_WTOTAL (rounded to 6536)
+  float* X = smem + 6536;                            // [256][BW_S]
+  float* Y = X + 256 * BW_S;                         // [256][BW_S]
+  load_weights_lds(W, f);
+  float box[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) box[i] = aabb[i];
+
+  const uint32_t t = threadIdx.x;
+  float* xr = X + t * BW_S;
+  float* yr = Y + t * BW_S;
+  // gradient strips owned by this thread
+  const uint32_t j1 = t >> 2, kb1 = (t & 3) * 16;    // dW1[j1][kb1..+15]
+  const uint32_t kb0 = (t & 3) * 8;                  // dW0[j1][kb0..+7]
+  const uint32_t o2 = t >> 6, k2 = t & 63;           // dW2[o2][k2]
+  float acc1[16], acc0[8], acc2 = 0.0f, accb1 = 0.0f, accb0 = 0.0f, accb2 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc1[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc0[i] = 0.0f;
+  __syncthreads();
+
+  const uint32_t n_tiles = (P + 255) / 256;
+#pragma unroll 1
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const uint32_t p = tile * 256 + t;
+    const bool live = p < P;
+    float x[3] = {0.f, 0.f, 0.f}, x01[3] = {0.f, 0.f, 0.f};
+    bool inside = false;
+    float feat[NGP_FEAT], dout[NGP_OUT];
+    if (live) {
+      const uint32_t n = p / T2;
+      const float o[3] = {rays_o[n * 3], rays_o[n * 3 + 1], rays_o[n * 3 + 2]};
+      const float d[3] = {rays_d[n * 3], rays_d[n * 3 + 1], rays_d[n * 3 + 2]};
+      ngp_point(o, d, z_s[p], box, x);
+      inside = ngp_unit(x, f.bound, x01) && live;
+    }
+    ngp_encode(lv, f.table, x01, inside, feat);
+    // ---- recompute the MLP forward: h1 -> own row of X, h2 -> own row of Y
+    bw_matvec<NGP_FEAT, true>(W + NGP_W0, W + NGP_B0, feat, xr);
+    {
+      float h1[NGP_HID];
+#pragma unroll
+      for (int k = 0; k < NGP_HID; ++k) h1[k] = xr[k];
+      bw_matvec<NGP_HID, true>(W + NGP_W1, W + NGP_B1, h1, yr);
+    }
+    {
+      float out[NGP_OUT];
+#pragma unroll
+      for (int j = 0; j < NGP_OUT; ++j) out[j] = W[NGP_B2 + j];
+#pragma unroll 4
+      for (int k = 0; k < NGP_HID; ++k) {
+        const float hk = yr[k];
+#pragma unroll
+        for (int j = 0; j < NGP_OUT; ++j) out[j] = fmaf(W[NGP_W2 + j * NGP_HID + k], hk, out[j]);
+      }
+      if (live) {
+        const float pre = out[0] + ngp_blob(x);
+        dout[0] = dsig[p] * expf(fminf(fmaxf(pre, -15.0f), 15.0f));     // trunc_exp backward
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float sg = ngp_sigmoid(out[1 + c]);
+          dout[1 + c] = drgb[p * 3 + c] * sg * (1.0f - sg);
+        }
+      } else {
+        dout[0] = dout[1] = dout[2] = dout[3] = 0.0f;
+      }
+    }
+    xr[64] = dout[0]; xr[65] = dout[1]; yr[64] = dout[2]; yr[65] = dout[3];
+    __syncthreads();                                                   // S1
+
+    // ---- dW2[o][k] += sum_p dout[p][o] * h2[p][k];  db2
+    {
+      const float* dcol = (o2 < 2 ? X : Y) + 64 + (o2 & 1);
+      float a = 0.0f, b = 0.0f;
+#pragma unroll 8
+      for (uint32_t q = 0; q < 256; ++q) {
+        const float dv = dcol[q * BW_S];
+        a = fmaf(dv, Y[q * BW_S + k2], a);
+        b += dv;
+      }
+      acc2 += a;
+      if (k2 == 0) accb2 += b;
+    }
+    {  // dh2 = W2^T dout, masked by own h2 (own row of Y)
+      float dh2[NGP_HID];
+#pragma unroll
+      for (int k = 0; k < NGP_HID; ++k) {
+        float a = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NGP_OUT; ++j) a = fmaf(W[NGP_W2 + j * NGP_HID + k], dout[j], a);
+        dh2[k] = yr[k] > 0.0f ? a : 0.0f;
+      }
+      __syncthreads();                                                 // S2: Y (h2) fully consumed
+#pragma unroll
+      for (int k = 0; k < NGP_HID; ++k) yr[k] = dh2[k];
+    }
+    __syncthreads();                                                   // S3
+
+    // ---- dW1[j][k] += sum_p dh2[p][j] * h1[p][k];  db1
+    {
+      float b = 0.0f;
+#pragma unroll 2
+      for (uint32_t q = 0; q < 256; ++q) {
+        const float dv = Y[q * BW_S + j1];
+        const float2* hv = reinterpret_cast<const float2*>(X + q * BW_S + kb1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float2 h = hv[i];
+          acc1[2 * i] = fmaf(dv, h.x, acc1[2 * i]);
+          acc1[2 * i + 1] = fmaf(dv, h.y, acc1[2 * i + 1]);
+        }
+        b += dv;
+      }
+      if ((t & 3) == 0) accb1 += b;
+    }
+    {  // dh1 = W1^T dh2 (own row of Y), masked by own h1 (own row of X)
+      float dh1[NGP_HID];
+      bw_matvec_t<NGP_HID>(W + NGP_W1, yr, dh1);
+#pragma unroll
+      for (int k = 0; k < NGP_HID; ++k) dh1[k] = xr[k] > 0.0f ? dh1[k] : 0.0f;
+      __syncthreads();                                                 // S4: X (h1), Y (dh2) consumed
+#pragma unroll
+      for (int k = 0; k < NGP_HID; ++k) xr[k] = dh1[k];
+#pragma unroll
+      for (int k = 0; k < NGP_FEAT; ++k) yr[k] = feat[k];
+    }
+    __syncthreads();                                                   // S5
+
+    // ---- dW0[j][k] += sum_p dh1[p][j] * feat[p][k];  db0
+    {
+      float b = 0.0f;
+#pragma unroll 4
+      for (uint32_t q = 0; q < 256; ++q) {
+        const float dv = X[q * BW_S + j1];
+        const float2* fv = reinterpret_cast<const float2*>(Y + q * BW_S + kb0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float2 h = fv[i];
+          acc0[2 * i] = fmaf(dv, h.x, acc0[2 * i]);
+          acc0[2 * i + 1] = fmaf(dv, h.y, acc0[2 * i + 1]);
+        }
+        b += dv;
+      }
+      if ((t & 3) == 0) accb0 += b;
+    }
+    // ---- d(features) = W0^T dh1 (own row of X) and table scatter
+    {
+      float dfeat[NGP_FEAT];
+      bw_matvec_t<NGP_FEAT>(W + NGP_W0, xr, dfeat);
+      ngp_scatter(lv, g.g_table, x01, inside, dfeat);
+    }
+    __syncthreads();                                                   // S6: before the next tile restages
+  }
+
+  // flush this workgroup's MLP gradient strips
+#pragma unroll
+  for (int i = 0; i < 16; ++i) SF_ATOMIC_ADD(g.g_w1 + j1 * NGP_HID + kb1 + i, acc1[i]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) SF_ATOMIC_ADD(g.g_w0 + j1 * NGP_FEAT + kb0 + i, acc0[i]);
+  SF_ATOMIC_ADD(g.g_w2 + o2 * NGP_HID + k2, acc2);
+  if ((t & 3) == 0) { SF_ATOMIC_ADD(g.g_b1 + j1, accb1); SF_ATOMIC_ADD(g.g_b0 + j1, accb0); }
+  if (k2 == 0) SF_ATOMIC_ADD(g.g_b2 + o2, accb2);
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static int make_levels(const sf_ngp_field* f, NgpLevels* out, hipStream_t st) {
+  if (!f || !f->h_offsets) SF_FAIL(SF_ERR_INVALID, "ngp: field/h_offsets must be given");
+  if (f->L > NGP_MAX_LEVELS) SF_FAIL(SF_ERR_INVALID, "ngp: at most %d levels", NGP_MAX_LEVELS);
+  struct { float scale[32]; uint32_t resolution[32]; uint32_t offset[32]; uint32_t hsize[32]; } tmp;
+  if (int rc = sf_fill_levels(reinterpret_cast<GridLevels*>(&tmp), nullptr, f->h_offsets, f->L, f->S, f->H, st)) return rc;
+  for (uint32_t l = 0; l < NGP_MAX_LEVELS; ++l) {
+    const bool on = l < f->L;
+    out->scale[l] = on ? tmp.scale[l] : 0.f;
+    out->resolution[l] = on ? tmp.resolution[l] : 1;
+    out->offset[l] = on ? tmp.offset[l] : 0;
+    out->hsize[l] = on ? tmp.hsize[l] : 1;
+  }
+  out->L = f->L;
+  out->gridtype = f->gridtype;
+  return SF_OK;
+}
+
+static FieldPtrs field_ptrs(const sf_ngp_field* f) {
+  return FieldPtrs{f->embeddings, f->w0, f->b0, f->w1, f->b1, f->w2, f->b2, f->bound};
+}
+
+extern "C" int sf_ngp_density(const sf_ngp_field* f, const float* xyz, uint32_t P, float* sigma, float* albedo,
+                              void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  NgpLevels lv;
+  if (int rc = make_levels(f, &lv, st)) return rc;
+  if (P == 0) return SF_OK;
+  k_ngp_field<2><<<sf_grid_cap(sf_div_up(P, 256)), 256, 0, st>>>(field_ptrs(f), lv, nullptr, nullptr, nullptr, nullptr,
+                                                                 nullptr, nullptr, nullptr, nullptr, xyz, P, 1, nullptr,
+                                                                 sigma, albedo);
+  SF_CHECK_LAUNCH("ngp_density");
+  return SF_OK;
+}
+
+// workspace (floats): z_c, sig_c [N*T]; rgb_c [3NT]; z_f, sig_f [N*T]; rgb_f [3NT]  -> 10*N*T
+// backward reuses it for dsig [2NT] + drgb [6NT] = 8*N*T.
+extern "C" uint64_t sf_ngp_render_workspace_bytes(uint32_t N, uint32_t T) {
+  return (uint64_t)10 * N * T * sizeof(float);
+}
+
+extern "C" int sf_ngp_render_forward(const sf_ngp_field* f, const float* rays_o, const float* rays_d,
+                                     const float* aabb, uint32_t N, uint32_t T, float min_near,
+                                     const float* lin, const float* u_coarse, const float* u_fine,
+                                     uint32_t u_fine_row_stride, float bg_color, float* nears, float* fars,
+                                     float* z_sorted, float* sigma_s, float* rgb_s, float* image, float* depth,
+                                     float* weights_sum, float* workspace, uint64_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (N == 0) return SF_OK;
+  if (T < 4 || T > 64) SF_FAIL(SF_ERR_INVALID, "ngp_render: T must be in [4,64]");
+  if (workspace_bytes < sf_ngp_render_workspace_bytes(N, T)) SF_FAIL(SF_ERR_INVALID, "ngp_render: workspace too small");
+  if (!lin || !u_fine) SF_FAIL(SF_ERR_INVALID, "ngp_render: lin and u_fine tables are required");
+  NgpLevels lv;
+  if (int rc = make_levels(f, &lv, st)) return rc;
+  if (int rc = sf_near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars, stream)) return rc;
+  const uint64_t NT = (uint64_t)N * T;
+  float* z_c = workspace;           float* sig_c = z_c + NT;     float* rgb_c = sig_c + NT;
+  float* z_f = rgb_c + 3 * NT;      float* sig_f = z_f + NT;     float* rgb_f = sig_f + NT;
+  const FieldPtrs fp = field_ptrs(f);
+  const uint32_t P = (uint32_t)NT;
+  const uint32_t gridp = sf_grid_cap(sf_div_up(P, 256));
+  k_ngp_field<0><<<gridp, 256, 0, st>>>(fp, lv, rays_o, rays_d, aabb, nears, fars, lin, u_coarse, nullptr, nullptr, P, T,
+                                        z_c, sig_c, rgb_c);
+  SF_CHECK_LAUNCH("ngp_field_coarse");
+  const uint32_t gridr = sf_div_up(N, 64);
+  k_ngp_sample_fine<<<gridr, 64, 2 * T * 64 * sizeof(float), st>>>(z_c, sig_c, u_fine, u_fine_row_stride, nears, fars,
+                                                                  N, T, z_f);
+  SF_CHECK_LAUNCH("ngp_sample_fine");
+  k_ngp_field<1><<<gridp, 256, 0, st>>>(fp, lv, rays_o, rays_d, aabb, nears, fars, nullptr, nullptr, z_f, nullptr, P, T,
+                                        nullptr, sig_f, rgb_f);
+  SF_CHECK_LAUNCH("ngp_field_fine");
+  k_ngp_composite<<<gridr, 64, 2 * T * 64 * sizeof(float), st>>>(z_c, sig_c, rgb_c, z_f, sig_f, rgb_f, nears, fars, N, T,
+                                                                bg_color, z_sorted, sigma_s, rgb_s, image, depth,
+                                                                weights_sum);
+  SF_CHECK_LAUNCH("ngp_composite");
+  return SF_OK;
+}
+
+extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_grad* g, const float* rays_o,
+                                      const float* rays_d, const float* aabb, uint32_t N, uint32_t T,
+                                      const float* nears, const float* fars, const float* z_sorted,
+                                      const float* sigma_s, const float* rgb_s, float bg_color,
+                                      const float* grad_image, const float* grad_weights_sum, float* workspace,
+                                      uint64_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (N == 0) return SF_OK;
+  if (T < 4 || T > 64) SF_FAIL(SF_ERR_INVALID, "ngp_render: T must be in [4,64]");
+  if (workspace_bytes < sf_ngp_render_workspace_bytes(N, T)) SF_FAIL(SF_ERR_INVALID, "ngp_render: workspace too small");
+  if (!grad_image) SF_FAIL(SF_ERR_INVALID, "ngp_render_backward: grad_image required");
+  NgpLevels lv;
+  if (int rc = make_levels(f, &lv, st)) return rc;
+  const uint64_t M = (uint64_t)N * 2 * T;
+  float* dsig = workspace;
+  float* drgb = dsig + M;
+  k_ngp_composite_bwd<<<sf_div_up(N, 64), 64, 4 * T * 64 * sizeof(float), st>>>(
+      z_sorted, sigma_s, rgb_s, nears, fars, N, T, bg_color, grad_image, grad_weights_sum, dsig, drgb);
+  SF_CHECK_LAUNCH("ngp_composite_bwd");
+  const FieldGrad fg{g->g_embeddings, g->g_w0, g->g_b0, g->g_w1, g->g_b1, g->g_w2, g->g_b2};
+  const size_t lds = (6536 + 2 * 256 * BW_S) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_field_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      SF_FAIL(SF_ERR_LAUNCH, "ngp_field_bwd: cannot raise dynamic LDS limit to %zu", lds);
+    attr_set = true;
+  }
+  const uint32_t n_tiles = sf_div_up(M, 256);
+  const uint32_t grid = n_tiles < 256 ? n_tiles : 256;      // one resident workgroup per CU (LDS-bound)
+  k_ngp_field_bwd<<<grid, 256, lds, st>>>(field_ptrs(f), fg, lv, rays_o, rays_d, aabb, z_sorted, dsig, drgb,
+                                          (uint32_t)M, 2 * T);
+  SF_CHECK_LAUNCH("ngp_field_bwd");
+  return SF_OK;
+}

@@ -1,0 +1,228 @@
+"""Volume renderer with the reference's call surface on the fused HIP render.
+
+Mirrors the public behaviour of external/nerf/renderer_df.py:64-717 for the configuration the
+distillation loop uses (cuda_ray=False, shading='albedo', bg_radius=0): `render`,
+`render_batched`, `run`, buffers `aabb_train` / `aabb_infer`, result dict keys
+`image [B,N,3]`, `depth [B,N]`, `weights_sum [N]`, `mask [B,N]`.  The whole of `run`
+(:310-468) is ONE autograd node backed by sf_ngp_render_forward / _backward.
+
+RNG: the reference draws, in this order, randn(3) (light direction, unused for 'albedo'),
+rand(N,T) (stratified jitter, if perturb) and rand(N,T) (inverse-CDF draw, if training) from
+the global generator (renderer_df.py:351,363,31); `run` draws the same tensors in the same
+order so a seeded run consumes the generator identically.  Tests inject them via `noise=`."""
+import argparse
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+def get_default_torch_ngp_opt():
+    """Options namespace of sparsefusion/distillation.py:500-525 (same field names)."""
+    opt = argparse.Namespace()
+    opt.cuda_ray = False
+    opt.max_steps = 256
+    opt.num_steps = 64
+    opt.upsample_steps = 64
+    opt.update_extra_interval = 16
+    opt.max_ray_batch = 4096
+    opt.albedo_iters = 1000
+    opt.bg_radius = 0
+    opt.density_thresh = 10
+    opt.fp16 = True
+    opt.backbone = 'grid'
+    opt.w = 128
+    opt.h = 128
+    opt.hw_scale = 2
+    opt.bound = 4
+    opt.min_near = 0.1
+    opt.dt_gamma = 0
+    opt.lambda_entropy = 1e-4
+    opt.lambda_opacity = 0
+    opt.lambda_orient = 1e-2
+    opt.lambda_smooth = 0
+    return opt
+
+
+class _FieldHandle:
+    """ctypes view of the field parameters; keeps the host offsets alive."""
+
+    def __init__(self, net):
+        enc = net.encoder
+        lin = net.sigma_net.net
+        self.tensors = [enc.embeddings, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, lin[2].weight,
+                        lin[2].bias]
+        self.host_offsets = enc.host_offsets
+        self.L = enc.num_levels
+        self.S = float(math.log2(enc.per_level_scale))
+        self.H = int(enc.base_resolution)
+        self.gridtype = int(enc.gridtype_id)
+        self.bound = float(net.bound)
+
+    def struct(self, tensors):
+        f = _lib.SfNgpField()
+        f.embeddings = tensors[0].data_ptr()
+        f.h_offsets = self.host_offsets.ctypes.data
+        f.L, f.S, f.H, f.gridtype = self.L, self.S, self.H, self.gridtype
+        f.w0, f.b0, f.w1, f.b1, f.w2, f.b2 = (t.data_ptr() for t in tensors[1:])
+        f.bound = self.bound
+        return f
+
+
+class _RenderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, handle, rays_o, rays_d, aabb, T, min_near, lin, u_coarse, u_fine, u_stride, bg, *params):
+        _lib.require_cuda(rays_o, rays_d, aabb, *params)
+        params = [p.detach().contiguous() for p in params]
+        N = rays_o.shape[0]
+        dev = rays_o.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        nears, fars = torch.empty(N, **f32), torch.empty(N, **f32)
+        z_s, sig_s = torch.empty(N, 2 * T, **f32), torch.empty(N, 2 * T, **f32)
+        rgb_s = torch.empty(N, 2 * T, 3, **f32)
+        image, depth, ws = torch.empty(N, 3, **f32), torch.empty(N, **f32), torch.empty(N, **f32)
+        lib = _lib.lib()
+        wbytes = lib.sf_ngp_render_workspace_bytes(N, T)
+        work = torch.empty(max(1, wbytes // 4), **f32)
+        f = handle.struct(params)
+        rc = lib.sf_ngp_render_forward(C.byref(f), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(aabb), N, T,
+                                       float(min_near), _lib.ptr(lin), _lib.ptr(u_coarse), _lib.ptr(u_fine),
+                                       int(u_stride), float(bg), _lib.ptr(nears), _lib.ptr(fars), _lib.ptr(z_s),
+                                       _lib.ptr(sig_s), _lib.ptr(rgb_s), _lib.ptr(image), _lib.ptr(depth), _lib.ptr(ws),
+                                       _lib.ptr(work), wbytes, _lib.stream_ptr())
+        _lib.check(rc, "ngp_render_forward")
+        ctx.handle, ctx.T, ctx.bg = handle, T, float(bg)
+        ctx.save_for_backward(rays_o, rays_d, aabb, nears, fars, z_s, sig_s, rgb_s, *params)
+        ctx.mark_non_differentiable(depth, nears, fars)
+        return image, ws, depth, nears, fars
+
+    @staticmethod
+    def backward(ctx, g_image, g_ws, _gd, _gn, _gf):
+        rays_o, rays_d, aabb, nears, fars, z_s, sig_s, rgb_s, *params = ctx.saved_tensors
+        N, T = rays_o.shape[0], ctx.T
+        grads = [torch.zeros_like(p) for p in params]
+        g = _lib.SfNgpFieldGrad()
+        (g.g_embeddings, g.g_w0, g.g_b0, g.g_w1, g.g_b1, g.g_w2, g.g_b2) = (t.data_ptr() for t in grads)
+        f = ctx.handle.struct(params)
+        lib = _lib.lib()
+        wbytes = lib.sf_ngp_render_workspace_bytes(N, T)
+        work = torch.empty(max(1, wbytes // 4), dtype=torch.float32, device=rays_o.device)
+        g_image = (g_image if g_image is not None else torch.zeros(N, 3, device=rays_o.device)).contiguous().float()
+        g_ws = g_ws.contiguous().float() if g_ws is not None else None
+        rc = lib.sf_ngp_render_backward(C.byref(f), C.byref(g), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(aabb), N, T,
+                                        _lib.ptr(nears), _lib.ptr(fars), _lib.ptr(z_s), _lib.ptr(sig_s), _lib.ptr(rgb_s),
+                                        ctx.bg, _lib.ptr(g_image), _lib.ptr(g_ws), _lib.ptr(work), wbytes,
+                                        _lib.stream_ptr())
+        _lib.check(rc, "ngp_render_backward")
+        return (None,) * 11 + tuple(grads)
+
+
+class NeRFRenderer(nn.Module):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        self.bound = opt.bound
+        self.cascade = 1 + math.ceil(math.log2(opt.bound))
+        self.grid_size = 128
+        self.cuda_ray = opt.cuda_ray
+        self.min_near = opt.min_near
+        self.density_thresh = opt.density_thresh
+        self.bg_radius = opt.bg_radius
+        if self.cuda_ray:
+            raise NotImplementedError("cuda_ray=True (occupancy-grid marching) is a SURVEY.md 8(f) 'next' row; the "
+                                      "reference distillation path runs with cuda_ray=False (distillation.py:505)")
+        if self.bg_radius > 0:
+            raise NotImplementedError("bg_radius > 0 is not on the distillation path (distillation.py:512)")
+        box = torch.tensor([-opt.bound] * 3 + [opt.bound] * 3, dtype=torch.float32)
+        self.register_buffer('aabb_train', box)
+        self.register_buffer('aabb_infer', box.clone())
+        self._tables = {}
+
+    # ---- hooks implemented by the field (network_grid.NeRFNetwork)
+    def forward(self, x, d):
+        raise NotImplementedError()
+
+    def density(self, x):
+        raise NotImplementedError()
+
+    def reset_extra_state(self):
+        return
+
+    @torch.no_grad()
+    def update_extra_state(self, decay=0.95, S=128):
+        return   # only meaningful with cuda_ray (renderer_df.py:590-591)
+
+    def _table(self, T, device):
+        key = (T, str(device))
+        if key not in self._tables:
+            lin = torch.linspace(0.0, 1.0, T, device=device)
+            det = torch.linspace(0. + 0.5 / T, 1. - 0.5 / T, steps=T, device=device)
+            self._tables[key] = (lin.contiguous(), det.contiguous())
+        return self._tables[key]
+
+    def run(self, rays_o, rays_d, num_steps=128, upsample_steps=128, light_d=None, ambient_ratio=1.0,
+            shading='albedo', bg_color=None, perturb=False, fixed_light=False, noise=None, **kwargs):
+        """rays_o, rays_d: [B, N, 3] (B == 1).  `noise` = dict(u_coarse=[N,T], u_fine=[N,T]) injects the draws."""
+        if shading != 'albedo':
+            raise NotImplementedError("only shading='albedo' is on the distillation path (distillation.py:209,282)")
+        if num_steps != upsample_steps:
+            raise NotImplementedError("the fused render needs num_steps == upsample_steps (reference: 64/64)")
+        prefix = rays_o.shape[:-1]
+        o = rays_o.contiguous().view(-1, 3).float()
+        d = rays_d.contiguous().view(-1, 3).float()
+        N, T, dev = o.shape[0], int(num_steps), o.device
+        aabb = self.aabb_train if self.training else self.aabb_infer
+        lin, det = self._table(T, dev)
+        if noise is None:
+            if light_d is None and not fixed_light:
+                torch.randn(3, device=dev, dtype=torch.float)          # consumed, unused for 'albedo' (:351)
+            u_coarse = torch.rand(N, T, device=dev) if perturb else None   # :363
+            u_fine = torch.rand(N, T, device=dev) if self.training else None  # sample_pdf det=not training (:31)
+        else:
+            u_coarse, u_fine = noise.get("u_coarse"), noise.get("u_fine")
+        u_f, stride = (u_fine.contiguous(), T) if u_fine is not None else (det, 0)
+        if u_coarse is not None:
+            u_coarse = u_coarse.contiguous()
+        if bg_color is None:
+            bg_color = 1
+        if torch.is_tensor(bg_color):
+            raise NotImplementedError("per-ray bg_color tensors are not on the distillation path (bg_color=0)")
+        image, weights_sum, depth, nears, fars = _RenderFn.apply(
+            self._field_handle(), o, d, aabb, T, self.min_near, lin, u_coarse, u_f, stride, float(bg_color),
+            *self._field_params())
+        return {'image': image.view(*prefix, 3), 'depth': depth.view(*prefix), 'weights_sum': weights_sum,
+                'mask': (nears < fars).view(*prefix)}
+
+    def run_cuda(self, *args, **kwargs):
+        raise NotImplementedError("cuda_ray=True path: SURVEY.md 8(f) 'next' row")
+
+    def _chunked(self, rays_o, rays_d, max_ray_batch, kwargs):
+        B, N = rays_o.shape[:2]
+        dev = rays_o.device
+        depth, image = torch.empty((B, N), device=dev), torch.empty((B, N, 3), device=dev)
+        weights_sum = torch.empty((B, N), device=dev)
+        for b in range(B):
+            for head in range(0, N, max_ray_batch):
+                tail = min(head + max_ray_batch, N)
+                r = self.run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], **kwargs)
+                depth[b:b + 1, head:tail] = r['depth']
+                weights_sum[b:b + 1, head:tail] = r['weights_sum']
+                image[b:b + 1, head:tail] = r['image']
+        return {'depth': depth, 'image': image, 'weights_sum': weights_sum}
+
+    def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
+        """renderer_df.py:643-679: one `run` over all rays, or chunks of max_ray_batch when staged."""
+        if staged:
+            return self._chunked(rays_o, rays_d, max_ray_batch, kwargs)
+        return self.run(rays_o, rays_d, **kwargs)
+
+    def render_batched(self, rays_o, rays_d, batched=False, max_ray_batch=128 * 128, **kwargs):
+        """renderer_df.py:681-717: no-grad render, optionally in chunks of max_ray_batch rays."""
+        kwargs.pop('max_ray_batch', None)
+        with torch.no_grad():
+            if batched:
+                return self._chunked(rays_o, rays_d, max_ray_batch, kwargs)
+            return self.run(rays_o, rays_d, **kwargs)

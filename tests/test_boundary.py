@@ -1,0 +1,81 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol the header
+declares, and the product package never touches the oracle (no CPU fallback)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = set()
+    inc = os.path.join(ROOT, "include")
+    for f in os.listdir(inc):
+        if f.endswith(".h"):
+            src = open(os.path.join(inc, f)).read()
+            src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+            names |= set(re.findall(r"\b(sf_[a-zA-Z0-9_]+)\s*\(", src))
+    return names
+
+
+def test_library_built_and_exports_header_symbols():
+    from sparsefusion_amd import build, _lib
+    build.build(verbose=False)
+    import ctypes
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 10
+    missing = [n for n in sorted(declared) if not hasattr(handle, n)]
+    assert not missing, f"header declares symbols the .so lacks: {missing}"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert _lib.lib().sf_abi_version() >= 1
+
+
+def test_product_never_imports_oracle_or_reference():
+    pkg = os.path.join(ROOT, "sparsefusion_amd")
+    bad = []
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "/root/reference" in txt \
+                        or re.search(r"#include\s+[\"<].*oracle", txt):
+                    bad.append(os.path.join(d, f))
+    assert not bad, bad
+
+
+def test_no_cpu_fallback_for_cpu_tensors():
+    import torch
+    from sparsefusion_amd import raymarching
+    with pytest.raises(RuntimeError):
+        raymarching.near_far_from_aabb(torch.zeros(4, 3), torch.ones(4, 3), torch.tensor([-1., -1, -1, 1, 1, 1]), 0.1)
+
+
+def test_missing_library_fails_loudly():
+    code = ("import sparsefusion_amd._lib as L, os; L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), 'nope.so');\n"
+            "try:\n    L.lib()\nexcept RuntimeError as e:\n    print('RAISED', 'no CPU fallback' in str(e))\n")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert "RAISED True" in out.stdout, out.stdout + out.stderr
+
+
+def test_grid_offsets_match_reference_layout():
+    from sparsefusion_amd.gridencoder import GridEncoder
+    enc = GridEncoder(input_dim=3, num_levels=16, level_dim=2, base_resolution=16, log2_hashmap_size=16,
+                      desired_resolution=8192, gridtype='tiled')
+    assert tuple(enc.embeddings.shape) == (929336, 2)
+    assert enc.offsets.dtype.is_floating_point is False and enc.offsets.numel() == 17
+    assert list(enc.host_offsets[:4]) == [0, 4920, 22496, 77368]
+    assert set(enc.state_dict().keys()) == {"embeddings", "offsets"}
+
+
+def test_ngp_state_dict_keys():
+    from sparsefusion_amd.nerf import NeRFNetwork, get_default_torch_ngp_opt
+    net = NeRFNetwork(get_default_torch_ngp_opt())
+    want = {"aabb_train", "aabb_infer", "encoder.embeddings", "encoder.offsets"} | {
+        f"sigma_net.net.{i}.{w}" for i in range(3) for w in ("weight", "bias")}
+    assert set(net.state_dict().keys()) == want
+    groups = net.get_params(5e-4)
+    assert groups[0]["lr"] == pytest.approx(5e-3) and groups[1]["lr"] == pytest.approx(5e-4)
