@@ -338,10 +338,10 @@ extern "C" int sf_grid_encode_forward(const float* inputs, const float* embeddin
                                       float* dy_dx, uint32_t gridtype, int align_corners,
                                       const int32_t* h_offsets, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  if (B == 0) return SF_OK;                      // empty batch: nothing to do (empty tensors have null data)
   if (!inputs || !embeddings || !outputs) SF_FAIL(SF_ERR_INVALID, "grid_encode_forward: null tensor");
   GridLevels lv;
   if (int rc = sf_fill_levels(&lv, offsets, h_offsets, L, S, H, st)) return rc;
-  if (B == 0) return SF_OK;
   const uint32_t ac = align_corners ? 1u : 0u;
   switch (D) {
     case 1: return launch_forward<1>(inputs, embeddings, outputs, dy_dx, B, C, L, lv, gridtype, ac, st);
@@ -361,12 +361,12 @@ extern "C" int sf_grid_encode_backward(const float* grad, const float* inputs,
                                        const int32_t* h_offsets, void* stream) {
   (void)embeddings;
   hipStream_t st = (hipStream_t)stream;
+  if (B == 0) return SF_OK;
   if (!grad || !inputs || !grad_embeddings) SF_FAIL(SF_ERR_INVALID, "grid_encode_backward: null tensor");
   if ((dy_dx == nullptr) != (grad_inputs == nullptr))
     SF_FAIL(SF_ERR_INVALID, "grid_encode_backward: dy_dx and grad_inputs must be given together");
   GridLevels lv;
   if (int rc = sf_fill_levels(&lv, offsets, h_offsets, L, S, H, st)) return rc;
-  if (B == 0) return SF_OK;
   const uint32_t ac = align_corners ? 1u : 0u;
   switch (D) {
     case 1: return launch_backward<1>(grad, inputs, grad_embeddings, dy_dx, grad_inputs, B, C, L, lv, gridtype, ac, st);

@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256) void k_ngp_field_bwd(
     {
       float dfeat[NGP_FEAT];
       bw_matvec_t<NGP_FEAT>(W + NGP_W0, xr, dfeat);
-      ngp_scatter(lv, g.g_table, x01, inside, dfeat);
+      if (g.g_table) ngp_scatter(lv, g.g_table, x01, inside, dfeat);   // NULL = table frozen
     }
     __syncthreads();                                                   // S6: before the next tile restages
   }

@@ -179,7 +179,10 @@ def test_render_matches_reference_golden(golden, name):
 
 def test_render_backward_isolated_tight(golden):
     """C-ABI backward fed with the ORACLE's sorted samples: isolates the gradient kernels from the
-    sample-position sensitivity; fp32 atomics / summation order only."""
+    sample-position sensitivity.  Upstream d(sigma), d(rgb) and the last layer agree to 1e-5; deeper
+    gradients differ by ReLU-mask flips of pre-activations within fp32 rounding of zero (a flip rate eps gives a
+    relative L2 difference ~sqrt(eps); measured 4e-4 .. 4e-3 on the MI355X), so the bound is 1e-2
+    in norm together with a cosine bound."""
     from sparsefusion_amd import _lib
     from sparsefusion_amd.nerf.renderer import _FieldHandle
     g = golden["teacher"]
@@ -187,6 +190,7 @@ def test_render_backward_isolated_tight(golden):
     pl = grad_leaf(p)
     ref = ngp_ref.render_run(pl, g["rays_o"], g["rays_d"], u_coarse=g["u_coarse"], u_fine=g["u_fine"], bg_color=0.0,
                              training=True, return_aux=True)
+    ref["sigma_sorted"].retain_grad()
     ((ref["image"] * g["g_image"]).sum() + (ref["weights_sum"] * g["g_ws"]).sum()).backward()
     net = _net(p)
     h = _FieldHandle(net)
@@ -212,7 +216,11 @@ def test_render_backward_isolated_tight(golden):
     for n, got in zip(names, grads):
         want = pl[n].grad
         rel = ((got.cpu() - want).norm() / want.norm()).item()
-        assert rel < 5e-4, (n, rel)
+        cos = torch.nn.functional.cosine_similarity(got.cpu().flatten(), want.flatten(), dim=0).item()
+        tight = n.startswith("sigma_net.net.2")
+        assert rel < (2e-5 if tight else 1e-2) and cos > 0.99995, (n, rel, cos)
+    dsig = work[:N * 2 * T].view(N, 2 * T).cpu()
+    assert ((dsig - ref["sigma_sorted"].grad).norm() / ref["sigma_sorted"].grad.norm()).item() < 1e-5
 
 
 def test_render_full_size_properties(golden):
