@@ -143,6 +143,56 @@ int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_grad* g,
 
 uint64_t sf_ngp_render_workspace_bytes(uint32_t N, uint32_t T);
 
+/* ------------------------------------------------------------------------ */
+/* UNet op executor (external/imagen_pytorch.py:1470-1671) -- the host side  */
+/* builds a static launch plan once (sparsefusion_amd/unet.py) and the       */
+/* library replays it on a stream; see DESIGN.md section 4.                  */
+/* ------------------------------------------------------------------------ */
+
+enum {
+  SF_OP_CONV = 1,      /* implicit-GEMM conv / linear on MFMA bf16          */
+  SF_OP_GN_ACT = 2,    /* GroupNorm(+scale/shift)+SiLU -> bf16              */
+  SF_OP_LN = 3,        /* LayerNorm over channels (+GELU) -> bf16 / f32     */
+  SF_OP_GEMV = 4,      /* small-M linear (time path, gca net, context kv)   */
+  SF_OP_ATTN = 5,      /* 16-token attention core                           */
+  SF_OP_GCA_POOL = 6,  /* GlobalContext softmax pooling                     */
+  SF_OP_ELTWISE = 7,   /* gate*h + residual, adds, pixel-shuffle, packing   */
+  SF_OP_MEMSET = 8,    /* zero a region of the activation arena             */
+  SF_OP_TIME_EMB = 9   /* learned sinusoidal embedding of log-snr           */
+};
+
+/* One op = one kernel launch.  Interpretation of p[]/i[]/f[] per op type is
+ * documented next to each kernel in sparsefusion_amd/csrc/unet_ops.hip. */
+typedef struct {
+  int32_t type;
+  int32_t flags;
+  void* p[8];
+  int32_t i[16];
+  float f[4];
+} sf_op;
+
+int sf_plan_run(const sf_op* ops, uint32_t n_ops, void* stream);
+
+/* Weight packing helpers (host pointers in, device-ready blobs out). */
+/* Pack a conv weight [Cout, Cin, kh, kw] f32 (host) into MFMA-fragment order
+ * bf16 (host buffer `out`, size sf_conv_packed_elems()*2 bytes). Cin is padded
+ * to cin_pad (multiple of 32), Cout to a multiple of 16. */
+uint64_t sf_conv_packed_elems(uint32_t Cout, uint32_t cin_pad, uint32_t kh, uint32_t kw);
+int sf_conv_pack_weights(const float* h_w, uint32_t Cout, uint32_t Cin,
+                         uint32_t cin_pad, uint32_t kh, uint32_t kw,
+                         uint16_t* h_out);
+
+/* Fused PLMS latent update (external/plms.py:158-214 get_model_output):
+ * x0 = clamp((x - sigma*e)/max(alpha,1e-8), +-clip); mean = a_next*(x*(1-c)/alpha + c*x0);
+ * x_prev = mean + noise_scale*noise.  coef = {alpha, sigma, alpha_next, c, noise_scale, clip}. */
+int sf_plms_update(const float* x, const float* eps, const float* noise,
+                   const float* h_coef6, uint64_t n, float* x_prev, float* x0,
+                   void* stream);
+/* e' = c0*e0 + c1*e1 + c2*e2 + c3*e3 (Adams-Bashforth combination, plms.py:137-152) */
+int sf_plms_combine(const float* e0, const float* e1, const float* e2,
+                    const float* e3, const float* h_c4, uint64_t n, float* out,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,785 @@
+// UNet operator set for gfx950 + the plan executor (sf_plan_run).
+//
+// Covers the op inventory of the view-conditioned latent UNet (external/imagen_pytorch.py):
+//   conv / linear          Conv2d k in {1,3,4,7,15}, nn.Linear on token maps        :641-662, :608-610, :1017-1042
+//   GN_ACT                 nn.GroupNorm(8) [+ x*(scale+1)+shift] + SiLU  (Block)    :641-662
+//   LN                     LayerNorm / ChanLayerNorm (gain only) / nn.LayerNorm     :301-329, :1214
+//   GEMV                   time MLPs, GlobalContext net, context k/v projections    :682-686, :916-941, :1175-1190
+//   ATTN                   16-query attention core (self multi-query / cross)        :480-566, :731-805
+//   GCA_POOL               GlobalContext softmax pooling                             :930-941
+//   ELTWISE                gating + residual, NCHW<->NHWC packing                    :727-729
+//   TIME_EMB               LearnedSinusoidalPosEmb                                   :624-639
+//
+// Design (MI355X-first, not a translation of the torch op sequence):
+//   * activations are NHWC; the residual stream and every reduction stay fp32, MFMA operands are
+//     bf16 with fp32 accumulation (v_mfma_f32_16x16x32_bf16);
+//   * conv = implicit GEMM, one wave per (16*WM x 16*WN) output tile and K slice.  Weights are
+//     pre-packed in MFMA-fragment order so a wave streams its weight slice as contiguous 1 KiB
+//     loads straight into registers (each weight byte is read once: no LDS round trip);
+//     activations come from L2 as 16-byte fragments.  The 4 waves of a workgroup take 4 K slices
+//     of the same tile, reduce through LDS, and one fp32 atomic add per element lands in a
+//     pre-zeroed output (split-K keeps all 256 CUs streaming on the 4x4 / 8x8 layers where
+//     M = 16..64 rows; several convs may accumulate into one output: res_conv, Parallel()).
+//   * one op = one launch; the host builds the op list once and replays it (HIP-graph friendly:
+//     static pointers, the only per-eval inputs are device buffers).
+//
+// Operand encodings are documented at each launcher (`run_*`).
+
+#include "sf_common.h"
+#include <math.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(1))) float gfloat;
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) {
+  (void)__builtin_amdgcn_global_atomic_fadd_f32((gfloat*)p, v);
+}
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CONV: implicit GEMM on MFMA.
+//   p[0] in (NHWC, bf16 or f32 by flag), p[1] packed weights (bf16), p[2] bias f32 [Cout] or NULL,
+//   p[3] out f32, p[4] residual f32 (same indexing as out) or NULL
+//   i[0..] = B, H, W, Cin_pad, Ho, Wo, Cout, ldc, co_off, kh, kw, stride, pad, ksplit_groups, tile (WM*16+WN), 0
+//   flags: 1 = A is f32, 2 = epilogue SiLU + PixelShuffle(2) (no split-K, plain stores)
+// Packed weight layout: [n_frag = Cout_pad/16][ks = tap*(Cin_pad/32)+cc][lane 64][8] bf16 with
+//   element (lane, j) = W[n = n_frag*16 + (lane&15)][tap][c = cc*32 + 8*(lane>>4) + j].
+// ---------------------------------------------------------------------------------------------
+struct ConvArgs {
+  const void* in; const bf16x8* w; const float* bias; float* out; const float* resid;
+  int B, H, W, Cin, Ho, Wo, Cout, ldc, co_off, kh, kw, stride, pad, groups;
+  int KS, cchunks, m_frags, n_frags, m_tiles, n_tiles, steps_per_wave;
+  int pixshuf;
+};
+
+template <int WM, int WN, bool A_FP32>
+__global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[3][WM * WN * 4 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x % (a.m_tiles * a.n_tiles);
+  const int grp = blockIdx.x / (a.m_tiles * a.n_tiles);
+  const int nt = tile % a.n_tiles, mt = tile / a.n_tiles;
+  const int k0 = (grp * 4 + wave) * a.steps_per_wave;
+  const int k1 = min(a.KS, k0 + a.steps_per_wave);
+  const int M = a.B * a.Ho * a.Wo;
+
+  // per m-fragment pixel coordinates of this lane's A row
+  int pb[WM], py[WM], px[WM];
+  bool pv[WM];
+#pragma unroll
+  for (int mi = 0; mi < WM; ++mi) {
+    const int m = (mt * WM + mi) * 16 + (lane & 15);
+    pv[mi] = m < M;
+    const int mm = pv[mi] ? m : 0;
+    pb[mi] = mm / (a.Ho * a.Wo);
+    const int r = mm - pb[mi] * (a.Ho * a.Wo);
+    const int oy = r / a.Wo;
+    py[mi] = oy * a.stride - a.pad;
+    px[mi] = (r - oy * a.Wo) * a.stride - a.pad;
+  }
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int cgrp = (lane >> 4) * 8;
+  int ks = k0;
+  while (ks < k1) {
+    const int tap = ks / a.cchunks;
+    const int cc0 = ks - tap * a.cchunks;
+    const int cc1 = min(a.cchunks, cc0 + (k1 - ks));
+    const int ky = tap / a.kw, kx = tap - ky * a.kw;
+    long aoff[WM];
+    bool ain[WM];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi) {
+      const int iy = py[mi] + ky, ix = px[mi] + kx;
+      ain[mi] = pv[mi] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      aoff[mi] = (((long)pb[mi] * a.H + (ain[mi] ? iy : 0)) * a.W + (ain[mi] ? ix : 0)) * a.Cin + cgrp;
+    }
+    const bf16x8* wp[WN];
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+      const int nf = min(nt * WN + ni, a.n_frags - 1);
+      wp[ni] = a.w + ((long)nf * a.KS + ks) * 64 + lane;
+    }
+#pragma unroll 2
+    for (int cc = cc0; cc < cc1; ++cc) {
+      bf16x8 af[WM], bf[WN];
+#pragma unroll
+      for (int ni = 0; ni < WN; ++ni) { bf[ni] = *wp[ni]; wp[ni] += 64; }
+#pragma unroll
+      for (int mi = 0; mi < WM; ++mi) {
+        if (A_FP32) {
+          const float* src = reinterpret_cast<const float*>(a.in) + aoff[mi] + cc * 32;
+          f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+          if (ain[mi]) { lo = *reinterpret_cast<const f32x4*>(src); hi = *reinterpret_cast<const f32x4*>(src + 4); }
+          bf16x8 v;
+          v[0] = (__bf16)lo[0]; v[1] = (__bf16)lo[1]; v[2] = (__bf16)lo[2]; v[3] = (__bf16)lo[3];
+          v[4] = (__bf16)hi[0]; v[5] = (__bf16)hi[1]; v[6] = (__bf16)hi[2]; v[7] = (__bf16)hi[3];
+          af[mi] = v;
+        } else {
+          const __bf16* src = reinterpret_cast<const __bf16*>(a.in) + aoff[mi] + cc * 32;
+          bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (ain[mi]) v = *reinterpret_cast<const bf16x8*>(src);
+          af[mi] = v;
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+    }
+    ks += cc1 - cc0;
+  }
+
+  // reduce the 4 K-slices of this workgroup through LDS
+  if (wave > 0) {
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave - 1][((mi * WN + ni) * 4 + r) * 64 + lane] = acc[mi][ni][r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = ((mi * WN + ni) * 4 + r) * 64 + lane;
+        acc[mi][ni][r] += red[0][idx] + red[1][idx] + red[2][idx];
+      }
+
+  const bool first = grp == 0;
+#pragma unroll
+  for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+      const int n = (nt * WN + ni) * 16 + (lane & 15);
+      if (n >= a.Cout || nt * WN + ni >= a.n_frags) continue;
+      const float bv = (first && a.bias) ? a.bias[n] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = (mt * WM + mi) * 16 + (lane >> 4) * 4 + r;
+        if (m >= M) continue;
+        float v = acc[mi][ni][r] + bv;
+        if (a.pixshuf) {
+          // out[b, 2*oy+i, 2*ox+j, c] = silu(conv[b, oy, ox, c*4 + i*2 + j])   (PixelShuffle(2), :578-606)
+          v = silu_f(v);
+          const int b = m / (a.Ho * a.Wo);
+          const int rr = m - b * (a.Ho * a.Wo);
+          const int oy = rr / a.Wo, ox = rr - oy * a.Wo;
+          const int c = n >> 2, ii = (n >> 1) & 1, jj = n & 1;
+          a.out[(((long)b * (2 * a.Ho) + 2 * oy + ii) * (2 * a.Wo) + 2 * ox + jj) * a.ldc + a.co_off + c] = v;
+        } else {
+          const long o = (long)m * a.ldc + a.co_off + n;
+          if (first && a.resid) v += a.resid[o];
+          atomic_add_f32(a.out + o, v);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GN_ACT: GroupNorm(G=8, eps) over a (virtual) channel concat of two NHWC f32 sources, optional
+// x*(scale+1)+shift, SiLU, -> bf16 NHWC; optional raw bf16 copy of the concat.
+//   p[0] src1 f32 [B,HW,C1], p[1] src2 f32 [B,HW,C2] or NULL, p[2] gamma [C], p[3] beta [C],
+//   p[4] scale_shift f32 (row b at p[4] + b*ss_stride: scale[C] then shift[C]) or NULL,
+//   p[5] out bf16 [B,HW,C], p[6] raw bf16 [B,HW,C] or NULL
+//   i = B, HW, C1, C2, ss_stride ; f = eps, src2_scale ; flags: 1 = no SiLU
+// One 1024-thread workgroup per (b, group); the group slab stays in registers (<= 64 floats/lane).
+// ---------------------------------------------------------------------------------------------
+#define GN_MAXV 16   // float4 chunks per thread: 16*4*1024 = 65536 elements per (b, group)
+__global__ __launch_bounds__(1024) void k_gn_act(const float* __restrict__ s1, const float* __restrict__ s2,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 const float* __restrict__ ss, __bf16* __restrict__ out,
+                                                 __bf16* __restrict__ raw, int B, int HW, int C1, int C2, int ss_stride,
+                                                 float eps, float s2_scale, int no_silu) {
+  __shared__ float red[32];
+  __shared__ float stat[2];
+  const int C = C1 + C2, Cg = C / 8, cg4 = Cg / 4;
+  const int b = blockIdx.x / 8, g = blockIdx.x % 8;
+  const int chunks = HW * cg4;
+  f32x4 v[GN_MAXV];
+  float sum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < GN_MAXV; ++i) {
+    const int ch = threadIdx.x + i * 1024;
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ch < chunks) {
+      const int p = ch / cg4, c = g * Cg + (ch - p * cg4) * 4;
+      if (c < C1) v[i] = *reinterpret_cast<const f32x4*>(s1 + ((long)b * HW + p) * C1 + c);
+      else { v[i] = *reinterpret_cast<const f32x4*>(s2 + ((long)b * HW + p) * C2 + (c - C1)); v[i] *= s2_scale; }
+      sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  sum = wave_sum(sum);
+  if (lane == 0) red[wv] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) { float t = 0; for (int i = 0; i < 16; ++i) t += red[i]; stat[0] = t / (float)(HW * Cg); }
+  __syncthreads();
+  const float mean = stat[0];
+  float sq = 0.0f;
+#pragma unroll
+  for (int i = 0; i < GN_MAXV; ++i) {
+    const int ch = threadIdx.x + i * 1024;
+    if (ch < chunks) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; sq = fmaf(d, d, sq); }
+    }
+  }
+  sq = wave_sum(sq);
+  if (lane == 0) red[16 + wv] = sq;
+  __syncthreads();
+  if (threadIdx.x == 0) { float t = 0; for (int i = 0; i < 16; ++i) t += red[16 + i]; stat[1] = rsqrtf(t / (float)(HW * Cg) + eps); }
+  __syncthreads();
+  const float rstd = stat[1];
+#pragma unroll
+  for (int i = 0; i < GN_MAXV; ++i) {
+    const int ch = threadIdx.x + i * 1024;
+    if (ch < chunks) {
+      const int p = ch / cg4, c = g * Cg + (ch - p * cg4) * 4;
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+      bf16x4 o, r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float y = (v[i][j] - mean) * rstd * ga[j] + be[j];
+        if (ss) y = y * (ss[(long)b * ss_stride + c + j] + 1.0f) + ss[(long)b * ss_stride + C + c + j];
+        if (!no_silu) y = silu_f(y);
+        o[j] = (__bf16)y;
+        r[j] = (__bf16)v[i][j];
+      }
+      *reinterpret_cast<bf16x4*>(out + ((long)b * HW + p) * C + c) = o;
+      if (raw) *reinterpret_cast<bf16x4*>(raw + ((long)b * HW + p) * C + c) = r;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LN: per-row normalisation over C (biased variance), one wave per row.
+//   p[0] in f32 [R,C], p[1] gain [C], p[2] bias [C] or NULL, p[3] out (bf16 or f32), p[4] residual f32 or NULL
+//   i = R, C ; f = eps ; flags: 1 = GELU(x) before normalising, 2 = f32 output (+ residual), else bf16 output
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in, const float* __restrict__ gain,
+                                                   const float* __restrict__ bias, void* __restrict__ out,
+                                                   const float* __restrict__ resid, int R, int C, float eps, int pre_gelu,
+                                                   int out_f32) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* x = in + (long)row * C;
+  float v[32];                       // C <= 2048
+  float s = 0.0f;
+  const int per = C / 64;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    if (i < per) {
+      float t = x[lane + i * 64];
+      if (pre_gelu) t = gelu_f(t);
+      v[i] = t;
+      s += t;
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i)
+    if (i < per) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    if (i < per) {
+      const int c = lane + i * 64;
+      float y = (v[i] - mean) * rstd * gain[c];
+      if (bias) y += bias[c];
+      if (out_f32) {
+        if (resid) y += resid[(long)row * C + c];
+        reinterpret_cast<float*>(out)[(long)row * C + c] = y;
+      } else {
+        reinterpret_cast<__bf16*>(out)[(long)row * C + c] = (__bf16)y;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMV: y[m][n] = act_out(bias[n] + sum_k W[n][k] * act_in(x[m][k])), M <= 8 rows, one wave per n.
+//   p[0] x f32 (row stride ldx), p[1] W bf16 [N][Kp] (Kp = K padded to 8), p[2] bias f32 or NULL, p[3] y f32 (row stride ldy)
+//   i = M, N, K, Kp, ldx, ldy ; flags: bit0 SiLU on input, bits 1-2 output act (0 none, 1 SiLU, 2 sigmoid)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gemv(const float* __restrict__ x, const __bf16* __restrict__ W,
+                                              const float* __restrict__ bias, float* __restrict__ y, int M, int N, int K,
+                                              int Kp, int ldx, int ldy, int in_silu, int out_act) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float acc[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) acc[m] = 0.0f;
+  const __bf16* wr = W + (long)n * Kp;
+  for (int k = lane * 8; k < Kp; k += 512) {
+    const bf16x8 w = *reinterpret_cast<const bf16x8*>(wr + k);
+    float wf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wf[j] = (float)w[j];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      if (m < M) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (k + j < K) {
+            float xv = x[(long)m * ldx + k + j];
+            if (in_silu) xv = silu_f(xv);
+            acc[m] = fmaf(wf[j], xv, acc[m]);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    if (m < M) {
+      float v = wave_sum(acc[m]);
+      if (lane == 0) {
+        if (bias) v += bias[n];
+        if (out_act == 1) v = silu_f(v);
+        else if (out_act == 2) v = sigmoid_f(v);
+        y[(long)m * ldy + n] = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ATTN: softmax(q k^T) v for 16 queries, head dim 64, <= 24 keys built from up to 3 segments.
+//   p[0] q f32 [B*16, ldq] (head h at column h*64), p[1] out bf16 [B*16, 512]
+//   segment s (s = 0..2): p[2+2s] keys, p[3+2s] values (f32); i[4+4s..] = rows, row_stride, batch_stride, head_stride
+//   i[0] = B, i[1] = heads, i[2] = ldq ; f[0] = q scale.   One 64-thread workgroup per (b, head).
+// ---------------------------------------------------------------------------------------------
+struct AttnSeg { const float* k; const float* v; int rows, row_stride, batch_stride, head_stride; };
+__global__ __launch_bounds__(64) void k_attn16(const float* __restrict__ q, __bf16* __restrict__ out, AttnSeg s0, AttnSeg s1,
+                                               AttnSeg s2, int heads, int ldq, float scale) {
+  __shared__ float sq[16][65];
+  __shared__ float sk[24][65];
+  __shared__ float sv[24][65];
+  __shared__ float sim[16][25];
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads, t = threadIdx.x;
+  for (int i = 0; i < 16; ++i) sq[i][t] = q[((long)b * 16 + i) * ldq + h * 64 + t] * scale;
+  const AttnSeg segs[3] = {s0, s1, s2};
+  int J = 0;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    for (int r = 0; r < segs[s].rows; ++r) {
+      const long off = (long)b * segs[s].batch_stride + (long)r * segs[s].row_stride + (long)h * segs[s].head_stride + t;
+      sk[J + r][t] = segs[s].k[off];
+      sv[J + r][t] = segs[s].v[off];
+    }
+    J += segs[s].rows;
+  }
+  __syncthreads();
+  for (int e = t; e < 16 * J; e += 64) {
+    const int i = e / J, j = e - i * J;
+    float a = 0.0f;
+#pragma unroll 8
+    for (int d = 0; d < 64; ++d) a = fmaf(sq[i][d], sk[j][d], a);
+    sim[i][j] = a;
+  }
+  __syncthreads();
+  if (t < 16) {
+    float mx = -INFINITY;
+    for (int j = 0; j < J; ++j) mx = fmaxf(mx, sim[t][j]);
+    float den = 0.0f;
+    for (int j = 0; j < J; ++j) { const float e = expf(sim[t][j] - mx); sim[t][j] = e; den += e; }
+    const float inv = 1.0f / den;
+    for (int j = 0; j < J; ++j) sim[t][j] *= inv;
+  }
+  __syncthreads();
+  for (int i = 0; i < 16; ++i) {
+    float a = 0.0f;
+    for (int j = 0; j < J; ++j) a = fmaf(sim[i][j], sv[j][t], a);
+    out[((long)b * 16 + i) * (heads * 64) + h * 64 + t] = (__bf16)a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GCA_POOL: pooled[b][c] = sum_p softmax_p(h[b,p,:] . wk + bk) * h[b,p,c]     (GlobalContext :930-941)
+//   p[0] h f32 [B,HW,C], p[1] wk f32 [C], p[2] bk f32 [1], p[3] pooled f32 [B,C] ; i = B, HW, C
+// One 1024-thread workgroup per b.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_gca_pool(const float* __restrict__ h, const float* __restrict__ wk,
+                                                   const float* __restrict__ bk, float* __restrict__ pooled, int HW, int C) {
+  __shared__ float logit[1024];
+  __shared__ float red[16];
+  __shared__ float bc[2];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float* hb = h + (long)b * HW * C;
+  for (int p = wv; p < HW; p += 16) {
+    float a = 0.0f;
+    for (int c = lane * 4; c < C; c += 256) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(hb + (long)p * C + c);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(wk + c);
+      a += x[0] * w[0] + x[1] * w[1] + x[2] * w[2] + x[3] * w[3];
+    }
+    a = wave_sum(a);
+    if (lane == 0) logit[p] = a + bk[0];
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int p = threadIdx.x; p < HW; p += 1024) mx = fmaxf(mx, logit[p]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wv] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) { float m = red[0]; for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]); bc[0] = m; }
+  __syncthreads();
+  mx = bc[0];
+  float s = 0.0f;
+  for (int p = threadIdx.x; p < HW; p += 1024) { const float e = expf(logit[p] - mx); logit[p] = e; s += e; }
+  s = wave_sum(s);
+  __syncthreads();
+  if (lane == 0) red[wv] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { float t = 0; for (int i = 0; i < 16; ++i) t += red[i]; bc[1] = 1.0f / t; }
+  __syncthreads();
+  const float inv = bc[1];
+  for (int c = threadIdx.x; c < C; c += 1024) {
+    float a = 0.0f;
+    for (int p = 0; p < HW; ++p) a = fmaf(logit[p], hb[(long)p * C + c], a);
+    pooled[(long)b * C + c] = a * inv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ELTWISE (flags = mode):
+//   1 GATE_RES   out[b,p,c] = h[b,p,c]*gate[b,c] + res[b,p,c]   p0 h, p1 gate [B,C], p2 res or NULL (then out holds it), p3 out ; i = B,HW,C
+//   2 PACK_IN    out NHWC f32 [B,HW,Cp] = concat(cond NCHW [B,Cc,HW], x NCHW [B,Cx,HW]), zero pad ; p0 cond, p1 x, p3 out ; i = B,HW,Cc,Cx,Cp
+//   3 UNPACK_OUT out NCHW [B,C,HW] = in NHWC [B,HW,ldi] first C channels ; p0 in, p3 out ; i = B,HW,C,ldi
+//   4 ADD        out[i] += p0[i] ; i[0] = n
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gate_res(const float* __restrict__ h, const float* __restrict__ gate,
+                                                  const float* __restrict__ res, float* __restrict__ out, int B, int HW,
+                                                  int C) {
+  const long n4 = (long)B * HW * C / 4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long e = i * 4;
+    const int c = (int)(e % C);
+    const int b = (int)(e / ((long)HW * C));
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(h + e);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(gate + (long)b * C + c);
+    const f32x4 rv = *reinterpret_cast<const f32x4*>((res ? res : out) + e);
+    *reinterpret_cast<f32x4*>(out + e) = hv * gv + rv;
+  }
+}
+__global__ __launch_bounds__(256) void k_pack_in(const float* __restrict__ cond, const float* __restrict__ x,
+                                                 float* __restrict__ out, int B, int HW, int Cc, int Cx, int Cp) {
+  const long n = (long)B * HW * Cp;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % Cp);
+    const long bp = i / Cp;
+    const int p = (int)(bp % HW), b = (int)(bp / HW);
+    float v = 0.0f;
+    if (c < Cc) v = cond[((long)b * Cc + c) * HW + p];
+    else if (c < Cc + Cx) v = x[((long)b * Cx + (c - Cc)) * HW + p];
+    out[i] = v;
+  }
+}
+__global__ __launch_bounds__(256) void k_unpack_out(const float* __restrict__ in, float* __restrict__ out, int B, int HW,
+                                                    int C, int ldi) {
+  const long n = (long)B * C * HW;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int p = (int)(i % HW);
+    const long bc = i / HW;
+    const int c = (int)(bc % C), b = (int)(bc / C);
+    out[i] = in[((long)b * HW + p) * ldi + c];
+  }
+}
+__global__ __launch_bounds__(256) void k_add(const float* __restrict__ a, float* __restrict__ out, long n) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] += a[i];
+}
+
+// TIME_EMB: f[b] = [t, sin(2*pi*t*w_i) (i<half), cos(2*pi*t*w_i) (i<half)]   (LearnedSinusoidalPosEmb :624-639)
+//   p0 t f32 [B], p1 w f32 [half], p3 out f32 [B, 1+2*half] ; i = B, half
+__global__ void k_time_emb(const float* __restrict__ t, const float* __restrict__ w, float* __restrict__ out, int B,
+                           int half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, j = i - b * half;
+  const float fr = t[b] * w[j] * 2.0f * 3.14159265358979323846f;
+  float* o = out + (long)b * (1 + 2 * half);
+  if (j == 0) o[0] = t[b];
+  o[1 + j] = sinf(fr);
+  o[1 + half + j] = cosf(fr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+template <int WM, int WN>
+static void launch_conv(const ConvArgs& a, bool a_fp32, int blocks, hipStream_t st) {
+  if (a_fp32) k_conv_igemm<WM, WN, true><<<blocks, 256, 0, st>>>(a);
+  else k_conv_igemm<WM, WN, false><<<blocks, 256, 0, st>>>(a);
+}
+
+static int run_conv(const sf_op& op, hipStream_t st) {
+  ConvArgs a;
+  a.in = op.p[0]; a.w = (const bf16x8*)op.p[1]; a.bias = (const float*)op.p[2]; a.out = (float*)op.p[3];
+  a.resid = (const float*)op.p[4];
+  a.B = op.i[0]; a.H = op.i[1]; a.W = op.i[2]; a.Cin = op.i[3]; a.Ho = op.i[4]; a.Wo = op.i[5]; a.Cout = op.i[6];
+  a.ldc = op.i[7]; a.co_off = op.i[8]; a.kh = op.i[9]; a.kw = op.i[10]; a.stride = op.i[11]; a.pad = op.i[12];
+  a.groups = op.i[13] > 0 ? op.i[13] : 1;
+  const int tile = op.i[14];
+  const int WM = tile / 16, WN = tile % 16;
+  a.pixshuf = (op.flags & 2) ? 1 : 0;
+  if (a.Cin % 32) SF_FAIL(SF_ERR_INVALID, "conv: Cin_pad must be a multiple of 32");
+  if (a.pixshuf && a.groups != 1) SF_FAIL(SF_ERR_INVALID, "conv: pixel-shuffle epilogue cannot be split-K");
+  a.cchunks = a.Cin / 32;
+  a.KS = a.kh * a.kw * a.cchunks;
+  const int M = a.B * a.Ho * a.Wo;
+  a.m_frags = (M + 15) / 16;
+  a.n_frags = (a.Cout + 15) / 16;
+  a.m_tiles = (a.m_frags + WM - 1) / WM;
+  a.n_tiles = (a.n_frags + WN - 1) / WN;
+  if (a.pixshuf) a.groups = 1;
+  a.steps_per_wave = (a.KS + a.groups * 4 - 1) / (a.groups * 4);
+  const int blocks = a.m_tiles * a.n_tiles * a.groups;
+  const bool f32 = (op.flags & 1) != 0;
+  switch (tile) {
+    case 1 * 16 + 1: launch_conv<1, 1>(a, f32, blocks, st); break;
+    case 1 * 16 + 2: launch_conv<1, 2>(a, f32, blocks, st); break;
+    case 1 * 16 + 4: launch_conv<1, 4>(a, f32, blocks, st); break;
+    case 2 * 16 + 1: launch_conv<2, 1>(a, f32, blocks, st); break;
+    case 2 * 16 + 2: launch_conv<2, 2>(a, f32, blocks, st); break;
+    case 2 * 16 + 4: launch_conv<2, 4>(a, f32, blocks, st); break;
+    case 4 * 16 + 1: launch_conv<4, 1>(a, f32, blocks, st); break;
+    case 4 * 16 + 2: launch_conv<4, 2>(a, f32, blocks, st); break;
+    case 4 * 16 + 4: launch_conv<4, 4>(a, f32, blocks, st); break;
+    default: SF_FAIL(SF_ERR_INVALID, "conv: unsupported wave tile %dx%d", WM, WN);
+  }
+  SF_CHECK_LAUNCH("conv_igemm");
+  return SF_OK;
+}
+
+static int run_gn(const sf_op& op, hipStream_t st) {
+  const int B = op.i[0], HW = op.i[1], C1 = op.i[2], C2 = op.i[3];
+  const int C = C1 + C2;
+  if (C % 32 || C1 % 4 || (long)HW * (C / 8) > (long)GN_MAXV * 4 * 1024)
+    SF_FAIL(SF_ERR_INVALID, "gn_act: unsupported shape HW=%d C=%d", HW, C);
+  k_gn_act<<<B * 8, 1024, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], (const float*)op.p[3],
+                                   (const float*)op.p[4], (__bf16*)op.p[5], (__bf16*)op.p[6], B, HW, C1, C2, op.i[4], op.f[0],
+                                   op.f[1], op.flags & 1);
+  SF_CHECK_LAUNCH("gn_act");
+  return SF_OK;
+}
+
+static int run_ln(const sf_op& op, hipStream_t st) {
+  const int R = op.i[0], C = op.i[1];
+  if (C % 64 || C > 2048) SF_FAIL(SF_ERR_INVALID, "layernorm: C must be a multiple of 64 and <= 2048");
+  k_layernorm<<<sf_div_up(R, 4), 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3],
+                                              (const float*)op.p[4], R, C, op.f[0], op.flags & 1, (op.flags & 2) ? 1 : 0);
+  SF_CHECK_LAUNCH("layernorm");
+  return SF_OK;
+}
+
+static int run_gemv(const sf_op& op, hipStream_t st) {
+  const int M = op.i[0], N = op.i[1];
+  if (M > 8) SF_FAIL(SF_ERR_INVALID, "gemv: at most 8 rows");
+  k_gemv<<<sf_div_up(N, 4), 256, 0, st>>>((const float*)op.p[0], (const __bf16*)op.p[1], (const float*)op.p[2], (float*)op.p[3],
+                                         M, N, op.i[2], op.i[3], op.i[4], op.i[5], op.flags & 1, (op.flags >> 1) & 3);
+  SF_CHECK_LAUNCH("gemv");
+  return SF_OK;
+}
+
+static int run_attn(const sf_op& op, hipStream_t st) {
+  AttnSeg s[3];
+  int J = 0;
+  for (int k = 0; k < 3; ++k) {
+    s[k].k = (const float*)op.p[2 + 2 * k]; s[k].v = (const float*)op.p[3 + 2 * k];
+    s[k].rows = op.i[4 + 4 * k]; s[k].row_stride = op.i[5 + 4 * k]; s[k].batch_stride = op.i[6 + 4 * k];
+    s[k].head_stride = op.i[7 + 4 * k];
+    J += s[k].rows;
+  }
+  if (J < 1 || J > 24) SF_FAIL(SF_ERR_INVALID, "attn: 1..24 keys");
+  k_attn16<<<op.i[0] * op.i[1], 64, 0, st>>>((const float*)op.p[0], (__bf16*)op.p[1], s[0], s[1], s[2], op.i[1], op.i[2], op.f[0]);
+  SF_CHECK_LAUNCH("attn16");
+  return SF_OK;
+}
+
+static int run_gca_pool(const sf_op& op, hipStream_t st) {
+  if (op.i[1] > 1024 || op.i[2] % 4) SF_FAIL(SF_ERR_INVALID, "gca_pool: HW <= 1024, C %% 4 == 0");
+  k_gca_pool<<<op.i[0], 1024, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], (float*)op.p[3],
+                                       op.i[1], op.i[2]);
+  SF_CHECK_LAUNCH("gca_pool");
+  return SF_OK;
+}
+
+static int run_eltwise(const sf_op& op, hipStream_t st) {
+  switch (op.flags) {
+    case 1: {
+      const long n4 = (long)op.i[0] * op.i[1] * op.i[2] / 4;
+      k_gate_res<<<sf_grid_cap(sf_div_up(n4, 256)), 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1],
+                                                                 (const float*)op.p[2], (float*)op.p[3], op.i[0], op.i[1], op.i[2]);
+      break;
+    }
+    case 2: {
+      const long n = (long)op.i[0] * op.i[1] * op.i[4];
+      k_pack_in<<<sf_grid_cap(sf_div_up(n, 256)), 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (float*)op.p[3],
+                                                               op.i[0], op.i[1], op.i[2], op.i[3], op.i[4]);
+      break;
+    }
+    case 3: {
+      const long n = (long)op.i[0] * op.i[1] * op.i[2];
+      k_unpack_out<<<sf_grid_cap(sf_div_up(n, 256)), 256, 0, st>>>((const float*)op.p[0], (float*)op.p[3], op.i[0], op.i[1],
+                                                                  op.i[2], op.i[3]);
+      break;
+    }
+    case 4: {
+      const long n = (long)(uint32_t)op.i[0];
+      k_add<<<sf_grid_cap(sf_div_up(n, 256)), 256, 0, st>>>((const float*)op.p[0], (float*)op.p[3], n);
+      break;
+    }
+    default: SF_FAIL(SF_ERR_INVALID, "eltwise: unknown mode %d", op.flags);
+  }
+  SF_CHECK_LAUNCH("eltwise");
+  return SF_OK;
+}
+
+extern "C" int sf_plan_run(const sf_op* ops, uint32_t n_ops, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  for (uint32_t k = 0; k < n_ops; ++k) {
+    const sf_op& op = ops[k];
+    int rc = SF_OK;
+    switch (op.type) {
+      case SF_OP_CONV: rc = run_conv(op, st); break;
+      case SF_OP_GN_ACT: rc = run_gn(op, st); break;
+      case SF_OP_LN: rc = run_ln(op, st); break;
+      case SF_OP_GEMV: rc = run_gemv(op, st); break;
+      case SF_OP_ATTN: rc = run_attn(op, st); break;
+      case SF_OP_GCA_POOL: rc = run_gca_pool(op, st); break;
+      case SF_OP_ELTWISE: rc = run_eltwise(op, st); break;
+      case SF_OP_MEMSET:
+        if (hipMemsetAsync(op.p[0], 0, (size_t)(uint32_t)op.i[0] * 4, st) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "memset failed");
+        break;
+      case SF_OP_TIME_EMB:
+        k_time_emb<<<sf_div_up(op.i[0] * op.i[1], 64), 64, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (float*)op.p[3],
+                                                                  op.i[0], op.i[1]);
+        if (hipGetLastError() != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "time_emb launch failed");
+        break;
+      default: SF_FAIL(SF_ERR_INVALID, "plan: unknown op type %d at %u", op.type, k);
+    }
+    if (rc) {
+      char tmp[400];
+      snprintf(tmp, sizeof(tmp), "%s", sf_err_buf);
+      snprintf(sf_err_buf, sizeof(sf_err_buf), "plan op %u (type %d): %s", k, op.type, tmp);
+      return rc;
+    }
+  }
+  return SF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side weight packing (round-to-nearest-even bf16)
+// ---------------------------------------------------------------------------------------------
+static inline uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+extern "C" uint64_t sf_conv_packed_elems(uint32_t Cout, uint32_t cin_pad, uint32_t kh, uint32_t kw) {
+  const uint64_t nfr = (Cout + 15) / 16;
+  return nfr * kh * kw * (cin_pad / 32) * 64 * 8;
+}
+
+extern "C" int sf_conv_pack_weights(const float* h_w, uint32_t Cout, uint32_t Cin, uint32_t cin_pad, uint32_t kh,
+                                    uint32_t kw, uint16_t* h_out) {
+  if (cin_pad % 32 || cin_pad < Cin) SF_FAIL(SF_ERR_INVALID, "pack: cin_pad must be a multiple of 32 and >= Cin");
+  const uint32_t nfr = (Cout + 15) / 16, cch = cin_pad / 32, taps = kh * kw;
+  const uint64_t KS = (uint64_t)taps * cch;
+  for (uint32_t nf = 0; nf < nfr; ++nf)
+    for (uint32_t tap = 0; tap < taps; ++tap)
+      for (uint32_t cc = 0; cc < cch; ++cc)
+        for (uint32_t lane = 0; lane < 64; ++lane) {
+          const uint32_t n = nf * 16 + (lane & 15);
+          uint16_t* dst = h_out + (((uint64_t)nf * KS + (uint64_t)tap * cch + cc) * 64 + lane) * 8;
+          for (uint32_t j = 0; j < 8; ++j) {
+            const uint32_t c = cc * 32 + 8 * (lane >> 4) + j;
+            float v = 0.0f;
+            if (n < Cout && c < Cin) v = h_w[((uint64_t)n * Cin + c) * taps + tap];     // [Cout][Cin][kh][kw]
+            dst[j] = f32_to_bf16_rne(v);
+          }
+        }
+  return SF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// PLMS latent updates (external/plms.py:122-214, imagen_pytorch.py:242-297)
+// ---------------------------------------------------------------------------------------------
+struct Coef6 { float alpha, sigma, alpha_next, c, noise_scale, clip; };
+__global__ __launch_bounds__(256) void k_plms_update(const float* __restrict__ x, const float* __restrict__ eps,
+                                                     const float* __restrict__ noise, Coef6 k, long n,
+                                                     float* __restrict__ x_prev, float* __restrict__ x0) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float xv = x[i];
+    float s = __fdiv_rn(__fsub_rn(xv, __fmul_rn(k.sigma, eps[i])), fmaxf(k.alpha, 1e-8f));   // predict_start_from_noise
+    s = fminf(fmaxf(s, -k.clip), k.clip);
+    // q_posterior mean: alpha_next * (x_t * (1 - c) / alpha + c * x_start)
+    const float mean = __fmul_rn(k.alpha_next, __fadd_rn(__fdiv_rn(__fmul_rn(xv, __fsub_rn(1.0f, k.c)), k.alpha), __fmul_rn(k.c, s)));
+    float out = mean;
+    if (noise) out = __fadd_rn(mean, __fmul_rn(k.noise_scale, noise[i]));
+    x_prev[i] = out;
+    if (x0) x0[i] = s;
+  }
+}
+__global__ __launch_bounds__(256) void k_plms_combine(const float* __restrict__ e0, const float* __restrict__ e1,
+                                                      const float* __restrict__ e2, const float* __restrict__ e3, float c0,
+                                                      float c1, float c2, float c3, long n, float* __restrict__ out) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v = c0 * e0[i];
+    if (e1) v += c1 * e1[i];
+    if (e2) v += c2 * e2[i];
+    if (e3) v += c3 * e3[i];
+    out[i] = v;
+  }
+}
+
+extern "C" int sf_plms_update(const float* x, const float* eps, const float* noise, const float* h_coef6, uint64_t n,
+                              float* x_prev, float* x0, void* stream) {
+  if (!x || !eps || !h_coef6 || !x_prev) SF_FAIL(SF_ERR_INVALID, "plms_update: null argument");
+  if (n == 0) return SF_OK;
+  Coef6 k{h_coef6[0], h_coef6[1], h_coef6[2], h_coef6[3], h_coef6[4], h_coef6[5]};
+  k_plms_update<<<sf_grid_cap(sf_div_up(n, 256)), 256, 0, (hipStream_t)stream>>>(x, eps, noise, k, (long)n, x_prev, x0);
+  SF_CHECK_LAUNCH("plms_update");
+  return SF_OK;
+}
+
+extern "C" int sf_plms_combine(const float* e0, const float* e1, const float* e2, const float* e3, const float* h_c4,
+                               uint64_t n, float* out, void* stream) {
+  if (!e0 || !h_c4 || !out) SF_FAIL(SF_ERR_INVALID, "plms_combine: null argument");
+  if (n == 0) return SF_OK;
+  k_plms_combine<<<sf_grid_cap(sf_div_up(n, 256)), 256, 0, (hipStream_t)stream>>>(e0, e1, e2, e3, h_c4[0], h_c4[1], h_c4[2],
+                                                                                  h_c4[3], (long)n, out);
+  SF_CHECK_LAUNCH("plms_combine");
+  return SF_OK;
+}

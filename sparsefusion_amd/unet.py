@@ -1,0 +1,610 @@
+"""View-conditioned latent UNet on the HIP op set (libsparsefusion_hip.so, csrc/unet_ops.hip).
+
+Drop-in for the reference's `Unet` (external/imagen_pytorch.py:1078-1671) in the configuration
+SparseFusion builds (utils/load_model.py:58-69): same constructor keywords, the same 477
+state-dict keys/shapes (checkpoints load unchanged through `load_state_dict`), the same call
+surface `forward(x, time, cond_images=...)` / `forward_with_cond_scale(..., cond_scale=1.)`
+with NCHW fp32 tensors at the boundary.
+
+Inside, nothing of the torch module graph survives: `nn.Parameter`s only hold the weights; the
+forward is a static list of ~330 kernel launches (an "op plan") built once per batch size over
+pre-packed bf16 weights and two device arenas, replayed by ONE C call (`sf_plan_run`).  See
+DESIGN.md section 4 for the dataflow and the fusion map."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+OP_CONV, OP_GN_ACT, OP_LN, OP_GEMV, OP_ATTN, OP_GCA_POOL, OP_ELTWISE, OP_MEMSET, OP_TIME_EMB = range(1, 10)
+SKIP_SCALE = 2 ** -0.5            # scale_skip_connection (imagen_pytorch.py:1283)
+
+
+def _cast_tuple(v, n):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v,) * n
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter specification (names + shapes of the reference state dict)
+# ------------------------------------------------------------------------------------------------
+def unet_param_spec(dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2),
+                    layer_attns=(False, False, False, True), cond_images_channels=256, channels=4, cond_dim=None,
+                    attn_heads=8, attn_dim_head=64, ff_mult=2, learned_sinu_pos_emb_dim=16, max_conditional_len=256):
+    """Ordered (name, shape) list of every tensor `Unet(...).state_dict()` holds in the reference for
+    this family of configurations (cond_on_z=False, attn_pool_text=False, init_cross_embed, pixel
+    shuffle upsampling, gca, final resnet block)."""
+    cond_dim = cond_dim or dim
+    tdim = dim * 4
+    inner = attn_heads * attn_dim_head
+    dims = [dim] + [dim * m for m in dim_mults]
+    in_out = list(zip(dims[:-1], dims[1:]))
+    n_lv = len(in_out)
+    nres = _cast_tuple(num_resnet_blocks, n_lv)
+    attns = _cast_tuple(layer_attns, n_lv)
+    spec = [("null_conditional_embed", (1, max_conditional_len, cond_dim)), ("null_conditional_hidden", (1, tdim))]
+    cin0 = channels + cond_images_channels
+    scales = [dim // 2, dim // 4]
+    scales.append(dim - sum(scales))
+    for i, (k, co) in enumerate(zip((3, 7, 15), scales)):
+        spec += [(f"init_conv.convs.{i}.weight", (co, cin0, k, k)), (f"init_conv.convs.{i}.bias", (co,))]
+    spec += [("to_time_hiddens.0.weights", (learned_sinu_pos_emb_dim // 2,)),
+             ("to_time_hiddens.1.weight", (tdim, learned_sinu_pos_emb_dim + 1)), ("to_time_hiddens.1.bias", (tdim,)),
+             ("to_time_cond.0.weight", (tdim, tdim)), ("to_time_cond.0.bias", (tdim,)),
+             ("to_time_tokens.0.weight", (cond_dim * 2, tdim)), ("to_time_tokens.0.bias", (cond_dim * 2,)),
+             ("norm_cond.weight", (cond_dim,)), ("norm_cond.bias", (cond_dim,))]
+
+    def resnet(p, cin, cout, gca, cross):
+        s = [(f"{p}.time_mlp.1.weight", (cout * 2, tdim)), (f"{p}.time_mlp.1.bias", (cout * 2,))]
+        if cross:
+            s += [(f"{p}.cross_attn.fn.null_kv", (2, attn_dim_head)), (f"{p}.cross_attn.fn.norm.g", (cout,)),
+                  (f"{p}.cross_attn.fn.to_q.weight", (inner, cout)), (f"{p}.cross_attn.fn.to_kv.weight", (inner * 2, cond_dim)),
+                  (f"{p}.cross_attn.fn.to_out.0.weight", (cout, inner)), (f"{p}.cross_attn.fn.to_out.1.g", (cout,))]
+        for b, ci in (("block1", cin), ("block2", cout)):
+            s += [(f"{p}.{b}.groupnorm.weight", (ci,)), (f"{p}.{b}.groupnorm.bias", (ci,)),
+                  (f"{p}.{b}.project.weight", (cout, ci, 3, 3)), (f"{p}.{b}.project.bias", (cout,))]
+        if gca:
+            s += [(f"{p}.gca.to_k.weight", (1, cout, 1, 1)), (f"{p}.gca.to_k.bias", (1,)),
+                  (f"{p}.gca.net.0.weight", (max(3, cout // 2), cout, 1, 1)), (f"{p}.gca.net.0.bias", (max(3, cout // 2),)),
+                  (f"{p}.gca.net.2.weight", (cout, max(3, cout // 2), 1, 1)), (f"{p}.gca.net.2.bias", (cout,))]
+        if cin != cout:
+            s += [(f"{p}.res_conv.weight", (cout, cin, 1, 1)), (f"{p}.res_conv.bias", (cout,))]
+        return s
+
+    def attention(p, d, context):
+        s = [(f"{p}.null_kv", (2, attn_dim_head)), (f"{p}.norm.g", (d,)), (f"{p}.to_q.weight", (inner, d)),
+             (f"{p}.to_kv.weight", (attn_dim_head * 2, d))]
+        if context:
+            s += [(f"{p}.to_context.0.weight", (cond_dim,)), (f"{p}.to_context.0.bias", (cond_dim,)),
+                  (f"{p}.to_context.1.weight", (attn_dim_head * 2, cond_dim)), (f"{p}.to_context.1.bias", (attn_dim_head * 2,))]
+        return s + [(f"{p}.to_out.0.weight", (d, inner)), (f"{p}.to_out.1.g", (d,))]
+
+    def transformer(p, d):
+        hid = int(d * ff_mult)
+        return attention(f"{p}.layers.0.0.fn", d, True) + [
+            (f"{p}.layers.0.1.0.g", (1, d, 1, 1)), (f"{p}.layers.0.1.1.weight", (hid, d, 1, 1)),
+            (f"{p}.layers.0.1.3.g", (1, hid, 1, 1)), (f"{p}.layers.0.1.4.weight", (d, hid, 1, 1))]
+
+    for lv, (di, do) in enumerate(in_out):
+        last = lv == n_lv - 1
+        spec += resnet(f"downs.{lv}.1", di, di, False, False)
+        for r in range(nres[lv]):
+            spec += resnet(f"downs.{lv}.2.{r}", di, di, True, False)
+        if attns[lv]:
+            spec += transformer(f"downs.{lv}.3", di)
+        if not last:
+            spec += [(f"downs.{lv}.4.weight", (do, di, 4, 4)), (f"downs.{lv}.4.bias", (do,))]
+        else:
+            spec += [(f"downs.{lv}.4.fns.0.weight", (do, di, 3, 3)), (f"downs.{lv}.4.fns.0.bias", (do,)),
+                     (f"downs.{lv}.4.fns.1.weight", (do, di, 1, 1)), (f"downs.{lv}.4.fns.1.bias", (do,))]
+    for ui, lv in enumerate(reversed(range(n_lv))):
+        di, do = in_out[lv]
+        last = ui == n_lv - 1
+        spec += resnet(f"ups.{ui}.0", do + di, do, False, False)
+        for r in range(nres[lv]):
+            spec += resnet(f"ups.{ui}.1.{r}", do + di, do, True, False)
+        if attns[lv]:
+            spec += transformer(f"ups.{ui}.2", do)
+        if not last:
+            spec += [(f"ups.{ui}.3.net.0.weight", (di * 4, do, 1, 1)), (f"ups.{ui}.3.net.0.bias", (di * 4,))]
+    mid = dims[-1]
+    spec += resnet("mid_block1", mid, mid, False, True)
+    spec += attention("mid_attn.fn.fn", mid, False)
+    spec += resnet("mid_block2", mid, mid, False, True)
+    spec += resnet("final_res_block", dim, dim, True, False)
+    spec += [("final_conv.weight", (channels, dim, 3, 3)), ("final_conv.bias", (channels,))]
+    return spec
+
+
+class _Node(nn.Module):
+    """Anonymous container used to reproduce the reference's dotted parameter names."""
+
+
+def _register(root, dotted, tensor):
+    parts = dotted.split(".")
+    node = root
+    for p in parts[:-1]:
+        if p not in node._modules:
+            node.add_module(p, _Node())
+        node = node._modules[p]
+    node.register_parameter(parts[-1], nn.Parameter(tensor))
+
+
+# ------------------------------------------------------------------------------------------------
+# plan building
+# ------------------------------------------------------------------------------------------------
+class _Arena:
+    """Bump allocator over one device tensor.  `base=None` = sizing pass (offsets only)."""
+
+    def __init__(self, nbytes=None, device=None):
+        self.off = 0
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None
+
+    def alloc(self, nbytes):
+        nbytes = (nbytes + 255) // 256 * 256
+        off = self.off
+        self.off += nbytes
+        return (self.buf.data_ptr() + off) if self.buf is not None else (1 << 20) + off
+
+
+class _T:
+    """A planned activation: device pointer + logical shape [B, HW, C] (NHWC) or [rows, C]."""
+    __slots__ = ("ptr", "rows", "C", "HW")
+
+    def __init__(self, ptr, rows, C, HW=None):
+        self.ptr, self.rows, self.C, self.HW = ptr, rows, C, HW
+
+
+class _Plan:
+    def __init__(self, unet, B, device, sizing=None):
+        self.u, self.B, self.dev = unet, B, device
+        self.ops = []
+        if sizing is None:
+            self.zero, self.misc = _Arena(), _Arena()
+        else:
+            self.zero, self.misc = _Arena(sizing[0], device), _Arena(sizing[1], device)
+        self.w = unet._packed(device)
+
+    # -------- allocation helpers
+    def zf32(self, rows, C, HW=None):
+        return _T(self.zero.alloc(rows * C * 4), rows, C, HW)
+
+    def f32(self, rows, C, HW=None):
+        return _T(self.misc.alloc(rows * C * 4), rows, C, HW)
+
+    def bf16(self, rows, C, HW=None):
+        return _T(self.misc.alloc(rows * C * 2), rows, C, HW)
+
+    def op(self, type_, flags=0, p=(), i=(), f=()):
+        o = _lib.SfOp()
+        o.type, o.flags = type_, flags
+        for k, v in enumerate(p):
+            o.p[k] = v if v else None
+        for k, v in enumerate(i):
+            o.i[k] = int(v)
+        for k, v in enumerate(f):
+            o.f[k] = float(v)
+        self.ops.append(o)
+
+    def wptr(self, name):
+        return self.w[name].data_ptr()
+
+    # -------- op emitters
+    def conv(self, x, x_f32, H, W, wname, bname, out, ldc, co_off, Cout, k, stride=1, pad=0, resid=None, pixshuf=False):
+        B = self.B
+        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        M = B * Ho * Wo
+        m_frags, n_frags = (M + 15) // 16, (Cout + 15) // 16
+        WM = 4 if m_frags % 4 == 0 else (2 if m_frags % 2 == 0 else 1)
+        WN = 4 if n_frags % 4 == 0 else (2 if n_frags % 2 == 0 else 1)
+        if pixshuf:                       # no split-K here: use small tiles to spread over the chip
+            WM, WN = min(WM, 2), min(WN, 2)
+        KS = k * k * (x.C // 32)
+        tiles = (m_frags // WM) * (n_frags // WN)
+        groups = 1 if pixshuf else max(1, min(round(self.u.conv_blocks_target / tiles), KS // 8))
+        self.op(OP_CONV, (1 if x_f32 else 0) | (2 if pixshuf else 0),
+                p=(x.ptr, self.wptr(wname), self.wptr(bname) if bname else 0, out.ptr, resid.ptr if resid else 0),
+                i=(B, H, W, x.C, Ho, Wo, Cout, ldc, co_off, k, k, stride, pad, groups, WM * 16 + WN))
+        return Ho, Wo
+
+    def gn_act(self, x, skip, gname, ss_ptr, out, raw=None, silu=True):
+        C1, C2 = x.C, (skip.C if skip else 0)
+        self.op(OP_GN_ACT, 0 if silu else 1,
+                p=(x.ptr, skip.ptr if skip else 0, self.wptr(gname + ".weight"), self.wptr(gname + ".bias"), ss_ptr, out.ptr,
+                   raw.ptr if raw else 0),
+                i=(self.B, x.HW, C1, C2, self.u.ss_total), f=(1e-5, SKIP_SCALE))
+
+    def ln(self, x, gname, bname, out, C, rows, eps=1e-5, gelu=False, out_f32=False, resid=None):
+        self.op(OP_LN, (1 if gelu else 0) | (2 if out_f32 else 0),
+                p=(x.ptr, self.wptr(gname), self.wptr(bname) if bname else 0, out.ptr, resid.ptr if resid else 0),
+                i=(rows, C), f=(eps,))
+
+    def gemv(self, x_ptr, M, ldx, wname, bname, y_ptr, ldy, N, K, in_silu=False, out_act=0):
+        Kp = (K + 7) // 8 * 8
+        for m0 in range(0, M, 8):
+            mm = min(8, M - m0)
+            self.op(OP_GEMV, (1 if in_silu else 0) | (out_act << 1),
+                    p=(x_ptr + m0 * ldx * 4, self.wptr(wname), self.wptr(bname) if bname else 0, y_ptr + m0 * ldy * 4),
+                    i=(mm, N, K, Kp, ldx, ldy))
+
+    def attn(self, q, out, segs, heads, ldq, scale):
+        p = [q.ptr, out.ptr]
+        i = [self.B, heads, ldq, 0]
+        for s in (segs + [None] * 3)[:3]:
+            if s is None:
+                p += [0, 0]
+                i += [0, 0, 0, 0]
+            else:
+                p += [s[0], s[1]]
+                i += list(s[2:])
+        self.op(OP_ATTN, 0, p=p, i=i, f=(scale,))
+
+    # -------- blocks
+    def resnet(self, name, x, skip, cout, H, gca=False, cross=False):
+        B, HW = self.B, H * H
+        cin = x.C + (skip.C if skip else 0)
+        rows = B * HW
+        a1 = self.bf16(rows, cin, HW)
+        raw = self.bf16(rows, cin, HW) if cin != cout else None
+        self.gn_act(x, skip, f"{name}.block1.groupnorm", 0, a1, raw)
+        h = self.zf32(rows, cout, HW)
+        self.conv(a1, False, H, H, f"{name}.block1.project.weight", f"{name}.block1.project.bias", h, cout, 0, cout, 3, 1, 1)
+        if cross:
+            h = self.cross_attention(f"{name}.cross_attn.fn", h)
+        a2 = self.bf16(rows, cout, HW)
+        ss_ptr = self.ss.ptr + self.u.ss_offset[name] * 4
+        self.gn_act(h, None, f"{name}.block2.groupnorm", ss_ptr, a2)
+        out = self.zf32(rows, cout, HW)
+        w2, b2 = f"{name}.block2.project.weight", f"{name}.block2.project.bias"
+        if gca:
+            h2 = self.zf32(rows, cout, HW)
+            self.conv(a2, False, H, H, w2, b2, h2, cout, 0, cout, 3, 1, 1)
+            pooled, hid = self.f32(B, cout), self.f32(B, max(3, cout // 2))
+            gate = self.f32(B, cout)
+            self.op(OP_GCA_POOL, 0, p=(h2.ptr, self.wptr(f"{name}.gca.to_k.weight"), self.wptr(f"{name}.gca.to_k.bias"), pooled.ptr),
+                    i=(B, HW, cout))
+            self.gemv(pooled.ptr, B, cout, f"{name}.gca.net.0.weight", f"{name}.gca.net.0.bias", hid.ptr, hid.C, hid.C, cout,
+                      out_act=1)
+            self.gemv(hid.ptr, B, hid.C, f"{name}.gca.net.2.weight", f"{name}.gca.net.2.bias", gate.ptr, cout, cout, hid.C,
+                      out_act=2)
+            if raw is not None:
+                self.conv(raw, False, H, H, f"{name}.res_conv.weight", f"{name}.res_conv.bias", out, cout, 0, cout, 1)
+                self.op(OP_ELTWISE, 1, p=(h2.ptr, gate.ptr, 0, out.ptr), i=(B, HW, cout))
+            else:
+                self.op(OP_ELTWISE, 1, p=(h2.ptr, gate.ptr, x.ptr, out.ptr), i=(B, HW, cout))
+        else:
+            if raw is not None:
+                self.conv(raw, False, H, H, f"{name}.res_conv.weight", f"{name}.res_conv.bias", out, cout, 0, cout, 1)
+                self.conv(a2, False, H, H, w2, b2, out, cout, 0, cout, 3, 1, 1)
+            else:
+                self.conv(a2, False, H, H, w2, b2, out, cout, 0, cout, 3, 1, 1, resid=x)
+        return out
+
+    def _attn_out(self, name, att, x, d, rows):
+        o = self.zf32(rows, d)
+        self.conv(att, False, 1, rows // self.B, f"{name}.to_out.0.weight", None, o, d, 0, d, 1)
+        y = self.f32(rows, d, x.HW)
+        self.ln(o, f"{name}.to_out.1.g", None, y, d, rows, out_f32=True, resid=x)
+        return y
+
+    def cross_attention(self, name, h):
+        """h + CrossAttention(h, context=c)  (imagen_pytorch.py:731-805; keys = [null, 2 time tokens])."""
+        B, d, rows = self.B, h.C, h.rows
+        heads, dh = self.u.attn_heads, self.u.attn_dim_head
+        inner = heads * dh
+        xn = self.bf16(rows, d)
+        self.ln(h, f"{name}.norm.g", None, xn, d, rows)
+        q = self.zf32(rows, inner)
+        self.conv(xn, False, 1, rows // B, f"{name}.to_q.weight", None, q, inner, 0, inner, 1)
+        kv = self.f32(2 * B, inner * 2)
+        self.gemv(self.c.ptr, 2 * B, self.u.cond_dim, f"{name}.to_kv.weight", None, kv.ptr, inner * 2, inner * 2, self.u.cond_dim)
+        att = self.bf16(rows, inner)
+        nk = self.wptr(f"{name}.null_kv")
+        segs = [(nk, nk + dh * 4, 1, 0, 0, 0), (kv.ptr, kv.ptr + inner * 4, 2, inner * 2, 2 * inner * 2, dh)]
+        self.attn(q, att, segs, heads, inner, dh ** -0.5)
+        return self._attn_out(name, att, h, d, rows)
+
+    def self_attention(self, name, x, context):
+        """x + Attention(x[, context=c])  (imagen_pytorch.py:480-566; one shared k/v head)."""
+        B, d, rows = self.B, x.C, x.rows
+        heads, dh = self.u.attn_heads, self.u.attn_dim_head
+        inner = heads * dh
+        xn = self.bf16(rows, d)
+        self.ln(x, f"{name}.norm.g", None, xn, d, rows)
+        q, kv = self.zf32(rows, inner), self.zf32(rows, 2 * dh)
+        self.conv(xn, False, 1, rows // B, f"{name}.to_q.weight", None, q, inner, 0, inner, 1)
+        self.conv(xn, False, 1, rows // B, f"{name}.to_kv.weight", None, kv, 2 * dh, 0, 2 * dh, 1)
+        segs = []
+        if context:
+            cn, ckv = self.f32(2 * B, self.u.cond_dim), self.f32(2 * B, 2 * dh)
+            self.ln(self.c, f"{name}.to_context.0.weight", f"{name}.to_context.0.bias", cn, self.u.cond_dim, 2 * B, out_f32=True)
+            self.gemv(cn.ptr, 2 * B, self.u.cond_dim, f"{name}.to_context.1.weight", f"{name}.to_context.1.bias", ckv.ptr,
+                      2 * dh, 2 * dh, self.u.cond_dim)
+            segs.append((ckv.ptr, ckv.ptr + dh * 4, 2, 2 * dh, 2 * 2 * dh, 0))
+        nk = self.wptr(f"{name}.null_kv")
+        tok = rows // B
+        segs += [(nk, nk + dh * 4, 1, 0, 0, 0), (kv.ptr, kv.ptr + dh * 4, tok, 2 * dh, tok * 2 * dh, 0)]
+        att = self.bf16(rows, inner)
+        self.attn(q, att, segs, heads, inner, dh ** -0.5)
+        return self._attn_out(name, att, x, d, rows)
+
+    def transformer(self, name, x):
+        B, d, rows = self.B, x.C, x.rows
+        x1 = self.self_attention(f"{name}.layers.0.0.fn", x, True)
+        hid = int(d * self.u.ff_mult)
+        xn = self.bf16(rows, d)
+        self.ln(x1, f"{name}.layers.0.1.0.g", None, xn, d, rows)
+        f1 = self.zf32(rows, hid)
+        self.conv(xn, False, 1, rows // B, f"{name}.layers.0.1.1.weight", None, f1, hid, 0, hid, 1)
+        xn3 = self.bf16(rows, hid)
+        self.ln(f1, f"{name}.layers.0.1.3.g", None, xn3, hid, rows, gelu=True)
+        x2 = self.zf32(rows, d, x.HW)
+        self.conv(xn3, False, 1, rows // B, f"{name}.layers.0.1.4.weight", None, x2, d, 0, d, 1, resid=x1)
+        return x2
+
+    # -------- whole network
+    def build(self):
+        u, B = self.u, self.B
+        R = u.image_size
+        HW = R * R
+        cin0 = u.channels + u.cond_images_channels
+        cpad = (cin0 + 31) // 32 * 32
+        self.x_in, self.t_in = self.f32(B, u.channels * HW), self.f32(B, 1)
+        self.cond_in = self.f32(B, u.cond_images_channels * HW)
+        self.op(OP_MEMSET, 0, p=(self.zero.buf.data_ptr() if self.zero.buf is not None else 1,), i=(0,))   # size patched below
+        memset_op = self.ops[-1]
+        xin = self.f32(B * HW, cpad, HW)
+        self.op(OP_ELTWISE, 2, p=(self.cond_in.ptr, self.x_in.ptr, 0, xin.ptr), i=(B, HW, u.cond_images_channels, u.channels, cpad))
+        # time path (imagen_pytorch.py:1175-1190, :1514-1604)
+        half = u.learned_sinu_pos_emb_dim // 2
+        four, hid, t = self.f32(B, 2 * half + 1), self.f32(B, u.tdim), self.f32(B, u.tdim)
+        tok = self.f32(B, 2 * u.cond_dim)
+        self.op(OP_TIME_EMB, 0, p=(self.t_in.ptr, self.wptr("to_time_hiddens.0.weights"), 0, four.ptr), i=(B, half))
+        self.gemv(four.ptr, B, four.C, "to_time_hiddens.1.weight", "to_time_hiddens.1.bias", hid.ptr, u.tdim, u.tdim, four.C, out_act=1)
+        self.gemv(hid.ptr, B, u.tdim, "to_time_cond.0.weight", "to_time_cond.0.bias", t.ptr, u.tdim, u.tdim, u.tdim)
+        self.gemv(hid.ptr, B, u.tdim, "to_time_tokens.0.weight", "to_time_tokens.0.bias", tok.ptr, 2 * u.cond_dim, 2 * u.cond_dim, u.tdim)
+        self.c = self.f32(2 * B, u.cond_dim)
+        self.ln(tok, "norm_cond.weight", "norm_cond.bias", self.c, u.cond_dim, 2 * B, out_f32=True)
+        self.ss = self.f32(B, u.ss_total)                 # all 27 time_mlp outputs in one GEMV (SiLU -> Linear)
+        self.gemv(t.ptr, B, u.tdim, "__time_mlps__.weight", "__time_mlps__.bias", self.ss.ptr, u.ss_total, u.ss_total, u.tdim,
+                  in_silu=True)
+        # init conv: CrossEmbedLayer k = 3 / 7 / 15 into channel slices (:1017-1042)
+        x = self.zf32(B * HW, u.dim, HW)
+        co = 0
+        for i, k in enumerate((3, 7, 15)):
+            cw = u.spec_shapes[f"init_conv.convs.{i}.weight"][0]
+            self.conv(xin, True, R, R, f"init_conv.convs.{i}.weight", f"init_conv.convs.{i}.bias", x, u.dim, co, cw, k, 1, k // 2)
+            co += cw
+        hiddens = []
+        H = R
+        n_lv = len(u.in_out)
+        for lv, (di, do) in enumerate(u.in_out):
+            x = self.resnet(f"downs.{lv}.1", x, None, di, H)
+            for r in range(u.nres[lv]):
+                x = self.resnet(f"downs.{lv}.2.{r}", x, None, di, H, gca=True)
+                hiddens.append(x)
+            if u.attns[lv]:
+                x = self.transformer(f"downs.{lv}.3", x)
+            hiddens.append(x)
+            if lv < n_lv - 1:
+                y = self.zf32(B * (H // 2) ** 2, do, (H // 2) ** 2)
+                self.conv(x, True, H, H, f"downs.{lv}.4.weight", f"downs.{lv}.4.bias", y, do, 0, do, 4, 2, 1)
+                H //= 2
+            else:
+                y = self.zf32(B * H * H, do, H * H)
+                self.conv(x, True, H, H, f"downs.{lv}.4.fns.0.weight", f"downs.{lv}.4.fns.0.bias", y, do, 0, do, 3, 1, 1)
+                self.conv(x, True, H, H, f"downs.{lv}.4.fns.1.weight", f"downs.{lv}.4.fns.1.bias", y, do, 0, do, 1)
+            x = y
+        mid = x.C
+        x = self.resnet("mid_block1", x, None, mid, H, cross=True)
+        x = self.self_attention("mid_attn.fn.fn", x, False)
+        x = self.resnet("mid_block2", x, None, mid, H, cross=True)
+        for ui, lv in enumerate(reversed(range(n_lv))):
+            di, do = u.in_out[lv]
+            x = self.resnet(f"ups.{ui}.0", x, hiddens.pop(), do, H)
+            for r in range(u.nres[lv]):
+                x = self.resnet(f"ups.{ui}.1.{r}", x, hiddens.pop(), do, H, gca=True)
+            if u.attns[lv]:
+                x = self.transformer(f"ups.{ui}.2", x)
+            if ui < n_lv - 1:
+                y = self.f32(B * 4 * H * H, di, 4 * H * H)
+                self.conv(x, True, H, H, f"ups.{ui}.3.net.0.weight", f"ups.{ui}.3.net.0.bias", y, di, 0, di * 4, 1, pixshuf=True)
+                H *= 2
+                x = y
+        x = self.resnet("final_res_block", x, None, u.dim, H, gca=True)
+        o = self.zf32(B * HW, u.channels, HW)
+        self.conv(x, True, R, R, "final_conv.weight", "final_conv.bias", o, u.channels, 0, u.channels, 3, 1, 1)
+        self.out = self.f32(B, u.channels * HW)
+        self.op(OP_ELTWISE, 3, p=(o.ptr, 0, 0, self.out.ptr), i=(B, HW, u.channels, u.channels))
+        memset_op.i[0] = (self.zero.off + 3) // 4
+        self.op_array = (_lib.SfOp * len(self.ops))(*self.ops)
+        if self.misc.buf is not None:
+            self.x_view, self.t_view = self.tview(self.x_in), self.tview(self.t_in)
+            self.cond_view, self.out_view = self.tview(self.cond_in), self.tview(self.out)
+        return self
+
+    def tview(self, t):
+        """torch view of a planned fp32 buffer of the misc arena (static input / output staging)."""
+        off = t.ptr - self.misc.buf.data_ptr()
+        return self.misc.buf[off:off + t.rows * t.C * 4].view(torch.float32).view(t.rows, t.C)
+
+
+class Unet(nn.Module):
+    def __init__(self, *, dim, dim_mults=(1, 2, 4, 8), num_resnet_blocks=1, layer_attns=True, layer_cross_attns=True,
+                 cond_images_channels=0, channels=3, channels_out=None, attn_pool_text=True, cond_dim=None,
+                 attn_dim_head=64, attn_heads=8, ff_mult=2., learned_sinu_pos_emb_dim=16, max_conditional_len=256,
+                 cond_on_z=False, lowres_cond=False, image_size=32, **unsupported):
+        super().__init__()
+        n_lv = len(dim_mults)
+        if any(_cast_tuple(layer_cross_attns, n_lv)) or lowres_cond or cond_on_z or cond_images_channels <= 0:
+            raise NotImplementedError("sparsefusion_amd.Unet covers the SparseFusion configuration only "
+                                      "(utils/load_model.py:58-69: image-conditioned, no text, no lowres, no layer cross-attn)")
+        for k, v in unsupported.items():
+            if k not in ("image_embed_dim", "conditional_embed_dim", "num_image_tokens", "num_time_tokens", "out_dim"):
+                raise NotImplementedError(f"Unet keyword '{k}' is not supported by the HIP plan")
+        if channels_out not in (None, channels):
+            raise NotImplementedError("channels_out != channels")
+        self.dim, self.channels, self.cond_images_channels = dim, channels, cond_images_channels
+        self.channels_out = channels
+        self.cond_dim = cond_dim or dim
+        self.tdim = dim * 4
+        self.attn_heads, self.attn_dim_head, self.ff_mult = attn_heads, attn_dim_head, ff_mult
+        self.learned_sinu_pos_emb_dim = learned_sinu_pos_emb_dim
+        self.image_size = image_size
+        self.lowres_cond, self.cond_on_z, self.has_cond_image = False, False, True
+        dims = [dim] + [dim * m for m in dim_mults]
+        self.in_out = list(zip(dims[:-1], dims[1:]))
+        self.nres = _cast_tuple(num_resnet_blocks, n_lv)
+        self.attns = _cast_tuple(layer_attns, n_lv)
+        self._locals = dict(dim=dim, dim_mults=tuple(dim_mults), num_resnet_blocks=num_resnet_blocks, layer_attns=layer_attns,
+                            layer_cross_attns=layer_cross_attns, cond_images_channels=cond_images_channels, channels=channels,
+                            attn_pool_text=attn_pool_text, cond_dim=cond_dim, attn_dim_head=attn_dim_head, attn_heads=attn_heads,
+                            ff_mult=ff_mult, learned_sinu_pos_emb_dim=learned_sinu_pos_emb_dim,
+                            max_conditional_len=max_conditional_len, image_size=image_size)
+        if attn_heads * attn_dim_head != 512 or attn_dim_head != 64:
+            raise NotImplementedError("attention kernel is built for 8 heads x 64")
+        spec = unet_param_spec(dim, tuple(dim_mults), self.nres, self.attns, cond_images_channels, channels, self.cond_dim,
+                               attn_heads, attn_dim_head, ff_mult, learned_sinu_pos_emb_dim, max_conditional_len)
+        self.spec_shapes = dict(spec)
+        g = torch.Generator().manual_seed(0)
+        for name, shape in spec:
+            _register(self, name, self._default_init(name, shape, g))
+        # offsets of each ResnetBlock's (scale, shift) inside the batched time-MLP output
+        self.ss_offset, off = {}, 0
+        for name, shape in spec:
+            if name.endswith(".time_mlp.1.weight"):
+                self.ss_offset[name[:-len(".time_mlp.1.weight")]] = off
+                off += shape[0]
+        self.ss_total = off
+        self.conv_blocks_target = 512
+        self._pack_cache = None
+        self._plans = {}
+
+    @staticmethod
+    def _default_init(name, shape, g):
+        """Plain deterministic init (checkpoints overwrite it).  final_conv is zero like the reference (:1388)."""
+        if name.startswith("final_conv"):
+            return torch.zeros(shape)
+        if name.endswith(".g") or name.endswith("groupnorm.weight") or name in ("norm_cond.weight",) or name.endswith("to_context.0.weight"):
+            return torch.ones(shape)
+        if name.endswith("bias"):
+            return torch.zeros(shape)
+        if name.endswith("null_kv") or name.startswith("null_conditional") or name.endswith("weights"):
+            return torch.randn(shape, generator=g)
+        fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+        return (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+
+    # ---- reference API odds and ends
+    def cast_model_parameters(self, *, lowres_cond, conditional_embed_dim, channels, channels_out, cond_on_z):
+        if lowres_cond or cond_on_z or channels != self.channels or channels_out != self.channels_out:
+            raise NotImplementedError("only the first, unconditional-on-text unet of a cascade is supported")
+        return self
+
+    def to_config_and_state_dict(self):
+        return self._locals, self.state_dict()
+
+    @classmethod
+    def from_config_and_state_dict(klass, config, state_dict):
+        unet = klass(**config)
+        unet.load_state_dict(state_dict)
+        return unet
+
+    def load_state_dict(self, *args, **kwargs):
+        r = super().load_state_dict(*args, **kwargs)
+        self.invalidate()
+        return r
+
+    def invalidate(self):
+        """Forget packed weights / plans (call after mutating parameters in place)."""
+        self._pack_cache, self._plans = None, {}
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self.invalidate()
+        return r
+
+    # ---- weight packing
+    def _packed(self, device):
+        if self._pack_cache is not None and self._pack_cache[0] == str(device):
+            return self._pack_cache[1]
+        lib = _lib.lib()
+        packed = {}
+        sd = {k: v.detach() for k, v in self.named_parameters()}
+        tm_w, tm_b = [], []
+        for name, w in sd.items():
+            wc = w.float().cpu().contiguous()
+            is_conv = name.endswith(".weight") and (
+                w.dim() == 4 or any(s in name for s in (".to_q.", ".to_out.0.")) or
+                (".to_kv." in name and ".cross_attn." not in name))
+            if name.endswith(".time_mlp.1.weight"):
+                tm_w.append(wc)
+                tm_b.append(sd[name[:-6] + "bias"].float().cpu())
+            elif name.endswith(".time_mlp.1.bias"):
+                pass
+            elif ".gca.to_k.weight" in name:
+                packed[name] = wc.reshape(-1).to(device)
+            elif ".gca.net." in name and name.endswith(".weight"):
+                packed[name] = self._gemv_pack(wc.reshape(wc.shape[0], -1), device)
+            elif is_conv:
+                w4 = wc if wc.dim() == 4 else wc.reshape(wc.shape[0], wc.shape[1], 1, 1)
+                co, ci, kh, kw = w4.shape
+                cpad = (ci + 31) // 32 * 32
+                n = lib.sf_conv_packed_elems(co, cpad, kh, kw)
+                buf = torch.empty(n, dtype=torch.int16)
+                _lib.check(lib.sf_conv_pack_weights(w4.data_ptr(), co, ci, cpad, kh, kw, buf.data_ptr()), "pack " + name)
+                packed[name] = buf.to(device)
+            elif name.endswith(".weight") and w.dim() == 2:
+                packed[name] = self._gemv_pack(wc, device)
+            else:
+                packed[name] = wc.reshape(-1).to(device)      # biases, gains, null_kv, sinusoid weights: fp32
+        packed["__time_mlps__.weight"] = self._gemv_pack(torch.cat(tm_w, 0), device)
+        packed["__time_mlps__.bias"] = torch.cat(tm_b, 0).to(device)
+        self._pack_cache = (str(device), packed)
+        return packed
+
+    @staticmethod
+    def _gemv_pack(w2, device):
+        K = w2.shape[1]
+        Kp = (K + 7) // 8 * 8
+        if Kp != K:
+            w2 = torch.nn.functional.pad(w2, (0, Kp - K))
+        return w2.to(torch.bfloat16).contiguous().to(device)
+
+    def _plan(self, B, device):
+        key = (B, str(device))
+        if key not in self._plans:
+            sizing = _Plan(self, B, device).build()
+            plan = _Plan(self, B, device, (sizing.zero.off, sizing.misc.off)).build()
+            self._plans[key] = plan
+        return self._plans[key]
+
+    # ---- forward
+    @torch.no_grad()
+    def forward(self, x, time, *, cond_images=None, cond_drop_prob=0., **unsupported):
+        if cond_images is None:
+            raise AssertionError("you requested to condition on an image on the unet, but the conditioning image is not supplied")
+        if cond_drop_prob != 0.:
+            raise NotImplementedError("conditioning dropout is a training feature; sampling uses cond_drop_prob=0 (cond_scale=1)")
+        for k, v in unsupported.items():
+            if v is not None:
+                raise NotImplementedError(f"Unet.forward argument '{k}' is not supported")
+        _lib.require_cuda(x, time, cond_images)
+        B = x.shape[0]
+        assert x.shape[1:] == (self.channels, self.image_size, self.image_size), x.shape
+        assert cond_images.shape[1] == self.cond_images_channels, \
+            'the number of channels on the conditioning image you are passing in does not match'
+        if cond_images.shape[-1] != self.image_size:        # resize_image_to: nearest (imagen_pytorch.py:150-165)
+            cond_images = torch.nn.functional.interpolate(cond_images, self.image_size, mode='nearest')
+        plan = self._plan(B, x.device)
+        plan.x_view.copy_(x.reshape(B, -1))
+        plan.t_view.copy_(time.reshape(-1).expand(B).reshape(B, 1))
+        plan.cond_view.copy_(cond_images.reshape(B, -1))
+        rc = _lib.lib().sf_plan_run(plan.op_array, len(plan.ops), _lib.stream_ptr())
+        _lib.check(rc, "unet plan")
+        return plan.out_view.clone().view(B, self.channels, self.image_size, self.image_size)
+
+    def forward_with_cond_scale(self, *args, cond_scale=1., **kwargs):
+        if cond_scale != 1:
+            raise NotImplementedError("classifier-free guidance (cond_scale != 1) is not used by the distillation path")
+        return self.forward(*args, **kwargs)

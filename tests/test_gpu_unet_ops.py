@@ -1,0 +1,256 @@
+"""GPU tests of the individual UNet kernels (csrc/unet_ops.hip) through the C-ABI plan executor, each against
+a plain PyTorch fp32 reference of the same op.  MFMA operands are bf16, so the references are fed the
+bf16-rounded operands: what is left is fp32 accumulation order (tolerances ~1e-4 relative)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _run(ops):
+    from sparsefusion_amd import _lib
+    arr = (_lib.SfOp * len(ops))(*ops)
+    _lib.check(_lib.lib().sf_plan_run(arr, len(ops), _lib.stream_ptr()), "plan")
+    torch.cuda.synchronize()
+
+
+def _op(type_, flags=0, p=(), i=(), f=()):
+    from sparsefusion_amd import _lib
+    o = _lib.SfOp()
+    o.type, o.flags = type_, flags
+    for k, v in enumerate(p):
+        o.p[k] = v.data_ptr() if torch.is_tensor(v) else (v or None)
+    for k, v in enumerate(i):
+        o.i[k] = int(v)
+    for k, v in enumerate(f):
+        o.f[k] = float(v)
+    return o
+
+
+def _pack_conv(w):
+    from sparsefusion_amd import _lib
+    lib = _lib.lib()
+    co, ci, kh, kw = w.shape
+    cpad = (ci + 31) // 32 * 32
+    buf = torch.empty(lib.sf_conv_packed_elems(co, cpad, kh, kw), dtype=torch.int16)
+    _lib.check(lib.sf_conv_pack_weights(w.contiguous().data_ptr(), co, ci, cpad, kh, kw, buf.data_ptr()))
+    return buf.to(DEV), cpad
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+CONV_CASES = [
+    # B, H, Cin, Cout, k, stride, pad, groups, tile(WM,WN), a_f32, resid
+    (1, 4, 1024, 1024, 3, 1, 1, 8, (1, 4), False, True),      # 4x4 weight-streaming layer, split-K
+    (2, 8, 512, 512, 3, 1, 1, 2, (4, 4), False, False),
+    (1, 32, 256, 256, 3, 1, 1, 2, (4, 4), False, False),
+    (1, 32, 260, 64, 15, 1, 7, 16, (4, 4), True, False),      # init CrossEmbed k=15, Cin padded 260 -> 288
+    (1, 32, 260, 64, 7, 1, 3, 4, (2, 2), True, False),
+    (1, 16, 256, 512, 4, 2, 1, 3, (4, 2), True, False),       # Downsample conv4x4 s2 p1
+    (1, 32, 256, 4, 3, 1, 1, 1, (4, 1), True, False),         # final conv: Cout 4 (N padded to 16)
+    (3, 4, 768, 128, 1, 1, 0, 1, (1, 2), False, False),       # 1x1 / linear, odd batch
+    (1, 4, 2048, 1024, 1, 1, 0, 5, (1, 1), False, True),
+    (1, 8, 96, 48, 3, 1, 1, 1, (2, 1), False, False),         # small-config sizes: Cout 48 = 3 n-frags
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_igemm(case):
+    B, H, Cin, Cout, k, stride, pad, groups, (WM, WN), a_f32, use_res = case
+    g = torch.Generator().manual_seed(Cin + Cout + k)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    wp, cpad = _pack_conv(w)
+    xh = torch.zeros(B, H, H, cpad)
+    xh[..., :Cin] = x.permute(0, 2, 3, 1)
+    xd = xh.to(DEV) if a_f32 else xh.to(torch.bfloat16).to(DEV)
+    Ho = (H + 2 * pad - k) // stride + 1
+    ldc, co_off = Cout + 8, 4                                                 # exercise ldc / channel offset
+    out = torch.zeros(B, Ho, Ho, ldc, device=DEV)
+    res = torch.randn(B, Ho, Ho, ldc, generator=g).to(DEV) if use_res else None
+    _run([_op(1, 1 if a_f32 else 0, p=(xd, wp, bias.to(DEV), out, res),
+              i=(B, H, H, cpad, Ho, Ho, Cout, ldc, co_off, k, k, stride, pad, groups, WM * 16 + WN))])
+    ref = F.conv2d(bf(x), bf(w), bias, stride=stride, padding=pad).permute(0, 2, 3, 1)
+    if use_res:
+        ref = ref + res.cpu()[..., co_off:co_off + Cout]
+    got = out.cpu()[..., co_off:co_off + Cout]
+    assert torch.allclose(got, ref, rtol=2e-4, atol=2e-4), (got - ref).abs().max()
+    assert out.cpu()[..., :co_off].abs().max() == 0 and out.cpu()[..., co_off + Cout:].abs().max() == 0
+
+
+def test_conv_accumulates_and_pixel_shuffle():
+    g = torch.Generator().manual_seed(3)
+    B, H, C = 2, 8, 128
+    x = torch.randn(B, C, H, H, generator=g)
+    w3, w1 = torch.randn(C, C, 3, 3, generator=g) / 34, torch.randn(C, C, 1, 1, generator=g) / 11
+    b3, b1 = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    p3, _ = _pack_conv(w3)
+    p1, _ = _pack_conv(w1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = torch.zeros(B, H, H, C, device=DEV)
+    common = (B, H, H, C, H, H, C, C, 0)
+    _run([_op(1, 1, p=(xd, p3, b3.to(DEV), out, None), i=common + (3, 3, 1, 1, 2, 2 * 16 + 4)),
+          _op(1, 1, p=(xd, p1, b1.to(DEV), out, None), i=common + (1, 1, 1, 0, 1, 2 * 16 + 4))])   # Parallel(conv3x3, conv1x1)
+    ref = (F.conv2d(bf(x), bf(w3), b3, padding=1) + F.conv2d(bf(x), bf(w1), b1)).permute(0, 2, 3, 1)
+    assert torch.allclose(out.cpu(), ref, rtol=2e-4, atol=2e-4)
+    # PixelShuffleUpsample: conv1x1 -> SiLU -> PixelShuffle(2)
+    wu, bu = torch.randn(4 * 64, C, 1, 1, generator=g) / 11, torch.randn(4 * 64, generator=g)
+    pu, _ = _pack_conv(wu)
+    up = torch.full((B, 2 * H, 2 * H, 64), float("nan"), device=DEV)
+    _run([_op(1, 1 | 2, p=(xd, pu, bu.to(DEV), up, None), i=(B, H, H, C, H, H, 256, 64, 0, 1, 1, 1, 0, 1, 2 * 16 + 2))])
+    ref = F.pixel_shuffle(F.silu(F.conv2d(bf(x), bf(wu), bu)), 2).permute(0, 2, 3, 1)
+    assert torch.allclose(up.cpu(), ref, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("B,H,C1,C2,with_ss", [(1, 32, 256, 256, True), (2, 8, 1024, 512, False), (1, 4, 1024, 0, True),
+                                                 (3, 16, 64, 0, True), (1, 32, 512, 0, False)])
+def test_gn_act(B, H, C1, C2, with_ss):
+    g = torch.Generator().manual_seed(C1 + C2 + H)
+    HW, C = H * H, C1 + C2
+    x1 = torch.randn(B, HW, C1, generator=g) * 2 + 0.5
+    x2 = torch.randn(B, HW, C2, generator=g) if C2 else None
+    gamma, beta = 1 + 0.2 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+    ss_all = torch.randn(B, 3 * C, generator=g) * 0.3
+    out = torch.empty(B, HW, C, dtype=torch.bfloat16, device=DEV)
+    raw = torch.empty(B, HW, C, dtype=torch.bfloat16, device=DEV)
+    ssd = ss_all.to(DEV)
+    ss_ptr = ssd.data_ptr() + C * 4 if with_ss else 0        # the block's slice starts at column C
+    _run([_op(2, 0, p=(x1.to(DEV), x2.to(DEV) if C2 else None, gamma.to(DEV), beta.to(DEV), ss_ptr, out, raw),
+              i=(B, HW, C1, C2, 3 * C), f=(1e-5, 2 ** -0.5))])
+    xc = torch.cat([x1, x2 * 2 ** -0.5], -1) if C2 else x1
+    ref = F.group_norm(xc.permute(0, 2, 1).reshape(B, C, H, H), 8, gamma, beta, eps=1e-5)
+    if with_ss:
+        sc, sh = ss_all[:, C:2 * C], ss_all[:, 2 * C:3 * C]
+        ref = ref * (sc[:, :, None, None] + 1) + sh[:, :, None, None]
+    ref = F.silu(ref).reshape(B, C, HW).permute(0, 2, 1)
+    assert torch.allclose(out.float().cpu(), ref, rtol=1.2e-2, atol=1e-2)       # bf16 output rounding (2^-8)
+    assert (out.float().cpu() - ref).abs().mean() < 2e-3
+    assert torch.equal(raw.cpu(), xc.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("R,C,gelu,bias,f32,res", [(16, 1024, False, False, False, False), (32, 2048, True, False, False, False),
+                                                     (4, 256, False, True, True, False), (48, 1024, False, False, True, True),
+                                                     (7, 64, False, False, True, False)])
+def test_layernorm(R, C, gelu, bias, f32, res):
+    g = torch.Generator().manual_seed(R + C)
+    x = torch.randn(R, C, generator=g) * 3 + 1
+    gain, b = 1 + 0.2 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g)
+    r = torch.randn(R, C, generator=g)
+    out = torch.empty(R, C, dtype=torch.float32 if f32 else torch.bfloat16, device=DEV)
+    _run([_op(3, (1 if gelu else 0) | (2 if f32 else 0), p=(x.to(DEV), gain.to(DEV), b.to(DEV) if bias else None, out,
+                                                            r.to(DEV) if res else None), i=(R, C), f=(1e-5,))])
+    y = F.gelu(x) if gelu else x
+    ref = (y - y.mean(-1, keepdim=True)) * (y.var(-1, unbiased=False, keepdim=True) + 1e-5).rsqrt() * gain
+    if bias:
+        ref = ref + b
+    if res:
+        ref = ref + r
+    if f32:
+        assert torch.allclose(out.cpu(), ref, rtol=1e-5, atol=2e-5)
+    else:
+        assert torch.allclose(out.float().cpu(), ref, rtol=1.2e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("M,N,K,in_silu,act", [(1, 1024, 17, False, 1), (2, 5000, 1024, True, 0), (8, 128, 256, False, 0),
+                                                (4, 512, 1024, False, 2), (1, 33, 40, False, 0)])
+def test_gemv(M, N, K, in_silu, act):
+    g = torch.Generator().manual_seed(N + K)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    x = torch.randn(M, K + 3, generator=g)
+    Kp = (K + 7) // 8 * 8
+    wp = F.pad(w, (0, Kp - K)).to(torch.bfloat16).contiguous().to(DEV)
+    y = torch.zeros(M, N + 2, device=DEV)
+    _run([_op(4, (1 if in_silu else 0) | (act << 1), p=(x.to(DEV), wp, b.to(DEV), y), i=(M, N, K, Kp, K + 3, N + 2))])
+    xin = x[:, :K]
+    ref = F.linear(F.silu(xin) if in_silu else xin, bf(w), b)
+    ref = F.silu(ref) if act == 1 else torch.sigmoid(ref) if act == 2 else ref
+    assert torch.allclose(y.cpu()[:, :N], ref, rtol=1e-4, atol=1e-4)
+
+
+def test_attention_core_self_and_cross():
+    g = torch.Generator().manual_seed(9)
+    B, heads, dh = 2, 8, 64
+    q = torch.randn(B * 16, 512, generator=g)
+    kv = torch.randn(B * 16, 128, generator=g)
+    ckv = torch.randn(B * 2, 128, generator=g)
+    null = torch.randn(2, 64, generator=g)
+    out = torch.empty(B * 16, 512, dtype=torch.bfloat16, device=DEV)
+    qd, kvd, ckvd, nd = q.to(DEV), kv.to(DEV), ckv.to(DEV), null.to(DEV)
+    _run([_op(5, 0, p=(qd, out, ckvd, ckvd.data_ptr() + 256, nd, nd.data_ptr() + 256, kvd, kvd.data_ptr() + 256),
+              i=(B, heads, 512, 0, 2, 128, 256, 0, 1, 0, 0, 0, 16, 128, 2048, 0), f=(dh ** -0.5,))])
+    qh = q.view(B, 16, heads, dh).permute(0, 2, 1, 3) * dh ** -0.5
+    k = torch.cat([ckv[:, :64].view(B, 2, 64), null[0].view(1, 1, 64).expand(B, 1, 64), kv[:, :64].view(B, 16, 64)], 1)
+    v = torch.cat([ckv[:, 64:].view(B, 2, 64), null[1].view(1, 1, 64).expand(B, 1, 64), kv[:, 64:].view(B, 16, 64)], 1)
+    att = torch.einsum('bhid,bjd->bhij', qh, k).softmax(-1)
+    ref = torch.einsum('bhij,bjd->bhid', att, v).permute(0, 2, 1, 3).reshape(B * 16, 512)
+    assert torch.allclose(out.float().cpu(), ref, rtol=1.2e-2, atol=1e-2)
+    # cross attention: per-head k/v from 2 context tokens + shared null
+    kvc = torch.randn(B * 2, 1024, generator=g).to(DEV)
+    _run([_op(5, 0, p=(qd, out, nd, nd.data_ptr() + 256, kvc, kvc.data_ptr() + 2048, None, None),
+              i=(B, heads, 512, 0, 1, 0, 0, 0, 2, 1024, 2048, 64, 0, 0, 0, 0), f=(dh ** -0.5,))])
+    kc = kvc.cpu()[:, :512].view(B, 2, heads, dh).permute(0, 2, 1, 3)
+    vc = kvc.cpu()[:, 512:].view(B, 2, heads, dh).permute(0, 2, 1, 3)
+    kk = torch.cat([null[0].view(1, 1, 1, 64).expand(B, heads, 1, 64), kc], 2)
+    vv = torch.cat([null[1].view(1, 1, 1, 64).expand(B, heads, 1, 64), vc], 2)
+    att = torch.einsum('bhid,bhjd->bhij', qh, kk).softmax(-1)
+    ref = torch.einsum('bhij,bhjd->bhid', att, vv).permute(0, 2, 1, 3).reshape(B * 16, 512)
+    assert torch.allclose(out.float().cpu(), ref, rtol=1.2e-2, atol=1e-2)
+
+
+def test_gca_pool_gate_and_layout_ops():
+    g = torch.Generator().manual_seed(10)
+    B, HW, C = 2, 256, 512
+    h = torch.randn(B, HW, C, generator=g)
+    wk, bk = torch.randn(C, generator=g) / 8, torch.randn(1, generator=g)
+    pooled = torch.empty(B, C, device=DEV)
+    hd = h.to(DEV)
+    _run([_op(6, 0, p=(hd, wk.to(DEV), bk.to(DEV), pooled), i=(B, HW, C))])
+    att = (h @ wk + bk).softmax(-1)
+    assert torch.allclose(pooled.cpu(), torch.einsum('bn,bnc->bc', att, h), rtol=1e-4, atol=1e-5)
+    gate, res = torch.rand(B, C, generator=g), torch.randn(B, HW, C, generator=g)
+    out = torch.empty(B, HW, C, device=DEV)
+    _run([_op(7, 1, p=(hd, gate.to(DEV), res.to(DEV), out), i=(B, HW, C))])
+    assert torch.allclose(out.cpu(), h * gate[:, None] + res, rtol=1e-6, atol=1e-6)
+    out2 = res.to(DEV).clone()
+    _run([_op(7, 1, p=(hd, gate.to(DEV), None, out2), i=(B, HW, C))])      # residual already in `out`
+    assert torch.allclose(out2.cpu(), h * gate[:, None] + res, rtol=1e-6, atol=1e-6)
+    cond, x = torch.randn(B, 60, 1024, generator=g), torch.randn(B, 4, 1024, generator=g)
+    packed = torch.full((B, 1024, 64), float("nan"), device=DEV)
+    _run([_op(7, 2, p=(cond.to(DEV), x.to(DEV), None, packed), i=(B, 1024, 60, 4, 64))])
+    assert torch.equal(packed.cpu(), torch.cat([cond, x], 1).permute(0, 2, 1))
+    nhwc = torch.randn(B, 1024, 4, generator=g)
+    un = torch.empty(B, 4, 1024, device=DEV)
+    _run([_op(7, 3, p=(nhwc.to(DEV), None, None, un), i=(B, 1024, 4, 4))])
+    assert torch.equal(un.cpu(), nhwc.permute(0, 2, 1))
+    t, w = torch.tensor([0.3, -2.5]), torch.randn(8, generator=g)
+    emb = torch.empty(2, 17, device=DEV)
+    _run([_op(9, 0, p=(t.to(DEV), w.to(DEV), None, emb), i=(2, 8))])
+    fr = t[:, None] * w[None] * 2 * torch.pi
+    assert torch.allclose(emb.cpu(), torch.cat([t[:, None], fr.sin(), fr.cos()], -1), atol=2e-6)
+
+
+def test_plms_update_kernels():
+    from sparsefusion_amd import _lib
+    from sparsefusion_amd.plms import step_coefficients
+    from oracle import unet_ref
+    g = torch.Generator().manual_seed(12)
+    x, e, nz = (torch.randn(2, 4, 32, 32, generator=g) for _ in range(3))
+    for t, tn in ((0.5, 0.49), (0.02, 0.0), (0.97, 0.5)):
+        coef = step_coefficients(t, tn, 10.0)
+        xp, x0 = torch.empty_like(x, device=DEV), torch.empty_like(x, device=DEV)
+        _lib.check(_lib.lib().sf_plms_update(_lib.ptr(x.to(DEV)), _lib.ptr(e.to(DEV)), _lib.ptr(nz.to(DEV)), coef.ctypes.data,
+                                             x.numel(), _lib.ptr(xp), _lib.ptr(x0), _lib.stream_ptr()))
+        tb, tnb = torch.full((2, 1, 1, 1), t), torch.full((2, 1, 1, 1), tn)
+        a, s = unet_ref.alpha_sigma(unet_ref.log_snr(tb))
+        xs = ((x - s * e) / a.clamp(min=1e-8)).clamp(-10, 10)
+        mean, _, logvar = unet_ref.q_posterior(xs, x, tb, tnb)
+        ref = mean + (0.0 if tn == 0 else 1.0) * (0.5 * logvar).exp() * nz
+        assert torch.allclose(x0.cpu(), xs, rtol=1e-6, atol=1e-6) and torch.allclose(xp.cpu(), ref, rtol=1e-5, atol=1e-6)
