@@ -18,11 +18,16 @@ def _run(ops):
     torch.cuda.synchronize()
 
 
+_KEEP = []          # device temporaries referenced by raw pointer must outlive the launch
+
+
 def _op(type_, flags=0, p=(), i=(), f=()):
     from sparsefusion_amd import _lib
     o = _lib.SfOp()
     o.type, o.flags = type_, flags
     for k, v in enumerate(p):
+        if torch.is_tensor(v):
+            _KEEP.append(v)
         o.p[k] = v.data_ptr() if torch.is_tensor(v) else (v or None)
     for k, v in enumerate(i):
         o.i[k] = int(v)
@@ -246,8 +251,10 @@ def test_plms_update_kernels():
     for t, tn in ((0.5, 0.49), (0.02, 0.0), (0.97, 0.5)):
         coef = step_coefficients(t, tn, 10.0)
         xp, x0 = torch.empty_like(x, device=DEV), torch.empty_like(x, device=DEV)
-        _lib.check(_lib.lib().sf_plms_update(_lib.ptr(x.to(DEV)), _lib.ptr(e.to(DEV)), _lib.ptr(nz.to(DEV)), coef.ctypes.data,
-                                             x.numel(), _lib.ptr(xp), _lib.ptr(x0), _lib.stream_ptr()))
+        xd, ed, nd = x.to(DEV), e.to(DEV), nz.to(DEV)
+        _lib.check(_lib.lib().sf_plms_update(_lib.ptr(xd), _lib.ptr(ed), _lib.ptr(nd), coef.ctypes.data, x.numel(), _lib.ptr(xp),
+                                             _lib.ptr(x0), _lib.stream_ptr()))
+        torch.cuda.synchronize()
         tb, tnb = torch.full((2, 1, 1, 1), t), torch.full((2, 1, 1, 1), tn)
         a, s = unet_ref.alpha_sigma(unet_ref.log_snr(tb))
         xs = ((x - s * e) / a.clamp(min=1e-8)).clamp(-10, 10)
