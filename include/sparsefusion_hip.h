@@ -172,6 +172,9 @@ typedef struct {
 } sf_op;
 
 int sf_plan_run(const sf_op* ops, uint32_t n_ops, void* stream);
+/* sf_plan_run with a HIP event before every op on the launch stream; h_ms[n_ops] (host) gets per-op
+ * elapsed milliseconds.  Synchronises; measurement aid for bench.py (per-kernel roofline). */
+int sf_plan_profile(const sf_op* ops, uint32_t n_ops, void* stream, float* h_ms);
 
 /* Weight packing helpers (host pointers in, device-ready blobs out). */
 /* Pack a conv weight [Cout, Cin, kh, kw] f32 (host) into MFMA-fragment order

@@ -58,6 +58,7 @@ SIGNATURES = {
                                          C.c_float, c_f32p, c_f32p, c_f32p, u64, C.c_void_p]),
     "sf_ngp_render_workspace_bytes": (u64, [u32, u32]),
     "sf_plan_run": (C.c_int, [C.POINTER(SfOp), u32, C.c_void_p]),
+    "sf_plan_profile": (C.c_int, [C.POINTER(SfOp), u32, C.c_void_p, C.c_void_p]),
     "sf_conv_packed_elems": (u64, [u32, u32, u32, u32]),
     "sf_conv_pack_weights": (C.c_int, [C.c_void_p, u32, u32, u32, u32, u32, C.c_void_p]),
     "sf_plms_update": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_void_p, u64, c_f32p, c_f32p, C.c_void_p]),

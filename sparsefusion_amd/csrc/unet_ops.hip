@@ -663,11 +663,11 @@ static int run_eltwise(const sf_op& op, hipStream_t st) {
   return SF_OK;
 }
 
-extern "C" int sf_plan_run(const sf_op* ops, uint32_t n_ops, void* stream) {
-  hipStream_t st = (hipStream_t)stream;
+static int plan_run_impl(const sf_op* ops, uint32_t n_ops, hipStream_t st, hipEvent_t* ev) {
   for (uint32_t k = 0; k < n_ops; ++k) {
     const sf_op& op = ops[k];
     int rc = SF_OK;
+    if (ev && hipEventRecord(ev[k], st) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "plan: hipEventRecord failed");
     switch (op.type) {
       case SF_OP_CONV: rc = run_conv(op, st); break;
       case SF_OP_GN_ACT: rc = run_gn(op, st); break;
@@ -693,7 +693,26 @@ extern "C" int sf_plan_run(const sf_op* ops, uint32_t n_ops, void* stream) {
       return rc;
     }
   }
+  if (ev && hipEventRecord(ev[n_ops], st) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "plan: hipEventRecord failed");
   return SF_OK;
+}
+
+extern "C" int sf_plan_run(const sf_op* ops, uint32_t n_ops, void* stream) {
+  return plan_run_impl(ops, n_ops, (hipStream_t)stream, nullptr);
+}
+
+// Same as sf_plan_run with a HIP event recorded before every op ON THE LAUNCH STREAM; h_ms[k] receives the
+// elapsed milliseconds of op k (synchronises).  Used by bench.py for per-kernel roofline numbers.
+extern "C" int sf_plan_profile(const sf_op* ops, uint32_t n_ops, void* stream, float* h_ms) {
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t* ev = new hipEvent_t[n_ops + 1];
+  for (uint32_t k = 0; k <= n_ops; ++k) hipEventCreate(&ev[k]);
+  int rc = plan_run_impl(ops, n_ops, st, ev);
+  if (rc == SF_OK && hipEventSynchronize(ev[n_ops]) != hipSuccess) rc = SF_ERR_LAUNCH;
+  for (uint32_t k = 0; k < n_ops && rc == SF_OK; ++k) hipEventElapsedTime(&h_ms[k], ev[k], ev[k + 1]);
+  for (uint32_t k = 0; k <= n_ops; ++k) hipEventDestroy(ev[k]);
+  delete[] ev;
+  return rc;
 }
 
 // ---------------------------------------------------------------------------------------------
