@@ -55,13 +55,19 @@ __device__ __forceinline__ float wave_max(float v) {
 // CONV: implicit GEMM on MFMA.
 //   p[0] in (NHWC, bf16 or f32 by flag), p[1] packed weights (bf16), p[2] bias f32 [Cout] or NULL,
 //   p[3] out f32, p[4] residual f32 (same indexing as out) or NULL
+//   p[5] split-K workspace f32 [groups][M][Npad] (groups > 1 only)
 //   i[0..] = B, H, W, Cin_pad, Ho, Wo, Cout, ldc, co_off, kh, kw, stride, pad, ksplit_groups, tile (WM*16+WN), 0
-//   flags: 1 = A is f32, 2 = epilogue SiLU + PixelShuffle(2) (no split-K, plain stores)
+//   flags: 1 = A is f32, 2 = epilogue SiLU + PixelShuffle(2) (no split-K), 4 = accumulate into out (out += ...)
+// No atomics: with groups == 1 every output element is owned by one wave (plain store / read-modify-write);
+// with groups > 1 each K-slice group stores its partial tile to the workspace and k_splitk_reduce sums them
+// (fp32 L2 atomics top out at ~25 G lane-ops/s on MI355X, which made the atomic split-K epilogue 10x the
+// weight-streaming time of the 4x4 layers).
 // Packed weight layout: [n_frag = Cout_pad/16][ks = tap*(Cin_pad/32)+cc][lane 64][8] bf16 with
 //   element (lane, j) = W[n = n_frag*16 + (lane&15)][tap][c = cc*32 + 8*(lane>>4) + j].
 // ---------------------------------------------------------------------------------------------
 struct ConvArgs {
-  const void* in; const bf16x8* w; const float* bias; float* out; const float* resid;
+  const void* in; const bf16x8* w; const float* bias; float* out; const float* resid; float* ws;
+  int accum, npad;
   int B, H, W, Cin, Ho, Wo, Cout, ldc, co_off, kh, kw, stride, pad, groups;
   int KS, cchunks, m_frags, n_frags, m_tiles, n_tiles, steps_per_wave;
   int pixshuf;
@@ -171,14 +177,22 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
         acc[mi][ni][r] += red[0][idx] + red[1][idx] + red[2][idx];
       }
 
-  const bool first = grp == 0;
 #pragma unroll
   for (int mi = 0; mi < WM; ++mi) {
 #pragma unroll
     for (int ni = 0; ni < WN; ++ni) {
       const int n = (nt * WN + ni) * 16 + (lane & 15);
-      if (n >= a.Cout || nt * WN + ni >= a.n_frags) continue;
-      const float bv = (first && a.bias) ? a.bias[n] : 0.0f;
+      if (nt * WN + ni >= a.n_frags) continue;
+      if (a.groups > 1) {                       // split-K partial tile -> workspace [grp][m][npad]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = (mt * WM + mi) * 16 + (lane >> 4) * 4 + r;
+          if (m < M) a.ws[((long)grp * M + m) * a.npad + n] = acc[mi][ni][r];
+        }
+        continue;
+      }
+      if (n >= a.Cout) continue;
+      const float bv = a.bias ? a.bias[n] : 0.0f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = (mt * WM + mi) * 16 + (lane >> 4) * 4 + r;
@@ -194,11 +208,28 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
           a.out[(((long)b * (2 * a.Ho) + 2 * oy + ii) * (2 * a.Wo) + 2 * ox + jj) * a.ldc + a.co_off + c] = v;
         } else {
           const long o = (long)m * a.ldc + a.co_off + n;
-          if (first && a.resid) v += a.resid[o];
-          atomic_add_f32(a.out + o, v);
+          if (a.resid) v += a.resid[o];
+          if (a.accum) v += a.out[o];
+          a.out[o] = v;
         }
       }
     }
+  }
+}
+
+// out[m][co_off+n] (+)= bias[n] + resid + sum_g ws[g][m][n]      (second half of a split-K conv)
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                       const float* __restrict__ resid, float* __restrict__ out, int M,
+                                                       int Cout, int npad, int groups, int ldc, int co_off, int accum) {
+  const long total = (long)M * Cout;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int m = (int)(i / Cout), n = (int)(i - (long)m * Cout);
+    float v = bias ? bias[n] : 0.0f;
+    for (int g = 0; g < groups; ++g) v += ws[((long)g * M + m) * npad + n];
+    const long o = (long)m * ldc + co_off + n;
+    if (resid) v += resid[o];
+    if (accum) v += out[o];
+    out[o] = v;
   }
 }
 
@@ -207,74 +238,76 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
 // x*(scale+1)+shift, SiLU, -> bf16 NHWC; optional raw bf16 copy of the concat.
 //   p[0] src1 f32 [B,HW,C1], p[1] src2 f32 [B,HW,C2] or NULL, p[2] gamma [C], p[3] beta [C],
 //   p[4] scale_shift f32 (row b at p[4] + b*ss_stride: scale[C] then shift[C]) or NULL,
-//   p[5] out bf16 [B,HW,C], p[6] raw bf16 [B,HW,C] or NULL
+//   p[5] out bf16 [B,HW,C], p[6] raw bf16 [B,HW,C] or NULL, p[7] stats f64 [B*8][2], zeroed by the caller
 //   i = B, HW, C1, C2, ss_stride ; f = eps, src2_scale ; flags: 1 = no SiLU
-// One 1024-thread workgroup per (b, group); the group slab stays in registers (<= 64 floats/lane).
+// Two launches so that a B=1 eval still fills the chip: k_gn_stats (grid B*8*slices; per-block fp32 partial
+// sums, combined in f64 with one L2 atomic pair per block) and k_gn_apply (pure elementwise).
 // ---------------------------------------------------------------------------------------------
-#define GN_MAXV 16   // float4 chunks per thread: 16*4*1024 = 65536 elements per (b, group)
-__global__ __launch_bounds__(1024) void k_gn_act(const float* __restrict__ s1, const float* __restrict__ s2,
-                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                 const float* __restrict__ ss, __bf16* __restrict__ out,
-                                                 __bf16* __restrict__ raw, int B, int HW, int C1, int C2, int ss_stride,
-                                                 float eps, float s2_scale, int no_silu) {
-  __shared__ float red[32];
-  __shared__ float stat[2];
+#define GN_CHUNKS_PER_BLOCK 2048     // float4 chunks per stats workgroup (256 threads x 8)
+__device__ __forceinline__ f32x4 gn_load(const float* __restrict__ s1, const float* __restrict__ s2, int b, int HW, int C1,
+                                         int C2, int p, int c, float s2_scale) {
+  if (c < C1) return *reinterpret_cast<const f32x4*>(s1 + ((long)b * HW + p) * C1 + c);
+  f32x4 v = *reinterpret_cast<const f32x4*>(s2 + ((long)b * HW + p) * C2 + (c - C1));
+  return v * s2_scale;
+}
+
+__global__ __launch_bounds__(256) void k_gn_stats(const float* __restrict__ s1, const float* __restrict__ s2,
+                                                  double* __restrict__ stats, int HW, int C1, int C2, int slices,
+                                                  float s2_scale) {
+  __shared__ double red[8];
   const int C = C1 + C2, Cg = C / 8, cg4 = Cg / 4;
-  const int b = blockIdx.x / 8, g = blockIdx.x % 8;
+  const int bg = blockIdx.x / slices, sl = blockIdx.x % slices;
+  const int b = bg / 8, g = bg % 8;
   const int chunks = HW * cg4;
-  f32x4 v[GN_MAXV];
-  float sum = 0.0f;
-#pragma unroll
-  for (int i = 0; i < GN_MAXV; ++i) {
-    const int ch = threadIdx.x + i * 1024;
-    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (ch < chunks) {
-      const int p = ch / cg4, c = g * Cg + (ch - p * cg4) * 4;
-      if (c < C1) v[i] = *reinterpret_cast<const f32x4*>(s1 + ((long)b * HW + p) * C1 + c);
-      else { v[i] = *reinterpret_cast<const f32x4*>(s2 + ((long)b * HW + p) * C2 + (c - C1)); v[i] *= s2_scale; }
-      sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    }
+  const int per = (chunks + slices - 1) / slices;
+  const int c0 = sl * per, c1 = min(chunks, c0 + per);
+  float s = 0.0f, q = 0.0f;
+  for (int ch = c0 + threadIdx.x; ch < c1; ch += 256) {
+    const int p = ch / cg4, c = g * Cg + (ch - p * cg4) * 4;
+    const f32x4 v = gn_load(s1, s2, b, HW, C1, C2, p, c, s2_scale);
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+    q = fmaf(v[0], v[0], q); q = fmaf(v[1], v[1], q); q = fmaf(v[2], v[2], q); q = fmaf(v[3], v[3], q);
   }
+  double ds = (double)wave_sum(s), dq = (double)wave_sum(q);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  sum = wave_sum(sum);
-  if (lane == 0) red[wv] = sum;
+  if (lane == 0) { red[wv] = ds; red[4 + wv] = dq; }
   __syncthreads();
-  if (threadIdx.x == 0) { float t = 0; for (int i = 0; i < 16; ++i) t += red[i]; stat[0] = t / (float)(HW * Cg); }
-  __syncthreads();
-  const float mean = stat[0];
-  float sq = 0.0f;
-#pragma unroll
-  for (int i = 0; i < GN_MAXV; ++i) {
-    const int ch = threadIdx.x + i * 1024;
-    if (ch < chunks) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; sq = fmaf(d, d, sq); }
-    }
+  if (threadIdx.x == 0) {
+    typedef __attribute__((address_space(1))) double gdouble;
+    (void)__builtin_amdgcn_global_atomic_fadd_f64((gdouble*)(stats + bg * 2), red[0] + red[1] + red[2] + red[3]);
+    (void)__builtin_amdgcn_global_atomic_fadd_f64((gdouble*)(stats + bg * 2 + 1), red[4] + red[5] + red[6] + red[7]);
   }
-  sq = wave_sum(sq);
-  if (lane == 0) red[16 + wv] = sq;
-  __syncthreads();
-  if (threadIdx.x == 0) { float t = 0; for (int i = 0; i < 16; ++i) t += red[16 + i]; stat[1] = rsqrtf(t / (float)(HW * Cg) + eps); }
-  __syncthreads();
-  const float rstd = stat[1];
+}
+
+__global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ s1, const float* __restrict__ s2,
+                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                  const float* __restrict__ ss, const double* __restrict__ stats,
+                                                  __bf16* __restrict__ out, __bf16* __restrict__ raw, int B, int HW, int C1,
+                                                  int C2, int ss_stride, float eps, float s2_scale, int no_silu) {
+  const int C = C1 + C2, Cg = C / 8, c4 = C / 4;
+  const long total = (long)B * HW * c4;
+  const double inv_n = 1.0 / ((double)HW * Cg);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % c4) * 4;
+    const long bp = i / c4;
+    const int p = (int)(bp % HW), b = (int)(bp / HW);
+    const int g = c / Cg;
+    const double m = stats[(b * 8 + g) * 2] * inv_n;
+    const double var = stats[(b * 8 + g) * 2 + 1] * inv_n - m * m;
+    const float mean = (float)m, rstd = rsqrtf((float)(var > 0.0 ? var : 0.0) + eps);
+    const f32x4 v = gn_load(s1, s2, b, HW, C1, C2, p, c, s2_scale);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+    bf16x4 o, r;
 #pragma unroll
-  for (int i = 0; i < GN_MAXV; ++i) {
-    const int ch = threadIdx.x + i * 1024;
-    if (ch < chunks) {
-      const int p = ch / cg4, c = g * Cg + (ch - p * cg4) * 4;
-      const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
-      bf16x4 o, r;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float y = (v[i][j] - mean) * rstd * ga[j] + be[j];
-        if (ss) y = y * (ss[(long)b * ss_stride + c + j] + 1.0f) + ss[(long)b * ss_stride + C + c + j];
-        if (!no_silu) y = silu_f(y);
-        o[j] = (__bf16)y;
-        r[j] = (__bf16)v[i][j];
-      }
-      *reinterpret_cast<bf16x4*>(out + ((long)b * HW + p) * C + c) = o;
-      if (raw) *reinterpret_cast<bf16x4*>(raw + ((long)b * HW + p) * C + c) = r;
+    for (int j = 0; j < 4; ++j) {
+      float y = (v[j] - mean) * rstd * ga[j] + be[j];
+      if (ss) y = y * (ss[(long)b * ss_stride + c + j] + 1.0f) + ss[(long)b * ss_stride + C + c + j];
+      if (!no_silu) y = silu_f(y);
+      o[j] = (__bf16)y;
+      r[j] = (__bf16)v[j];
     }
+    *reinterpret_cast<bf16x4*>(out + ((long)b * HW + p) * C + c) = o;
+    if (raw) *reinterpret_cast<bf16x4*>(raw + ((long)b * HW + p) * C + c) = r;
   }
 }
 
@@ -290,36 +323,21 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in,
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= R) return;
   const float* x = in + (long)row * C;
-  float v[32];                       // C <= 2048
   float s = 0.0f;
-  const int per = C / 64;
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    if (i < per) {
-      float t = x[lane + i * 64];
-      if (pre_gelu) t = gelu_f(t);
-      v[i] = t;
-      s += t;
-    }
-  }
+  for (int c = lane; c < C; c += 64) { const float t = x[c]; s += pre_gelu ? gelu_f(t) : t; }
   const float mean = wave_sum(s) / (float)C;
   float q = 0.0f;
-#pragma unroll
-  for (int i = 0; i < 32; ++i)
-    if (i < per) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+  for (int c = lane; c < C; c += 64) { const float t = x[c]; const float d = (pre_gelu ? gelu_f(t) : t) - mean; q = fmaf(d, d, q); }
   const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-#pragma unroll
-  for (int i = 0; i < 32; ++i) {
-    if (i < per) {
-      const int c = lane + i * 64;
-      float y = (v[i] - mean) * rstd * gain[c];
-      if (bias) y += bias[c];
-      if (out_f32) {
-        if (resid) y += resid[(long)row * C + c];
-        reinterpret_cast<float*>(out)[(long)row * C + c] = y;
-      } else {
-        reinterpret_cast<__bf16*>(out)[(long)row * C + c] = (__bf16)y;
-      }
+  for (int c = lane; c < C; c += 64) {
+    const float t = x[c];
+    float y = ((pre_gelu ? gelu_f(t) : t) - mean) * rstd * gain[c];
+    if (bias) y += bias[c];
+    if (out_f32) {
+      if (resid) y += resid[(long)row * C + c];
+      reinterpret_cast<float*>(out)[(long)row * C + c] = y;
+    } else {
+      reinterpret_cast<__bf16*>(out)[(long)row * C + c] = (__bf16)y;
     }
   }
 }
@@ -329,43 +347,52 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in,
 //   p[0] x f32 (row stride ldx), p[1] W bf16 [N][Kp] (Kp = K padded to 8), p[2] bias f32 or NULL, p[3] y f32 (row stride ldy)
 //   i = M, N, K, Kp, ldx, ldy ; flags: bit0 SiLU on input, bits 1-2 output act (0 none, 1 SiLU, 2 sigmoid)
 // ---------------------------------------------------------------------------------------------
+#define GEMV_ROWS 4    // output rows per wave: 4 independent 16-byte weight loads in flight per lane and step
 __global__ __launch_bounds__(256) void k_gemv(const float* __restrict__ x, const __bf16* __restrict__ W,
                                               const float* __restrict__ bias, float* __restrict__ y, int M, int N, int K,
                                               int Kp, int ldx, int ldy, int in_silu, int out_act) {
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (n >= N) return;
-  float acc[8];
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GEMV_ROWS, lane = threadIdx.x & 63;
+  if (n0 >= N) return;
+  float acc[GEMV_ROWS][8];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) acc[m] = 0.0f;
-  const __bf16* wr = W + (long)n * Kp;
+  for (int r = 0; r < GEMV_ROWS; ++r)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[r][m] = 0.0f;
   for (int k = lane * 8; k < Kp; k += 512) {
-    const bf16x8 w = *reinterpret_cast<const bf16x8*>(wr + k);
-    float wf[8];
+    bf16x8 w[GEMV_ROWS];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) wf[j] = (float)w[j];
+    for (int r = 0; r < GEMV_ROWS; ++r) {
+      const int n = min(n0 + r, N - 1);
+      w[r] = *reinterpret_cast<const bf16x8*>(W + (long)n * Kp + k);
+    }
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       if (m < M) {
+        float xv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          if (k + j < K) {
-            float xv = x[(long)m * ldx + k + j];
-            if (in_silu) xv = silu_f(xv);
-            acc[m] = fmaf(wf[j], xv, acc[m]);
-          }
+          xv[j] = (k + j < K) ? x[(long)m * ldx + k + j] : 0.0f;
+          if (in_silu) xv[j] = silu_f(xv[j]);
         }
+#pragma unroll
+        for (int r = 0; r < GEMV_ROWS; ++r)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[r][m] = fmaf((float)w[r][j], xv[j], acc[r][m]);
       }
     }
   }
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    if (m < M) {
-      float v = wave_sum(acc[m]);
-      if (lane == 0) {
-        if (bias) v += bias[n];
-        if (out_act == 1) v = silu_f(v);
-        else if (out_act == 2) v = sigmoid_f(v);
-        y[(long)m * ldy + n] = v;
+  for (int r = 0; r < GEMV_ROWS; ++r) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      if (m < M) {
+        float v = wave_sum(acc[r][m]);
+        if (lane == 0 && n0 + r < N) {
+          if (bias) v += bias[n0 + r];
+          if (out_act == 1) v = silu_f(v);
+          else if (out_act == 2) v = sigmoid_f(v);
+          y[(long)m * ldy + n0 + r] = v;
+        }
       }
     }
   }
@@ -424,48 +451,54 @@ __global__ __launch_bounds__(64) void k_attn16(const float* __restrict__ q, __bf
 
 // ---------------------------------------------------------------------------------------------
 // GCA_POOL: pooled[b][c] = sum_p softmax_p(h[b,p,:] . wk + bk) * h[b,p,c]     (GlobalContext :930-941)
-//   p[0] h f32 [B,HW,C], p[1] wk f32 [C], p[2] bk f32 [1], p[3] pooled f32 [B,C] ; i = B, HW, C
-// One 1024-thread workgroup per b.
+//   p[0] h f32 [B,HW,C], p[1] wk f32 [C], p[2] bk f32 [1], p[3] pooled f32 [B,C], p[4] logits scratch f32 [B*HW]
+//   i = B, HW, C.  Two launches: one wave per pixel for the logits, then one workgroup per (b, 32 channels).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_gca_pool(const float* __restrict__ h, const float* __restrict__ wk,
-                                                   const float* __restrict__ bk, float* __restrict__ pooled, int HW, int C) {
-  __shared__ float logit[1024];
-  __shared__ float red[16];
-  __shared__ float bc[2];
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const float* hb = h + (long)b * HW * C;
-  for (int p = wv; p < HW; p += 16) {
-    float a = 0.0f;
-    for (int c = lane * 4; c < C; c += 256) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(hb + (long)p * C + c);
-      const f32x4 w = *reinterpret_cast<const f32x4*>(wk + c);
-      a += x[0] * w[0] + x[1] * w[1] + x[2] * w[2] + x[3] * w[3];
-    }
-    a = wave_sum(a);
-    if (lane == 0) logit[p] = a + bk[0];
+__global__ __launch_bounds__(256) void k_gca_logits(const float* __restrict__ h, const float* __restrict__ wk,
+                                                    const float* __restrict__ bk, float* __restrict__ logit, int rows, int C) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= rows) return;
+  float a = 0.0f;
+  for (int c = lane * 4; c < C; c += 256) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(h + (long)p * C + c);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(wk + c);
+    a += x[0] * w[0] + x[1] * w[1] + x[2] * w[2] + x[3] * w[3];
   }
-  __syncthreads();
+  a = wave_sum(a);
+  if (lane == 0) logit[p] = a + bk[0];
+}
+
+__global__ __launch_bounds__(256) void k_gca_pool(const float* __restrict__ h, const float* __restrict__ logit,
+                                                  float* __restrict__ pooled, int HW, int C) {
+  __shared__ float e[1024];
+  __shared__ float red[8];
+  __shared__ float part[8][33];
+  const int b = blockIdx.x / (C / 32), cc = blockIdx.x % (C / 32);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float* lg = logit + (long)b * HW;
   float mx = -INFINITY;
-  for (int p = threadIdx.x; p < HW; p += 1024) mx = fmaxf(mx, logit[p]);
+  for (int p = threadIdx.x; p < HW; p += 256) mx = fmaxf(mx, lg[p]);
   mx = wave_max(mx);
   if (lane == 0) red[wv] = mx;
   __syncthreads();
-  if (threadIdx.x == 0) { float m = red[0]; for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]); bc[0] = m; }
-  __syncthreads();
-  mx = bc[0];
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float s = 0.0f;
-  for (int p = threadIdx.x; p < HW; p += 1024) { const float e = expf(logit[p] - mx); logit[p] = e; s += e; }
+  for (int p = threadIdx.x; p < HW; p += 256) { const float v = expf(lg[p] - mx); e[p] = v; s += v; }
   s = wave_sum(s);
+  if (lane == 0) red[4 + wv] = s;
   __syncthreads();
-  if (lane == 0) red[wv] = s;
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const float* hb = h + (long)b * HW * C + cc * 32 + cl;
+  float a = 0.0f;
+  for (int p = sl; p < HW; p += 8) a = fmaf(e[p], hb[(long)p * C], a);
+  part[sl][cl] = a;
   __syncthreads();
-  if (threadIdx.x == 0) { float t = 0; for (int i = 0; i < 16; ++i) t += red[i]; bc[1] = 1.0f / t; }
-  __syncthreads();
-  const float inv = bc[1];
-  for (int c = threadIdx.x; c < C; c += 1024) {
-    float a = 0.0f;
-    for (int p = 0; p < HW; ++p) a = fmaf(logit[p], hb[(long)p * C + c], a);
-    pooled[(long)b * C + c] = a * inv;
+  if (threadIdx.x < 32) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += part[k][threadIdx.x];
+    pooled[(long)b * C + cc * 32 + threadIdx.x] = t * inv;
   }
 }
 
@@ -543,7 +576,8 @@ static void launch_conv(const ConvArgs& a, bool a_fp32, int blocks, hipStream_t 
 static int run_conv(const sf_op& op, hipStream_t st) {
   ConvArgs a;
   a.in = op.p[0]; a.w = (const bf16x8*)op.p[1]; a.bias = (const float*)op.p[2]; a.out = (float*)op.p[3];
-  a.resid = (const float*)op.p[4];
+  a.resid = (const float*)op.p[4]; a.ws = (float*)op.p[5];
+  a.accum = (op.flags & 4) ? 1 : 0;
   a.B = op.i[0]; a.H = op.i[1]; a.W = op.i[2]; a.Cin = op.i[3]; a.Ho = op.i[4]; a.Wo = op.i[5]; a.Cout = op.i[6];
   a.ldc = op.i[7]; a.co_off = op.i[8]; a.kh = op.i[9]; a.kw = op.i[10]; a.stride = op.i[11]; a.pad = op.i[12];
   a.groups = op.i[13] > 0 ? op.i[13] : 1;
@@ -559,6 +593,7 @@ static int run_conv(const sf_op& op, hipStream_t st) {
   a.n_frags = (a.Cout + 15) / 16;
   a.m_tiles = (a.m_frags + WM - 1) / WM;
   a.n_tiles = (a.n_frags + WN - 1) / WN;
+  a.npad = a.n_frags * 16;
   if (a.pixshuf) a.groups = 1;
   a.steps_per_wave = (a.KS + a.groups * 4 - 1) / (a.groups * 4);
   const int blocks = a.m_tiles * a.n_tiles * a.groups;
@@ -576,18 +611,29 @@ static int run_conv(const sf_op& op, hipStream_t st) {
     default: SF_FAIL(SF_ERR_INVALID, "conv: unsupported wave tile %dx%d", WM, WN);
   }
   SF_CHECK_LAUNCH("conv_igemm");
+  if (a.groups > 1) {
+    if (!a.ws) SF_FAIL(SF_ERR_INVALID, "conv: split-K needs a workspace");
+    k_splitk_reduce<<<sf_grid_cap(sf_div_up((long)M * a.Cout, 256)), 256, 0, st>>>(a.ws, a.bias, a.resid, a.out, M, a.Cout, a.npad,
+                                                                                  a.groups, a.ldc, a.co_off, a.accum);
+    SF_CHECK_LAUNCH("splitk_reduce");
+  }
   return SF_OK;
 }
 
 static int run_gn(const sf_op& op, hipStream_t st) {
   const int B = op.i[0], HW = op.i[1], C1 = op.i[2], C2 = op.i[3];
   const int C = C1 + C2;
-  if (C % 32 || C1 % 4 || (long)HW * (C / 8) > (long)GN_MAXV * 4 * 1024)
-    SF_FAIL(SF_ERR_INVALID, "gn_act: unsupported shape HW=%d C=%d", HW, C);
-  k_gn_act<<<B * 8, 1024, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], (const float*)op.p[3],
-                                   (const float*)op.p[4], (__bf16*)op.p[5], (__bf16*)op.p[6], B, HW, C1, C2, op.i[4], op.f[0],
-                                   op.f[1], op.flags & 1);
-  SF_CHECK_LAUNCH("gn_act");
+  if (C % 32 || C1 % 4 || !op.p[7]) SF_FAIL(SF_ERR_INVALID, "gn_act: unsupported shape HW=%d C=%d (or missing stats buffer)", HW, C);
+  const int chunks = HW * (C / 8) / 4;
+  const int slices = (chunks + GN_CHUNKS_PER_BLOCK - 1) / GN_CHUNKS_PER_BLOCK;
+  k_gn_stats<<<B * 8 * slices, 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (double*)op.p[7], HW, C1, C2, slices,
+                                             op.f[1]);
+  SF_CHECK_LAUNCH("gn_stats");
+  const long total = (long)B * HW * (C / 4);
+  k_gn_apply<<<sf_grid_cap(sf_div_up(total, 256)), 256, 0, st>>>(
+      (const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const float*)op.p[4],
+      (const double*)op.p[7], (__bf16*)op.p[5], (__bf16*)op.p[6], B, HW, C1, C2, op.i[4], op.f[0], op.f[1], op.flags & 1);
+  SF_CHECK_LAUNCH("gn_apply");
   return SF_OK;
 }
 
@@ -603,8 +649,9 @@ static int run_ln(const sf_op& op, hipStream_t st) {
 static int run_gemv(const sf_op& op, hipStream_t st) {
   const int M = op.i[0], N = op.i[1];
   if (M > 8) SF_FAIL(SF_ERR_INVALID, "gemv: at most 8 rows");
-  k_gemv<<<sf_div_up(N, 4), 256, 0, st>>>((const float*)op.p[0], (const __bf16*)op.p[1], (const float*)op.p[2], (float*)op.p[3],
-                                         M, N, op.i[2], op.i[3], op.i[4], op.i[5], op.flags & 1, (op.flags >> 1) & 3);
+  k_gemv<<<sf_div_up(N, 4 * GEMV_ROWS), 256, 0, st>>>((const float*)op.p[0], (const __bf16*)op.p[1], (const float*)op.p[2],
+                                                     (float*)op.p[3], M, N, op.i[2], op.i[3], op.i[4], op.i[5], op.flags & 1,
+                                                     (op.flags >> 1) & 3);
   SF_CHECK_LAUNCH("gemv");
   return SF_OK;
 }
@@ -625,9 +672,12 @@ static int run_attn(const sf_op& op, hipStream_t st) {
 }
 
 static int run_gca_pool(const sf_op& op, hipStream_t st) {
-  if (op.i[1] > 1024 || op.i[2] % 4) SF_FAIL(SF_ERR_INVALID, "gca_pool: HW <= 1024, C %% 4 == 0");
-  k_gca_pool<<<op.i[0], 1024, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], (float*)op.p[3],
-                                       op.i[1], op.i[2]);
+  const int B = op.i[0], HW = op.i[1], C = op.i[2];
+  if (HW > 1024 || C % 32 || !op.p[4]) SF_FAIL(SF_ERR_INVALID, "gca_pool: HW <= 1024, C %% 32 == 0, logits scratch required");
+  k_gca_logits<<<sf_div_up(B * HW, 4), 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2],
+                                                    (float*)op.p[4], B * HW, C);
+  SF_CHECK_LAUNCH("gca_logits");
+  k_gca_pool<<<B * (C / 32), 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[4], (float*)op.p[3], HW, C);
   SF_CHECK_LAUNCH("gca_pool");
   return SF_OK;
 }

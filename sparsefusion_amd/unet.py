@@ -165,10 +165,13 @@ class _Plan:
         else:
             self.zero, self.misc = _Arena(sizing[0], device), _Arena(sizing[1], device)
         self.w = unet._packed(device)
+        self.written = set()                 # (ptr, channel offset) of conv outputs that already hold data
+        self.ws_bytes = 0                    # split-K workspace demand (max over ops; ops run serially)
+        self.ws_ptr = self.misc.alloc(sizing[2]) if sizing is not None else 0
 
     # -------- allocation helpers
-    def zf32(self, rows, C, HW=None):
-        return _T(self.zero.alloc(rows * C * 4), rows, C, HW)
+    def zf32(self, rows, C, HW=None):        # conv outputs: first writer stores, later writers accumulate
+        return self.f32(rows, C, HW)
 
     def f32(self, rows, C, HW=None):
         return _T(self.misc.alloc(rows * C * 4), rows, C, HW)
@@ -196,23 +199,25 @@ class _Plan:
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         M = B * Ho * Wo
         m_frags, n_frags = (M + 15) // 16, (Cout + 15) // 16
-        WM = 4 if m_frags % 4 == 0 else (2 if m_frags % 2 == 0 else 1)
-        WN = 4 if n_frags % 4 == 0 else (2 if n_frags % 2 == 0 else 1)
-        if pixshuf:                       # no split-K here: use small tiles to spread over the chip
-            WM, WN = min(WM, 2), min(WN, 2)
         KS = k * k * (x.C // 32)
-        tiles = (m_frags // WM) * (n_frags // WN)
-        groups = 1 if pixshuf else max(1, min(round(self.u.conv_blocks_target / tiles), KS // 8))
-        self.op(OP_CONV, (1 if x_f32 else 0) | (2 if pixshuf else 0),
-                p=(x.ptr, self.wptr(wname), self.wptr(bname) if bname else 0, out.ptr, resid.ptr if resid else 0),
+        WM, WN, groups = self.u.conv_tiling(m_frags, n_frags, KS, pixshuf)
+        accum = (out.ptr, co_off) in self.written
+        self.written.add((out.ptr, co_off))
+        ws = 0
+        if groups > 1:
+            self.ws_bytes = max(self.ws_bytes, groups * M * n_frags * 16 * 4)
+            ws = self.ws_ptr
+        self.op(OP_CONV, (1 if x_f32 else 0) | (2 if pixshuf else 0) | (4 if accum else 0),
+                p=(x.ptr, self.wptr(wname), self.wptr(bname) if bname else 0, out.ptr, resid.ptr if resid else 0, ws),
                 i=(B, H, W, x.C, Ho, Wo, Cout, ldc, co_off, k, k, stride, pad, groups, WM * 16 + WN))
         return Ho, Wo
 
     def gn_act(self, x, skip, gname, ss_ptr, out, raw=None, silu=True):
         C1, C2 = x.C, (skip.C if skip else 0)
+        stats = self.zero.alloc(self.B * 8 * 2 * 8)          # f64 (sum, sum of squares) per (b, group), zeroed per eval
         self.op(OP_GN_ACT, 0 if silu else 1,
                 p=(x.ptr, skip.ptr if skip else 0, self.wptr(gname + ".weight"), self.wptr(gname + ".bias"), ss_ptr, out.ptr,
-                   raw.ptr if raw else 0),
+                   raw.ptr if raw else 0, stats),
                 i=(self.B, x.HW, C1, C2, self.u.ss_total), f=(1e-5, SKIP_SCALE))
 
     def ln(self, x, gname, bname, out, C, rows, eps=1e-5, gelu=False, out_f32=False, resid=None):
@@ -262,8 +267,9 @@ class _Plan:
             self.conv(a2, False, H, H, w2, b2, h2, cout, 0, cout, 3, 1, 1)
             pooled, hid = self.f32(B, cout), self.f32(B, max(3, cout // 2))
             gate = self.f32(B, cout)
-            self.op(OP_GCA_POOL, 0, p=(h2.ptr, self.wptr(f"{name}.gca.to_k.weight"), self.wptr(f"{name}.gca.to_k.bias"), pooled.ptr),
-                    i=(B, HW, cout))
+            logits = self.f32(B, HW)
+            self.op(OP_GCA_POOL, 0, p=(h2.ptr, self.wptr(f"{name}.gca.to_k.weight"), self.wptr(f"{name}.gca.to_k.bias"), pooled.ptr,
+                                       logits.ptr), i=(B, HW, cout))
             self.gemv(pooled.ptr, B, cout, f"{name}.gca.net.0.weight", f"{name}.gca.net.0.bias", hid.ptr, hid.C, hid.C, cout,
                       out_act=1)
             self.gemv(hid.ptr, B, hid.C, f"{name}.gca.net.2.weight", f"{name}.gca.net.2.bias", gate.ptr, cout, cout, hid.C,
@@ -477,7 +483,7 @@ class Unet(nn.Module):
                 self.ss_offset[name[:-len(".time_mlp.1.weight")]] = off
                 off += shape[0]
         self.ss_total = off
-        self.conv_blocks_target = 512
+        self.conv_waves_target = 1024       # waves wanted per conv launch (4 per CU) before split-K stops
         self._pack_cache = None
         self._plans = {}
 
@@ -494,6 +500,36 @@ class Unet(nn.Module):
             return torch.randn(shape, generator=g)
         fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
         return (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+
+    def conv_tiling(self, m_frags, n_frags, KS, pixshuf=False):
+        """(WM, WN, split-K groups) of one implicit-GEMM launch, by a small cost model.  A wave owns a
+        (16*WM x 16*WN) tile; the 4 waves of a workgroup split K four ways (reduced in LDS); `groups` further K
+        slices go through the workspace + k_splitk_reduce.  Terms: weight streaming from HBM (needs ~4 waves/CU
+        to saturate), fragment traffic from L2 (1 KiB per fragment, amortised over the tile), MFMA issue, and the
+        partial-tile round trip of split-K."""
+        best = None
+        mfma = m_frags * n_frags * KS
+        w_bytes = n_frags * KS * 1024
+        for WM in (1, 2, 4):
+            if m_frags % WM or (m_frags <= 4 and WM != m_frags and m_frags in (1, 2, 4)):
+                continue                                   # small maps: all rows in one tile -> weights fetched once
+            for WN in (1, 2, 4):
+                if n_frags % WN:
+                    continue
+                tiles = (m_frags // WM) * (n_frags // WN)
+                for groups in ((1,) if pixshuf else (1, 2, 4, 8, 16, 32)):
+                    if groups > 1 and KS // (4 * groups) < 2:
+                        continue
+                    waves = tiles * groups * 4
+                    util = min(1.0, waves / self.conv_waves_target)
+                    t_hbm = w_bytes / 4.0e12 / util
+                    t_l2 = mfma * 1024 * (1.0 / WN + 1.0 / WM) / 12.0e12 / util
+                    t_mfma = mfma * 20 / (1024 * 2.1e9) / util
+                    t_part = (2.0 * groups * m_frags * n_frags * 1024 / 3.0e12 + 2.0e-6) if groups > 1 else 0.0
+                    cost = max(t_hbm, t_l2, t_mfma) + t_part + 1e-9 * WM * WN
+                    if best is None or cost < best[0]:
+                        best = (cost, WM, WN, groups)
+        return best[1], best[2], best[3]
 
     # ---- reference API odds and ends
     def cast_model_parameters(self, *, lowres_cond, conditional_embed_dim, channels, channels_out, cond_on_z):
@@ -575,7 +611,7 @@ class Unet(nn.Module):
         key = (B, str(device))
         if key not in self._plans:
             sizing = _Plan(self, B, device).build()
-            plan = _Plan(self, B, device, (sizing.zero.off, sizing.misc.off)).build()
+            plan = _Plan(self, B, device, (sizing.zero.off, sizing.misc.off + sizing.ws_bytes + 256, sizing.ws_bytes)).build()
             self._plans[key] = plan
         return self._plans[key]
 

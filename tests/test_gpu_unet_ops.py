@@ -80,7 +80,8 @@ def test_conv_igemm(case):
     ldc, co_off = Cout + 8, 4                                                 # exercise ldc / channel offset
     out = torch.zeros(B, Ho, Ho, ldc, device=DEV)
     res = torch.randn(B, Ho, Ho, ldc, generator=g).to(DEV) if use_res else None
-    _run([_op(1, 1 if a_f32 else 0, p=(xd, wp, bias.to(DEV), out, res),
+    ws = torch.empty(groups * B * Ho * Ho * ((Cout + 15) // 16 * 16), device=DEV) if groups > 1 else None
+    _run([_op(1, 1 if a_f32 else 0, p=(xd, wp, bias.to(DEV), out, res, ws),
               i=(B, H, H, cpad, Ho, Ho, Cout, ldc, co_off, k, k, stride, pad, groups, WM * 16 + WN))])
     ref = F.conv2d(bf(x), bf(w), bias, stride=stride, padding=pad).permute(0, 2, 3, 1)
     if use_res:
@@ -99,10 +100,11 @@ def test_conv_accumulates_and_pixel_shuffle():
     p3, _ = _pack_conv(w3)
     p1, _ = _pack_conv(w1)
     xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
-    out = torch.zeros(B, H, H, C, device=DEV)
+    out = torch.full((B, H, H, C), float("nan"), device=DEV)      # the first conv stores, the second accumulates (flag 4)
+    ws = torch.empty(2 * B * H * H * C, device=DEV)
     common = (B, H, H, C, H, H, C, C, 0)
-    _run([_op(1, 1, p=(xd, p3, b3.to(DEV), out, None), i=common + (3, 3, 1, 1, 2, 2 * 16 + 4)),
-          _op(1, 1, p=(xd, p1, b1.to(DEV), out, None), i=common + (1, 1, 1, 0, 1, 2 * 16 + 4))])   # Parallel(conv3x3, conv1x1)
+    _run([_op(1, 1, p=(xd, p3, b3.to(DEV), out, None, ws), i=common + (3, 3, 1, 1, 2, 2 * 16 + 4)),
+          _op(1, 1 | 4, p=(xd, p1, b1.to(DEV), out, None, None), i=common + (1, 1, 1, 0, 1, 2 * 16 + 4))])   # Parallel(conv3x3, conv1x1)
     ref = (F.conv2d(bf(x), bf(w3), b3, padding=1) + F.conv2d(bf(x), bf(w1), b1)).permute(0, 2, 3, 1)
     assert torch.allclose(out.cpu(), ref, rtol=2e-4, atol=2e-4)
     # PixelShuffleUpsample: conv1x1 -> SiLU -> PixelShuffle(2)
@@ -127,7 +129,8 @@ def test_gn_act(B, H, C1, C2, with_ss):
     raw = torch.empty(B, HW, C, dtype=torch.bfloat16, device=DEV)
     ssd = ss_all.to(DEV)
     ss_ptr = ssd.data_ptr() + C * 4 if with_ss else 0        # the block's slice starts at column C
-    _run([_op(2, 0, p=(x1.to(DEV), x2.to(DEV) if C2 else None, gamma.to(DEV), beta.to(DEV), ss_ptr, out, raw),
+    stats = torch.zeros(B * 8 * 2, dtype=torch.float64, device=DEV)
+    _run([_op(2, 0, p=(x1.to(DEV), x2.to(DEV) if C2 else None, gamma.to(DEV), beta.to(DEV), ss_ptr, out, raw, stats),
               i=(B, HW, C1, C2, 3 * C), f=(1e-5, 2 ** -0.5))])
     xc = torch.cat([x1, x2 * 2 ** -0.5], -1) if C2 else x1
     ref = F.group_norm(xc.permute(0, 2, 1).reshape(B, C, H, H), 8, gamma, beta, eps=1e-5)
@@ -217,7 +220,7 @@ def test_gca_pool_gate_and_layout_ops():
     wk, bk = torch.randn(C, generator=g) / 8, torch.randn(1, generator=g)
     pooled = torch.empty(B, C, device=DEV)
     hd = h.to(DEV)
-    _run([_op(6, 0, p=(hd, wk.to(DEV), bk.to(DEV), pooled), i=(B, HW, C))])
+    _run([_op(6, 0, p=(hd, wk.to(DEV), bk.to(DEV), pooled, torch.empty(B * HW, device=DEV)), i=(B, HW, C))])
     att = (h @ wk + bk).softmax(-1)
     assert torch.allclose(pooled.cpu(), torch.einsum('bn,bnc->bc', att, h), rtol=1e-4, atol=1e-5)
     gate, res = torch.rand(B, C, generator=g), torch.randn(B, HW, C, generator=g)
