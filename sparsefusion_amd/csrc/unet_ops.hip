@@ -125,33 +125,45 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
       const int nf = min(nt * WN + ni, a.n_frags - 1);
       wp[ni] = a.w + ((long)nf * a.KS + ks) * 64 + lane;
     }
-#pragma unroll 2
-    for (int cc = cc0; cc < cc1; ++cc) {
-      bf16x8 af[WM], bf[WN];
+    // U k-steps per trip: all 16-byte fragment loads of the trip are issued before its MFMAs so that a wave
+    // keeps U*(WM+WN) KiB in flight (weight streaming on the small-M layers is latency x bytes-in-flight bound).
+    constexpr int U = (WM * WN == 1) ? 8 : (WM * WN <= 4 ? 4 : 2);
+    for (int cc = cc0; cc < cc1; cc += U) {
+      bf16x8 af[U][WM], bf[U][WN];
 #pragma unroll
-      for (int ni = 0; ni < WN; ++ni) { bf[ni] = *wp[ni]; wp[ni] += 64; }
+      for (int u = 0; u < U; ++u) {
+        const bool live = cc + u < cc1;
 #pragma unroll
-      for (int mi = 0; mi < WM; ++mi) {
-        if (A_FP32) {
-          const float* src = reinterpret_cast<const float*>(a.in) + aoff[mi] + cc * 32;
-          f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
-          if (ain[mi]) { lo = *reinterpret_cast<const f32x4*>(src); hi = *reinterpret_cast<const f32x4*>(src + 4); }
-          bf16x8 v;
-          v[0] = (__bf16)lo[0]; v[1] = (__bf16)lo[1]; v[2] = (__bf16)lo[2]; v[3] = (__bf16)lo[3];
-          v[4] = (__bf16)hi[0]; v[5] = (__bf16)hi[1]; v[6] = (__bf16)hi[2]; v[7] = (__bf16)hi[3];
-          af[mi] = v;
-        } else {
-          const __bf16* src = reinterpret_cast<const __bf16*>(a.in) + aoff[mi] + cc * 32;
+        for (int ni = 0; ni < WN; ++ni) {
+          bf[u][ni] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          if (live) bf[u][ni] = wp[ni][(long)u * 64];
+        }
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) {
           bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-          if (ain[mi]) v = *reinterpret_cast<const bf16x8*>(src);
-          af[mi] = v;
+          if (live) {                                   // address is always in bounds (clamped); zero-fill by select
+            if (A_FP32) {
+              const float* src = reinterpret_cast<const float*>(a.in) + aoff[mi] + (cc + u) * 32;
+              const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+              v[0] = (__bf16)lo[0]; v[1] = (__bf16)lo[1]; v[2] = (__bf16)lo[2]; v[3] = (__bf16)lo[3];
+              v[4] = (__bf16)hi[0]; v[5] = (__bf16)hi[1]; v[6] = (__bf16)hi[2]; v[7] = (__bf16)hi[3];
+            } else {
+              v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.in) + aoff[mi] + (cc + u) * 32);
+            }
+            if (!ain[mi]) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+          }
+          af[u][mi] = v;
         }
       }
 #pragma unroll
-      for (int mi = 0; mi < WM; ++mi)
+      for (int ni = 0; ni < WN; ++ni) wp[ni] += U * 64;
 #pragma unroll
-        for (int ni = 0; ni < WN; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < WN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][mi], bf[u][ni], acc[mi][ni], 0, 0, 0);
     }
     ks += cc1 - cc0;
   }
@@ -312,7 +324,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ s1, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// LN: per-row normalisation over C (biased variance), one wave per row.
+// LN: per-row normalisation over C (biased variance), one 256-thread workgroup per row.
 //   p[0] in f32 [R,C], p[1] gain [C], p[2] bias [C] or NULL, p[3] out (bf16 or f32), p[4] residual f32 or NULL
 //   i = R, C ; f = eps ; flags: 1 = GELU(x) before normalising, 2 = f32 output (+ residual), else bf16 output
 // ---------------------------------------------------------------------------------------------
@@ -320,24 +332,41 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in,
                                                    const float* __restrict__ bias, void* __restrict__ out,
                                                    const float* __restrict__ resid, int R, int C, float eps, int pre_gelu,
                                                    int out_f32) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= R) return;
+  __shared__ float red[8];
+  const int row = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* x = in + (long)row * C;
+  float v[8];                                   // C <= 2048 = 8 * 256
   float s = 0.0f;
-  for (int c = lane; c < C; c += 64) { const float t = x[c]; s += pre_gelu ? gelu_f(t) : t; }
-  const float mean = wave_sum(s) / (float)C;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x + i * 256;
+    v[i] = 0.0f;
+    if (c < C) { const float t = x[c]; v[i] = pre_gelu ? gelu_f(t) : t; s += v[i]; }
+  }
+  s = wave_sum(s);
+  if (lane == 0) red[wv] = s;
+  __syncthreads();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
   float q = 0.0f;
-  for (int c = lane; c < C; c += 64) { const float t = x[c]; const float d = (pre_gelu ? gelu_f(t) : t) - mean; q = fmaf(d, d, q); }
-  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-  for (int c = lane; c < C; c += 64) {
-    const float t = x[c];
-    float y = ((pre_gelu ? gelu_f(t) : t) - mean) * rstd * gain[c];
-    if (bias) y += bias[c];
-    if (out_f32) {
-      if (resid) y += resid[(long)row * C + c];
-      reinterpret_cast<float*>(out)[(long)row * C + c] = y;
-    } else {
-      reinterpret_cast<__bf16*>(out)[(long)row * C + c] = (__bf16)y;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (threadIdx.x + i * 256 < C) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+  q = wave_sum(q);
+  if (lane == 0) red[4 + wv] = q;
+  __syncthreads();
+  const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < C) {
+      float y = (v[i] - mean) * rstd * gain[c];
+      if (bias) y += bias[c];
+      if (out_f32) {
+        if (resid) y += resid[(long)row * C + c];
+        reinterpret_cast<float*>(out)[(long)row * C + c] = y;
+      } else {
+        reinterpret_cast<__bf16*>(out)[(long)row * C + c] = (__bf16)y;
+      }
     }
   }
 }
@@ -451,7 +480,7 @@ __global__ __launch_bounds__(64) void k_attn16(const float* __restrict__ q, __bf
 
 // ---------------------------------------------------------------------------------------------
 // GCA_POOL: pooled[b][c] = sum_p softmax_p(h[b,p,:] . wk + bk) * h[b,p,c]     (GlobalContext :930-941)
-//   p[0] h f32 [B,HW,C], p[1] wk f32 [C], p[2] bk f32 [1], p[3] pooled f32 [B,C], p[4] logits scratch f32 [B*HW]
+//   p[0] h f32 [B,HW,C], p[1] wk f32 [C], p[2] bk f32 [1], p[3] pooled f32 [B,C] ZEROED by the caller, p[4] logits scratch f32 [B*HW]
 //   i = B, HW, C.  Two launches: one wave per pixel for the logits, then one workgroup per (b, 32 channels).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gca_logits(const float* __restrict__ h, const float* __restrict__ wk,
@@ -468,12 +497,13 @@ __global__ __launch_bounds__(256) void k_gca_logits(const float* __restrict__ h,
   if (lane == 0) logit[p] = a + bk[0];
 }
 
+// grid (B, ceil(HW/32)): every workgroup re-derives the softmax normaliser from the <=1024 logits, then
+// accumulates its 32 pixels for ALL channels (coalesced along C) and adds into the pre-zeroed pooled[b][:].
 __global__ __launch_bounds__(256) void k_gca_pool(const float* __restrict__ h, const float* __restrict__ logit,
-                                                  float* __restrict__ pooled, int HW, int C) {
-  __shared__ float e[1024];
+                                                  float* __restrict__ pooled, int HW, int C, int chunks) {
   __shared__ float red[8];
-  __shared__ float part[8][33];
-  const int b = blockIdx.x / (C / 32), cc = blockIdx.x % (C / 32);
+  __shared__ float e[32];
+  const int b = blockIdx.x / chunks, pc = blockIdx.x % chunks;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* lg = logit + (long)b * HW;
   float mx = -INFINITY;
@@ -483,22 +513,19 @@ __global__ __launch_bounds__(256) void k_gca_pool(const float* __restrict__ h, c
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float s = 0.0f;
-  for (int p = threadIdx.x; p < HW; p += 256) { const float v = expf(lg[p] - mx); e[p] = v; s += v; }
+  for (int p = threadIdx.x; p < HW; p += 256) s += expf(lg[p] - mx);
   s = wave_sum(s);
   if (lane == 0) red[4 + wv] = s;
+  const int p0 = pc * 32;
+  if (threadIdx.x < 32) e[threadIdx.x] = (p0 + (int)threadIdx.x < HW) ? expf(lg[p0 + threadIdx.x] - mx) : 0.0f;
   __syncthreads();
   const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
-  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const float* hb = h + (long)b * HW * C + cc * 32 + cl;
-  float a = 0.0f;
-  for (int p = sl; p < HW; p += 8) a = fmaf(e[p], hb[(long)p * C], a);
-  part[sl][cl] = a;
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    float t = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) t += part[k][threadIdx.x];
-    pooled[(long)b * C + cc * 32 + threadIdx.x] = t * inv;
+  const int np = min(32, HW - p0);
+  const float* hb = h + ((long)b * HW + p0) * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.0f;
+    for (int p = 0; p < np; ++p) a = fmaf(e[p], hb[(long)p * C + c], a);
+    atomic_add_f32(pooled + (long)b * C + c, a * inv);
   }
 }
 
@@ -640,7 +667,7 @@ static int run_gn(const sf_op& op, hipStream_t st) {
 static int run_ln(const sf_op& op, hipStream_t st) {
   const int R = op.i[0], C = op.i[1];
   if (C % 64 || C > 2048) SF_FAIL(SF_ERR_INVALID, "layernorm: C must be a multiple of 64 and <= 2048");
-  k_layernorm<<<sf_div_up(R, 4), 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3],
+  k_layernorm<<<R, 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3],
                                               (const float*)op.p[4], R, C, op.f[0], op.flags & 1, (op.flags & 2) ? 1 : 0);
   SF_CHECK_LAUNCH("layernorm");
   return SF_OK;
@@ -677,7 +704,8 @@ static int run_gca_pool(const sf_op& op, hipStream_t st) {
   k_gca_logits<<<sf_div_up(B * HW, 4), 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2],
                                                     (float*)op.p[4], B * HW, C);
   SF_CHECK_LAUNCH("gca_logits");
-  k_gca_pool<<<B * (C / 32), 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[4], (float*)op.p[3], HW, C);
+  const int chunks = (HW + 31) / 32;
+  k_gca_pool<<<B * chunks, 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[4], (float*)op.p[3], HW, C, chunks);
   SF_CHECK_LAUNCH("gca_pool");
   return SF_OK;
 }

@@ -160,6 +160,7 @@ class _Plan:
     def __init__(self, unet, B, device, sizing=None):
         self.u, self.B, self.dev = unet, B, device
         self.ops = []
+        self.graph = None
         if sizing is None:
             self.zero, self.misc = _Arena(), _Arena()
         else:
@@ -265,7 +266,8 @@ class _Plan:
         if gca:
             h2 = self.zf32(rows, cout, HW)
             self.conv(a2, False, H, H, w2, b2, h2, cout, 0, cout, 3, 1, 1)
-            pooled, hid = self.f32(B, cout), self.f32(B, max(3, cout // 2))
+            pooled = _T(self.zero.alloc(B * cout * 4), B, cout)        # accumulated with atomics: zeroed per eval
+            hid = self.f32(B, max(3, cout // 2))
             gate = self.f32(B, cout)
             logits = self.f32(B, HW)
             self.op(OP_GCA_POOL, 0, p=(h2.ptr, self.wptr(f"{name}.gca.to_k.weight"), self.wptr(f"{name}.gca.to_k.bias"), pooled.ptr,
@@ -484,6 +486,7 @@ class Unet(nn.Module):
                 off += shape[0]
         self.ss_total = off
         self.conv_waves_target = 1024       # waves wanted per conv launch (4 per CU) before split-K stops
+        self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches
         self._pack_cache = None
         self._plans = {}
 
@@ -636,9 +639,22 @@ class Unet(nn.Module):
         plan.x_view.copy_(x.reshape(B, -1))
         plan.t_view.copy_(time.reshape(-1).expand(B).reshape(B, 1))
         plan.cond_view.copy_(cond_images.reshape(B, -1))
-        rc = _lib.lib().sf_plan_run(plan.op_array, len(plan.ops), _lib.stream_ptr())
-        _lib.check(rc, "unet plan")
+        if self.use_hip_graph and not torch.cuda.is_current_stream_capturing():
+            if plan.graph is None:                     # first call: eager warm-up, then capture the ~370 launches once
+                self._run_plan(plan)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._run_plan(plan)
+                plan.graph = g
+            plan.graph.replay()
+        else:
+            self._run_plan(plan)
         return plan.out_view.clone().view(B, self.channels, self.image_size, self.image_size)
+
+    @staticmethod
+    def _run_plan(plan):
+        _lib.check(_lib.lib().sf_plan_run(plan.op_array, len(plan.ops), _lib.stream_ptr()), "unet plan")
 
     def forward_with_cond_scale(self, *args, cond_scale=1., **kwargs):
         if cond_scale != 1:

@@ -218,7 +218,7 @@ def test_gca_pool_gate_and_layout_ops():
     B, HW, C = 2, 256, 512
     h = torch.randn(B, HW, C, generator=g)
     wk, bk = torch.randn(C, generator=g) / 8, torch.randn(1, generator=g)
-    pooled = torch.empty(B, C, device=DEV)
+    pooled = torch.zeros(B, C, device=DEV)          # accumulated with atomics: the caller zeroes it
     hd = h.to(DEV)
     _run([_op(6, 0, p=(hd, wk.to(DEV), bk.to(DEV), pooled, torch.empty(B * HW, device=DEV)), i=(B, HW, C))])
     att = (h @ wk + bk).softmax(-1)

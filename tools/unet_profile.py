@@ -38,3 +38,10 @@ for target in [int(a) for a in sys.argv[2:]] or [512]:
         _lib.check(_lib.lib().sf_plan_run(plan.op_array, len(plan.ops), _lib.stream_ptr()))
     torch.cuda.synchronize()
     print(f"   plain sf_plan_run wall: {(time.time() - t) / 20 * 1e3:.3f} ms per eval")
+    x, ls, cond = torch.randn(B, 4, 32, 32, device=dev), torch.zeros(B, device=dev), torch.randn(B, 256, 32, 32, device=dev)
+    unet.forward(x, ls, cond_images=cond); torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(20):
+        unet.forward(x, ls, cond_images=cond)
+    torch.cuda.synchronize()
+    print(f"   Unet.forward (hipGraph replay + I/O copies) wall: {(time.time() - t) / 20 * 1e3:.3f} ms per eval")
