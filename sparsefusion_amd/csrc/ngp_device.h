@@ -375,7 +375,10 @@ SF_HD void ngp_mlp_backward(const float* __restrict__ W, const float h1[NGP_HID]
 }
 
 // Scatter d(loss)/d(features) of ONE point into the table gradient (kernel_grid_backward,
-// gridencoder.cu:226-313) -- hardware fp32 atomics on the GPU.
+// gridencoder.cu:226-313) -- hardware fp32 atomics on the GPU.  On tiled levels whose (res+1)^2 already
+// exceeds the level size the index rule drops z (gridencoder.cu:60), so the two z-corners of every (x,y)
+// pair hit the SAME row with weights w_xy*(1-pz) and w_xy*pz: they are merged into one add of w_xy*g
+// (identical sum, half the atomics on levels >= 7 of the reference geometry).
 SF_HD void ngp_scatter(const NgpLevels& lv, float* __restrict__ gtable, const float x01[3], bool inside,
                        const float dfeat[NGP_FEAT]) {
   if (!inside) return;
@@ -385,10 +388,21 @@ SF_HD void ngp_scatter(const NgpLevels& lv, float* __restrict__ gtable, const fl
       NgpCell c;
       ngp_cell(lv, l, x01, c);
       float* tab = gtable + (size_t)lv.offset[l] * 2;
+      const uint32_t step = lv.resolution[l] + 1;
+      const bool z_dropped = lv.gridtype == 1 && (uint64_t)step * step > lv.hsize[l] && step <= lv.hsize[l];
+      if (z_dropped) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        SF_ATOMIC_ADD(tab + (size_t)c.row[i] * 2 + 0, SF_MUL(c.w[i], dfeat[2 * l]));
-        SF_ATOMIC_ADD(tab + (size_t)c.row[i] * 2 + 1, SF_MUL(c.w[i], dfeat[2 * l + 1]));
+        for (int i = 0; i < 4; ++i) {                  // corners i and i+4 differ only in z
+          const float w = SF_ADD(c.w[i], c.w[i + 4]);
+          SF_ATOMIC_ADD(tab + (size_t)c.row[i] * 2 + 0, SF_MUL(w, dfeat[2 * l]));
+          SF_ATOMIC_ADD(tab + (size_t)c.row[i] * 2 + 1, SF_MUL(w, dfeat[2 * l + 1]));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          SF_ATOMIC_ADD(tab + (size_t)c.row[i] * 2 + 0, SF_MUL(c.w[i], dfeat[2 * l]));
+          SF_ATOMIC_ADD(tab + (size_t)c.row[i] * 2 + 1, SF_MUL(c.w[i], dfeat[2 * l + 1]));
+        }
       }
     }
   }

@@ -125,45 +125,75 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
       const int nf = min(nt * WN + ni, a.n_frags - 1);
       wp[ni] = a.w + ((long)nf * a.KS + ks) * 64 + lane;
     }
-    // U k-steps per trip: all 16-byte fragment loads of the trip are issued before its MFMAs so that a wave
-    // keeps U*(WM+WN) KiB in flight (weight streaming on the small-M layers is latency x bytes-in-flight bound).
-    constexpr int U = (WM * WN == 1) ? 8 : (WM * WN <= 4 ? 4 : 2);
-    for (int cc = cc0; cc < cc1; cc += U) {
-      bf16x8 af[U][WM], bf[U][WN];
+    // Software pipeline over trips of U k-steps: the 16-byte fragment loads of trip t+1 are issued (branch
+    // free, unconditionally) before the MFMAs of trip t, so a wave keeps U*(WM+WN) KiB in flight while the
+    // matrix pipe works -- weight streaming on the small-M layers is latency x bytes-in-flight bound.
+    // Out-of-image taps read a clamped in-bounds pixel and are zeroed by a select, never by a branch.
+    const __bf16* abase16[WM];
+    const float* abase32[WM];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi) {
+      abase16[mi] = reinterpret_cast<const __bf16*>(a.in) + aoff[mi];
+      abase32[mi] = reinterpret_cast<const float*>(a.in) + aoff[mi];
+    }
+    auto load_a = [&](int mi, int cc) -> bf16x8 {
+      bf16x8 v;
+      if (A_FP32) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(abase32[mi] + cc * 32);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(abase32[mi] + cc * 32 + 4);
+        v[0] = (__bf16)lo[0]; v[1] = (__bf16)lo[1]; v[2] = (__bf16)lo[2]; v[3] = (__bf16)lo[3];
+        v[4] = (__bf16)hi[0]; v[5] = (__bf16)hi[1]; v[6] = (__bf16)hi[2]; v[7] = (__bf16)hi[3];
+      } else {
+        v = *reinterpret_cast<const bf16x8*>(abase16[mi] + cc * 32);
+      }
+      return ain[mi] ? v : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    };
+    constexpr int U = (WM + WN <= 2) ? 8 : (WM + WN <= 4 ? 4 : 2);
+    const int n_full = (cc1 - cc0) / U;
+    if (n_full > 0) {
+      bf16x8 fa[2][U][WM], fb[2][U][WN];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const bool live = cc + u < cc1;
 #pragma unroll
-        for (int ni = 0; ni < WN; ++ni) {
-          bf[u][ni] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-          if (live) bf[u][ni] = wp[ni][(long)u * 64];
-        }
+        for (int ni = 0; ni < WN; ++ni) fb[0][u][ni] = wp[ni][(long)u * 64];
 #pragma unroll
-        for (int mi = 0; mi < WM; ++mi) {
-          bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-          if (live) {                                   // address is always in bounds (clamped); zero-fill by select
-            if (A_FP32) {
-              const float* src = reinterpret_cast<const float*>(a.in) + aoff[mi] + (cc + u) * 32;
-              const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
-              v[0] = (__bf16)lo[0]; v[1] = (__bf16)lo[1]; v[2] = (__bf16)lo[2]; v[3] = (__bf16)lo[3];
-              v[4] = (__bf16)hi[0]; v[5] = (__bf16)hi[1]; v[6] = (__bf16)hi[2]; v[7] = (__bf16)hi[3];
-            } else {
-              v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(a.in) + aoff[mi] + (cc + u) * 32);
+        for (int mi = 0; mi < WM; ++mi) fa[0][u][mi] = load_a(mi, cc0 + u);
+      }
+      for (int t = 0; t < n_full; t += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          if (t + half < n_full) {
+            const int tn = min(t + half + 1, n_full - 1);        // the last trip re-reads itself: no tail branch
+            const int ccn = cc0 + tn * U;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+              for (int ni = 0; ni < WN; ++ni) fb[half ^ 1][u][ni] = wp[ni][((long)tn * U + u) * 64];
+#pragma unroll
+              for (int mi = 0; mi < WM; ++mi) fa[half ^ 1][u][mi] = load_a(mi, ccn + u);
             }
-            if (!ain[mi]) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+              for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni)
+                  acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[half][u][mi], fb[half][u][ni], acc[mi][ni], 0, 0, 0);
           }
-          af[u][mi] = v;
         }
       }
+    }
+    for (int cc = cc0 + n_full * U; cc < cc1; ++cc) {              // ragged tail (< U steps)
+      bf16x8 ta[WM], tb[WN];
 #pragma unroll
-      for (int ni = 0; ni < WN; ++ni) wp[ni] += U * 64;
+      for (int ni = 0; ni < WN; ++ni) tb[ni] = wp[ni][(long)(cc - cc0) * 64];
 #pragma unroll
-      for (int u = 0; u < U; ++u)
+      for (int mi = 0; mi < WM; ++mi) ta[mi] = load_a(mi, cc);
 #pragma unroll
-        for (int mi = 0; mi < WM; ++mi)
+      for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < WN; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u][mi], bf[u][ni], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < WN; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ta[mi], tb[ni], acc[mi][ni], 0, 0, 0);
     }
     ks += cc1 - cc0;
   }
