@@ -103,17 +103,8 @@ class HotPath:
 
     def sync_grads(self):
         """mean all-reduce of the NGP gradients over the replicas (one flat RCCL call)."""
-        if self.world == 1:
-            return
-        import torch.distributed as dist
-        grads = [p.grad for p in self.ngp.parameters()]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat)
-        flat /= self.world
-        off = 0
-        for g in grads:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
+        from sparsefusion_amd.distributed import all_reduce_grads
+        all_reduce_grads(self.ngp.parameters())
 
     def step(self):
         # A: input view
@@ -131,10 +122,8 @@ class HotPath:
         sil256 = F.interpolate(sil, scale_factor=2, mode='bilinear')
         with torch.no_grad():
             latents = self.encode_standin(img256, sil256)
-            if self.world > 1:                                    # latents of all novel views of this step (8(e))
-                import torch.distributed as dist
-                gathered = [torch.empty_like(latents) for _ in range(self.world)]
-                dist.all_gather(gathered, latents)
+            from sparsefusion_amd.distributed import all_gather_latents
+            self.step_latents = all_gather_latents(latents)        # latents of all novel views of this step (8(e))
             pred_x0, x_noisy, noise, acp = self.plms.sample(latents, cond_images=self.features, use_tqdm=False,
                                                             return_noise=True, max_thres=self.max_thres)
             pred_img = self.decode_standin(pred_x0).clip(0.0, 1.0)
@@ -197,8 +186,9 @@ def cpu_baseline(max_thres):
     from oracle import ngp_ref, unet_ref
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from unet_common import spec
-    cores = os.cpu_count() or 1
+    cores = min(32, os.cpu_count() or 1)          # torch CPU kernels stop scaling (and oversubscribe) beyond ~32 threads
     torch.set_num_threads(cores)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     p = ngp_ref.init_params(bound=4, seed=1, table_std=0.5, sigma_bias=-3.0)
     pl = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "aabb" not in k else v) for k, v in p.items()}
     o, d = ngp_ref.circle_rays(32, view=3)                          # 1024 of the 16384 rays
@@ -219,9 +209,10 @@ def cpu_baseline(max_thres):
     n_evals = min(int(max_thres * 100), 50) + 1
     step_s = 2 * t_render + n_evals * t_eval
     return {"value": round(1.0 / step_s, 5), "unit": "views/s", "cores": cores, "kind": "port",
-            "ms_per_step": round(step_s * 1e3, 1),
+            "ms_per_step": round(step_s * 1e3, 1), "unet_eval_ms": round(t_eval * 1e3, 1),
+            "ngp_render_fwd_bwd_ms": round(t_render * 1e3, 1),
             "sample": f"1 NGP render fwd+bwd on 1024/16384 rays (x16) + 3 UNet evals B=1 (x{n_evals}/3), oracle fp32, "
-                      f"{cores} threads; reference has no CPU path for grid-encode/near-far (port)"}
+                      f"{cores} threads of {os.cpu_count()}; the reference has no CPU path for grid-encode/near-far (port)"}
 
 
 def main():

@@ -1,0 +1,63 @@
+"""World-size-2 tests of the view-sharding helpers on the gloo backend (runs on CPU; RCCL uses the same code)."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sparsefusion_amd import distributed as sfd
+    try:
+        # view sharding: 7 views over 2 ranks -> 4 + 3, disjoint, ordered
+        mine = sfd.shard_views(7, rank, world)
+        assert mine == ([0, 1, 2, 3] if rank == 0 else [4, 5, 6])
+        # all-gather of per-rank latents keeps rank order
+        lat = torch.full((2, 4, 32, 32), float(rank + 1))
+        full = sfd.all_gather_latents(lat)
+        assert full.shape == (4, 4, 32, 32) and torch.equal(full[:2], torch.ones(2, 4, 32, 32)) \
+            and torch.equal(full[2:], 2 * torch.ones(2, 4, 32, 32))
+        # replicas: identical start, different local grads, identical after the mean all-reduce + step
+        torch.manual_seed(rank)
+        net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4))
+        sfd.broadcast_params(net)
+        ref = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4))
+        ref.load_state_dict(net.state_dict())
+        opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+        g = torch.Generator().manual_seed(100)
+        xs = torch.randn(2, 5, 8, generator=g)                  # the two ranks' "views"
+        net(xs[rank]).pow(2).mean().backward()
+        sfd.all_reduce_grads(net.parameters())
+        opt.step()
+        # single-process reference: mean of the two view losses
+        ropt = torch.optim.Adam(ref.parameters(), lr=1e-2)
+        (0.5 * (ref(xs[0]).pow(2).mean() + ref(xs[1]).pow(2).mean())).backward()
+        ropt.step()
+        for a, b in zip(net.parameters(), ref.parameters()):
+            assert torch.allclose(a, b, atol=1e-6), (a - b).abs().max()
+        flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+        both = [torch.empty_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1])                      # replicas stay bit-identical
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_view_sharding_gloo_world2():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert dict(ret) == {0: "ok", 1: "ok"}
+
+
+def test_shard_views_partition():
+    from sparsefusion_amd.distributed import shard_views
+    for n, w in ((32, 8), (7, 2), (3, 4), (0, 2)):
+        parts = [shard_views(n, r, w) for r in range(w)]
+        assert sum(parts, []) == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert shard_views(32, 3, 8) == [12, 13, 14, 15]               # BASELINE config 4: 4 views per GPU
