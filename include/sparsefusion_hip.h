@@ -130,7 +130,9 @@ int sf_ngp_render_forward(const sf_ngp_field* f, const float* rays_o,
 
 /* Backward of sf_ngp_render_forward w.r.t. the field parameters given
  * grad_image [N,3] and grad_weights_sum [N] or NULL (depth carries no gradient
- * in the reference losses).  Gradients are ACCUMULATED into caller-zeroed buffers. */
+ * in the reference losses).  Gradients are ACCUMULATED into caller-zeroed buffers.
+ * rays_per_row: image width if the N rays are a row-major H x W image (lets the table
+ * scatter work on 8x8 patches), 0 if unknown. */
 int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_grad* g,
                            const float* rays_o, const float* rays_d,
                            const float* aabb, uint32_t N, uint32_t T,
@@ -138,6 +140,7 @@ int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_grad* g,
                            const float* z_sorted, const float* sigma_s,
                            const float* rgb_s, float bg_color,
                            const float* grad_image, const float* grad_weights_sum,
+                           uint32_t rays_per_row,
                            float* workspace, uint64_t workspace_bytes,
                            void* stream);
 

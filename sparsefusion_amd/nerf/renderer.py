@@ -74,7 +74,7 @@ class _FieldHandle:
 
 class _RenderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, handle, rays_o, rays_d, aabb, T, min_near, lin, u_coarse, u_fine, u_stride, bg, *params):
+    def forward(ctx, handle, rays_o, rays_d, aabb, T, min_near, lin, u_coarse, u_fine, u_stride, bg, rays_per_row, *params):
         _lib.require_cuda(rays_o, rays_d, aabb, *params)
         params = [p.detach().contiguous() for p in params]
         N = rays_o.shape[0]
@@ -94,7 +94,7 @@ class _RenderFn(torch.autograd.Function):
                                        _lib.ptr(sig_s), _lib.ptr(rgb_s), _lib.ptr(image), _lib.ptr(depth), _lib.ptr(ws),
                                        _lib.ptr(work), wbytes, _lib.stream_ptr())
         _lib.check(rc, "ngp_render_forward")
-        ctx.handle, ctx.T, ctx.bg = handle, T, float(bg)
+        ctx.handle, ctx.T, ctx.bg, ctx.rays_per_row = handle, T, float(bg), int(rays_per_row)
         ctx.save_for_backward(rays_o, rays_d, aabb, nears, fars, z_s, sig_s, rgb_s, *params)
         ctx.mark_non_differentiable(depth, nears, fars)
         return image, ws, depth, nears, fars
@@ -114,10 +114,10 @@ class _RenderFn(torch.autograd.Function):
         g_ws = g_ws.contiguous().float() if g_ws is not None else None
         rc = lib.sf_ngp_render_backward(C.byref(f), C.byref(g), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(aabb), N, T,
                                         _lib.ptr(nears), _lib.ptr(fars), _lib.ptr(z_s), _lib.ptr(sig_s), _lib.ptr(rgb_s),
-                                        ctx.bg, _lib.ptr(g_image), _lib.ptr(g_ws), _lib.ptr(work), wbytes,
-                                        _lib.stream_ptr())
+                                        ctx.bg, _lib.ptr(g_image), _lib.ptr(g_ws), int(ctx.rays_per_row), _lib.ptr(work),
+                                        wbytes, _lib.stream_ptr())
         _lib.check(rc, "ngp_render_backward")
-        return (None,) * 11 + tuple(grads)
+        return (None,) * 12 + tuple(grads)
 
 
 class NeRFRenderer(nn.Module):
@@ -192,9 +192,16 @@ class NeRFRenderer(nn.Module):
             raise NotImplementedError("per-ray bg_color tensors are not on the distillation path (bg_color=0)")
         image, weights_sum, depth, nears, fars = _RenderFn.apply(
             self._field_handle(), o, d, aabb, T, self.min_near, lin, u_coarse, u_f, stride, float(bg_color),
-            *self._field_params())
+            self._rays_per_row(N, kwargs), *self._field_params())
         return {'image': image.view(*prefix, 3), 'depth': depth.view(*prefix), 'weights_sum': weights_sum,
                 'mask': (nears < fars).view(*prefix)}
+
+    @staticmethod
+    def _rays_per_row(N, kwargs):
+        """Image width when the rays are a full row-major w x h image (opt.w / opt.h travel in **vars(opt)): a
+        locality hint for the gradient scatter only, results do not depend on it."""
+        w, h = kwargs.get('w'), kwargs.get('h')
+        return int(w) if w and h and int(w) * int(h) == N else 0
 
     def run_cuda(self, *args, **kwargs):
         raise NotImplementedError("cuda_ray=True path: SURVEY.md 8(f) 'next' row")

@@ -209,7 +209,7 @@ def test_render_backward_isolated_tight(golden):
     work = torch.empty(wb // 4, device=DEV)
     rc = lib.sf_ngp_render_backward(C.byref(f), C.byref(gs), _lib.ptr(o), _lib.ptr(dd), _lib.ptr(aabb), N, T, _lib.ptr(nears),
                                     _lib.ptr(fars), _lib.ptr(zs), _lib.ptr(ss), _lib.ptr(rs), 0.0, _lib.ptr(gi), _lib.ptr(gw),
-                                    _lib.ptr(work), wb, _lib.stream_ptr())
+                                    0, _lib.ptr(work), wb, _lib.stream_ptr())
     _lib.check(rc)
     torch.cuda.synchronize()
     names = ["encoder.embeddings"] + [f"sigma_net.net.{i}.{w}" for i in range(3) for w in ("weight", "bias")]

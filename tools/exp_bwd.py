@@ -47,7 +47,7 @@ for label, (o, d) in {"one view 128x128": ngp_ref.circle_rays(128, view=7)}.item
         if not scatter: gs.g_embeddings = 0
         def run():
             _lib.check(lib.sf_ngp_render_backward(C.byref(f), C.byref(gs), _lib.ptr(o), _lib.ptr(d), _lib.ptr(net.aabb_train), N, T, _lib.ptr(nears), _lib.ptr(fars),
-                       _lib.ptr(zs), _lib.ptr(ss), _lib.ptr(rs), 0.0, _lib.ptr(gi), _lib.ptr(gw), _lib.ptr(work), wb, _lib.stream_ptr()))
+                       _lib.ptr(zs), _lib.ptr(ss), _lib.ptr(rs), 0.0, _lib.ptr(gi), _lib.ptr(gw), 0, _lib.ptr(work), wb, _lib.stream_ptr()))
         run(); torch.cuda.synchronize(); t = time.time()
         for _ in range(5): run()
         torch.cuda.synchronize(); print(f"{label}: backward scatter={scatter}: {(time.time()-t)/5*1e3:.3f} ms")

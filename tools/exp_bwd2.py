@@ -24,7 +24,7 @@ o, dd, aabb = d(g["rays_o"]), d(g["rays_d"]), d(p["aabb_train"])
 nears, fars, zs, ss, rs = d(ref["nears"]), d(ref["fars"]), d(ref["z_sorted"]), d(ref["sigma_sorted"]), d(ref["rgb_sorted"])
 gi, gw = d(g["g_image"]), d(g["g_ws"])
 lib = _lib.lib(); wb = lib.sf_ngp_render_workspace_bytes(N, T); work = torch.zeros(wb // 4, device=dev)
-_lib.check(lib.sf_ngp_render_backward(C.byref(f), C.byref(gs), _lib.ptr(o), _lib.ptr(dd), _lib.ptr(aabb), N, T, _lib.ptr(nears), _lib.ptr(fars), _lib.ptr(zs), _lib.ptr(ss), _lib.ptr(rs), 0.0, _lib.ptr(gi), _lib.ptr(gw), _lib.ptr(work), wb, _lib.stream_ptr()))
+_lib.check(lib.sf_ngp_render_backward(C.byref(f), C.byref(gs), _lib.ptr(o), _lib.ptr(dd), _lib.ptr(aabb), N, T, _lib.ptr(nears), _lib.ptr(fars), _lib.ptr(zs), _lib.ptr(ss), _lib.ptr(rs), 0.0, _lib.ptr(gi), _lib.ptr(gw), 0, _lib.ptr(work), wb, _lib.stream_ptr()))
 torch.cuda.synchronize()
 dsig = work[:N * 128].view(N, 128).cpu(); drgb = work[N * 128:N * 128 * 4].view(N, 128, 3).cpu()
 # sigma gradient of the oracle: sigma_sorted is used by weights only; rgb_sorted by image only
