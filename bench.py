@@ -52,12 +52,12 @@ def huber(x, y, scaling=0.1):
 
 
 class HotPath:
-    def __init__(self, device, rank, world, max_thres, seed=0):
+    def __init__(self, device, rank, world, max_thres, views=1, seed=0):
         from sparsefusion_amd.nerf import NeRFNetwork, get_default_torch_ngp_opt
         from sparsefusion_amd.unet import Unet
         from sparsefusion_amd.vldm import DDPM
         from sparsefusion_amd.plms import PLMSSampler
-        self.dev, self.rank, self.world, self.max_thres = device, rank, world, max_thres
+        self.dev, self.rank, self.world, self.max_thres, self.views = device, rank, world, max_thres, views
         torch.manual_seed(seed)                                   # identical replicas on every rank
         self.opt = get_default_torch_ngp_opt()
         ngp = NeRFNetwork(self.opt)
@@ -78,10 +78,10 @@ class HotPath:
         self.plms = PLMSSampler(self.vldm, 50)
         g = torch.Generator().manual_seed(100 + rank)
         self.rays_in = pinhole_rays(128, rank % 2, 34, device)                 # one of the 2 input views
-        self.rays_novel = pinhole_rays(128, 2 + rank, 34, device)              # this rank's novel view
+        self.rays_novel = [pinhole_rays(128, 2 + rank * views + v, 34, device) for v in range(views)]   # this rank's novel views
         self.target_rgb = torch.rand(1, 3, 128, 128, generator=g).to(device)
         self.target_mask = (torch.rand(1, 1, 128, 128, generator=g) > 0.5).float().to(device)
-        self.features = torch.randn(1, 256, 32, 32, generator=g).to(device)     # cached EFT features of the novel view
+        self.features = torch.randn(views, 256, 32, 32, generator=g).to(device)  # cached EFT features of the novel views
         self.flat_grads = None
 
     # -- latent <-> pixel stand-ins for the SD-VAE (out of the north-star path)
@@ -115,9 +115,10 @@ class HotPath:
         loss.backward()
         self.sync_grads()
         self.optim.step()
-        # B: novel view + diffusion distillation
+        # B: novel view(s) + diffusion distillation (V views per GPU share one batched PLMS call)
         self.optim.zero_grad()
-        img, sil = self.render(self.rays_novel)
+        imgs, sils = zip(*[self.render(r) for r in self.rays_novel])
+        img, sil = torch.cat(imgs, 0), torch.cat(sils, 0)
         img256 = F.interpolate(img, scale_factor=2, mode='bilinear')
         sil256 = F.interpolate(sil, scale_factor=2, mode='bilinear')
         with torch.no_grad():
@@ -221,6 +222,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--max-thres", type=float, default=0.5)
+    ap.add_argument("--views-per-gpu", type=int, default=1, help="novel views distilled per GPU and step (BASELINE config 4: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -235,7 +237,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)             # RCCL over xGMI
 
-    hp = HotPath(dev, rank, world, args.max_thres)
+    hp = HotPath(dev, rank, world, args.max_thres, args.views_per_gpu)
     for _ in range(args.warmup):
         hp.step()
 
@@ -259,20 +261,20 @@ def main():
         res = {
             "metric": "novel views/sec, hot-path distillation steps (2 NGP renders fwd+bwd + %d-eval PLMS), 256^2 / 32x32 latents, "
                       "2-view synthetic hydrant" % n_evals,
-            "value": round(world / (ms_per_step * 1e-3), 4), "unit": "views/s", "n_gpus": world, "steps": args.steps,
+            "value": round(world * args.views_per_gpu / (ms_per_step * 1e-3), 4), "unit": "views/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16 MFMA operands / f32 accumulate (UNet); f32 (NGP render)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: single MI355X, 256^2 hydrant-like synthetic scene, 2 input views, "
-                                   "32x32 latent UNet (400.68M params, B=1 per GPU) + NGP render 128x128 rays x (64+64) samples; "
-                                   "max_thres=%.2f; SD-VAE/LPIPS replaced by a linear stand-in (outside north_star)" % args.max_thres,
-                       "views_per_gpu": 1, "unet_evals_per_step": n_evals, "rays_per_render": 16384,
+                                   "32x32 latent UNet (400.68M params, B=%d per GPU) + NGP render 128x128 rays x (64+64) samples; "
+                                   "max_thres=%.2f; SD-VAE/LPIPS replaced by a linear stand-in (outside north_star)" % (args.views_per_gpu, args.max_thres),
+                       "views_per_gpu": args.views_per_gpu, "unet_evals_per_step": n_evals, "rays_per_render": 16384,
                        "parallelism": "view-sharded replicas x%d, RCCL all-gather(latents) + all-reduce(NGP grads)" % world},
         }
         # component timings + roofline of the dominant kernel (after the timed region)
         res["breakdown_ms"] = {
-            "ngp_render_fwd": round(time_region(lambda: hp.render(hp.rays_novel), 5), 3),
+            "ngp_render_fwd": round(time_region(lambda: hp.render(hp.rays_novel[0]), 5), 3),
             "unet_eval_wall": round(time_region(lambda: hp.unet.forward_with_cond_scale(
-                torch.zeros(1, 4, 32, 32, device=dev), torch.zeros(1, device=dev), cond_images=hp.features), 10), 3),
+                torch.zeros(1, 4, 32, 32, device=dev), torch.zeros(1, device=dev), cond_images=hp.features[:1]), 10), 3),
         }
         res["roofline"] = unet_roofline(hp)
         if world == 1 and not args.no_cpu_baseline:
