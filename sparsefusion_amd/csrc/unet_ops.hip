@@ -49,12 +49,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // (batch, channel chunk): any GroupNorm(8) group of any (virtual) channel concat is a union of such chunks,
 // so no separate statistics pass over the tensor is needed (54 launches per eval saved).  Chunk = 32 channels
 // when every GroupNorm group is a multiple of 32 channels (the SparseFusion UNet), else 8.
-// Same-address device atomics serialise at the memory side (~50 ns each), so every (batch, chunk) cell has
-// SF_STATS_REP replicas; producers pick one by workgroup / tile id and the consumer sums them.
-#define SF_STATS_REP 8
 typedef __attribute__((address_space(1))) double gdouble;
-__device__ __forceinline__ void stats_add(double* stats, int b, int chunk, int nchunks, int rep, float s, float q) {
-  double* p = stats + (((long)b * nchunks + chunk) * SF_STATS_REP + (rep & (SF_STATS_REP - 1))) * 2;
+__device__ __forceinline__ void stats_add(double* stats, int b, int chunk, int nchunks, float s, float q) {
+  double* p = stats + ((long)b * nchunks + chunk) * 2;
   (void)__builtin_amdgcn_global_atomic_fadd_f64((gdouble*)p, (double)s);
   (void)__builtin_amdgcn_global_atomic_fadd_f64((gdouble*)(p + 1), (double)q);
 }
@@ -290,7 +287,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
         if (writer && m0 < M) {
           const int n0 = (nt * WN + ni) * 16 + (lane & 8);
           const int ch = a.pixshuf ? (a.co_off + (n0 >> 2)) : (a.co_off + n0);
-          stats_add(a.stats, m0 / (a.Ho * a.Wo), ch / a.chunk, a.ldc / a.chunk, mt * WM + mi, st_s, st_q);
+          stats_add(a.stats, m0 / (a.Ho * a.Wo), ch / a.chunk, a.ldc / a.chunk, st_s, st_q);
         }
       }
     }
@@ -304,15 +301,9 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
                                                        const float* __restrict__ resid, float* __restrict__ out, int M,
                                                        int Cout, int npad, int groups, int ldc, int co_off, int accum,
                                                        double* __restrict__ stats, int HW, int chunk) {
-  // With statistics the launcher picks gridDim.x * 256 as a multiple of Cout: a thread keeps its channel (and its
-  // chunk) across the grid-stride loop and accumulates its partial sums in registers; they are flushed (reduced over
-  // the `chunk` lanes that share the chunk, one atomic pair per lane group) when the batch index changes and at the end.
   const long total = (long)M * Cout;
-  float acc_s = 0.0f, acc_q = 0.0f;
-  int acc_b = -1, acc_n = 0;
-  const long iters = (total + (long)gridDim.x * 256 - 1) / ((long)gridDim.x * 256);
-  for (long it = 0; it < iters; ++it) {
-    const long i = (it * gridDim.x + blockIdx.x) * 256L + threadIdx.x;
+  for (long base = blockIdx.x * 256L; base < total; base += (long)gridDim.x * 256) {
+    const long i = base + threadIdx.x;
     const bool live = i < total;
     float v = 0.0f;
     int m = 0, n = 0;
@@ -326,21 +317,10 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
       out[o] = v;
     }
     if (stats) {
-      const int b = live ? m / HW : acc_b;
-      // batch change is uniform over the `chunk` lanes of a group (they share the row), so the shuffle is convergent
-      if (b != acc_b && acc_b >= 0) {
-        const float s = chunk == 32 ? group_sum<32>(acc_s) : group_sum<8>(acc_s);
-        const float q = chunk == 32 ? group_sum<32>(acc_q) : group_sum<8>(acc_q);
-        if ((threadIdx.x & (chunk - 1)) == 0) stats_add(stats, acc_b, (co_off + acc_n) / chunk, ldc / chunk, blockIdx.x, s, q);
-        acc_s = acc_q = 0.0f;
-      }
-      if (live) { acc_b = b; acc_n = n; acc_s += v; acc_q = fmaf(v, v, acc_q); }
+      const float s = chunk == 32 ? group_sum<32>(v) : group_sum<8>(v);
+      const float q = chunk == 32 ? group_sum<32>(v * v) : group_sum<8>(v * v);
+      if ((threadIdx.x & (chunk - 1)) == 0 && live) stats_add(stats, m / HW, (co_off + n) / chunk, ldc / chunk, s, q);
     }
-  }
-  if (stats && acc_b >= 0) {
-    const float s = chunk == 32 ? group_sum<32>(acc_s) : group_sum<8>(acc_s);
-    const float q = chunk == 32 ? group_sum<32>(acc_q) : group_sum<8>(acc_q);
-    if ((threadIdx.x & (chunk - 1)) == 0) stats_add(stats, acc_b, (co_off + acc_n) / chunk, ldc / chunk, blockIdx.x, s, q);
   }
 }
 
@@ -373,13 +353,13 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ s1, 
     const int b = threadIdx.x / 8, g = threadIdx.x % 8;
     double s = 0.0, q = 0.0;
     for (int c = g * Cg; c < (g + 1) * Cg; c += chunk) {  // the group as a union of producer chunks
-      double cs = 0.0, cq = 0.0;
-      const double* p = (c < C1) ? st1 + ((long)b * (C1 / chunk) + c / chunk) * SF_STATS_REP * 2
-                                 : st2 + ((long)b * (C2 / chunk) + (c - C1) / chunk) * SF_STATS_REP * 2;
-#pragma unroll
-      for (int r = 0; r < SF_STATS_REP; ++r) { cs += p[2 * r]; cq += p[2 * r + 1]; }
-      if (c < C1) { s += cs; q += cq; }
-      else { s += cs * (double)s2_scale; q += cq * (double)s2_scale * (double)s2_scale; }
+      if (c < C1) {
+        const double* p = st1 + ((long)b * (C1 / chunk) + c / chunk) * 2;
+        s += p[0]; q += p[1];
+      } else {
+        const double* p = st2 + ((long)b * (C2 / chunk) + (c - C1) / chunk) * 2;
+        s += p[0] * (double)s2_scale; q += p[1] * (double)s2_scale * (double)s2_scale;
+      }
     }
     const double inv_n = 1.0 / ((double)HW * Cg);
     const double m = s * inv_n;
@@ -459,7 +439,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in,
       if (stats) {                                   // `chunk` consecutive lanes share one chunk (C % chunk == 0)
         const float s = chunk == 32 ? group_sum<32>(y) : group_sum<8>(y);
         const float q = chunk == 32 ? group_sum<32>(y * y) : group_sum<8>(y * y);
-        if ((threadIdx.x & (chunk - 1)) == 0) stats_add(stats, row / rows_per_batch, c / chunk, C / chunk, row, s, q);
+        if ((threadIdx.x & (chunk - 1)) == 0) stats_add(stats, row / rows_per_batch, c / chunk, C / chunk, s, q);
       }
     }
   }
@@ -634,18 +614,12 @@ __global__ __launch_bounds__(256) void k_gca_pool(const float* __restrict__ h, c
 __global__ __launch_bounds__(256) void k_gate_res(const float* __restrict__ h, const float* __restrict__ gate,
                                                   const float* __restrict__ res, float* __restrict__ out, int B, int HW,
                                                   int C, double* __restrict__ stats, int chunk) {
-  // gridDim.x * 1024 is a multiple of C (launcher): a thread keeps its 4 channels over the grid-stride loop and
-  // accumulates its statistics in registers, flushed when the batch index changes and at the end.
   const long n4 = (long)B * HW * C / 4;
-  float acc_s = 0.0f, acc_q = 0.0f;
-  int acc_b = -1, acc_c = 0;
-  const int lanes = chunk / 4;                        // lanes that share one chunk
-  const long iters = (n4 + (long)gridDim.x * 256 - 1) / ((long)gridDim.x * 256);
-  for (long it = 0; it < iters; ++it) {
-    const long i = (it * gridDim.x + blockIdx.x) * 256L + threadIdx.x;
+  for (long base = blockIdx.x * 256L; base < n4; base += (long)gridDim.x * 256) {
+    const long i = base + threadIdx.x;
     const bool live = i < n4;
     float s = 0.0f, q = 0.0f;
-    int c = acc_c, b = acc_b;
+    int c = 0, b = 0;
     if (live) {
       const long e = i * 4;
       c = (int)(e % C);
@@ -658,20 +632,10 @@ __global__ __launch_bounds__(256) void k_gate_res(const float* __restrict__ h, c
       s = (o[0] + o[1]) + (o[2] + o[3]);
       q = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
     }
-    if (stats) {
-      if (b != acc_b && acc_b >= 0) {
-        const float fs = lanes == 8 ? group_sum<8>(acc_s) : group_sum<2>(acc_s);
-        const float fq = lanes == 8 ? group_sum<8>(acc_q) : group_sum<2>(acc_q);
-        if ((threadIdx.x & (lanes - 1)) == 0) stats_add(stats, acc_b, acc_c / chunk, C / chunk, blockIdx.x, fs, fq);
-        acc_s = acc_q = 0.0f;
-      }
-      if (live) { acc_b = b; acc_c = c; acc_s += s; acc_q += q; }
+    if (stats) {                                     // chunk/4 lanes x 4 channels = one chunk of one pixel
+      if (chunk == 32) { s = group_sum<8>(s); q = group_sum<8>(q); } else { s = group_sum<2>(s); q = group_sum<2>(q); }
+      if ((threadIdx.x & (chunk / 4 - 1)) == 0 && live) stats_add(stats, b, c / chunk, C / chunk, s, q);
     }
-  }
-  if (stats && acc_b >= 0) {
-    const float fs = lanes == 8 ? group_sum<8>(acc_s) : group_sum<2>(acc_s);
-    const float fq = lanes == 8 ? group_sum<8>(acc_q) : group_sum<2>(acc_q);
-    if ((threadIdx.x & (lanes - 1)) == 0) stats_add(stats, acc_b, acc_c / chunk, C / chunk, blockIdx.x, fs, fq);
   }
 }
 __global__ __launch_bounds__(256) void k_pack_in(const float* __restrict__ cond, const float* __restrict__ x,
@@ -770,13 +734,7 @@ static int run_conv(const sf_op& op, hipStream_t st) {
   SF_CHECK_LAUNCH("conv_igemm");
   if (a.groups > 1) {
     if (!a.ws) SF_FAIL(SF_ERR_INVALID, "conv: split-K needs a workspace");
-    uint32_t rgrid = sf_grid_cap(sf_div_up((long)M * a.Cout, 256));
-    if (final_stats) {                               // few workgroups, each a whole number of rows per sweep
-      const uint32_t unit = a.Cout % 256 == 0 ? a.Cout / 256 : a.Cout;     // blocks per row multiple
-      rgrid = rgrid > 64 ? 64 : rgrid;
-      rgrid = (rgrid + unit - 1) / unit * unit;
-    }
-    k_splitk_reduce<<<rgrid, 256, 0, st>>>(a.ws, a.bias, a.resid, a.out, M, a.Cout, a.npad,
+    k_splitk_reduce<<<sf_grid_cap(sf_div_up((long)M * a.Cout, 256)), 256, 0, st>>>(a.ws, a.bias, a.resid, a.out, M, a.Cout, a.npad,
                                                                                   a.groups, a.ldc, a.co_off, a.accum, final_stats,
                                                                                   a.Ho * a.Wo, a.chunk);
     SF_CHECK_LAUNCH("splitk_reduce");
@@ -854,13 +812,7 @@ static int run_eltwise(const sf_op& op, hipStream_t st) {
       const long n4 = (long)op.i[0] * op.i[1] * op.i[2] / 4;
       const int gr_chunk = op.i[3] == 8 ? 8 : 32;
       if (op.p[4] && op.i[2] % gr_chunk) SF_FAIL(SF_ERR_INVALID, "gate_res: statistics need C %% chunk == 0");
-      uint32_t ggrid = sf_grid_cap(sf_div_up(n4, 256));
-      if (op.p[4]) {
-        const uint32_t unit = op.i[2] % 1024 == 0 ? op.i[2] / 1024 : op.i[2];
-        ggrid = ggrid > 64 ? 64 : ggrid;
-        ggrid = (ggrid + unit - 1) / unit * unit;
-      }
-      k_gate_res<<<ggrid, 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1],
+      k_gate_res<<<sf_grid_cap(sf_div_up(n4, 256)), 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1],
                                                                  (const float*)op.p[2], (float*)op.p[3], op.i[0], op.i[1], op.i[2],
                                                                  (double*)op.p[4], gr_chunk);
       break;

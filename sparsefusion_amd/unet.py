@@ -20,7 +20,6 @@ from . import _lib
 
 OP_CONV, OP_GN_ACT, OP_LN, OP_GEMV, OP_ATTN, OP_GCA_POOL, OP_ELTWISE, OP_MEMSET, OP_TIME_EMB = range(1, 10)
 SKIP_SCALE = 2 ** -0.5            # scale_skip_connection (imagen_pytorch.py:1283)
-STATS_REP = 8                     # replicas of every GroupNorm statistics cell (SF_STATS_REP in unet_ops.hip)
 
 
 def _cast_tuple(v, n):
@@ -182,7 +181,7 @@ class _Plan:
         t = self.f32(rows, C, HW)
         ch = self.u.stats_chunk
         if C % ch == 0 and HW % 16 == 0:
-            t.stats = self.zero.alloc(self.B * (C // ch) * 16 * STATS_REP)
+            t.stats = self.zero.alloc(self.B * (C // ch) * 16)
         return t
 
     def f32(self, rows, C, HW=None):
