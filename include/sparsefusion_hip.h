@@ -169,7 +169,7 @@ enum {
 typedef struct {
   int32_t type;
   int32_t flags;
-  void* p[10];
+  void* p[8];
   int32_t i[16];
   float f[4];
 } sf_op;

@@ -45,22 +45,6 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
-// GroupNorm statistics are emitted by the PRODUCER of a tensor as f64 (sum, sum of squares) per
-// (batch, channel chunk): any GroupNorm(8) group of any (virtual) channel concat is a union of such chunks,
-// so no separate statistics pass over the tensor is needed (54 launches per eval saved).  Chunk = 32 channels
-// when every GroupNorm group is a multiple of 32 channels (the SparseFusion UNet), else 8.
-typedef __attribute__((address_space(1))) double gdouble;
-__device__ __forceinline__ void stats_add(double* stats, int b, int chunk, int nchunks, float s, float q) {
-  double* p = stats + ((long)b * nchunks + chunk) * 2;
-  (void)__builtin_amdgcn_global_atomic_fadd_f64((gdouble*)p, (double)s);
-  (void)__builtin_amdgcn_global_atomic_fadd_f64((gdouble*)(p + 1), (double)q);
-}
-template <int WIDTH>
-__device__ __forceinline__ float group_sum(float v) {      // sum over aligned groups of WIDTH lanes
-#pragma unroll
-  for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
@@ -72,8 +56,7 @@ __device__ __forceinline__ float wave_max(float v) {
 //   p[0] in (NHWC, bf16 or f32 by flag), p[1] packed weights (bf16), p[2] bias f32 [Cout] or NULL,
 //   p[3] out f32, p[4] residual f32 (same indexing as out) or NULL
 //   p[5] split-K workspace f32 [groups][M][Npad] (groups > 1 only)
-//   p[6] chunk statistics f64 [B][ldc/32][2] to emit for the finished output (final writer only), or NULL
-//   i[0..] = B, H, W, Cin_pad, Ho, Wo, Cout, ldc, co_off, kh, kw, stride, pad, ksplit_groups, tile (WM*16+WN), stats chunk (8|32)
+//   i[0..] = B, H, W, Cin_pad, Ho, Wo, Cout, ldc, co_off, kh, kw, stride, pad, ksplit_groups, tile (WM*16+WN), 0
 //   flags: 1 = A is f32, 2 = epilogue SiLU + PixelShuffle(2) (no split-K), 4 = accumulate into out (out += ...)
 // No atomics: with groups == 1 every output element is owned by one wave (plain store / read-modify-write);
 // with groups > 1 each K-slice group stores its partial tile to the workspace and k_splitk_reduce sums them
@@ -83,8 +66,8 @@ __device__ __forceinline__ float wave_max(float v) {
 //   element (lane, j) = W[n = n_frag*16 + (lane&15)][tap][c = cc*32 + 8*(lane>>4) + j].
 // ---------------------------------------------------------------------------------------------
 struct ConvArgs {
-  const void* in; const bf16x8* w; const float* bias; float* out; const float* resid; float* ws; double* stats;
-  int accum, npad, chunk;
+  const void* in; const bf16x8* w; const float* bias; float* out; const float* resid; float* ws;
+  int accum, npad;
   int B, H, W, Cin, Ho, Wo, Cout, ldc, co_off, kh, kw, stride, pad, groups;
   int KS, cchunks, m_frags, n_frags, m_tiles, n_tiles, steps_per_wave;
   int pixshuf;
@@ -250,13 +233,12 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
         }
         continue;
       }
-      const bool ncol = n < a.Cout;
-      const float bv = (ncol && a.bias) ? a.bias[n] : 0.0f;
-      float st_s = 0.0f, st_q = 0.0f;
+      if (n >= a.Cout) continue;
+      const float bv = a.bias ? a.bias[n] : 0.0f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = (mt * WM + mi) * 16 + (lane >> 4) * 4 + r;
-        if (m >= M || !ncol) continue;
+        if (m >= M) continue;
         float v = acc[mi][ni][r] + bv;
         if (a.pixshuf) {
           // out[b, 2*oy+i, 2*ox+j, c] = silu(conv[b, oy, ox, c*4 + i*2 + j])   (PixelShuffle(2), :578-606)
@@ -272,55 +254,24 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
           if (a.accum) v += a.out[o];
           a.out[o] = v;
         }
-        st_s += v;
-        st_q = fmaf(v, v, st_q);
-      }
-      if (a.stats) {         // a fragment = 16 rows of one image x 16 channels: one chunk (>= 16 ch) or two 8-channel chunks
-#pragma unroll
-        for (int o = 1; o <= 32; o <<= 1) {
-          if (o == 8 && a.chunk == 8 && !a.pixshuf) continue;     // keep the two 8-lane halves apart
-          st_s += __shfl_xor(st_s, o, 64);
-          st_q += __shfl_xor(st_q, o, 64);
-        }
-        const int m0 = (mt * WM + mi) * 16;
-        const bool writer = (a.chunk == 8 && !a.pixshuf) ? ((lane & 55) == 0) : (lane == 0);     // lanes 0 (and 8)
-        if (writer && m0 < M) {
-          const int n0 = (nt * WN + ni) * 16 + (lane & 8);
-          const int ch = a.pixshuf ? (a.co_off + (n0 >> 2)) : (a.co_off + n0);
-          stats_add(a.stats, m0 / (a.Ho * a.Wo), ch / a.chunk, a.ldc / a.chunk, st_s, st_q);
-        }
       }
     }
   }
 }
 
 // out[m][co_off+n] (+)= bias[n] + resid + sum_g ws[g][m][n]      (second half of a split-K conv)
-// Optionally emits the GroupNorm chunk statistics of the finished tensor (Cout % 32 == 0 then: 32 consecutive
-// lanes share one (row, chunk)).
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ ws, const float* __restrict__ bias,
                                                        const float* __restrict__ resid, float* __restrict__ out, int M,
-                                                       int Cout, int npad, int groups, int ldc, int co_off, int accum,
-                                                       double* __restrict__ stats, int HW, int chunk) {
+                                                       int Cout, int npad, int groups, int ldc, int co_off, int accum) {
   const long total = (long)M * Cout;
-  for (long base = blockIdx.x * 256L; base < total; base += (long)gridDim.x * 256) {
-    const long i = base + threadIdx.x;
-    const bool live = i < total;
-    float v = 0.0f;
-    int m = 0, n = 0;
-    if (live) {
-      m = (int)(i / Cout); n = (int)(i - (long)m * Cout);
-      v = bias ? bias[n] : 0.0f;
-      for (int g = 0; g < groups; ++g) v += ws[((long)g * M + m) * npad + n];
-      const long o = (long)m * ldc + co_off + n;
-      if (resid) v += resid[o];
-      if (accum) v += out[o];
-      out[o] = v;
-    }
-    if (stats) {
-      const float s = chunk == 32 ? group_sum<32>(v) : group_sum<8>(v);
-      const float q = chunk == 32 ? group_sum<32>(v * v) : group_sum<8>(v * v);
-      if ((threadIdx.x & (chunk - 1)) == 0 && live) stats_add(stats, m / HW, (co_off + n) / chunk, ldc / chunk, s, q);
-    }
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int m = (int)(i / Cout), n = (int)(i - (long)m * Cout);
+    float v = bias ? bias[n] : 0.0f;
+    for (int g = 0; g < groups; ++g) v += ws[((long)g * M + m) * npad + n];
+    const long o = (long)m * ldc + co_off + n;
+    if (resid) v += resid[o];
+    if (accum) v += out[o];
+    out[o] = v;
   }
 }
 
@@ -329,11 +280,12 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
 // x*(scale+1)+shift, SiLU, -> bf16 NHWC; optional raw bf16 copy of the concat.
 //   p[0] src1 f32 [B,HW,C1], p[1] src2 f32 [B,HW,C2] or NULL, p[2] gamma [C], p[3] beta [C],
 //   p[4] scale_shift f32 (row b at p[4] + b*ss_stride: scale[C] then shift[C]) or NULL,
-//   p[5] out bf16 [B,HW,C], p[6] raw bf16 [B,HW,C] or NULL,
-//   p[7] / p[8] chunk statistics of src1 / src2: f64 [B][C/32][2] = (sum, sum of squares) per 32-channel chunk,
-//   emitted by the kernels that produced the sources (conv epilogue, split-K reduce, gate_res, layernorm)
-//   i = B, HW, C1, C2, ss_stride, chunk (8|32) ; f = eps, src2_scale ; flags: 1 = no SiLU.   One elementwise launch.
+//   p[5] out bf16 [B,HW,C], p[6] raw bf16 [B,HW,C] or NULL, p[7] stats f64 [B*8][2], zeroed by the caller
+//   i = B, HW, C1, C2, ss_stride ; f = eps, src2_scale ; flags: 1 = no SiLU
+// Two launches so that a B=1 eval still fills the chip: k_gn_stats (grid B*8*slices; per-block fp32 partial
+// sums, combined in f64 with one L2 atomic pair per block) and k_gn_apply (pure elementwise).
 // ---------------------------------------------------------------------------------------------
+#define GN_CHUNKS_PER_BLOCK 2048     // float4 chunks per stats workgroup (256 threads x 8)
 __device__ __forceinline__ f32x4 gn_load(const float* __restrict__ s1, const float* __restrict__ s2, int b, int HW, int C1,
                                          int C2, int p, int c, float s2_scale) {
   if (c < C1) return *reinterpret_cast<const f32x4*>(s1 + ((long)b * HW + p) * C1 + c);
@@ -341,40 +293,50 @@ __device__ __forceinline__ f32x4 gn_load(const float* __restrict__ s1, const flo
   return v * s2_scale;
 }
 
+__global__ __launch_bounds__(256) void k_gn_stats(const float* __restrict__ s1, const float* __restrict__ s2,
+                                                  double* __restrict__ stats, int HW, int C1, int C2, int slices,
+                                                  float s2_scale) {
+  __shared__ double red[8];
+  const int C = C1 + C2, Cg = C / 8, cg4 = Cg / 4;
+  const int bg = blockIdx.x / slices, sl = blockIdx.x % slices;
+  const int b = bg / 8, g = bg % 8;
+  const int chunks = HW * cg4;
+  const int per = (chunks + slices - 1) / slices;
+  const int c0 = sl * per, c1 = min(chunks, c0 + per);
+  float s = 0.0f, q = 0.0f;
+  for (int ch = c0 + threadIdx.x; ch < c1; ch += 256) {
+    const int p = ch / cg4, c = g * Cg + (ch - p * cg4) * 4;
+    const f32x4 v = gn_load(s1, s2, b, HW, C1, C2, p, c, s2_scale);
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+    q = fmaf(v[0], v[0], q); q = fmaf(v[1], v[1], q); q = fmaf(v[2], v[2], q); q = fmaf(v[3], v[3], q);
+  }
+  double ds = (double)wave_sum(s), dq = (double)wave_sum(q);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { red[wv] = ds; red[4 + wv] = dq; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    typedef __attribute__((address_space(1))) double gdouble;
+    (void)__builtin_amdgcn_global_atomic_fadd_f64((gdouble*)(stats + bg * 2), red[0] + red[1] + red[2] + red[3]);
+    (void)__builtin_amdgcn_global_atomic_fadd_f64((gdouble*)(stats + bg * 2 + 1), red[4] + red[5] + red[6] + red[7]);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ s1, const float* __restrict__ s2,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                  const float* __restrict__ ss, const double* __restrict__ st1,
-                                                  const double* __restrict__ st2, __bf16* __restrict__ out,
-                                                  __bf16* __restrict__ raw, int B, int HW, int C1, int C2, int ss_stride,
-                                                  float eps, float s2_scale, int no_silu, int chunk) {
-  __shared__ float g_mean[256], g_rstd[256];          // B * 8 groups, B <= 32
+                                                  const float* __restrict__ ss, const double* __restrict__ stats,
+                                                  __bf16* __restrict__ out, __bf16* __restrict__ raw, int B, int HW, int C1,
+                                                  int C2, int ss_stride, float eps, float s2_scale, int no_silu) {
   const int C = C1 + C2, Cg = C / 8, c4 = C / 4;
-  if ((int)threadIdx.x < B * 8) {
-    const int b = threadIdx.x / 8, g = threadIdx.x % 8;
-    double s = 0.0, q = 0.0;
-    for (int c = g * Cg; c < (g + 1) * Cg; c += chunk) {  // the group as a union of producer chunks
-      if (c < C1) {
-        const double* p = st1 + ((long)b * (C1 / chunk) + c / chunk) * 2;
-        s += p[0]; q += p[1];
-      } else {
-        const double* p = st2 + ((long)b * (C2 / chunk) + (c - C1) / chunk) * 2;
-        s += p[0] * (double)s2_scale; q += p[1] * (double)s2_scale * (double)s2_scale;
-      }
-    }
-    const double inv_n = 1.0 / ((double)HW * Cg);
-    const double m = s * inv_n;
-    const double var = q * inv_n - m * m;
-    g_mean[threadIdx.x] = (float)m;
-    g_rstd[threadIdx.x] = rsqrtf((float)(var > 0.0 ? var : 0.0) + eps);
-  }
-  __syncthreads();
   const long total = (long)B * HW * c4;
+  const double inv_n = 1.0 / ((double)HW * Cg);
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = (int)(i % c4) * 4;
     const long bp = i / c4;
     const int p = (int)(bp % HW), b = (int)(bp / HW);
     const int g = c / Cg;
-    const float mean = g_mean[b * 8 + g], rstd = g_rstd[b * 8 + g];
+    const double m = stats[(b * 8 + g) * 2] * inv_n;
+    const double var = stats[(b * 8 + g) * 2 + 1] * inv_n - m * m;
+    const float mean = (float)m, rstd = rsqrtf((float)(var > 0.0 ? var : 0.0) + eps);
     const f32x4 v = gn_load(s1, s2, b, HW, C1, C2, p, c, s2_scale);
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
     bf16x4 o, r;
@@ -393,14 +355,13 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ s1, 
 
 // ---------------------------------------------------------------------------------------------
 // LN: per-row normalisation over C (biased variance), one 256-thread workgroup per row.
-//   p[0] in f32 [R,C], p[1] gain [C], p[2] bias [C] or NULL, p[3] out (bf16 or f32), p[4] residual f32 or NULL,
-//   p[5] chunk statistics of the (f32) output to emit, or NULL
-//   i = R, C, rows_per_batch, chunk (8|32) ; f = eps ; flags: 1 = GELU(x) before normalising, 2 = f32 output (+ residual), else bf16 output
+//   p[0] in f32 [R,C], p[1] gain [C], p[2] bias [C] or NULL, p[3] out (bf16 or f32), p[4] residual f32 or NULL
+//   i = R, C ; f = eps ; flags: 1 = GELU(x) before normalising, 2 = f32 output (+ residual), else bf16 output
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in, const float* __restrict__ gain,
                                                    const float* __restrict__ bias, void* __restrict__ out,
                                                    const float* __restrict__ resid, int R, int C, float eps, int pre_gelu,
-                                                   int out_f32, double* __restrict__ stats, int rows_per_batch, int chunk) {
+                                                   int out_f32) {
   __shared__ float red[8];
   const int row = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* x = in + (long)row * C;
@@ -435,11 +396,6 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in,
         reinterpret_cast<float*>(out)[(long)row * C + c] = y;
       } else {
         reinterpret_cast<__bf16*>(out)[(long)row * C + c] = (__bf16)y;
-      }
-      if (stats) {                                   // `chunk` consecutive lanes share one chunk (C % chunk == 0)
-        const float s = chunk == 32 ? group_sum<32>(y) : group_sum<8>(y);
-        const float q = chunk == 32 ? group_sum<32>(y * y) : group_sum<8>(y * y);
-        if ((threadIdx.x & (chunk - 1)) == 0) stats_add(stats, row / rows_per_batch, c / chunk, C / chunk, s, q);
       }
     }
   }
@@ -605,37 +561,23 @@ __global__ __launch_bounds__(256) void k_gca_pool(const float* __restrict__ h, c
 
 // ---------------------------------------------------------------------------------------------
 // ELTWISE (flags = mode):
-//   1 GATE_RES   out[b,p,c] = h[b,p,c]*gate[b,c] + res[b,p,c]   p0 h, p1 gate [B,C], p2 res or NULL (then out holds it), p3 out,
-//                p4 chunk statistics to emit or NULL ; i = B,HW,C,chunk
+//   1 GATE_RES   out[b,p,c] = h[b,p,c]*gate[b,c] + res[b,p,c]   p0 h, p1 gate [B,C], p2 res or NULL (then out holds it), p3 out ; i = B,HW,C
 //   2 PACK_IN    out NHWC f32 [B,HW,Cp] = concat(cond NCHW [B,Cc,HW], x NCHW [B,Cx,HW]), zero pad ; p0 cond, p1 x, p3 out ; i = B,HW,Cc,Cx,Cp
 //   3 UNPACK_OUT out NCHW [B,C,HW] = in NHWC [B,HW,ldi] first C channels ; p0 in, p3 out ; i = B,HW,C,ldi
 //   4 ADD        out[i] += p0[i] ; i[0] = n
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gate_res(const float* __restrict__ h, const float* __restrict__ gate,
                                                   const float* __restrict__ res, float* __restrict__ out, int B, int HW,
-                                                  int C, double* __restrict__ stats, int chunk) {
+                                                  int C) {
   const long n4 = (long)B * HW * C / 4;
-  for (long base = blockIdx.x * 256L; base < n4; base += (long)gridDim.x * 256) {
-    const long i = base + threadIdx.x;
-    const bool live = i < n4;
-    float s = 0.0f, q = 0.0f;
-    int c = 0, b = 0;
-    if (live) {
-      const long e = i * 4;
-      c = (int)(e % C);
-      b = (int)(e / ((long)HW * C));
-      const f32x4 hv = *reinterpret_cast<const f32x4*>(h + e);
-      const f32x4 gv = *reinterpret_cast<const f32x4*>(gate + (long)b * C + c);
-      const f32x4 rv = *reinterpret_cast<const f32x4*>((res ? res : out) + e);
-      const f32x4 o = hv * gv + rv;
-      *reinterpret_cast<f32x4*>(out + e) = o;
-      s = (o[0] + o[1]) + (o[2] + o[3]);
-      q = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
-    }
-    if (stats) {                                     // chunk/4 lanes x 4 channels = one chunk of one pixel
-      if (chunk == 32) { s = group_sum<8>(s); q = group_sum<8>(q); } else { s = group_sum<2>(s); q = group_sum<2>(q); }
-      if ((threadIdx.x & (chunk / 4 - 1)) == 0 && live) stats_add(stats, b, c / chunk, C / chunk, s, q);
-    }
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long e = i * 4;
+    const int c = (int)(e % C);
+    const int b = (int)(e / ((long)HW * C));
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(h + e);
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(gate + (long)b * C + c);
+    const f32x4 rv = *reinterpret_cast<const f32x4*>((res ? res : out) + e);
+    *reinterpret_cast<f32x4*>(out + e) = hv * gv + rv;
   }
 }
 __global__ __launch_bounds__(256) void k_pack_in(const float* __restrict__ cond, const float* __restrict__ x,
@@ -691,13 +633,12 @@ static void launch_conv(const ConvArgs& a, bool a_fp32, int blocks, hipStream_t 
 static int run_conv(const sf_op& op, hipStream_t st) {
   ConvArgs a;
   a.in = op.p[0]; a.w = (const bf16x8*)op.p[1]; a.bias = (const float*)op.p[2]; a.out = (float*)op.p[3];
-  a.resid = (const float*)op.p[4]; a.ws = (float*)op.p[5]; a.stats = (double*)op.p[6];
+  a.resid = (const float*)op.p[4]; a.ws = (float*)op.p[5];
   a.accum = (op.flags & 4) ? 1 : 0;
   a.B = op.i[0]; a.H = op.i[1]; a.W = op.i[2]; a.Cin = op.i[3]; a.Ho = op.i[4]; a.Wo = op.i[5]; a.Cout = op.i[6];
   a.ldc = op.i[7]; a.co_off = op.i[8]; a.kh = op.i[9]; a.kw = op.i[10]; a.stride = op.i[11]; a.pad = op.i[12];
   a.groups = op.i[13] > 0 ? op.i[13] : 1;
   const int tile = op.i[14];
-  a.chunk = op.i[15] == 8 ? 8 : 32;
   const int WM = tile / 16, WN = tile % 16;
   a.pixshuf = (op.flags & 2) ? 1 : 0;
   if (a.Cin % 32) SF_FAIL(SF_ERR_INVALID, "conv: Cin_pad must be a multiple of 32");
@@ -714,11 +655,6 @@ static int run_conv(const sf_op& op, hipStream_t st) {
   a.steps_per_wave = (a.KS + a.groups * 4 - 1) / (a.groups * 4);
   const int blocks = a.m_tiles * a.n_tiles * a.groups;
   const bool f32 = (op.flags & 1) != 0;
-  double* final_stats = a.stats;
-  if (final_stats && ((a.Ho * a.Wo) % 16 || a.ldc % a.chunk || a.co_off % a.chunk ||
-                      (a.pixshuf ? (a.Cout / 4) % a.chunk : a.Cout % a.chunk)))
-    SF_FAIL(SF_ERR_INVALID, "conv: chunk statistics need HW %% 16 == 0 and chunk-aligned channels");
-  if (a.groups > 1) a.stats = nullptr;             // the split-K reduce kernel is the final writer
   switch (tile) {
     case 1 * 16 + 1: launch_conv<1, 1>(a, f32, blocks, st); break;
     case 1 * 16 + 2: launch_conv<1, 2>(a, f32, blocks, st); break;
@@ -735,8 +671,7 @@ static int run_conv(const sf_op& op, hipStream_t st) {
   if (a.groups > 1) {
     if (!a.ws) SF_FAIL(SF_ERR_INVALID, "conv: split-K needs a workspace");
     k_splitk_reduce<<<sf_grid_cap(sf_div_up((long)M * a.Cout, 256)), 256, 0, st>>>(a.ws, a.bias, a.resid, a.out, M, a.Cout, a.npad,
-                                                                                  a.groups, a.ldc, a.co_off, a.accum, final_stats,
-                                                                                  a.Ho * a.Wo, a.chunk);
+                                                                                  a.groups, a.ldc, a.co_off, a.accum);
     SF_CHECK_LAUNCH("splitk_reduce");
   }
   return SF_OK;
@@ -745,14 +680,16 @@ static int run_conv(const sf_op& op, hipStream_t st) {
 static int run_gn(const sf_op& op, hipStream_t st) {
   const int B = op.i[0], HW = op.i[1], C1 = op.i[2], C2 = op.i[3];
   const int C = C1 + C2;
-  const int chunk = op.i[5] == 8 ? 8 : 32;
-  if (C % (8 * chunk) || C1 % chunk || C2 % chunk || B > 32 || !op.p[7] || (C2 && !op.p[8]))
-    SF_FAIL(SF_ERR_INVALID, "gn_act: unsupported shape B=%d HW=%d C=%d+%d (or missing chunk statistics)", B, HW, C1, C2);
+  if (C % 32 || C1 % 4 || !op.p[7]) SF_FAIL(SF_ERR_INVALID, "gn_act: unsupported shape HW=%d C=%d (or missing stats buffer)", HW, C);
+  const int chunks = HW * (C / 8) / 4;
+  const int slices = (chunks + GN_CHUNKS_PER_BLOCK - 1) / GN_CHUNKS_PER_BLOCK;
+  k_gn_stats<<<B * 8 * slices, 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (double*)op.p[7], HW, C1, C2, slices,
+                                             op.f[1]);
+  SF_CHECK_LAUNCH("gn_stats");
   const long total = (long)B * HW * (C / 4);
   k_gn_apply<<<sf_grid_cap(sf_div_up(total, 256)), 256, 0, st>>>(
       (const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const float*)op.p[4],
-      (const double*)op.p[7], (const double*)op.p[8], (__bf16*)op.p[5], (__bf16*)op.p[6], B, HW, C1, C2, op.i[4], op.f[0],
-      op.f[1], op.flags & 1, chunk);
+      (const double*)op.p[7], (__bf16*)op.p[5], (__bf16*)op.p[6], B, HW, C1, C2, op.i[4], op.f[0], op.f[1], op.flags & 1);
   SF_CHECK_LAUNCH("gn_apply");
   return SF_OK;
 }
@@ -760,11 +697,8 @@ static int run_gn(const sf_op& op, hipStream_t st) {
 static int run_ln(const sf_op& op, hipStream_t st) {
   const int R = op.i[0], C = op.i[1];
   if (C % 64 || C > 2048) SF_FAIL(SF_ERR_INVALID, "layernorm: C must be a multiple of 64 and <= 2048");
-  const int ln_chunk = op.i[3] == 8 ? 8 : 32;
-  if (op.p[5] && (!(op.flags & 2) || C % 256 || op.i[2] <= 0)) SF_FAIL(SF_ERR_INVALID, "layernorm: statistics need f32 output, C %% 256 == 0, rows_per_batch");
   k_layernorm<<<R, 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3],
-                                 (const float*)op.p[4], R, C, op.f[0], op.flags & 1, (op.flags & 2) ? 1 : 0, (double*)op.p[5],
-                                 op.i[2], ln_chunk);
+                                              (const float*)op.p[4], R, C, op.f[0], op.flags & 1, (op.flags & 2) ? 1 : 0);
   SF_CHECK_LAUNCH("layernorm");
   return SF_OK;
 }
@@ -810,11 +744,8 @@ static int run_eltwise(const sf_op& op, hipStream_t st) {
   switch (op.flags) {
     case 1: {
       const long n4 = (long)op.i[0] * op.i[1] * op.i[2] / 4;
-      const int gr_chunk = op.i[3] == 8 ? 8 : 32;
-      if (op.p[4] && op.i[2] % gr_chunk) SF_FAIL(SF_ERR_INVALID, "gate_res: statistics need C %% chunk == 0");
       k_gate_res<<<sf_grid_cap(sf_div_up(n4, 256)), 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1],
-                                                                 (const float*)op.p[2], (float*)op.p[3], op.i[0], op.i[1], op.i[2],
-                                                                 (double*)op.p[4], gr_chunk);
+                                                                 (const float*)op.p[2], (float*)op.p[3], op.i[0], op.i[1], op.i[2]);
       break;
     }
     case 2: {

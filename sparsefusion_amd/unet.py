@@ -149,12 +149,11 @@ class _Arena:
 
 
 class _T:
-    """A planned activation: device pointer + logical shape [B, HW, C] (NHWC) or [rows, C]; `stats` = device pointer of
-    its GroupNorm chunk statistics (f64 [B][C/chunk][2], filled by the producing kernel) or 0."""
-    __slots__ = ("ptr", "rows", "C", "HW", "stats")
+    """A planned activation: device pointer + logical shape [B, HW, C] (NHWC) or [rows, C]."""
+    __slots__ = ("ptr", "rows", "C", "HW")
 
-    def __init__(self, ptr, rows, C, HW=None, stats=0):
-        self.ptr, self.rows, self.C, self.HW, self.stats = ptr, rows, C, HW, stats
+    def __init__(self, ptr, rows, C, HW=None):
+        self.ptr, self.rows, self.C, self.HW = ptr, rows, C, HW
 
 
 class _Plan:
@@ -168,21 +167,12 @@ class _Plan:
             self.zero, self.misc = _Arena(sizing[0], device), _Arena(sizing[1], device)
         self.w = unet._packed(device)
         self.written = set()                 # (ptr, channel offset) of conv outputs that already hold data
-        self.last_writer = {}
         self.ws_bytes = 0                    # split-K workspace demand (max over ops; ops run serially)
         self.ws_ptr = self.misc.alloc(sizing[2]) if sizing is not None else 0
 
     # -------- allocation helpers
     def zf32(self, rows, C, HW=None):        # conv outputs: first writer stores, later writers accumulate
-        return self.spatial(rows, C, HW) if HW else self.f32(rows, C, HW)
-
-    def spatial(self, rows, C, HW):
-        """fp32 feature map [B, HW, C] whose producer also emits GroupNorm chunk statistics (zeroed per eval)."""
-        t = self.f32(rows, C, HW)
-        ch = self.u.stats_chunk
-        if C % ch == 0 and HW % 16 == 0:
-            t.stats = self.zero.alloc(self.B * (C // ch) * 16)
-        return t
+        return self.f32(rows, C, HW)
 
     def f32(self, rows, C, HW=None):
         return _T(self.misc.alloc(rows * C * 4), rows, C, HW)
@@ -219,27 +209,22 @@ class _Plan:
             self.ws_bytes = max(self.ws_bytes, groups * M * n_frags * 16 * 4)
             ws = self.ws_ptr
         self.op(OP_CONV, (1 if x_f32 else 0) | (2 if pixshuf else 0) | (4 if accum else 0),
-                p=(x.ptr, self.wptr(wname), self.wptr(bname) if bname else 0, out.ptr, resid.ptr if resid else 0, ws, out.stats),
-                i=(B, H, W, x.C, Ho, Wo, Cout, ldc, co_off, k, k, stride, pad, groups, WM * 16 + WN, self.u.stats_chunk))
-        prev = self.last_writer.get((out.ptr, co_off))
-        if prev is not None:
-            prev.p[6] = None                 # only the final writer of an accumulated output emits its statistics
-        self.last_writer[(out.ptr, co_off)] = self.ops[-1]
+                p=(x.ptr, self.wptr(wname), self.wptr(bname) if bname else 0, out.ptr, resid.ptr if resid else 0, ws),
+                i=(B, H, W, x.C, Ho, Wo, Cout, ldc, co_off, k, k, stride, pad, groups, WM * 16 + WN))
         return Ho, Wo
 
     def gn_act(self, x, skip, gname, ss_ptr, out, raw=None, silu=True):
         C1, C2 = x.C, (skip.C if skip else 0)
-        assert x.stats and (skip is None or skip.stats), "GroupNorm input without producer statistics"
+        stats = self.zero.alloc(self.B * 8 * 2 * 8)          # f64 (sum, sum of squares) per (b, group), zeroed per eval
         self.op(OP_GN_ACT, 0 if silu else 1,
                 p=(x.ptr, skip.ptr if skip else 0, self.wptr(gname + ".weight"), self.wptr(gname + ".bias"), ss_ptr, out.ptr,
-                   raw.ptr if raw else 0, x.stats, skip.stats if skip else 0),
-                i=(self.B, x.HW, C1, C2, self.u.ss_total, self.u.stats_chunk), f=(1e-5, SKIP_SCALE))
+                   raw.ptr if raw else 0, stats),
+                i=(self.B, x.HW, C1, C2, self.u.ss_total), f=(1e-5, SKIP_SCALE))
 
     def ln(self, x, gname, bname, out, C, rows, eps=1e-5, gelu=False, out_f32=False, resid=None):
         self.op(OP_LN, (1 if gelu else 0) | (2 if out_f32 else 0),
-                p=(x.ptr, self.wptr(gname), self.wptr(bname) if bname else 0, out.ptr, resid.ptr if resid else 0,
-                   out.stats if out_f32 else 0),
-                i=(rows, C, max(1, rows // self.B), self.u.stats_chunk), f=(eps,))
+                p=(x.ptr, self.wptr(gname), self.wptr(bname) if bname else 0, out.ptr, resid.ptr if resid else 0),
+                i=(rows, C), f=(eps,))
 
     def gemv(self, x_ptr, M, ldx, wname, bname, y_ptr, ldy, N, K, in_silu=False, out_act=0):
         Kp = (K + 7) // 8 * 8
@@ -293,10 +278,9 @@ class _Plan:
                       out_act=2)
             if raw is not None:
                 self.conv(raw, False, H, H, f"{name}.res_conv.weight", f"{name}.res_conv.bias", out, cout, 0, cout, 1)
-                self.ops[-1].p[6] = None                          # gate_res below is the final writer of `out`
-                self.op(OP_ELTWISE, 1, p=(h2.ptr, gate.ptr, 0, out.ptr, out.stats), i=(B, HW, cout, self.u.stats_chunk))
+                self.op(OP_ELTWISE, 1, p=(h2.ptr, gate.ptr, 0, out.ptr), i=(B, HW, cout))
             else:
-                self.op(OP_ELTWISE, 1, p=(h2.ptr, gate.ptr, x.ptr, out.ptr, out.stats), i=(B, HW, cout, self.u.stats_chunk))
+                self.op(OP_ELTWISE, 1, p=(h2.ptr, gate.ptr, x.ptr, out.ptr), i=(B, HW, cout))
         else:
             if raw is not None:
                 self.conv(raw, False, H, H, f"{name}.res_conv.weight", f"{name}.res_conv.bias", out, cout, 0, cout, 1)
@@ -308,7 +292,7 @@ class _Plan:
     def _attn_out(self, name, att, x, d, rows):
         o = self.zf32(rows, d)
         self.conv(att, False, 1, rows // self.B, f"{name}.to_out.0.weight", None, o, d, 0, d, 1)
-        y = self.spatial(rows, d, x.HW) if x.HW else self.f32(rows, d)
+        y = self.f32(rows, d, x.HW)
         self.ln(o, f"{name}.to_out.1.g", None, y, d, rows, out_f32=True, resid=x)
         return y
 
@@ -432,7 +416,7 @@ class _Plan:
             if u.attns[lv]:
                 x = self.transformer(f"ups.{ui}.2", x)
             if ui < n_lv - 1:
-                y = self.spatial(B * 4 * H * H, di, 4 * H * H)
+                y = self.f32(B * 4 * H * H, di, 4 * H * H)
                 self.conv(x, True, H, H, f"ups.{ui}.3.net.0.weight", f"ups.{ui}.3.net.0.bias", y, di, 0, di * 4, 1, pixshuf=True)
                 H *= 2
                 x = y
@@ -503,7 +487,6 @@ class Unet(nn.Module):
         self.ss_total = off
         self.conv_waves_target = 1024       # waves wanted per conv launch (4 per CU) before split-K stops
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches
-        self.stats_chunk = 32 if dim % 256 == 0 else 8   # channels per GroupNorm statistics chunk (divides every group)
         self._pack_cache = None
         self._plans = {}
 

@@ -50,13 +50,6 @@ def bf(t):
     return t.to(torch.bfloat16).float()
 
 
-def _chunk_stats(x, chunk):
-    """f64 (sum, sum of squares) per (batch, `chunk` channels) of an NHWC tensor [B, HW, C]."""
-    B, HW, C = x.shape
-    xd = x.double().view(B, HW, C // chunk, chunk)
-    return torch.stack([xd.sum((1, 3)), (xd * xd).sum((1, 3))], -1).contiguous()
-
-
 CONV_CASES = [
     # B, H, Cin, Cout, k, stride, pad, groups, tile(WM,WN), a_f32, resid
     (1, 4, 1024, 1024, 3, 1, 1, 8, (1, 4), False, True),      # 4x4 weight-streaming layer, split-K
@@ -136,11 +129,9 @@ def test_gn_act(B, H, C1, C2, with_ss):
     raw = torch.empty(B, HW, C, dtype=torch.bfloat16, device=DEV)
     ssd = ss_all.to(DEV)
     ss_ptr = ssd.data_ptr() + C * 4 if with_ss else 0        # the block's slice starts at column C
-    chunk = 32 if C % 256 == 0 else 8
-    st1 = _chunk_stats(x1, chunk).to(DEV)                    # what the producer kernels emit (unscaled sources)
-    st2 = _chunk_stats(x2, chunk).to(DEV) if C2 else None
-    _run([_op(2, 0, p=(x1.to(DEV), x2.to(DEV) if C2 else None, gamma.to(DEV), beta.to(DEV), ss_ptr, out, raw, st1, st2),
-              i=(B, HW, C1, C2, 3 * C, chunk), f=(1e-5, 2 ** -0.5))])
+    stats = torch.zeros(B * 8 * 2, dtype=torch.float64, device=DEV)
+    _run([_op(2, 0, p=(x1.to(DEV), x2.to(DEV) if C2 else None, gamma.to(DEV), beta.to(DEV), ss_ptr, out, raw, stats),
+              i=(B, HW, C1, C2, 3 * C), f=(1e-5, 2 ** -0.5))])
     xc = torch.cat([x1, x2 * 2 ** -0.5], -1) if C2 else x1
     ref = F.group_norm(xc.permute(0, 2, 1).reshape(B, C, H, H), 8, gamma, beta, eps=1e-5)
     if with_ss:
@@ -252,45 +243,6 @@ def test_gca_pool_gate_and_layout_ops():
     _run([_op(9, 0, p=(t.to(DEV), w.to(DEV), None, emb), i=(2, 8))])
     fr = t[:, None] * w[None] * 2 * torch.pi
     assert torch.allclose(emb.cpu(), torch.cat([t[:, None], fr.sin(), fr.cos()], -1), atol=2e-6)
-
-
-def test_producers_emit_groupnorm_chunk_statistics():
-    """conv epilogue (no split), split-K reduce, pixel-shuffle conv, gate_res and f32 layernorm emit f64 (sum, sumsq) per
-    (batch, channel chunk) of the tensor they finish; GN_ACT consumes them instead of re-reading the tensor."""
-    g = torch.Generator().manual_seed(21)
-    B, H, C = 2, 8, 256
-    x = torch.randn(B, C, H, H, generator=g)
-    w, b = torch.randn(C, C, 3, 3, generator=g) / 48, torch.randn(C, generator=g)
-    wp, _ = _pack_conv(w)
-    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
-    for chunk in (32, 8):
-        for groups, tile in ((1, 2 * 16 + 2), (4, 4 * 16 + 1), (1, 1 * 16 + 4)):
-            out = torch.empty(B, H, H, C, device=DEV)
-            st = torch.zeros(B, C // chunk, 2, dtype=torch.float64, device=DEV)
-            ws = torch.empty(groups * B * H * H * C, device=DEV)
-            _run([_op(1, 1, p=(xd, wp, b.to(DEV), out, None, ws, st), i=(B, H, H, C, H, H, C, C, 0, 3, 3, 1, 1, groups, tile, chunk))])
-            want = _chunk_stats(out.cpu().view(B, H * H, C), chunk)
-            assert torch.allclose(st.cpu(), want, rtol=1e-5, atol=1e-4), (chunk, groups, tile)
-    # pixel-shuffle epilogue: statistics of the shuffled, SiLU'd output
-    wu, bu = torch.randn(4 * 64, C, 1, 1, generator=g) / 16, torch.randn(4 * 64, generator=g)
-    pu, _ = _pack_conv(wu)
-    for chunk in (32, 8):
-        up = torch.empty(B, 2 * H, 2 * H, 64, device=DEV)
-        st = torch.zeros(B, 64 // chunk, 2, dtype=torch.float64, device=DEV)
-        _run([_op(1, 1 | 2, p=(xd, pu, bu.to(DEV), up, None, None, st), i=(B, H, H, C, H, H, 256, 64, 0, 1, 1, 1, 0, 1, 2 * 16 + 2, chunk))])
-        assert torch.allclose(st.cpu(), _chunk_stats(up.cpu().view(B, 4 * H * H, 64), chunk), rtol=1e-5, atol=1e-4)
-    # gate_res and layernorm(f32 + residual)
-    h, res, gate = torch.randn(B, 64, C, generator=g), torch.randn(B, 64, C, generator=g), torch.rand(B, C, generator=g)
-    for chunk in (32, 8):
-        out = torch.empty(B, 64, C, device=DEV)
-        st = torch.zeros(B, C // chunk, 2, dtype=torch.float64, device=DEV)
-        _run([_op(7, 1, p=(h.to(DEV), gate.to(DEV), res.to(DEV), out, st), i=(B, 64, C, chunk))])
-        assert torch.allclose(st.cpu(), _chunk_stats(out.cpu(), chunk), rtol=1e-5, atol=1e-4)
-        y = torch.empty(B * 16, 1024, device=DEV)
-        xin, gain, rr = torch.randn(B * 16, 1024, generator=g), torch.rand(1024, generator=g) + 0.5, torch.randn(B * 16, 1024, generator=g)
-        st = torch.zeros(B, 1024 // chunk, 2, dtype=torch.float64, device=DEV)
-        _run([_op(3, 2, p=(xin.to(DEV), gain.to(DEV), None, y, rr.to(DEV), st), i=(B * 16, 1024, 16, chunk), f=(1e-5,))])
-        assert torch.allclose(st.cpu(), _chunk_stats(y.cpu().view(B, 16, 1024), chunk), rtol=1e-5, atol=1e-4)
 
 
 def test_plms_update_kernels():
