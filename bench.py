@@ -173,8 +173,15 @@ def unet_roofline(hp):
     conv_bytes = conv_params * 2                                   # bf16 weights, each read once per eval
     achieved = conv_bytes / (conv_ms * 1e-3) / 1e9
     total_ms = float(acc.sum())
+    traffic = None                                                 # HBM bytes per conv launch from the committed PMC passes
+    pmc = os.path.join(ROOT, "profiles", "r01_unet_eval_b1_pmc_hbm.json")
+    if os.path.exists(pmc):
+        j = json.load(open(pmc))
+        traffic = round(j["conv_fetch_bytes_corrected"] / j["conv_launches_per_eval"])
     return {"bound": "hbm", "kernel": "k_conv_igemm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_note": "avg HBM fetch bytes per conv launch: rocprofv3 --pmc FETCH_SIZE pass (x2 gfx950 correction), "
+                            "profiles/r01_unet_eval_b1_pmc_hbm.json; algorithmic = %d B/launch" % (conv_bytes // n_conv),
             "launches_per_eval": n_conv, "avg_launch_us": round(conv_ms / n_conv * 1e3, 2),
             "algorithmic_bytes_per_eval": conv_bytes,
             "unet_eval_event_ms": round(total_ms, 3), "unet_ops_per_eval": len(plan.ops),
