@@ -161,15 +161,16 @@ enum {
   SF_OP_GCA_POOL = 6,  /* GlobalContext softmax pooling                     */
   SF_OP_ELTWISE = 7,   /* gate*h + residual, adds, pixel-shuffle, packing   */
   SF_OP_MEMSET = 8,    /* zero a region of the activation arena             */
-  SF_OP_TIME_EMB = 9   /* learned sinusoidal embedding of log-snr           */
+  SF_OP_TIME_EMB = 9,  /* learned sinusoidal embedding of log-snr           */
+  SF_OP_SPLITK_REDUCE = 10 /* stand-alone reduction of deferred split-K partials */
 };
 
-/* One op = one kernel launch.  Interpretation of p[]/i[]/f[] per op type is
+/* One op = one or two kernel launches.  Interpretation of p[]/i[]/f[] per op type is
  * documented next to each kernel in sparsefusion_amd/csrc/unet_ops.hip. */
 typedef struct {
   int32_t type;
   int32_t flags;
-  void* p[8];
+  void* p[12];
   int32_t i[16];
   float f[4];
 } sf_op;

@@ -33,7 +33,7 @@ class SfNgpFieldGrad(C.Structure):
 
 
 class SfOp(C.Structure):
-    _fields_ = [("type", C.c_int32), ("flags", C.c_int32), ("p", C.c_void_p * 8),
+    _fields_ = [("type", C.c_int32), ("flags", C.c_int32), ("p", C.c_void_p * 12),
                 ("i", C.c_int32 * 16), ("f", C.c_float * 4)]
 
 

@@ -57,7 +57,8 @@ __device__ __forceinline__ float wave_max(float v) {
 //   p[3] out f32, p[4] residual f32 (same indexing as out) or NULL
 //   p[5] split-K workspace f32 [groups][M][Npad] (groups > 1 only)
 //   i[0..] = B, H, W, Cin_pad, Ho, Wo, Cout, ldc, co_off, kh, kw, stride, pad, ksplit_groups, tile (WM*16+WN), 0
-//   flags: 1 = A is f32, 2 = epilogue SiLU + PixelShuffle(2) (no split-K), 4 = accumulate into out (out += ...)
+//   flags: 1 = A is f32, 2 = epilogue SiLU + PixelShuffle(2) (no split-K), 4 = accumulate into out (out += ...),
+//          8 = split-K partials stay in the workspace; the consumer reduces them (LazySrc mode 1)
 // No atomics: with groups == 1 every output element is owned by one wave (plain store / read-modify-write);
 // with groups > 1 each K-slice group stores its partial tile to the workspace and k_splitk_reduce sums them
 // (fp32 L2 atomics top out at ~25 G lane-ops/s on MI355X, which made the atomic split-K epilogue 10x the
@@ -281,11 +282,42 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
 //   p[0] src1 f32 [B,HW,C1], p[1] src2 f32 [B,HW,C2] or NULL, p[2] gamma [C], p[3] beta [C],
 //   p[4] scale_shift f32 (row b at p[4] + b*ss_stride: scale[C] then shift[C]) or NULL,
 //   p[5] out bf16 [B,HW,C], p[6] raw bf16 [B,HW,C] or NULL, p[7] stats f64 [B*8][2], zeroed by the caller
-//   i = B, HW, C1, C2, ss_stride ; f = eps, src2_scale ; flags: 1 = no SiLU
+//   i = B, HW, C1, C2, ss_stride, lazy mode, groups, npad ; f = eps, src2_scale ; flags: 1 = no SiLU
+//   p[8..10] lazy source operands of src1 (see LazySrc): k_gn_stats materialises src1 into p[0] while reading it
 // Two launches so that a B=1 eval still fills the chip: k_gn_stats (grid B*8*slices; per-block fp32 partial
 // sums, combined in f64 with one L2 atomic pair per block) and k_gn_apply (pure elementwise).
 // ---------------------------------------------------------------------------------------------
 #define GN_CHUNKS_PER_BLOCK 2048     // float4 chunks per stats workgroup (256 threads x 8)
+
+// A "lazy" fp32 NHWC tensor: the producer left it un-materialised and the FIRST consumer (k_gn_stats or
+// k_gca_logits) computes each element while reading it and stores it to its final address, which saves the
+// producer's own elementwise launch (every dependent launch costs ~4 us at B = 1).
+//   mode 1: split-K partials  v = bias[c] + sum_g ws[g][m][c] (+ resid[m][c])
+//   mode 2: gated residual    v = h[m][c] * gate[b][c] + (res ? res[m][c] : dst[m][c])
+struct LazySrc {
+  int mode, groups, npad, M;
+  const float* a;      // ws | h
+  const float* b;      // bias or NULL | gate [B, C]
+  const float* r;      // resid or NULL
+};
+
+__device__ __forceinline__ f32x4 lazy_load4(const LazySrc& L, float* __restrict__ dst, int b, long m, int c, int C) {
+  float* d = dst + m * C + c;
+  f32x4 v;
+  if (L.mode == 1) {
+    v = L.b ? *reinterpret_cast<const f32x4*>(L.b + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < L.groups; ++g) v += *reinterpret_cast<const f32x4*>(L.a + ((long)g * L.M + m) * L.npad + c);
+    if (L.r) v += *reinterpret_cast<const f32x4*>(L.r + m * C + c);
+  } else {
+    const f32x4 h = *reinterpret_cast<const f32x4*>(L.a + m * C + c);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(L.b + (long)b * C + c);
+    const f32x4 r = *reinterpret_cast<const f32x4*>((L.r ? L.r : d) + (L.r ? m * C + c : 0));
+    v = h * g + r;
+  }
+  *reinterpret_cast<f32x4*>(d) = v;
+  return v;
+}
+
 __device__ __forceinline__ f32x4 gn_load(const float* __restrict__ s1, const float* __restrict__ s2, int b, int HW, int C1,
                                          int C2, int p, int c, float s2_scale) {
   if (c < C1) return *reinterpret_cast<const f32x4*>(s1 + ((long)b * HW + p) * C1 + c);
@@ -293,9 +325,9 @@ __device__ __forceinline__ f32x4 gn_load(const float* __restrict__ s1, const flo
   return v * s2_scale;
 }
 
-__global__ __launch_bounds__(256) void k_gn_stats(const float* __restrict__ s1, const float* __restrict__ s2,
+__global__ __launch_bounds__(256) void k_gn_stats(float* __restrict__ s1, const float* __restrict__ s2,
                                                   double* __restrict__ stats, int HW, int C1, int C2, int slices,
-                                                  float s2_scale) {
+                                                  float s2_scale, LazySrc lz) {
   __shared__ double red[8];
   const int C = C1 + C2, Cg = C / 8, cg4 = Cg / 4;
   const int bg = blockIdx.x / slices, sl = blockIdx.x % slices;
@@ -306,7 +338,8 @@ __global__ __launch_bounds__(256) void k_gn_stats(const float* __restrict__ s1, 
   float s = 0.0f, q = 0.0f;
   for (int ch = c0 + threadIdx.x; ch < c1; ch += 256) {
     const int p = ch / cg4, c = g * Cg + (ch - p * cg4) * 4;
-    const f32x4 v = gn_load(s1, s2, b, HW, C1, C2, p, c, s2_scale);
+    const f32x4 v = (lz.mode && c < C1) ? lazy_load4(lz, s1, b, (long)b * HW + p, c, C1)
+                                        : gn_load(s1, s2, b, HW, C1, C2, p, c, s2_scale);
     s += (v[0] + v[1]) + (v[2] + v[3]);
     q = fmaf(v[0], v[0], q); q = fmaf(v[1], v[1], q); q = fmaf(v[2], v[2], q); q = fmaf(v[3], v[3], q);
   }
@@ -511,20 +544,38 @@ __global__ __launch_bounds__(64) void k_attn16(const float* __restrict__ q, __bf
 // ---------------------------------------------------------------------------------------------
 // GCA_POOL: pooled[b][c] = sum_p softmax_p(h[b,p,:] . wk + bk) * h[b,p,c]     (GlobalContext :930-941)
 //   p[0] h f32 [B,HW,C], p[1] wk f32 [C], p[2] bk f32 [1], p[3] pooled f32 [B,C] ZEROED by the caller, p[4] logits scratch f32 [B*HW]
-//   i = B, HW, C.  Two launches: one wave per pixel for the logits, then one workgroup per (b, 32 channels).
+//   i = B, HW, C, lazy mode, groups, npad (p[8..10]: h may be un-reduced split-K partials).  Two launches: one wave per pixel for the logits, then one workgroup per (b, 32 channels).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gca_logits(const float* __restrict__ h, const float* __restrict__ wk,
-                                                    const float* __restrict__ bk, float* __restrict__ logit, int rows, int C) {
+__global__ __launch_bounds__(256) void k_gca_logits(float* __restrict__ h, const float* __restrict__ wk,
+                                                    const float* __restrict__ bk, float* __restrict__ logit, int rows, int C,
+                                                    LazySrc lz) {
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (p >= rows) return;
   float a = 0.0f;
   for (int c = lane * 4; c < C; c += 256) {
-    const f32x4 x = *reinterpret_cast<const f32x4*>(h + (long)p * C + c);
+    const f32x4 x = lz.mode ? lazy_load4(lz, h, 0, (long)p, c, C) : *reinterpret_cast<const f32x4*>(h + (long)p * C + c);
     const f32x4 w = *reinterpret_cast<const f32x4*>(wk + c);
     a += x[0] * w[0] + x[1] * w[1] + x[2] * w[2] + x[3] * w[3];
   }
   a = wave_sum(a);
   if (lane == 0) logit[p] = a + bk[0];
+}
+
+// Small maps (<= 256 pixels): one workgroup per pixel so that the (lazy) row read is spread over 4x the lanes.
+__global__ __launch_bounds__(256) void k_gca_logits_wg(float* __restrict__ h, const float* __restrict__ wk,
+                                                       const float* __restrict__ bk, float* __restrict__ logit, int C, LazySrc lz) {
+  __shared__ float red[4];
+  const int p = blockIdx.x;
+  float a = 0.0f;
+  for (int c = threadIdx.x * 4; c < C; c += 1024) {
+    const f32x4 x = lz.mode ? lazy_load4(lz, h, 0, (long)p, c, C) : *reinterpret_cast<const f32x4*>(h + (long)p * C + c);
+    const f32x4 w = *reinterpret_cast<const f32x4*>(wk + c);
+    a += x[0] * w[0] + x[1] * w[1] + x[2] * w[2] + x[3] * w[3];
+  }
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) logit[p] = (red[0] + red[1]) + (red[2] + red[3]) + bk[0];
 }
 
 // grid (B, ceil(HW/32)): every workgroup re-derives the softmax normaliser from the <=1024 logits, then
@@ -670,10 +721,22 @@ static int run_conv(const sf_op& op, hipStream_t st) {
   SF_CHECK_LAUNCH("conv_igemm");
   if (a.groups > 1) {
     if (!a.ws) SF_FAIL(SF_ERR_INVALID, "conv: split-K needs a workspace");
+    if (op.flags & 8) return SF_OK;      // reduction deferred to the consumer (LazySrc mode 1)
     k_splitk_reduce<<<sf_grid_cap(sf_div_up((long)M * a.Cout, 256)), 256, 0, st>>>(a.ws, a.bias, a.resid, a.out, M, a.Cout, a.npad,
                                                                                   a.groups, a.ldc, a.co_off, a.accum);
     SF_CHECK_LAUNCH("splitk_reduce");
   }
+  return SF_OK;
+}
+
+// Lazy-source descriptor of an op: i[ibase] = mode, i[ibase+1] = groups, i[ibase+2] = npad ; p[8] = a, p[9] = b, p[10] = r.
+static int lazy_from_op(const sf_op& op, int ibase, int M, LazySrc& lz) {
+  lz.mode = op.i[ibase]; lz.groups = op.i[ibase + 1]; lz.npad = op.i[ibase + 2]; lz.M = M;
+  lz.a = (const float*)op.p[8]; lz.b = (const float*)op.p[9]; lz.r = (const float*)op.p[10];
+  if (lz.mode < 0 || lz.mode > 2) SF_FAIL(SF_ERR_INVALID, "lazy source: unknown mode %d", lz.mode);
+  if (lz.mode && !lz.a) SF_FAIL(SF_ERR_INVALID, "lazy source: missing operand");
+  if (lz.mode == 1 && (lz.groups < 1 || lz.npad % 4)) SF_FAIL(SF_ERR_INVALID, "lazy source: bad split-K geometry");
+  if (lz.mode == 2 && !lz.b) SF_FAIL(SF_ERR_INVALID, "lazy source: gate missing");
   return SF_OK;
 }
 
@@ -682,9 +745,13 @@ static int run_gn(const sf_op& op, hipStream_t st) {
   const int C = C1 + C2;
   if (C % 32 || C1 % 4 || !op.p[7]) SF_FAIL(SF_ERR_INVALID, "gn_act: unsupported shape HW=%d C=%d (or missing stats buffer)", HW, C);
   const int chunks = HW * (C / 8) / 4;
-  const int slices = (chunks + GN_CHUNKS_PER_BLOCK - 1) / GN_CHUNKS_PER_BLOCK;
-  k_gn_stats<<<B * 8 * slices, 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (double*)op.p[7], HW, C1, C2, slices,
-                                             op.f[1]);
+  LazySrc lz;
+  if (int rc = lazy_from_op(op, 5, B * HW, lz)) return rc;
+  // a lazy split-K source multiplies the loads per chunk by `groups`: one chunk per thread then
+  const int per_block = lz.mode == 1 ? 256 : GN_CHUNKS_PER_BLOCK;
+  const int slices = (chunks + per_block - 1) / per_block;
+  k_gn_stats<<<B * 8 * slices, 256, 0, st>>>((float*)op.p[0], (const float*)op.p[1], (double*)op.p[7], HW, C1, C2, slices,
+                                             op.f[1], lz);
   SF_CHECK_LAUNCH("gn_stats");
   const long total = (long)B * HW * (C / 4);
   k_gn_apply<<<sf_grid_cap(sf_div_up(total, 256)), 256, 0, st>>>(
@@ -731,8 +798,14 @@ static int run_attn(const sf_op& op, hipStream_t st) {
 static int run_gca_pool(const sf_op& op, hipStream_t st) {
   const int B = op.i[0], HW = op.i[1], C = op.i[2];
   if (HW > 1024 || C % 32 || !op.p[4]) SF_FAIL(SF_ERR_INVALID, "gca_pool: HW <= 1024, C %% 32 == 0, logits scratch required");
-  k_gca_logits<<<sf_div_up(B * HW, 4), 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2],
-                                                    (float*)op.p[4], B * HW, C);
+  LazySrc lz;
+  if (int rc = lazy_from_op(op, 3, B * HW, lz)) return rc;
+  if (lz.mode == 2) SF_FAIL(SF_ERR_INVALID, "gca_pool: only split-K lazy sources");
+  if (B * HW <= 256)
+    k_gca_logits_wg<<<B * HW, 256, 0, st>>>((float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], (float*)op.p[4], C, lz);
+  else
+    k_gca_logits<<<sf_div_up(B * HW, 4), 256, 0, st>>>((float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2],
+                                                      (float*)op.p[4], B * HW, C, lz);
   SF_CHECK_LAUNCH("gca_logits");
   const int chunks = (HW + 31) / 32;
   k_gca_pool<<<B * chunks, 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[4], (float*)op.p[3], HW, C, chunks);
@@ -787,6 +860,14 @@ static int plan_run_impl(const sf_op* ops, uint32_t n_ops, hipStream_t st, hipEv
       case SF_OP_MEMSET:
         if (hipMemsetAsync(op.p[0], 0, (size_t)(uint32_t)op.i[0] * 4, st) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "memset failed");
         break;
+      case SF_OP_SPLITK_REDUCE: {
+        const int M = op.i[0], Cout = op.i[1];
+        if (!op.p[0] || !op.p[3] || op.i[3] < 1) SF_FAIL(SF_ERR_INVALID, "splitk_reduce: bad operands");
+        k_splitk_reduce<<<sf_grid_cap(sf_div_up((long)M * Cout, 256)), 256, 0, st>>>(
+            (const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], (float*)op.p[3], M, Cout, op.i[2], op.i[3], Cout, 0, 0);
+        if (hipGetLastError() != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "splitk_reduce launch failed");
+        break;
+      }
       case SF_OP_TIME_EMB:
         k_time_emb<<<sf_div_up(op.i[0] * op.i[1], 64), 64, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (float*)op.p[3],
                                                                   op.i[0], op.i[1]);

@@ -18,7 +18,7 @@ import torch.nn as nn
 
 from . import _lib
 
-OP_CONV, OP_GN_ACT, OP_LN, OP_GEMV, OP_ATTN, OP_GCA_POOL, OP_ELTWISE, OP_MEMSET, OP_TIME_EMB = range(1, 10)
+OP_CONV, OP_GN_ACT, OP_LN, OP_GEMV, OP_ATTN, OP_GCA_POOL, OP_ELTWISE, OP_MEMSET, OP_TIME_EMB, OP_SPLITK_REDUCE = range(1, 11)
 SKIP_SCALE = 2 ** -0.5            # scale_skip_connection (imagen_pytorch.py:1283)
 
 
@@ -150,10 +150,13 @@ class _Arena:
 
 class _T:
     """A planned activation: device pointer + logical shape [B, HW, C] (NHWC) or [rows, C]."""
-    __slots__ = ("ptr", "rows", "C", "HW")
+    __slots__ = ("ptr", "rows", "C", "HW", "lazy")
 
     def __init__(self, ptr, rows, C, HW=None):
         self.ptr, self.rows, self.C, self.HW = ptr, rows, C, HW
+        # lazy: None, or how the first consumer must materialise the tensor (csrc/unet_ops.hip LazySrc):
+        #   ("splitk", ws, bias, resid, groups, npad)   or   ("gate", h, gate, res)
+        self.lazy = None
 
 
 class _Plan:
@@ -169,6 +172,7 @@ class _Plan:
         self.written = set()                 # (ptr, channel offset) of conv outputs that already hold data
         self.ws_bytes = 0                    # split-K workspace demand (max over ops; ops run serially)
         self.ws_ptr = self.misc.alloc(sizing[2]) if sizing is not None else 0
+        self.ws_owner = None                 # tensor whose un-reduced split-K partials currently live in the workspace
 
     # -------- allocation helpers
     def zf32(self, rows, C, HW=None):        # conv outputs: first writer stores, later writers accumulate
@@ -194,9 +198,38 @@ class _Plan:
     def wptr(self, name):
         return self.w[name].data_ptr()
 
+    # -------- lazy tensors: the first consumer materialises them (saves one dependent launch each)
+    def need(self, t):
+        """Emit the stand-alone materialisation of a lazy tensor for consumers that cannot do it themselves."""
+        if t is None or t.lazy is None:
+            return t
+        lz, t.lazy = t.lazy, None
+        if lz[0] == "splitk":
+            _, ws, bias, resid, groups, npad = lz
+            self.op(OP_SPLITK_REDUCE, 0, p=(ws, bias, resid, t.ptr), i=(t.rows, t.C, npad, groups))
+            self.ws_owner = None
+        else:
+            _, h, gate, res = lz
+            self.op(OP_ELTWISE, 1, p=(h, gate, res, t.ptr), i=(self.B, t.HW, t.C))
+        return t
+
+    def take_lazy(self, t, allow):
+        """(p[8..10], (mode, groups, npad)) for a consumer that materialises `t` itself; clears the lazy state."""
+        if t.lazy is None or t.lazy[0] not in allow:
+            self.need(t)
+            return (0, 0, 0), (0, 0, 0)
+        lz, t.lazy = t.lazy, None
+        if lz[0] == "splitk":
+            self.ws_owner = None
+            return (lz[1], lz[2], lz[3]), (1, lz[4], lz[5])
+        return (lz[1], lz[2], lz[3]), (2, 0, 0)
+
     # -------- op emitters
-    def conv(self, x, x_f32, H, W, wname, bname, out, ldc, co_off, Cout, k, stride=1, pad=0, resid=None, pixshuf=False):
+    def conv(self, x, x_f32, H, W, wname, bname, out, ldc, co_off, Cout, k, stride=1, pad=0, resid=None, pixshuf=False,
+             defer=False):
         B = self.B
+        self.need(x)
+        self.need(resid)
         Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         M = B * Ho * Wo
         m_frags, n_frags = (M + 15) // 16, (Cout + 15) // 16
@@ -206,22 +239,33 @@ class _Plan:
         self.written.add((out.ptr, co_off))
         ws = 0
         if groups > 1:
+            self.need(self.ws_owner)                          # the workspace is about to be overwritten
             self.ws_bytes = max(self.ws_bytes, groups * M * n_frags * 16 * 4)
             ws = self.ws_ptr
-        self.op(OP_CONV, (1 if x_f32 else 0) | (2 if pixshuf else 0) | (4 if accum else 0),
-                p=(x.ptr, self.wptr(wname), self.wptr(bname) if bname else 0, out.ptr, resid.ptr if resid else 0, ws),
+        defer = bool(defer and groups > 1 and not accum and not pixshuf and co_off == 0 and ldc == Cout == out.C and M == out.rows
+                     and (self.u.lazy_consumers & 1))
+        bias, res = self.wptr(bname) if bname else 0, resid.ptr if resid else 0
+        self.op(OP_CONV, (1 if x_f32 else 0) | (2 if pixshuf else 0) | (4 if accum else 0) | (8 if defer else 0),
+                p=(x.ptr, self.wptr(wname), bias, out.ptr, res, ws),
                 i=(B, H, W, x.C, Ho, Wo, Cout, ldc, co_off, k, k, stride, pad, groups, WM * 16 + WN))
+        if defer:
+            out.lazy = ("splitk", ws, bias, res, groups, n_frags * 16)
+            self.ws_owner = out
         return Ho, Wo
 
     def gn_act(self, x, skip, gname, ss_ptr, out, raw=None, silu=True):
         C1, C2 = x.C, (skip.C if skip else 0)
+        self.need(skip)
+        lp, li = self.take_lazy(x, ("splitk", "gate"))
         stats = self.zero.alloc(self.B * 8 * 2 * 8)          # f64 (sum, sum of squares) per (b, group), zeroed per eval
         self.op(OP_GN_ACT, 0 if silu else 1,
                 p=(x.ptr, skip.ptr if skip else 0, self.wptr(gname + ".weight"), self.wptr(gname + ".bias"), ss_ptr, out.ptr,
-                   raw.ptr if raw else 0, stats),
-                i=(self.B, x.HW, C1, C2, self.u.ss_total), f=(1e-5, SKIP_SCALE))
+                   raw.ptr if raw else 0, stats) + lp,
+                i=(self.B, x.HW, C1, C2, self.u.ss_total) + li, f=(1e-5, SKIP_SCALE))
 
     def ln(self, x, gname, bname, out, C, rows, eps=1e-5, gelu=False, out_f32=False, resid=None):
+        self.need(x)
+        self.need(resid)
         self.op(OP_LN, (1 if gelu else 0) | (2 if out_f32 else 0),
                 p=(x.ptr, self.wptr(gname), self.wptr(bname) if bname else 0, out.ptr, resid.ptr if resid else 0),
                 i=(rows, C), f=(eps,))
@@ -255,7 +299,8 @@ class _Plan:
         raw = self.bf16(rows, cin, HW) if cin != cout else None
         self.gn_act(x, skip, f"{name}.block1.groupnorm", 0, a1, raw)
         h = self.zf32(rows, cout, HW)
-        self.conv(a1, False, H, H, f"{name}.block1.project.weight", f"{name}.block1.project.bias", h, cout, 0, cout, 3, 1, 1)
+        self.conv(a1, False, H, H, f"{name}.block1.project.weight", f"{name}.block1.project.bias", h, cout, 0, cout, 3, 1, 1,
+                  defer=True)                                  # block2's GroupNorm statistics pass reduces the partials
         if cross:
             h = self.cross_attention(f"{name}.cross_attn.fn", h)
         a2 = self.bf16(rows, cout, HW)
@@ -265,22 +310,25 @@ class _Plan:
         w2, b2 = f"{name}.block2.project.weight", f"{name}.block2.project.bias"
         if gca:
             h2 = self.zf32(rows, cout, HW)
-            self.conv(a2, False, H, H, w2, b2, h2, cout, 0, cout, 3, 1, 1)
+            self.conv(a2, False, H, H, w2, b2, h2, cout, 0, cout, 3, 1, 1, defer=True)   # reduced by the gca logits pass
             pooled = _T(self.zero.alloc(B * cout * 4), B, cout)        # accumulated with atomics: zeroed per eval
             hid = self.f32(B, max(3, cout // 2))
             gate = self.f32(B, cout)
             logits = self.f32(B, HW)
+            lp, li = self.take_lazy(h2, ("splitk",))
             self.op(OP_GCA_POOL, 0, p=(h2.ptr, self.wptr(f"{name}.gca.to_k.weight"), self.wptr(f"{name}.gca.to_k.bias"), pooled.ptr,
-                                       logits.ptr), i=(B, HW, cout))
+                                       logits.ptr, 0, 0, 0) + lp, i=(B, HW, cout) + li)
             self.gemv(pooled.ptr, B, cout, f"{name}.gca.net.0.weight", f"{name}.gca.net.0.bias", hid.ptr, hid.C, hid.C, cout,
                       out_act=1)
             self.gemv(hid.ptr, B, hid.C, f"{name}.gca.net.2.weight", f"{name}.gca.net.2.bias", gate.ptr, cout, cout, hid.C,
                       out_act=2)
             if raw is not None:
                 self.conv(raw, False, H, H, f"{name}.res_conv.weight", f"{name}.res_conv.bias", out, cout, 0, cout, 1)
-                self.op(OP_ELTWISE, 1, p=(h2.ptr, gate.ptr, 0, out.ptr), i=(B, HW, cout))
+                out.lazy = ("gate", h2.ptr, gate.ptr, 0)               # out already holds res_conv(x)
             else:
-                self.op(OP_ELTWISE, 1, p=(h2.ptr, gate.ptr, x.ptr, out.ptr), i=(B, HW, cout))
+                out.lazy = ("gate", h2.ptr, gate.ptr, x.ptr)
+            if not (self.u.lazy_consumers & 2):
+                self.need(out)
         else:
             if raw is not None:
                 self.conv(raw, False, H, H, f"{name}.res_conv.weight", f"{name}.res_conv.bias", out, cout, 0, cout, 1)
@@ -486,6 +534,7 @@ class Unet(nn.Module):
                 off += shape[0]
         self.ss_total = off
         self.conv_waves_target = 1024       # waves wanted per conv launch (4 per CU) before split-K stops
+        self.lazy_consumers = 3             # bit 0: split-K reductions, bit 1: gated residuals are materialised by their first consumer
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches
         self._pack_cache = None
         self._plans = {}

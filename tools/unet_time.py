@@ -1,0 +1,26 @@
+"""Time the canonical UNet eval (graph replay and plain plan replay); prints launches per eval."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sparsefusion_amd.unet import Unet
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+dev = torch.device("cuda:0")
+unet = Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2), layer_attns=(False, False, False, True),
+            layer_cross_attns=(False,) * 4, cond_images_channels=256, attn_pool_text=False).to(dev)
+for k, v in os.environ.items():
+    if k == "SF_LAZY":
+        unet.lazy_consumers = int(v)
+x, ls, cond = torch.randn(B, 4, 32, 32, device=dev), torch.zeros(B, device=dev), torch.randn(B, 256, 32, 32, device=dev)
+for graph in (True,):
+    unet.use_hip_graph = graph
+    unet.invalidate()
+    for _ in range(5):
+        unet.forward(x, ls, cond_images=cond)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 100
+    for _ in range(n):
+        unet.forward(x, ls, cond_images=cond)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    plan = unet._plan(B, dev)
+    print(f"B={B} graph={graph} lazy={unet.lazy_consumers} ops={len(plan.ops)} eval={ms:.3f} ms", flush=True)
