@@ -105,3 +105,29 @@ def reference_plms(vldm, steps=50):
     install()
     from external.plms import PLMSSampler
     return PLMSSampler(vldm, steps)
+
+
+def reference_vae(cfg):
+    """The reference's own Encoder / Decoder (external/ldm/modules/diffusionmodules/model.py:368-569) wired as
+    AutoencoderKL.__init__ does (external/ldm/models/autoencoder.py:296-303).  AutoencoderKL itself cannot be
+    imported here (pytorch_lightning, taming); its encode()/decode() are three lines each (:324-333) and are
+    replayed by `encode_mode` / `decode` below with the reference's DiagonalGaussianDistribution."""
+    install()
+    from external.ldm.modules.diffusionmodules.model import Encoder, Decoder
+    dd = {k: v for k, v in cfg.items() if k != "embed_dim"}
+    dd["attn_resolutions"] = list(dd["attn_resolutions"])
+    m = torch.nn.Module()
+    m.encoder = Encoder(**dd)
+    m.decoder = Decoder(**dd)
+    m.quant_conv = torch.nn.Conv2d(2 * cfg["z_channels"], 2 * cfg["embed_dim"], 1)
+    m.post_quant_conv = torch.nn.Conv2d(cfg["embed_dim"], cfg["z_channels"], 1)
+
+    def encode_mode(x):
+        from external.ldm.modules.distributions.distributions import DiagonalGaussianDistribution
+        return DiagonalGaussianDistribution(m.quant_conv(m.encoder(x))).mode()
+
+    def decode(z):
+        return m.decoder(m.post_quant_conv(z))
+
+    m.encode_mode, m.decode = encode_mode, decode
+    return m

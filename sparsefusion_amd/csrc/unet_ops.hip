@@ -58,7 +58,8 @@ __device__ __forceinline__ float wave_max(float v) {
 //   p[5] split-K workspace f32 [groups][M][Npad] (groups > 1 only)
 //   i[0..] = B, H, W, Cin_pad, Ho, Wo, Cout, ldc, co_off, kh, kw, stride, pad, ksplit_groups, tile (WM*16+WN), 0
 //   flags: 1 = A is f32, 2 = epilogue SiLU + PixelShuffle(2) (no split-K), 4 = accumulate into out (out += ...),
-//          8 = split-K partials stay in the workspace; the consumer reduces them (LazySrc mode 1)
+//          8 = split-K partials stay in the workspace; the consumer reduces them (LazySrc mode 1),
+//          16 = the input is a nearest x2 upsampling of a stored [B, H/2, W/2, Cin] map (H, W = upsampled dims)
 // No atomics: with groups == 1 every output element is owned by one wave (plain store / read-modify-write);
 // with groups > 1 each K-slice group stores its partial tile to the workspace and k_splitk_reduce sums them
 // (fp32 L2 atomics top out at ~25 G lane-ops/s on MI355X, which made the atomic split-K epilogue 10x the
@@ -71,7 +72,7 @@ struct ConvArgs {
   int accum, npad;
   int B, H, W, Cin, Ho, Wo, Cout, ldc, co_off, kh, kw, stride, pad, groups;
   int KS, cchunks, m_frags, n_frags, m_tiles, n_tiles, steps_per_wave;
-  int pixshuf;
+  int pixshuf, ups;
 };
 
 template <int WM, int WN, bool A_FP32>
@@ -118,7 +119,9 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
     for (int mi = 0; mi < WM; ++mi) {
       const int iy = py[mi] + ky, ix = px[mi] + kx;
       ain[mi] = pv[mi] && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      aoff[mi] = (((long)pb[mi] * a.H + (ain[mi] ? iy : 0)) * a.W + (ain[mi] ? ix : 0)) * a.Cin + cgrp;
+      // a.ups = 1: the conv reads a nearest-neighbour x2 upsampling of a stored [H/2, W/2] map (fused Upsample)
+      aoff[mi] = (((long)pb[mi] * (a.H >> a.ups) + ((ain[mi] ? iy : 0) >> a.ups)) * (a.W >> a.ups) + ((ain[mi] ? ix : 0) >> a.ups)) *
+                     a.Cin + cgrp;
     }
     const bf16x8* wp[WN];
 #pragma unroll
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
 //   p[0] src1 f32 [B,HW,C1], p[1] src2 f32 [B,HW,C2] or NULL, p[2] gamma [C], p[3] beta [C],
 //   p[4] scale_shift f32 (row b at p[4] + b*ss_stride: scale[C] then shift[C]) or NULL,
 //   p[5] out bf16 [B,HW,C], p[6] raw bf16 [B,HW,C] or NULL, p[7] stats f64 [B*8][2], zeroed by the caller
-//   i = B, HW, C1, C2, ss_stride, lazy mode, groups, npad ; f = eps, src2_scale ; flags: 1 = no SiLU
+//   i = B, HW, C1, C2, ss_stride, lazy mode, groups, npad, G (0 = 8 groups) ; f = eps, src2_scale ; flags: 1 = no SiLU
 //   p[8..10] lazy source operands of src1 (see LazySrc): k_gn_stats materialises src1 into p[0] while reading it
 // Two launches so that a B=1 eval still fills the chip: k_gn_stats (grid B*8*slices; per-block fp32 partial
 // sums, combined in f64 with one L2 atomic pair per block) and k_gn_apply (pure elementwise).
@@ -327,11 +330,11 @@ __device__ __forceinline__ f32x4 gn_load(const float* __restrict__ s1, const flo
 
 __global__ __launch_bounds__(256) void k_gn_stats(float* __restrict__ s1, const float* __restrict__ s2,
                                                   double* __restrict__ stats, int HW, int C1, int C2, int slices,
-                                                  float s2_scale, LazySrc lz) {
+                                                  float s2_scale, LazySrc lz, int G) {
   __shared__ double red[8];
-  const int C = C1 + C2, Cg = C / 8, cg4 = Cg / 4;
+  const int C = C1 + C2, Cg = C / G, cg4 = Cg / 4;
   const int bg = blockIdx.x / slices, sl = blockIdx.x % slices;
-  const int b = bg / 8, g = bg % 8;
+  const int b = bg / G, g = bg % G;
   const int chunks = HW * cg4;
   const int per = (chunks + slices - 1) / slices;
   const int c0 = sl * per, c1 = min(chunks, c0 + per);
@@ -354,12 +357,45 @@ __global__ __launch_bounds__(256) void k_gn_stats(float* __restrict__ s1, const 
   }
 }
 
+// Pixel-major statistics for narrow groups (VAE: 32 groups of 4..16 channels): a workgroup walks whole pixels
+// (fully coalesced rows), each thread owns one fixed float4 channel chunk, per-group sums meet in LDS.
+// Needs C/4 <= 256, 256 % (C/4) == 0 and (C/G) % 4 == 0.
+__global__ __launch_bounds__(256) void k_gn_stats_px(const float* __restrict__ s1, double* __restrict__ stats, int HW, int C,
+                                                     int G, int slabs) {
+  __shared__ float ls[256], lq[256];
+  const int b = blockIdx.x / slabs, sl = blockIdx.x % slabs;
+  const int c4 = C / 4, ppi = 256 / c4;
+  const int chunk = threadIdx.x % c4, pofs = threadIdx.x / c4;
+  const int per = (HW + slabs - 1) / slabs;
+  const int p0 = sl * per, p1 = min(HW, p0 + per);
+  float s = 0.0f, q = 0.0f;
+  for (int p = p0 + pofs; p < p1; p += ppi) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(s1 + ((long)b * HW + p) * C + chunk * 4);
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+    q = fmaf(v[0], v[0], q); q = fmaf(v[1], v[1], q); q = fmaf(v[2], v[2], q); q = fmaf(v[3], v[3], q);
+  }
+  ls[threadIdx.x] = s; lq[threadIdx.x] = q;
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+    const int cpg = c4 / G;
+    double ds = 0.0, dq = 0.0;
+    for (int po = 0; po < ppi; ++po)
+      for (int k = 0; k < cpg; ++k) {
+        const int idx = po * c4 + threadIdx.x * cpg + k;
+        ds += (double)ls[idx]; dq += (double)lq[idx];
+      }
+    typedef __attribute__((address_space(1))) double gdouble;
+    (void)__builtin_amdgcn_global_atomic_fadd_f64((gdouble*)(stats + ((long)b * G + threadIdx.x) * 2), ds);
+    (void)__builtin_amdgcn_global_atomic_fadd_f64((gdouble*)(stats + ((long)b * G + threadIdx.x) * 2 + 1), dq);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ s1, const float* __restrict__ s2,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   const float* __restrict__ ss, const double* __restrict__ stats,
                                                   __bf16* __restrict__ out, __bf16* __restrict__ raw, int B, int HW, int C1,
-                                                  int C2, int ss_stride, float eps, float s2_scale, int no_silu) {
-  const int C = C1 + C2, Cg = C / 8, c4 = C / 4;
+                                                  int C2, int ss_stride, float eps, float s2_scale, int no_silu, int G) {
+  const int C = C1 + C2, Cg = C / G, c4 = C / 4;
   const long total = (long)B * HW * c4;
   const double inv_n = 1.0 / ((double)HW * Cg);
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -367,8 +403,8 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ s1, 
     const long bp = i / c4;
     const int p = (int)(bp % HW), b = (int)(bp / HW);
     const int g = c / Cg;
-    const double m = stats[(b * 8 + g) * 2] * inv_n;
-    const double var = stats[(b * 8 + g) * 2 + 1] * inv_n - m * m;
+    const double m = stats[(b * G + g) * 2] * inv_n;
+    const double var = stats[(b * G + g) * 2 + 1] * inv_n - m * m;
     const float mean = (float)m, rstd = rsqrtf((float)(var > 0.0 ? var : 0.0) + eps);
     const f32x4 v = gn_load(s1, s2, b, HW, C1, C2, p, c, s2_scale);
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
@@ -616,6 +652,8 @@ __global__ __launch_bounds__(256) void k_gca_pool(const float* __restrict__ h, c
 //   2 PACK_IN    out NHWC f32 [B,HW,Cp] = concat(cond NCHW [B,Cc,HW], x NCHW [B,Cx,HW]), zero pad ; p0 cond, p1 x, p3 out ; i = B,HW,Cc,Cx,Cp
 //   3 UNPACK_OUT out NCHW [B,C,HW] = in NHWC [B,HW,ldi] first C channels ; p0 in, p3 out ; i = B,HW,C,ldi
 //   4 ADD        out[i] += p0[i] ; i[0] = n
+//   5 PACK_ACT   p0 f32 [.., ld] -> p3 bf16 B-operand fragments ; i = N, K, ld, transpose
+//   6 SOFTMAX    p3 bf16 [R,N] = softmax(f[0] * p0 f32 [R,N]) ; i = R, N
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gate_res(const float* __restrict__ h, const float* __restrict__ gate,
                                                   const float* __restrict__ res, float* __restrict__ out, int B, int HW,
@@ -644,6 +682,49 @@ __global__ __launch_bounds__(256) void k_pack_in(const float* __restrict__ cond,
     out[i] = v;
   }
 }
+// PACK_ACT: an fp32 activation matrix becomes the B operand of k_conv_igemm (same fragment order as
+// sf_conv_pack_weights): W[n][c] = src[n*ld + c] (T = 0) or src[c*ld + n] (T = 1), n < N, c < K, zero padded.
+__global__ __launch_bounds__(256) void k_pack_act(const float* __restrict__ src, bf16x8* __restrict__ out, int N, int K, int ld,
+                                                  int T) {
+  const int kchunks = (K + 31) / 32, n_frags = (N + 15) / 16;
+  const long total = (long)n_frags * kchunks * 64;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int lane = (int)(i & 63);
+    const long r = i >> 6;
+    const int ks = (int)(r % kchunks), nf = (int)(r / kchunks);
+    const int n = nf * 16 + (lane & 15), c0 = ks * 32 + 8 * (lane >> 4);
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      float x = 0.0f;
+      if (n < N && c < K) x = T ? src[(long)c * ld + n] : src[(long)n * ld + c];
+      v[j] = (__bf16)x;
+    }
+    out[i] = v;
+  }
+}
+
+// SOFTMAX_ROWS: out bf16 [R, N] = softmax(scale * in f32 [R, N]) per row; one workgroup per row.
+__global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ in, __bf16* __restrict__ out, int N, float scale) {
+  __shared__ float red[8];
+  const float* x = in + (long)blockIdx.x * N;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < N; i += 256) mx = fmaxf(mx, x[i] * scale);
+  mx = wave_max(mx);
+  if (lane == 0) red[wv] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float s = 0.0f;
+  for (int i = threadIdx.x; i < N; i += 256) s += expf(x[i] * scale - mx);
+  s = wave_sum(s);
+  if (lane == 0) red[4 + wv] = s;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (int i = threadIdx.x; i < N; i += 256) out[(long)blockIdx.x * N + i] = (__bf16)(expf(x[i] * scale - mx) * inv);
+}
+
 __global__ __launch_bounds__(256) void k_unpack_out(const float* __restrict__ in, float* __restrict__ out, int B, int HW,
                                                     int C, int ldi) {
   const long n = (long)B * C * HW;
@@ -692,6 +773,8 @@ static int run_conv(const sf_op& op, hipStream_t st) {
   const int tile = op.i[14];
   const int WM = tile / 16, WN = tile % 16;
   a.pixshuf = (op.flags & 2) ? 1 : 0;
+  a.ups = (op.flags & 16) ? 1 : 0;
+  if (a.ups && ((a.H | a.W) & 1)) SF_FAIL(SF_ERR_INVALID, "conv: upsampled input dims must be even");
   if (a.Cin % 32) SF_FAIL(SF_ERR_INVALID, "conv: Cin_pad must be a multiple of 32");
   if (a.pixshuf && a.groups != 1) SF_FAIL(SF_ERR_INVALID, "conv: pixel-shuffle epilogue cannot be split-K");
   a.cchunks = a.Cin / 32;
@@ -742,21 +825,30 @@ static int lazy_from_op(const sf_op& op, int ibase, int M, LazySrc& lz) {
 
 static int run_gn(const sf_op& op, hipStream_t st) {
   const int B = op.i[0], HW = op.i[1], C1 = op.i[2], C2 = op.i[3];
-  const int C = C1 + C2;
-  if (C % 32 || C1 % 4 || !op.p[7]) SF_FAIL(SF_ERR_INVALID, "gn_act: unsupported shape HW=%d C=%d (or missing stats buffer)", HW, C);
-  const int chunks = HW * (C / 8) / 4;
+  const int C = C1 + C2, G = op.i[8] > 0 ? op.i[8] : 8;
+  if (C % (4 * G) || C1 % 4 || !op.p[7])
+    SF_FAIL(SF_ERR_INVALID, "gn_act: unsupported shape HW=%d C=%d G=%d (or missing stats buffer)", HW, C, G);
+  const int chunks = HW * (C / G) / 4;
   LazySrc lz;
   if (int rc = lazy_from_op(op, 5, B * HW, lz)) return rc;
-  // a lazy split-K source multiplies the loads per chunk by `groups`: one chunk per thread then
-  const int per_block = lz.mode == 1 ? 256 : GN_CHUNKS_PER_BLOCK;
-  const int slices = (chunks + per_block - 1) / per_block;
-  k_gn_stats<<<B * 8 * slices, 256, 0, st>>>((float*)op.p[0], (const float*)op.p[1], (double*)op.p[7], HW, C1, C2, slices,
-                                             op.f[1], lz);
+  const int c4 = C / 4;
+  if (!op.p[1] && !lz.mode && C / G <= 16 && c4 <= 256 && 256 % c4 == 0) {
+    const int ppi = 256 / c4;
+    int slabs = HW / (ppi * 16);                       // >= 16 pixels per thread row before splitting further
+    slabs = slabs < 1 ? 1 : (slabs > 1024 ? 1024 : slabs);
+    k_gn_stats_px<<<B * slabs, 256, 0, st>>>((const float*)op.p[0], (double*)op.p[7], HW, C, G, slabs);
+  } else {
+    // a lazy split-K source multiplies the loads per chunk by `groups`: one chunk per thread then
+    const int per_block = lz.mode == 1 ? 256 : GN_CHUNKS_PER_BLOCK;
+    const int slices = (chunks + per_block - 1) / per_block;
+    k_gn_stats<<<B * G * slices, 256, 0, st>>>((float*)op.p[0], (const float*)op.p[1], (double*)op.p[7], HW, C1, C2, slices,
+                                               op.f[1], lz, G);
+  }
   SF_CHECK_LAUNCH("gn_stats");
   const long total = (long)B * HW * (C / 4);
   k_gn_apply<<<sf_grid_cap(sf_div_up(total, 256)), 256, 0, st>>>(
       (const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const float*)op.p[4],
-      (const double*)op.p[7], (__bf16*)op.p[5], (__bf16*)op.p[6], B, HW, C1, C2, op.i[4], op.f[0], op.f[1], op.flags & 1);
+      (const double*)op.p[7], (__bf16*)op.p[5], (__bf16*)op.p[6], B, HW, C1, C2, op.i[4], op.f[0], op.f[1], op.flags & 1, G);
   SF_CHECK_LAUNCH("gn_apply");
   return SF_OK;
 }
@@ -838,6 +930,15 @@ static int run_eltwise(const sf_op& op, hipStream_t st) {
       k_add<<<sf_grid_cap(sf_div_up(n, 256)), 256, 0, st>>>((const float*)op.p[0], (float*)op.p[3], n);
       break;
     }
+    case 5: {
+      const long total = (long)((op.i[0] + 15) / 16) * ((op.i[1] + 31) / 32) * 64;
+      k_pack_act<<<sf_grid_cap(sf_div_up(total, 256)), 256, 0, st>>>((const float*)op.p[0], (bf16x8*)op.p[3], op.i[0], op.i[1],
+                                                                   op.i[2], op.i[3]);
+      break;
+    }
+    case 6:
+      k_softmax_rows<<<op.i[0], 256, 0, st>>>((const float*)op.p[0], (__bf16*)op.p[3], op.i[1], op.f[0]);
+      break;
     default: SF_FAIL(SF_ERR_INVALID, "eltwise: unknown mode %d", op.flags);
   }
   SF_CHECK_LAUNCH("eltwise");

@@ -226,11 +226,14 @@ class _Plan:
 
     # -------- op emitters
     def conv(self, x, x_f32, H, W, wname, bname, out, ldc, co_off, Cout, k, stride=1, pad=0, resid=None, pixshuf=False,
-             defer=False):
-        B = self.B
+             defer=False, w_ptr=None, batch=None, out_hw=None, upsampled=False):
+        """One implicit-GEMM launch.  `w_ptr` replaces the named weight by a device-packed B operand (attention),
+        `batch` overrides the plan batch (per-sample GEMMs), `out_hw` the output size (asymmetric padding),
+        `upsampled` makes (H, W) the dims of a nearest-x2 view of the stored [H/2, W/2] input."""
+        B = self.B if batch is None else batch
         self.need(x)
         self.need(resid)
-        Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        Ho, Wo = out_hw or ((H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1)
         M = B * Ho * Wo
         m_frags, n_frags = (M + 15) // 16, (Cout + 15) // 16
         KS = k * k * (x.C // 32)
@@ -245,23 +248,24 @@ class _Plan:
         defer = bool(defer and groups > 1 and not accum and not pixshuf and co_off == 0 and ldc == Cout == out.C and M == out.rows
                      and (self.u.lazy_consumers & 1))
         bias, res = self.wptr(bname) if bname else 0, resid.ptr if resid else 0
-        self.op(OP_CONV, (1 if x_f32 else 0) | (2 if pixshuf else 0) | (4 if accum else 0) | (8 if defer else 0),
-                p=(x.ptr, self.wptr(wname), bias, out.ptr, res, ws),
+        self.op(OP_CONV, (1 if x_f32 else 0) | (2 if pixshuf else 0) | (4 if accum else 0) | (8 if defer else 0) |
+                (16 if upsampled else 0),
+                p=(x.ptr, w_ptr if w_ptr is not None else self.wptr(wname), bias, out.ptr, res, ws),
                 i=(B, H, W, x.C, Ho, Wo, Cout, ldc, co_off, k, k, stride, pad, groups, WM * 16 + WN))
         if defer:
             out.lazy = ("splitk", ws, bias, res, groups, n_frags * 16)
             self.ws_owner = out
         return Ho, Wo
 
-    def gn_act(self, x, skip, gname, ss_ptr, out, raw=None, silu=True):
+    def gn_act(self, x, skip, gname, ss_ptr, out, raw=None, silu=True, groups=8, eps=1e-5):
         C1, C2 = x.C, (skip.C if skip else 0)
         self.need(skip)
         lp, li = self.take_lazy(x, ("splitk", "gate"))
-        stats = self.zero.alloc(self.B * 8 * 2 * 8)          # f64 (sum, sum of squares) per (b, group), zeroed per eval
+        stats = self.zero.alloc(self.B * groups * 2 * 8)     # f64 (sum, sum of squares) per (b, group), zeroed per eval
         self.op(OP_GN_ACT, 0 if silu else 1,
                 p=(x.ptr, skip.ptr if skip else 0, self.wptr(gname + ".weight"), self.wptr(gname + ".bias"), ss_ptr, out.ptr,
                    raw.ptr if raw else 0, stats) + lp,
-                i=(self.B, x.HW, C1, C2, self.u.ss_total) + li, f=(1e-5, SKIP_SCALE))
+                i=(self.B, x.HW, C1, C2, self.u.ss_total) + li + (groups,), f=(eps, SKIP_SCALE))
 
     def ln(self, x, gname, bname, out, C, rows, eps=1e-5, gelu=False, out_f32=False, resid=None):
         self.need(x)
