@@ -3,13 +3,12 @@
 
 One "step" = one pass of the north-star hot path for one novel view per GPU, synthetic 2-view scene:
   A  input-view NGP render (128x128 rays, 64+64 samples) fwd + bwd + Adam           distillation.py:185-247
-  B  novel-view NGP render fwd -> x2 bilinear -> latent stand-in -> PLMSSampler.sample(max_thres=0.5:
-     50 steps = 51 UNet evals at 32x32 latents, 256-ch view features) -> pixel stand-in ->
+  B  novel-view NGP render fwd -> x2 bilinear -> SD-VAE encode(.).mode() * z_scale -> PLMSSampler.sample(
+     max_thres=0.5: 50 steps = 51 UNet evals at 32x32 latents, 256-ch view features) -> SD-VAE decode ->
      (1-alpha_bar)*L1 + 1e-3*opacity -> bwd + Adam                                   distillation.py:262-352
-The SD-VAE encode/decode and LPIPS of the reference step are NOT part of the north-star path
-(SURVEY.md 8(f) 'next' rows 1-2): a fixed linear 8x8 pooling / nearest upsample stands in for them so
-that the render and the sampler are chained exactly as in the loop; their cost is excluded and said so
-in `config.workload`.  fp32 everywhere except the UNet's MFMA operands (bf16, fp32 accumulate).
+Everything runs on this repo's HIP path (NGP render, UNet/PLMS, and the SD-VAE of SURVEY.md 8(f) row 1).  Only
+the LPIPS-VGG perceptual term (8(f) row 2, lambda_percep) is left out, and `config.workload` says so.  fp32
+everywhere except the conv / linear MFMA operands of the UNet and VAE (bf16, fp32 accumulate).
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): every rank distils its own novel
@@ -76,6 +75,9 @@ class HotPath:
                          dynamic_thresholding_percentile=.68, clip_value=10).to(device)
         self.unet = self.vldm.unets[0]
         self.plms = PLMSSampler(self.vldm, 50)
+        from sparsefusion_amd.vae import AutoencoderKL
+        self.vae = AutoencoderKL().to(device)                     # sd-vae.yaml architecture, default (kaiming-range) init
+        self.z_scale = 0.18215                                    # args.z_scale_factor of the reference's demo
         g = torch.Generator().manual_seed(100 + rank)
         self.rays_in = pinhole_rays(128, rank % 2, 34, device)                 # one of the 2 input views
         self.rays_novel = [pinhole_rays(128, 2 + rank * views + v, 34, device) for v in range(views)]   # this rank's novel views
@@ -83,15 +85,6 @@ class HotPath:
         self.target_mask = (torch.rand(1, 1, 128, 128, generator=g) > 0.5).float().to(device)
         self.features = torch.randn(views, 256, 32, 32, generator=g).to(device)  # cached EFT features of the novel views
         self.flat_grads = None
-
-    # -- latent <-> pixel stand-ins for the SD-VAE (out of the north-star path)
-    @staticmethod
-    def encode_standin(img256, sil256):
-        return torch.cat([F.avg_pool2d(img256, 8) * 2 - 1, F.avg_pool2d(sil256, 8) * 2 - 1], 1) * 0.18215 * 4
-
-    @staticmethod
-    def decode_standin(lat):
-        return (F.interpolate(lat[:, :3] / (0.18215 * 4), scale_factor=8, mode='nearest') + 1) * 0.5
 
     def render(self, rays):
         o, d = rays
@@ -122,12 +115,12 @@ class HotPath:
         img256 = F.interpolate(img, scale_factor=2, mode='bilinear')
         sil256 = F.interpolate(sil, scale_factor=2, mode='bilinear')
         with torch.no_grad():
-            latents = self.encode_standin(img256, sil256)
+            latents = self.vae.encode(img256 * 2 - 1).mode() * self.z_scale          # distillation.py:299
             from sparsefusion_amd.distributed import all_gather_latents
             self.step_latents = all_gather_latents(latents)        # latents of all novel views of this step (8(e))
             pred_x0, x_noisy, noise, acp = self.plms.sample(latents, cond_images=self.features, use_tqdm=False,
                                                             return_noise=True, max_thres=self.max_thres)
-            pred_img = self.decode_standin(pred_x0).clip(0.0, 1.0)
+            pred_img = ((self.vae.decode(pred_x0 / self.z_scale) + 1) * 0.5).clip(0.0, 1.0)   # distillation.py:309
         fusion = ((1 - acp).view(-1, 1, 1, 1) * (img256 - pred_img).abs()).mean()
         loss = fusion + 1e-3 * torch.sqrt(sil256 ** 2 + .01).mean()
         loss.backward()
@@ -191,7 +184,7 @@ def unet_roofline(hp):
 def cpu_baseline(max_thres):
     """The CPU oracle (a port: the reference has no CPU path for its CUDA kernels) timed on this host, on a
     bounded sample of the same workload, scaled to one step."""
-    from oracle import ngp_ref, unet_ref
+    from oracle import ngp_ref, unet_ref, vae_ref
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from unet_common import spec
     cores = min(32, os.cpu_count() or 1)          # torch CPU kernels stop scaling (and oversubscribe) beyond ~32 threads
@@ -214,12 +207,18 @@ def cpu_baseline(max_thres):
         for _ in range(3):
             unet_ref.unet_forward(sd, x, ls, cond)
         t_eval = (time.time() - t0) / 3
+    vsd = vae_ref.init_state(vae_ref.vae_param_spec(vae_ref.CANONICAL), seed=0)
+    with torch.no_grad():
+        t0 = time.time()
+        vae_ref.encode_mode(vsd, vae_ref.CANONICAL, torch.rand(1, 3, 256, 256) * 2 - 1)
+        vae_ref.decode(vsd, vae_ref.CANONICAL, torch.randn(1, 4, 32, 32))
+        t_vae = time.time() - t0
     n_evals = min(int(max_thres * 100), 50) + 1
-    step_s = 2 * t_render + n_evals * t_eval
+    step_s = 2 * t_render + n_evals * t_eval + t_vae
     return {"value": round(1.0 / step_s, 5), "unit": "views/s", "cores": cores, "kind": "port",
             "ms_per_step": round(step_s * 1e3, 1), "unet_eval_ms": round(t_eval * 1e3, 1),
-            "ngp_render_fwd_bwd_ms": round(t_render * 1e3, 1),
-            "sample": f"1 NGP render fwd+bwd on 1024/16384 rays (x16) + 3 UNet evals B=1 (x{n_evals}/3), oracle fp32, "
+            "ngp_render_fwd_bwd_ms": round(t_render * 1e3, 1), "vae_enc_dec_ms": round(t_vae * 1e3, 1),
+            "sample": f"1 NGP render fwd+bwd on 1024/16384 rays (x16) + 3 UNet evals B=1 (x{n_evals}/3) + 1 VAE encode + decode, oracle fp32, "
                       f"{cores} threads of {os.cpu_count()}; the reference has no CPU path for grid-encode/near-far (port)"}
 
 
@@ -266,14 +265,15 @@ def main():
     if rank == 0:
         n_evals = min(int(args.max_thres * 100), 50) + 1
         res = {
-            "metric": "novel views/sec, hot-path distillation steps (2 NGP renders fwd+bwd + %d-eval PLMS), 256^2 / 32x32 latents, "
+            "metric": "novel views/sec, hot-path distillation steps (2 NGP renders fwd+bwd + VAE enc/dec + %d-eval PLMS), 256^2 / 32x32 latents, "
                       "2-view synthetic hydrant" % n_evals,
             "value": round(world * args.views_per_gpu / (ms_per_step * 1e-3), 4), "unit": "views/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16 MFMA operands / f32 accumulate (UNet); f32 (NGP render)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: single MI355X, 256^2 hydrant-like synthetic scene, 2 input views, "
                                    "32x32 latent UNet (400.68M params, B=%d per GPU) + NGP render 128x128 rays x (64+64) samples; "
-                                   "max_thres=%.2f; SD-VAE/LPIPS replaced by a linear stand-in (outside north_star)" % (args.views_per_gpu, args.max_thres),
+                                   "SD-VAE encode 256^2 -> 32x32x4 and decode back (83.65M params) every step; max_thres=%.2f; "
+                                   "LPIPS term of the reference loss not included" % (args.views_per_gpu, args.max_thres),
                        "views_per_gpu": args.views_per_gpu, "unet_evals_per_step": n_evals, "rays_per_render": 16384,
                        "parallelism": "view-sharded replicas x%d, RCCL all-gather(latents) + all-reduce(NGP grads)" % world},
         }
@@ -282,6 +282,8 @@ def main():
             "ngp_render_fwd": round(time_region(lambda: hp.render(hp.rays_novel[0]), 5), 3),
             "unet_eval_wall": round(time_region(lambda: hp.unet.forward_with_cond_scale(
                 torch.zeros(1, 4, 32, 32, device=dev), torch.zeros(1, device=dev), cond_images=hp.features[:1]), 10), 3),
+            "vae_encode": round(time_region(lambda: hp.vae.encode(torch.zeros(1, 3, 256, 256, device=dev)), 5), 3),
+            "vae_decode": round(time_region(lambda: hp.vae.decode(torch.zeros(1, 4, 32, 32, device=dev)), 5), 3),
         }
         res["roofline"] = unet_roofline(hp)
         if world == 1 and not args.no_cpu_baseline:

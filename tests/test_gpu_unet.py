@@ -49,6 +49,33 @@ def test_unet_layerwise_against_oracle():
     assert rel_err(y, y_ref) < TOL_REL
 
 
+@pytest.mark.parametrize("B", [1, 4])
+def test_lazy_consumers_do_not_change_the_result(B):
+    """Split-K partials / gated residuals materialised by their first consumer (GroupNorm statistics pass, gca
+    logits pass) instead of their own launch: same arithmetic in the same order, so the eval must agree to
+    fp32 round-off; B = 4 is the views-per-GPU batch of BASELINE config 4 and is checked against the oracle too."""
+    name = "canonical"
+    sd = state(name)
+    net = _unet(name, sd)
+    g = torch.Generator().manual_seed(33)
+    x = torch.randn(B, 4, 32, 32, generator=g)
+    cond = torch.randn(B, 256, 32, 32, generator=g)
+    ls = unet_ref.log_snr(torch.tensor([0.8, 0.3, 0.55, 0.02][:B]))
+    ys = {}
+    for mode in (0, 3):
+        net.lazy_consumers = mode
+        net.invalidate()
+        ys[mode] = net.forward_with_cond_scale(x.to(DEV), ls.to(DEV), cond_images=cond.to(DEV)).cpu()
+        n_ops = len(net._plan(B, torch.device(DEV)).ops)
+        print(f"B={B} lazy_consumers={mode}: {n_ops} ops")
+    assert rel_err(ys[3], ys[0]) < 1e-5
+    with torch.no_grad():
+        y_ref = unet_ref.unet_forward(sd, x, ls, cond)
+    r, c = rel_err(ys[3], y_ref), cosine(ys[3], y_ref)
+    print(f"B={B} vs oracle: rel L2 {r:.3e} cosine {c:.6f}")
+    assert r < TOL_REL and c > TOL_COS
+
+
 def test_unet_state_dict_roundtrip_and_errors():
     net = _unet("small")
     sd = net.state_dict()
