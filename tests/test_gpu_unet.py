@@ -52,8 +52,10 @@ def test_unet_layerwise_against_oracle():
 @pytest.mark.parametrize("B", [1, 4])
 def test_lazy_consumers_do_not_change_the_result(B):
     """Split-K partials / gated residuals materialised by their first consumer (GroupNorm statistics pass, gca
-    logits pass) instead of their own launch: same arithmetic in the same order, so the eval must agree to
-    fp32 round-off; B = 4 is the views-per-GPU batch of BASELINE config 4 and is checked against the oracle too."""
+    logits pass) instead of their own launch.  Element values are the same sums in the same order, but the
+    statistics pass slices its fp32 partial sums differently, so means differ in the last ulp and bf16 roundings
+    downstream decorrelate: the two plans agree to the bf16 tolerance and BOTH meet the oracle tolerance.
+    B = 4 is the views-per-GPU batch of BASELINE config 4."""
     name = "canonical"
     sd = state(name)
     net = _unet(name, sd)
@@ -68,12 +70,13 @@ def test_lazy_consumers_do_not_change_the_result(B):
         ys[mode] = net.forward_with_cond_scale(x.to(DEV), ls.to(DEV), cond_images=cond.to(DEV)).cpu()
         n_ops = len(net._plan(B, torch.device(DEV)).ops)
         print(f"B={B} lazy_consumers={mode}: {n_ops} ops")
-    assert rel_err(ys[3], ys[0]) < 1e-5
+    assert rel_err(ys[3], ys[0]) < TOL_REL
     with torch.no_grad():
         y_ref = unet_ref.unet_forward(sd, x, ls, cond)
-    r, c = rel_err(ys[3], y_ref), cosine(ys[3], y_ref)
-    print(f"B={B} vs oracle: rel L2 {r:.3e} cosine {c:.6f}")
-    assert r < TOL_REL and c > TOL_COS
+    for mode in (0, 3):
+        r, c = rel_err(ys[mode], y_ref), cosine(ys[mode], y_ref)
+        print(f"B={B} lazy_consumers={mode} vs oracle: rel L2 {r:.3e} cosine {c:.6f}")
+        assert r < TOL_REL and c > TOL_COS
 
 
 def test_unet_state_dict_roundtrip_and_errors():
