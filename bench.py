@@ -166,6 +166,25 @@ def unet_roofline(hp):
     conv_bytes = conv_params * 2                                   # bf16 weights, each read once per eval
     achieved = conv_bytes / (conv_ms * 1e-3) / 1e9
     total_ms = float(acc.sum())
+    # what an event pair adds around ANY op (record + kernel boundary + a near-empty kernel): 64 one-element adds
+    from sparsefusion_amd.unet import OP_ELTWISE
+    scratch = torch.zeros(64, device=hp.dev)
+    tiny = (_lib.SfOp * 64)()
+    for o in tiny:
+        o.type, o.flags = OP_ELTWISE, 4
+        o.p[0], o.p[3], o.i[0] = scratch.data_ptr(), scratch.data_ptr() + 128, 1
+    tms = (C.c_float * 64)()
+    for _ in range(2):
+        _lib.check(lib.sf_plan_profile(tiny, 64, _lib.stream_ptr(), tms))
+    event_floor_us = float(np.median(np.array(list(tms)))) * 1e3
+    rocprof_us = None                                              # trace-timed conv (+ split-K reduce) time per conv op
+    stats_csv = os.path.join(ROOT, "profiles", "r01_unet_eval_b1_kernel_stats.csv")
+    if os.path.exists(stats_csv):
+        import csv
+        rows = list(csv.DictReader(open(stats_csv)))
+        evals = max(int(r["Calls"]) for r in rows if r["Name"].startswith("k_pack_in"))
+        t = sum(float(r["TotalDurationNs"]) for r in rows if "k_conv_igemm" in r["Name"] or "k_splitk_reduce" in r["Name"])
+        rocprof_us = round(t / evals / n_conv / 1e3, 2)
     traffic = None                                                 # HBM bytes per conv launch from the committed PMC passes
     pmc = os.path.join(ROOT, "profiles", "r01_unet_eval_b1_pmc_hbm.json")
     if os.path.exists(pmc):
@@ -176,6 +195,10 @@ def unet_roofline(hp):
             "traffic_note": "avg HBM fetch bytes per conv launch: rocprofv3 --pmc FETCH_SIZE pass (x2 gfx950 correction), "
                             "profiles/r01_unet_eval_b1_pmc_hbm.json; algorithmic = %d B/launch" % (conv_bytes // n_conv),
             "launches_per_eval": n_conv, "avg_launch_us": round(conv_ms / n_conv * 1e3, 2),
+            "event_floor_us": round(event_floor_us, 2), "avg_launch_us_rocprof": rocprof_us,
+            "timing_note": "avg_launch_us = HIP events on the launch stream around each conv op (kernel + its split-K reduce "
+                           "+ one event/boundary, whose floor is event_floor_us for a one-element kernel); avg_launch_us_rocprof = "
+                           "same ops from the committed rocprofv3 kernel trace (profiles/r01_unet_eval_b1_kernel_stats.csv)",
             "algorithmic_bytes_per_eval": conv_bytes,
             "unet_eval_event_ms": round(total_ms, 3), "unet_ops_per_eval": len(plan.ops),
             "unet_eval_weight_stream_GBs": round(801.4e6 / (total_ms * 1e-3) / 1e9, 1)}
