@@ -80,6 +80,63 @@ int sf_packbits(const float* grid, uint32_t N, float density_thresh,
                 uint8_t* bitfield, void* stream);
 
 /* ------------------------------------------------------------------------ */
+/* `_raymarching` occupancy-grid entry points (cuda_ray=True path):          */
+/* raymarching/src/bindings.cpp:8,12-18, raymarching.h:8,12-18.              */
+/* All tensors f32 / i32 / u8 device pointers, caller-allocated, mutated in  */
+/* place exactly where the reference mutates them.                           */
+/* ------------------------------------------------------------------------ */
+
+/* Replaces sph_from_ray (raymarching.cu:159-204). coords [N,2] in [-1,1]. */
+int sf_sph_from_ray(const float* rays_o, const float* rays_d, float radius,
+                    uint32_t N, float* coords, void* stream);
+
+/* Replaces march_rays_train (raymarching.cu:302-492).
+ * grid: density bitfield [C*H^3/8]; xyzs/dirs [M,3], deltas [M,2] (caller
+ * zero-fills), rays [N,3] i32 = (ray id, point offset, point count),
+ * counter [2] i32 += (points, rays) as the reference's two atomicAdd do.
+ * Point slots are assigned in ray order by a scan (one of the reference's
+ * valid outcomes, deterministic). `workspace` holds the per-ray counts:
+ * sf_march_rays_train_workspace_bytes(N) bytes, caller-allocated. */
+uint64_t sf_march_rays_train_workspace_bytes(uint32_t N);
+int sf_march_rays_train(const float* rays_o, const float* rays_d,
+                        const uint8_t* grid, float bound, float dt_gamma,
+                        uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                        uint32_t M, const float* nears, const float* fars,
+                        float* xyzs, float* dirs, float* deltas, int32_t* rays,
+                        int32_t* counter, const float* noises,
+                        void* workspace, uint64_t workspace_bytes, void* stream);
+
+/* Replaces composite_rays_train_forward / _backward (raymarching.cu:495-688). */
+int sf_composite_rays_train_forward(const float* sigmas, const float* rgbs,
+                                    const float* deltas, const int32_t* rays,
+                                    uint32_t M, uint32_t N, float T_thresh,
+                                    float* weights_sum, float* depth,
+                                    float* image, void* stream);
+int sf_composite_rays_train_backward(const float* grad_weights_sum,
+                                     const float* grad_image,
+                                     const float* sigmas, const float* rgbs,
+                                     const float* deltas, const int32_t* rays,
+                                     const float* weights_sum,
+                                     const float* image, uint32_t M, uint32_t N,
+                                     float T_thresh, float* grad_sigmas,
+                                     float* grad_rgbs, void* stream);
+
+/* Replaces march_rays / composite_rays (inference, raymarching.cu:695-913).
+ * rays_alive [>= n_alive] i32 (set to -1 when a ray terminates), rays_t [N],
+ * weights_sum/depth/image accumulated in place. */
+int sf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive,
+                  const float* rays_t, const float* rays_o, const float* rays_d,
+                  float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
+                  uint32_t H, const uint8_t* grid, const float* nears,
+                  const float* fars, float* xyzs, float* dirs, float* deltas,
+                  const float* noises, void* stream);
+int sf_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh,
+                      int32_t* rays_alive, float* rays_t, const float* sigmas,
+                      const float* rgbs, const float* deltas,
+                      float* weights_sum, float* depth, float* image,
+                      void* stream);
+
+/* ------------------------------------------------------------------------ */
 /* Fused NGP render (external/nerf/renderer_df.py:310-468 `run`,             */
 /* network_grid.py:69-88 `common_forward`) -- see DESIGN.md section 3.       */
 /* ------------------------------------------------------------------------ */

@@ -77,6 +77,57 @@ def packbits(grid, N, thresh, bitfield):
     lib().oracle_packbits(_p(grid), C.c_uint32(N), C.c_float(thresh), _p(bitfield))
 
 
+def sph_from_ray(rays_o, rays_d, radius, N, coords):
+    _chk(rays_o); _chk(rays_d); _chk(coords)
+    lib().oracle_sph_from_ray(_p(rays_o), _p(rays_d), C.c_float(radius), C.c_uint32(N), _p(coords))
+
+
+def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C_, H, M, nears, fars, xyzs, dirs, deltas, rays,
+                     counter, noises):
+    for t in (rays_o, rays_d, nears, fars, xyzs, dirs, deltas, noises):
+        _chk(t)
+    _chk(grid, torch.uint8); _chk(rays, torch.int32); _chk(counter, torch.int32)
+    lib().oracle_march_rays_train(_p(rays_o), _p(rays_d), _p(grid), C.c_float(bound), C.c_float(dt_gamma),
+                                  C.c_uint32(max_steps), C.c_uint32(N), C.c_uint32(C_), C.c_uint32(H), C.c_uint32(M),
+                                  _p(nears), _p(fars), _p(xyzs), _p(dirs), _p(deltas), _p(rays), _p(counter), _p(noises))
+
+
+def composite_rays_train_forward(sigmas, rgbs, deltas, rays, M, N, T_thresh, weights_sum, depth, image):
+    for t in (sigmas, rgbs, deltas, weights_sum, depth, image):
+        _chk(t)
+    _chk(rays, torch.int32)
+    lib().oracle_composite_rays_train_forward(_p(sigmas), _p(rgbs), _p(deltas), _p(rays), C.c_uint32(M), C.c_uint32(N),
+                                              C.c_float(T_thresh), _p(weights_sum), _p(depth), _p(image))
+
+
+def composite_rays_train_backward(grad_weights_sum, grad_image, sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh,
+                                  grad_sigmas, grad_rgbs):
+    for t in (grad_weights_sum, grad_image, sigmas, rgbs, deltas, weights_sum, image, grad_sigmas, grad_rgbs):
+        _chk(t)
+    _chk(rays, torch.int32)
+    lib().oracle_composite_rays_train_backward(_p(grad_weights_sum), _p(grad_image), _p(sigmas), _p(rgbs), _p(deltas),
+                                               _p(rays), _p(weights_sum), _p(image), C.c_uint32(M), C.c_uint32(N),
+                                               C.c_float(T_thresh), _p(grad_sigmas), _p(grad_rgbs))
+
+
+def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C_, H, grid, nears, fars,
+               xyzs, dirs, deltas, noises):
+    for t in (rays_t, rays_o, rays_d, nears, fars, xyzs, dirs, deltas, noises):
+        _chk(t)
+    _chk(grid, torch.uint8); _chk(rays_alive, torch.int32)
+    lib().oracle_march_rays(C.c_uint32(n_alive), C.c_uint32(n_step), _p(rays_alive), _p(rays_t), _p(rays_o), _p(rays_d),
+                            C.c_float(bound), C.c_float(dt_gamma), C.c_uint32(max_steps), C.c_uint32(C_), C.c_uint32(H),
+                            _p(grid), _p(nears), _p(fars), _p(xyzs), _p(dirs), _p(deltas), _p(noises))
+
+
+def composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
+    for t in (rays_t, sigmas, rgbs, deltas, weights_sum, depth, image):
+        _chk(t)
+    _chk(rays_alive, torch.int32)
+    lib().oracle_composite_rays(C.c_uint32(n_alive), C.c_uint32(n_step), C.c_float(T_thresh), _p(rays_alive), _p(rays_t),
+                                _p(sigmas), _p(rgbs), _p(deltas), _p(weights_sum), _p(depth), _p(image))
+
+
 class GridEncodeCPU(torch.autograd.Function):
     """Autograd glue around the C oracle with the data flow of external/gridencoder/grid.py:19-88
     ([L,B,C] kernel layout, permuted to [B, L*C]; zero-initialised table gradient)."""

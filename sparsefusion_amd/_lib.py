@@ -49,6 +49,18 @@ SIGNATURES = {
     "sf_morton3D": (C.c_int, [c_i32p, u32, c_i32p, C.c_void_p]),
     "sf_morton3D_invert": (C.c_int, [c_i32p, u32, c_i32p, C.c_void_p]),
     "sf_packbits": (C.c_int, [c_f32p, u32, C.c_float, C.c_void_p, C.c_void_p]),
+    "sf_sph_from_ray": (C.c_int, [c_f32p, c_f32p, C.c_float, u32, c_f32p, C.c_void_p]),
+    "sf_march_rays_train_workspace_bytes": (u64, [u32]),
+    "sf_march_rays_train": (C.c_int, [c_f32p, c_f32p, C.c_void_p, C.c_float, C.c_float, u32, u32, u32, u32, u32, c_f32p,
+                                      c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p, c_f32p, C.c_void_p, u64, C.c_void_p]),
+    "sf_composite_rays_train_forward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, u32, u32, C.c_float, c_f32p, c_f32p,
+                                                  c_f32p, C.c_void_p]),
+    "sf_composite_rays_train_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, u32,
+                                                   u32, C.c_float, c_f32p, c_f32p, C.c_void_p]),
+    "sf_march_rays": (C.c_int, [u32, u32, c_i32p, c_f32p, c_f32p, c_f32p, C.c_float, C.c_float, u32, u32, u32,
+                                C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "sf_composite_rays": (C.c_int, [u32, u32, C.c_float, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                    c_f32p, C.c_void_p]),
     "sf_ngp_density": (C.c_int, [C.POINTER(SfNgpField), c_f32p, u32, c_f32p, c_f32p, C.c_void_p]),
     "sf_ngp_render_forward": (C.c_int, [C.POINTER(SfNgpField), c_f32p, c_f32p, c_f32p, u32, u32, C.c_float,
                                         c_f32p, c_f32p, c_f32p, u32, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p,
