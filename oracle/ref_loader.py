@@ -59,10 +59,100 @@ def install():
         ngp_native.near_far_from_aabb(o, d, aabb.float().contiguous(), o.shape[0], min_near, nears, fars)
         return nears, fars
 
-    _stub("raymarching", near_far_from_aabb=near_far_from_aabb)
+    _stub("raymarching", near_far_from_aabb=near_far_from_aabb, **_occupancy_api(ngp_native))
     _stub("_gridencoder", grid_encode_forward=ngp_native.grid_encode_forward,
           grid_encode_backward=ngp_native.grid_encode_backward)
     _installed = True
+
+
+def _occupancy_api(nn):
+    """CPU stand-ins for the Python-level functions of the reference's raymarching/raymarching.py:80-380 that its
+    `run_cuda` / `update_extra_state` call, on top of the C oracle (the reference's own versions force .cuda()).
+    Argument handling (M, align, noises, slicing to the counted points) restates raymarching.py:160-235, :296-346."""
+
+    def morton3D(coords):
+        c = coords.int().contiguous()
+        out = torch.empty(c.shape[0], dtype=torch.int32)
+        nn.morton3D(c, c.shape[0], out)
+        return out
+
+    def morton3D_invert(indices):
+        i = indices.int().contiguous()
+        out = torch.empty(i.shape[0], 3, dtype=torch.int32)
+        nn.morton3D_invert(i, i.shape[0], out)
+        return out
+
+    def packbits(grid, thresh, bitfield=None):
+        g = grid.contiguous()
+        C_, H3 = g.shape
+        n = C_ * H3 // 8
+        if bitfield is None:
+            bitfield = torch.empty(n, dtype=torch.uint8)
+        nn.packbits(g.view(-1), n, float(thresh), bitfield)
+        return bitfield
+
+    def march_rays_train(rays_o, rays_d, bound, density_bitfield, C_, H, nears, fars, step_counter=None, mean_count=-1,
+                         perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
+        rays_o, rays_d = rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3)
+        N = rays_o.shape[0]
+        M = N * max_steps
+        if not force_all_rays and mean_count > 0:
+            if align > 0:
+                mean_count += align - mean_count % align
+            M = mean_count
+        xyzs, dirs, deltas = torch.zeros(M, 3), torch.zeros(M, 3), torch.zeros(M, 2)
+        rays = torch.empty(N, 3, dtype=torch.int32)
+        if step_counter is None:
+            step_counter = torch.zeros(2, dtype=torch.int32)
+        noises = torch.rand(N) if perturb else torch.zeros(N)
+        nn.march_rays_train(rays_o, rays_d, density_bitfield.contiguous(), float(bound), float(dt_gamma), max_steps, N, C_, H, M,
+                            nears, fars, xyzs, dirs, deltas, rays, step_counter, noises)
+        if force_all_rays or mean_count <= 0:
+            m = step_counter[0].item()
+            if align > 0:
+                m += align - m % align
+            xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
+        return xyzs, dirs, deltas, rays
+
+    class _CompositeTrain(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, sigmas, rgbs, deltas, rays, T_thresh=1e-4):
+            sigmas, rgbs = sigmas.contiguous(), rgbs.contiguous()
+            M, N = sigmas.shape[0], rays.shape[0]
+            weights_sum, depth, image = torch.empty(N), torch.empty(N), torch.empty(N, 3)
+            nn.composite_rays_train_forward(sigmas, rgbs, deltas.contiguous(), rays, M, N, T_thresh, weights_sum, depth, image)
+            ctx.save_for_backward(sigmas, rgbs, deltas, rays, weights_sum, depth, image)
+            ctx.dims = [M, N, T_thresh]
+            return weights_sum, depth, image
+
+        @staticmethod
+        def backward(ctx, grad_weights_sum, grad_depth, grad_image):
+            sigmas, rgbs, deltas, rays, weights_sum, depth, image = ctx.saved_tensors
+            M, N, T_thresh = ctx.dims
+            grad_sigmas, grad_rgbs = torch.zeros_like(sigmas), torch.zeros_like(rgbs)
+            nn.composite_rays_train_backward(grad_weights_sum.contiguous(), grad_image.contiguous(), sigmas, rgbs,
+                                             deltas.contiguous(), rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs)
+            return grad_sigmas, grad_rgbs, None, None, None
+
+    def march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, bound, density_bitfield, C_, H, near, far, align=-1,
+                   perturb=False, dt_gamma=0, max_steps=1024):
+        rays_o, rays_d = rays_o.contiguous().view(-1, 3), rays_d.contiguous().view(-1, 3)
+        M = n_alive * n_step
+        if align > 0:
+            M += align - (M % align)
+        xyzs, dirs, deltas = torch.zeros(M, 3), torch.zeros(M, 3), torch.zeros(M, 2)
+        noises = torch.rand(n_alive) if perturb else torch.zeros(n_alive)
+        nn.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, float(bound), float(dt_gamma), max_steps, C_, H,
+                      density_bitfield.contiguous(), near, far, xyzs, dirs, deltas, noises)
+        return xyzs, dirs, deltas
+
+    def composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image, T_thresh=1e-2):
+        nn.composite_rays(n_alive, n_step, T_thresh, rays_alive, rays_t, sigmas.contiguous(), rgbs.contiguous(), deltas,
+                          weights_sum, depth, image)
+        return tuple()
+
+    return dict(morton3D=morton3D, morton3D_invert=morton3D_invert, packbits=packbits, march_rays_train=march_rays_train,
+                composite_rays_train=_CompositeTrain.apply, march_rays=march_rays, composite_rays=composite_rays)
 
 
 def ngp_opt():

@@ -131,15 +131,20 @@ class NeRFRenderer(nn.Module):
         self.min_near = opt.min_near
         self.density_thresh = opt.density_thresh
         self.bg_radius = opt.bg_radius
-        if self.cuda_ray:
-            raise NotImplementedError("cuda_ray=True (occupancy-grid marching) is a SURVEY.md 8(f) 'next' row; the "
-                                      "reference distillation path runs with cuda_ray=False (distillation.py:505)")
         if self.bg_radius > 0:
             raise NotImplementedError("bg_radius > 0 is not on the distillation path (distillation.py:512)")
         box = torch.tensor([-opt.bound] * 3 + [opt.bound] * 3, dtype=torch.float32)
         self.register_buffer('aabb_train', box)
         self.register_buffer('aabb_infer', box.clone())
         self._tables = {}
+        if self.cuda_ray:                                        # extra state of the occupancy-grid path (renderer_df.py:85-97)
+            self.register_buffer('density_grid', torch.zeros([self.cascade, self.grid_size ** 3]))
+            self.register_buffer('density_bitfield', torch.zeros(self.cascade * self.grid_size ** 3 // 8, dtype=torch.uint8))
+            self.mean_density = 0
+            self.iter_density = 0
+            self.register_buffer('step_counter', torch.zeros(16, 2, dtype=torch.int32))
+            self.mean_count = 0
+            self.local_step = 0
 
     # ---- hooks implemented by the field (network_grid.NeRFNetwork)
     def forward(self, x, d):
@@ -149,11 +154,51 @@ class NeRFRenderer(nn.Module):
         raise NotImplementedError()
 
     def reset_extra_state(self):
-        return
+        """renderer_df.py:108-119."""
+        if not self.cuda_ray:
+            return
+        self.density_grid.zero_()
+        self.mean_density = 0
+        self.iter_density = 0
+        self.step_counter.zero_()
+        self.mean_count = 0
+        self.local_step = 0
 
     @torch.no_grad()
-    def update_extra_state(self, decay=0.95, S=128):
-        return   # only meaningful with cuda_ray (renderer_df.py:590-591)
+    def update_extra_state(self, decay=0.95, S=128, noise=None):
+        """EMA update of the cascaded density grid and its bitfield, and of the mean sample count
+        (renderer_df.py:586-638).  `noise(like) -> U[0,1)` tensor injects the per-cascade jitter that the reference
+        draws with torch.rand_like."""
+        if not self.cuda_ray:
+            return
+        from .. import raymarching
+        dev = self.density_bitfield.device
+        tmp_grid = -torch.ones_like(self.density_grid)
+        rng = noise if noise is not None else torch.rand_like
+        axis = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
+        for xs in axis:
+            for ys in axis:
+                for zs in axis:
+                    xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing='ij')
+                    coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
+                    indices = raymarching.morton3D(coords).long()
+                    xyzs = 2 * coords.float() / (self.grid_size - 1) - 1
+                    for cas in range(self.cascade):
+                        bound = min(2 ** cas, self.bound)
+                        half_grid_size = bound / self.grid_size
+                        cas_xyzs = xyzs * (bound - half_grid_size)
+                        cas_xyzs += (rng(cas_xyzs) * 2 - 1) * half_grid_size
+                        tmp_grid[cas, indices] = self.density(cas_xyzs)['sigma'].reshape(-1).detach()
+        valid_mask = self.density_grid >= 0
+        self.density_grid[valid_mask] = torch.maximum(self.density_grid[valid_mask] * decay, tmp_grid[valid_mask])
+        self.mean_density = torch.mean(self.density_grid[valid_mask]).item()
+        self.iter_density += 1
+        density_thresh = min(self.mean_density, self.density_thresh)
+        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
+        total_step = min(16, self.local_step)
+        if total_step > 0:
+            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+        self.local_step = 0
 
     def _table(self, T, device):
         key = (T, str(device))
@@ -203,8 +248,67 @@ class NeRFRenderer(nn.Module):
         w, h = kwargs.get('w'), kwargs.get('h')
         return int(w) if w and h and int(w) * int(h) == N else 0
 
-    def run_cuda(self, *args, **kwargs):
-        raise NotImplementedError("cuda_ray=True path: SURVEY.md 8(f) 'next' row")
+    def run_cuda(self, rays_o, rays_d, dt_gamma=0, light_d=None, ambient_ratio=1.0, shading='albedo', bg_color=None,
+                 perturb=False, force_all_rays=False, max_steps=1024, T_thresh=1e-4, noise=None, **kwargs):
+        """Occupancy-grid render (renderer_df.py:471-584): march through the density bitfield, query the field at the
+        samples (autograd through the grid encoder), composite.  `noise` = per-ray jitter tensor [N] in place of
+        torch.rand (training: one draw; evaluation: the draw of the first round)."""
+        from .. import raymarching
+        if shading != 'albedo':
+            raise NotImplementedError("only shading='albedo' is on the distillation path (distillation.py:209,282)")
+        prefix = rays_o.shape[:-1]
+        rays_o = rays_o.contiguous().view(-1, 3).float()
+        rays_d = rays_d.contiguous().view(-1, 3).float()
+        N, device = rays_o.shape[0], rays_o.device
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer)
+        if light_d is None:
+            light_d = rays_o[0] + torch.randn(3, device=device, dtype=torch.float)      # consumed as the reference does (:486)
+        results = {}
+        if self.training:
+            counter = self.step_counter[self.local_step % 16]
+            counter.zero_()
+            self.local_step += 1
+            xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
+                                                                    self.grid_size, nears, fars, counter, self.mean_count, perturb,
+                                                                    128, force_all_rays, dt_gamma, max_steps, noises=noise)
+            sigmas, rgbs, normals = self(xyzs, dirs, light_d, ratio=ambient_ratio, shading=shading)
+            weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
+        else:
+            weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
+            depth = torch.zeros(N, dtype=torch.float32, device=device)
+            image = torch.zeros(N, 3, dtype=torch.float32, device=device)
+            n_alive = N
+            rays_alive = torch.arange(n_alive, dtype=torch.int32, device=device)
+            rays_t = nears.clone()
+            step = 0
+            while step < max_steps:
+                n_alive = rays_alive.shape[0]
+                if n_alive <= 0:
+                    break
+                n_step = max(min(N // n_alive, 8), 1)
+                xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound,
+                                                            self.density_bitfield, self.cascade, self.grid_size, nears, fars, 128,
+                                                            perturb if step == 0 else False, dt_gamma, max_steps,
+                                                            noises=noise if step == 0 else None)
+                sigmas, rgbs, normals = self(xyzs, dirs, light_d, ratio=ambient_ratio, shading=shading)
+                raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
+                                           T_thresh)
+                rays_alive = rays_alive[rays_alive >= 0]
+                step += n_step
+        if bg_color is None:
+            bg_color = 1
+        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
+        image = image.view(*prefix, 3)
+        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
+        results['image'] = image
+        results['depth'] = depth.view(*prefix)
+        results['weights_sum'] = weights_sum.reshape(*prefix)
+        results['mask'] = (nears < fars).reshape(*prefix)
+        return results
+
+    def _run(self, rays_o, rays_d, **kwargs):
+        """renderer_df.py:647-650: the occupancy-grid marcher when cuda_ray, the fused coarse+fine sampler otherwise."""
+        return (self.run_cuda if self.cuda_ray else self.run)(rays_o, rays_d, **kwargs)
 
     def _chunked(self, rays_o, rays_d, max_ray_batch, kwargs):
         B, N = rays_o.shape[:2]
@@ -214,7 +318,7 @@ class NeRFRenderer(nn.Module):
         for b in range(B):
             for head in range(0, N, max_ray_batch):
                 tail = min(head + max_ray_batch, N)
-                r = self.run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], **kwargs)
+                r = self._run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], **kwargs)
                 depth[b:b + 1, head:tail] = r['depth']
                 weights_sum[b:b + 1, head:tail] = r['weights_sum']
                 image[b:b + 1, head:tail] = r['image']
@@ -222,9 +326,9 @@ class NeRFRenderer(nn.Module):
 
     def render(self, rays_o, rays_d, staged=False, max_ray_batch=4096, **kwargs):
         """renderer_df.py:643-679: one `run` over all rays, or chunks of max_ray_batch when staged."""
-        if staged:
+        if staged and not self.cuda_ray:                         # "never stage when cuda_ray" (:655)
             return self._chunked(rays_o, rays_d, max_ray_batch, kwargs)
-        return self.run(rays_o, rays_d, **kwargs)
+        return self._run(rays_o, rays_d, **kwargs)
 
     def render_batched(self, rays_o, rays_d, batched=False, max_ray_batch=128 * 128, **kwargs):
         """renderer_df.py:681-717: no-grad render, optionally in chunks of max_ray_batch rays."""
@@ -232,4 +336,4 @@ class NeRFRenderer(nn.Module):
         with torch.no_grad():
             if batched:
                 return self._chunked(rays_o, rays_d, max_ray_batch, kwargs)
-            return self.run(rays_o, rays_d, **kwargs)
+            return self._run(rays_o, rays_d, **kwargs)
