@@ -6,9 +6,10 @@ One "step" = one pass of the north-star hot path for one novel view per GPU, syn
   B  novel-view NGP render fwd -> x2 bilinear -> SD-VAE encode(.).mode() * z_scale -> PLMSSampler.sample(
      max_thres=0.5: 50 steps = 51 UNet evals at 32x32 latents, 256-ch view features) -> SD-VAE decode ->
      (1-alpha_bar)*L1 + 1e-3*opacity -> bwd + Adam                                   distillation.py:262-352
-Everything runs on this repo's HIP path (NGP render, UNet/PLMS, and the SD-VAE of SURVEY.md 8(f) row 1).  Only
-the LPIPS-VGG perceptual term (8(f) row 2, lambda_percep) is left out, and `config.workload` says so.  fp32
-everywhere except the conv / linear MFMA operands of the UNet and VAE (bf16, fp32 accumulate).
+     + 0.1 * LPIPS-VGG(render, decoded)  (lambda_percep of itr > 1000, distillation.py:176-178,312-314)
+Everything runs on this repo's HIP path: NGP render, UNet/PLMS, the SD-VAE and the LPIPS
+term (row 2; VGG16 / lin weights are synthetic, the `lpips` package is not available).  fp32 everywhere except the
+conv / linear MFMA operands of the UNet, VAE and VGG (bf16, fp32 accumulate).
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): every rank distils its own novel
@@ -78,6 +79,9 @@ class HotPath:
         from sparsefusion_amd.vae import AutoencoderKL
         self.vae = AutoencoderKL().to(device)                     # sd-vae.yaml architecture, default (kaiming-range) init
         self.z_scale = 0.18215                                    # args.z_scale_factor of the reference's demo
+        from sparsefusion_amd.lpips import PerceptualLoss
+        self.percep = PerceptualLoss('vgg', device=device)        # distillation.py:161
+        self.lambda_percep = 0.1                                  # value after start_percep_step (:176-178)
         g = torch.Generator().manual_seed(100 + rank)
         self.rays_in = pinhole_rays(128, rank % 2, 34, device)                 # one of the 2 input views
         self.rays_novel = [pinhole_rays(128, 2 + rank * views + v, 34, device) for v in range(views)]   # this rank's novel views
@@ -122,6 +126,7 @@ class HotPath:
                                                             return_noise=True, max_thres=self.max_thres)
             pred_img = ((self.vae.decode(pred_x0 / self.z_scale) + 1) * 0.5).clip(0.0, 1.0)   # distillation.py:309
         fusion = ((1 - acp).view(-1, 1, 1, 1) * (img256 - pred_img).abs()).mean()
+        fusion = fusion + self.percep(img256, pred_img, normalize=True).mean() * self.lambda_percep      # :312-314
         loss = fusion + 1e-3 * torch.sqrt(sil256 ** 2 + .01).mean()
         loss.backward()
         self.sync_grads()
@@ -207,7 +212,7 @@ def unet_roofline(hp):
 def cpu_baseline(max_thres):
     """The CPU oracle (a port: the reference has no CPU path for its CUDA kernels) timed on this host, on a
     bounded sample of the same workload, scaled to one step."""
-    from oracle import ngp_ref, unet_ref, vae_ref
+    from oracle import lpips_ref, ngp_ref, unet_ref, vae_ref
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from unet_common import spec
     cores = min(32, os.cpu_count() or 1)          # torch CPU kernels stop scaling (and oversubscribe) beyond ~32 threads
@@ -236,12 +241,17 @@ def cpu_baseline(max_thres):
         vae_ref.encode_mode(vsd, vae_ref.CANONICAL, torch.rand(1, 3, 256, 256) * 2 - 1)
         vae_ref.decode(vsd, vae_ref.CANONICAL, torch.randn(1, 4, 32, 32))
         t_vae = time.time() - t0
+    lsd = lpips_ref.init_state(0)
+    pr = torch.rand(1, 3, 256, 256, requires_grad=True)
+    t0 = time.time()
+    lpips_ref.lpips(lsd, pr, torch.rand(1, 3, 256, 256), normalize=True).sum().backward()
+    t_lpips = time.time() - t0
     n_evals = min(int(max_thres * 100), 50) + 1
-    step_s = 2 * t_render + n_evals * t_eval + t_vae
+    step_s = 2 * t_render + n_evals * t_eval + t_vae + t_lpips
     return {"value": round(1.0 / step_s, 5), "unit": "views/s", "cores": cores, "kind": "port",
             "ms_per_step": round(step_s * 1e3, 1), "unet_eval_ms": round(t_eval * 1e3, 1),
-            "ngp_render_fwd_bwd_ms": round(t_render * 1e3, 1), "vae_enc_dec_ms": round(t_vae * 1e3, 1),
-            "sample": f"1 NGP render fwd+bwd on 1024/16384 rays (x16) + 3 UNet evals B=1 (x{n_evals}/3) + 1 VAE encode + decode, oracle fp32, "
+            "ngp_render_fwd_bwd_ms": round(t_render * 1e3, 1), "vae_enc_dec_ms": round(t_vae * 1e3, 1), "lpips_fwd_bwd_ms": round(t_lpips * 1e3, 1),
+            "sample": f"1 NGP render fwd+bwd on 1024/16384 rays (x16) + 3 UNet evals B=1 (x{n_evals}/3) + 1 VAE encode + decode + 1 LPIPS fwd+bwd, oracle fp32, "
                       f"{cores} threads of {os.cpu_count()}; the reference has no CPU path for grid-encode/near-far (port)"}
 
 
@@ -288,15 +298,15 @@ def main():
     if rank == 0:
         n_evals = min(int(args.max_thres * 100), 50) + 1
         res = {
-            "metric": "novel views/sec, hot-path distillation steps (2 NGP renders fwd+bwd + VAE enc/dec + %d-eval PLMS), 256^2 / 32x32 latents, "
+            "metric": "novel views/sec, distillation steps (2 NGP renders fwd+bwd + VAE enc/dec + %d-eval PLMS + LPIPS), 256^2 / 32x32 latents, "
                       "2-view synthetic hydrant" % n_evals,
             "value": round(world * args.views_per_gpu / (ms_per_step * 1e-3), 4), "unit": "views/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16 MFMA operands / f32 accumulate (UNet); f32 (NGP render)", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: single MI355X, 256^2 hydrant-like synthetic scene, 2 input views, "
                                    "32x32 latent UNet (400.68M params, B=%d per GPU) + NGP render 128x128 rays x (64+64) samples; "
-                                   "SD-VAE encode 256^2 -> 32x32x4 and decode back (83.65M params) every step; max_thres=%.2f; "
-                                   "LPIPS term of the reference loss not included" % (args.views_per_gpu, args.max_thres),
+                                   "SD-VAE encode 256^2 -> 32x32x4 and decode back (83.65M params) and LPIPS-VGG16 fwd+bwd at 256^2 every step; "
+                                   "max_thres=%.2f" % (args.views_per_gpu, args.max_thres),
                        "views_per_gpu": args.views_per_gpu, "unet_evals_per_step": n_evals, "rays_per_render": 16384,
                        "parallelism": "view-sharded replicas x%d, RCCL all-gather(latents) + all-reduce(NGP grads)" % world},
         }
@@ -307,6 +317,8 @@ def main():
                 torch.zeros(1, 4, 32, 32, device=dev), torch.zeros(1, device=dev), cond_images=hp.features[:1]), 10), 3),
             "vae_encode": round(time_region(lambda: hp.vae.encode(torch.zeros(1, 3, 256, 256, device=dev)), 5), 3),
             "vae_decode": round(time_region(lambda: hp.vae.decode(torch.zeros(1, 4, 32, 32, device=dev)), 5), 3),
+            "lpips_fwd_bwd": round(time_region(lambda: hp.percep(torch.rand(1, 3, 256, 256, device=dev, requires_grad=True),
+                                                                 torch.rand(1, 3, 256, 256, device=dev)).sum().backward(), 5), 3),
         }
         res["roofline"] = unet_roofline(hp)
         if world == 1 and not args.no_cpu_baseline:

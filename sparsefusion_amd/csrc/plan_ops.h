@@ -1,0 +1,5 @@
+// Internal: ops of the plan executor that live outside unet_ops.hip (dispatched from plan_run_impl).
+#pragma once
+#include "sf_common.h"
+
+int sf_plan_extra_op(const sf_op* op, void* stream);

@@ -26,6 +26,7 @@
 // Operand encodings are documented at each launcher (`run_*`).
 
 #include "sf_common.h"
+#include "plan_ops.h"
 #include <math.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -59,7 +60,8 @@ __device__ __forceinline__ float wave_max(float v) {
 //   i[0..] = B, H, W, Cin_pad, Ho, Wo, Cout, ldc, co_off, kh, kw, stride, pad, ksplit_groups, tile (WM*16+WN), 0
 //   flags: 1 = A is f32, 2 = epilogue SiLU + PixelShuffle(2) (no split-K), 4 = accumulate into out (out += ...),
 //          8 = split-K partials stay in the workspace; the consumer reduces them (LazySrc mode 1),
-//          16 = the input is a nearest x2 upsampling of a stored [B, H/2, W/2, Cin] map (H, W = upsampled dims)
+//          16 = the input is a nearest x2 upsampling of a stored [B, H/2, W/2, Cin] map (H, W = upsampled dims),
+//          32 = ReLU in the epilogue (after bias / residual / accumulate)
 // No atomics: with groups == 1 every output element is owned by one wave (plain store / read-modify-write);
 // with groups > 1 each K-slice group stores its partial tile to the workspace and k_splitk_reduce sums them
 // (fp32 L2 atomics top out at ~25 G lane-ops/s on MI355X, which made the atomic split-K epilogue 10x the
@@ -72,7 +74,7 @@ struct ConvArgs {
   int accum, npad;
   int B, H, W, Cin, Ho, Wo, Cout, ldc, co_off, kh, kw, stride, pad, groups;
   int KS, cchunks, m_frags, n_frags, m_tiles, n_tiles, steps_per_wave;
-  int pixshuf, ups;
+  int pixshuf, ups, relu;
 };
 
 template <int WM, int WN, bool A_FP32>
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
           const long o = (long)m * a.ldc + a.co_off + n;
           if (a.resid) v += a.resid[o];
           if (a.accum) v += a.out[o];
+          if (a.relu) v = fmaxf(v, 0.0f);
           a.out[o] = v;
         }
       }
@@ -266,7 +269,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
 // out[m][co_off+n] (+)= bias[n] + resid + sum_g ws[g][m][n]      (second half of a split-K conv)
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ ws, const float* __restrict__ bias,
                                                        const float* __restrict__ resid, float* __restrict__ out, int M,
-                                                       int Cout, int npad, int groups, int ldc, int co_off, int accum) {
+                                                       int Cout, int npad, int groups, int ldc, int co_off, int accum,
+                                                       int relu) {
   const long total = (long)M * Cout;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int m = (int)(i / Cout), n = (int)(i - (long)m * Cout);
@@ -275,6 +279,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
     const long o = (long)m * ldc + co_off + n;
     if (resid) v += resid[o];
     if (accum) v += out[o];
+    if (relu) v = fmaxf(v, 0.0f);
     out[o] = v;
   }
 }
@@ -654,6 +659,7 @@ __global__ __launch_bounds__(256) void k_gca_pool(const float* __restrict__ h, c
 //   4 ADD        out[i] += p0[i] ; i[0] = n
 //   5 PACK_ACT   p0 f32 [.., ld] -> p3 bf16 B-operand fragments ; i = N, K, ld, transpose
 //   6 SOFTMAX    p3 bf16 [R,N] = softmax(f[0] * p0 f32 [R,N]) ; i = R, N
+//   7 RELU_BWD / 8 SCALE_IN / 9 SCALE_IN_BWD: lpips_ops.hip
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_gate_res(const float* __restrict__ h, const float* __restrict__ gate,
                                                   const float* __restrict__ res, float* __restrict__ out, int B, int HW,
@@ -774,6 +780,7 @@ static int run_conv(const sf_op& op, hipStream_t st) {
   const int WM = tile / 16, WN = tile % 16;
   a.pixshuf = (op.flags & 2) ? 1 : 0;
   a.ups = (op.flags & 16) ? 1 : 0;
+  a.relu = (op.flags & 32) ? 1 : 0;
   if (a.ups && ((a.H | a.W) & 1)) SF_FAIL(SF_ERR_INVALID, "conv: upsampled input dims must be even");
   if (a.Cin % 32) SF_FAIL(SF_ERR_INVALID, "conv: Cin_pad must be a multiple of 32");
   if (a.pixshuf && a.groups != 1) SF_FAIL(SF_ERR_INVALID, "conv: pixel-shuffle epilogue cannot be split-K");
@@ -806,7 +813,7 @@ static int run_conv(const sf_op& op, hipStream_t st) {
     if (!a.ws) SF_FAIL(SF_ERR_INVALID, "conv: split-K needs a workspace");
     if (op.flags & 8) return SF_OK;      // reduction deferred to the consumer (LazySrc mode 1)
     k_splitk_reduce<<<sf_grid_cap(sf_div_up((long)M * a.Cout, 256)), 256, 0, st>>>(a.ws, a.bias, a.resid, a.out, M, a.Cout, a.npad,
-                                                                                  a.groups, a.ldc, a.co_off, a.accum);
+                                                                                  a.groups, a.ldc, a.co_off, a.accum, a.relu);
     SF_CHECK_LAUNCH("splitk_reduce");
   }
   return SF_OK;
@@ -939,6 +946,7 @@ static int run_eltwise(const sf_op& op, hipStream_t st) {
     case 6:
       k_softmax_rows<<<op.i[0], 256, 0, st>>>((const float*)op.p[0], (__bf16*)op.p[3], op.i[1], op.f[0]);
       break;
+    case 7: case 8: case 9: return sf_plan_extra_op(&op, st);      // LPIPS helpers (lpips_ops.hip)
     default: SF_FAIL(SF_ERR_INVALID, "eltwise: unknown mode %d", op.flags);
   }
   SF_CHECK_LAUNCH("eltwise");
@@ -965,7 +973,7 @@ static int plan_run_impl(const sf_op* ops, uint32_t n_ops, hipStream_t st, hipEv
         const int M = op.i[0], Cout = op.i[1];
         if (!op.p[0] || !op.p[3] || op.i[3] < 1) SF_FAIL(SF_ERR_INVALID, "splitk_reduce: bad operands");
         k_splitk_reduce<<<sf_grid_cap(sf_div_up((long)M * Cout, 256)), 256, 0, st>>>(
-            (const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], (float*)op.p[3], M, Cout, op.i[2], op.i[3], Cout, 0, 0);
+            (const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], (float*)op.p[3], M, Cout, op.i[2], op.i[3], Cout, 0, 0, 0);
         if (hipGetLastError() != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "splitk_reduce launch failed");
         break;
       }
@@ -974,6 +982,8 @@ static int plan_run_impl(const sf_op* ops, uint32_t n_ops, hipStream_t st, hipEv
                                                                   op.i[0], op.i[1]);
         if (hipGetLastError() != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "time_emb launch failed");
         break;
+      case SF_OP_POOL:
+      case SF_OP_LPIPS: rc = sf_plan_extra_op(&op, st); break;
       default: SF_FAIL(SF_ERR_INVALID, "plan: unknown op type %d at %u", op.type, k);
     }
     if (rc) {

@@ -1,0 +1,250 @@
+"""LPIPS(net='vgg') perceptual loss on the HIP op plan -- the `lambda_percep` term of the distillation step.
+
+Mirrors `PerceptualLoss` of external/external_utils.py:11-50 (what sparsefusion/distillation.py:161,312-314 calls):
+`PerceptualLoss('vgg', device)(pred, target, normalize=True) -> [B, 1, 1, 1]`, differentiable w.r.t. `pred`
+(the rendered image); `target` is the no-grad decoded sample.  The arithmetic is the published LPIPS v0.1 algorithm of
+the third-party `lpips` package (not vendored by the reference): ScalingLayer, VGG16 conv stack with taps after
+relu1_2 / 2_2 / 3_3 / 4_3 / 5_3, channel unit-normalisation, squared difference, non-negative 1x1 `lin` weights,
+spatial mean, sum over layers.  State-dict keys follow that package (`net.slice{k}.{idx}.*`, `lin{k}.model.1.weight`)
+so its checkpoint loads unchanged; weights here default to a He initialisation.
+
+Forward = 13 implicit-GEMM convs (bf16 MFMA operands, fp32 accumulate, ReLU in the epilogue) on the stacked pair
+[pred; target], 4 max-pools, 5 head reductions.  Backward (pred only) = the same convs with flipped / transposed weights
+(backward-data), ReLU masks, pool routing, head gradients accumulated into the running gradient through the conv
+epilogue.  No CPU fallback."""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .unet import OP_CONV, OP_ELTWISE, OP_MEMSET, Unet, _Plan, _register, _T
+
+OP_POOL, OP_LPIPS = 11, 12
+SHIFT = (-.030, -.088, -.188)
+SCALE = (.458, .448, .450)
+VGG_CONVS = [(1, 0, 3, 64), (1, 2, 64, 64), (2, 5, 64, 128), (2, 7, 128, 128), (3, 10, 128, 256), (3, 12, 256, 256),
+             (3, 14, 256, 256), (4, 17, 256, 512), (4, 19, 512, 512), (4, 21, 512, 512), (5, 24, 512, 512),
+             (5, 26, 512, 512), (5, 28, 512, 512)]       # (slice, vgg16.features index, Cin, Cout)
+CHNS = (64, 128, 256, 512, 512)
+
+
+def lpips_param_spec():
+    spec = []
+    for sl, idx, cin, cout in VGG_CONVS:
+        spec += [(f"net.slice{sl}.{idx}.weight", (cout, cin, 3, 3)), (f"net.slice{sl}.{idx}.bias", (cout,))]
+    for k, c in enumerate(CHNS):
+        spec.append((f"lin{k}.model.1.weight", (1, c, 1, 1)))
+    return spec
+
+
+class _LpipsPlan(_Plan):
+    """kind 'fwd': features + distance for V pairs; kind 'bwd': d distance / d pred, reading the forward plan's buffers."""
+
+    def __init__(self, mod, V, R, device, sizing=None, fwd=None):
+        super().__init__(mod, 2 * V, device, sizing)
+        self.V, self.R, self.fwd = V, R, fwd
+
+    def build_forward(self):
+        V, R = self.V, self.R
+        B = 2 * V
+        self.op(OP_MEMSET, 0, p=(self.zero.buf.data_ptr() if self.zero.buf is not None else 1,), i=(0,))
+        memset_op = self.ops[-1]
+        HW = R * R
+        self.x_in = self.f32(B, 3 * HW)
+        xin = self.f32(B * HW, 32, HW)
+        self.op(OP_ELTWISE, 8, p=(self.x_in.ptr, self.wptr("__scaling__"), 0, xin.ptr), i=(B, HW, 32))
+        self.conv_in, self.conv_out, self.pool_in, self.taps = [], [], {}, []
+        h, H, cur = xin, R, 1
+        for ci, (sl, idx, cin, cout) in enumerate(VGG_CONVS):
+            if sl != cur:                                          # slice boundary: tap the ReLU output, then 2x2 max-pool
+                self.taps.append((h, H))
+                y = self.f32(B * (H // 2) ** 2, h.C, (H // 2) ** 2)
+                self.op(OP_POOL, 0, p=(h.ptr, 0, 0, y.ptr), i=(B, H, H, h.C))
+                self.pool_in[ci] = (h, H)                          # conv ci reads the pooled copy of h
+                h, H, cur = y, H // 2, sl
+            y = self.zf32(B * H * H, cout, H * H)
+            name = f"net.slice{sl}.{idx}"
+            self.conv(h, True, H, H, name + ".weight", name + ".bias", y, cout, 0, cout, 3, 1, 1, relu=True)
+            self.conv_in.append(h)
+            self.conv_out.append(y)
+            h = y
+        self.taps.append((h, H))
+        self.dist = _T(self.zero.alloc(V * 4), V, 1)               # accumulated with one atomic per workgroup: zeroed per run
+        for k, (t, Hk) in enumerate(self.taps):
+            self.op(OP_LPIPS, 0, p=(t.ptr, self.wptr(f"lin{k}.model.1.weight"), 0, self.dist.ptr), i=(V, Hk * Hk, t.C))
+        memset_op.i[0] = (self.zero.off + 3) // 4
+        self.op_array = (_lib.SfOp * len(self.ops))(*self.ops)
+        if self.misc.buf is not None:
+            self.x_view = self.tview(self.x_in)
+            off = self.dist.ptr - self.zero.buf.data_ptr()
+            self.dist_view = self.zero.buf[off:off + V * 4].view(torch.float32)
+        return self
+
+    def build_backward(self):
+        """Gradient w.r.t. the first V images.  g_k = d loss / d (ReLU output at tap k) starts as the head gradient and
+        the backward-data conv of the layer above ACCUMULATES into it (conv epilogue flag 4)."""
+        V, R, f = self.V, self.R, self.fwd
+        self.B = V                                                 # every op of this plan works on the first V samples
+        self.gscale = self.f32(V, 1)
+        grads = {}
+        for k, (t, Hk) in enumerate(f.taps):                       # head gradients (overwrite) -> one buffer per tap
+            g = self.f32(V * Hk * Hk, t.C, Hk * Hk)
+            self.op(OP_LPIPS, 1, p=(t.ptr, self.wptr(f"lin{k}.model.1.weight"), self.gscale.ptr, g.ptr), i=(V, Hk * Hk, t.C))
+            grads[id(t)] = g
+        g = grads[id(f.taps[-1][0])]                               # gradient w.r.t. the last ReLU output
+        H = f.taps[-1][1]
+        for ci in reversed(range(len(VGG_CONVS))):
+            sl, idx, cin, cout = VGG_CONVS[ci]
+            y = f.conv_out[ci]
+            gz = self.bf16(V * H * H, cout, H * H)                 # ReLU backward: dz = g * (y > 0), bf16 operand of the conv
+            self.op(OP_ELTWISE, 7, p=(g.ptr, y.ptr, 0, gz.ptr), i=(V * H * H * cout,))
+            cpad = 32 if cin == 3 else cin
+            gx = self.zf32(V * H * H, cpad, H * H)                 # gradient w.r.t. this conv's input
+            name = f"net.slice{sl}.{idx}"
+            self.conv(gz, False, H, H, name + ".weight.T", None, gx, cpad, 0, cpad, 3, 1, 1)
+            g = gx
+            if ci in f.pool_in:                                    # the input was a pooled copy: route to the argmax positions
+                src, Hs = f.pool_in[ci]                            # and add to the tap's head gradient one resolution up
+                gt = grads[id(src)]
+                gp = self.f32(V * Hs * Hs, src.C, Hs * Hs)
+                self.op(OP_POOL, 1, p=(g.ptr, src.ptr, 0, gp.ptr), i=(V, Hs, Hs, src.C))
+                self.op(OP_ELTWISE, 4, p=(gp.ptr, 0, 0, gt.ptr), i=(V * Hs * Hs * src.C,))
+                g, H = gt, Hs
+        self.out = self.f32(V, 3 * R * R)
+        self.op(OP_ELTWISE, 9, p=(g.ptr, self.wptr("__scaling__"), 0, self.out.ptr), i=(V, R * R, 32))
+        self.op_array = (_lib.SfOp * len(self.ops))(*self.ops)
+        if self.misc.buf is not None:
+            self.out_view, self.gscale_view = self.tview(self.out), self.tview(self.gscale)
+        return self
+
+
+class _LpipsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, pred, target):
+        V = pred.shape[0]
+        fwd, bwd = mod._plans_for(V, pred.shape[-1], pred.device)
+        fwd.x_view.copy_(torch.cat([pred, target], 0).reshape(2 * V, -1))
+        _lib.check(_lib.lib().sf_plan_run(fwd.op_array, len(fwd.ops), _lib.stream_ptr()), "lpips forward plan")
+        ctx.mod, ctx.bwd, ctx.shape = mod, bwd, pred.shape
+        ctx.serial = mod._serial = mod._serial + 1
+        return fwd.dist_view.clone().view(V, 1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.serial != ctx.mod._serial:
+            raise RuntimeError("PerceptualLoss: backward after another forward -- the feature maps live in one static arena")
+        bwd = ctx.bwd
+        bwd.gscale_view.copy_(g.reshape(-1, 1).float())
+        _lib.check(_lib.lib().sf_plan_run(bwd.op_array, len(bwd.ops), _lib.stream_ptr()), "lpips backward plan")
+        return None, bwd.out_view.clone().view(ctx.shape), None
+
+
+class LPIPS(nn.Module):
+    """lpips.LPIPS(net='vgg', verbose=False) surface: forward(in0, in1, normalize=False) -> [B,1,1,1]."""
+
+    def __init__(self, net='vgg', verbose=False, **unsupported):
+        super().__init__()
+        if net not in ('vgg', 'vgg16'):
+            raise NotImplementedError("only net='vgg' is used by the reference (distillation.py:161)")
+        g = torch.Generator().manual_seed(0)
+        for name, shape in lpips_param_spec():
+            if name.startswith("lin"):
+                t = torch.rand(shape, generator=g) / shape[1] * 4
+            elif name.endswith("bias"):
+                t = torch.zeros(shape)
+            else:
+                t = torch.randn(shape, generator=g) * math.sqrt(2.0 / (shape[1] * 9))
+            _register(self, name, nn.Parameter(t, requires_grad=False))
+        self.conv_waves_target = 1024
+        self.lazy_consumers = 0
+        self.ss_total = 0
+        self._pack_cache, self._plans, self._serial = None, {}, 0
+
+    conv_tiling = Unet.conv_tiling
+
+    def invalidate(self):
+        self._pack_cache, self._plans = None, {}
+
+    def load_state_dict(self, sd, strict=True):
+        # the package also registers the lin layers a second time under `lins.{k}.*` and the scaling buffers
+        own = {k: v for k, v in sd.items() if not k.startswith("lins.") and not k.startswith("scaling_layer.")}
+        r = super().load_state_dict(own, strict=strict)
+        self.invalidate()
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self.invalidate()
+        return r
+
+    def _packed(self, device):
+        if self._pack_cache is not None and self._pack_cache[0] == str(device):
+            return self._pack_cache[1]
+        lib = _lib.lib()
+        packed = {"__scaling__": torch.tensor(SHIFT + SCALE, dtype=torch.float32, device=device)}
+
+        def pack(w4):
+            co, ci, kh, kw = w4.shape
+            cpad = (ci + 31) // 32 * 32
+            buf = torch.empty(lib.sf_conv_packed_elems(co, cpad, kh, kw), dtype=torch.int16)
+            _lib.check(lib.sf_conv_pack_weights(w4.data_ptr(), co, ci, cpad, kh, kw, buf.data_ptr()), "pack")
+            return buf.to(device)
+
+        for name, w in self.named_parameters():
+            wc = w.detach().float().cpu().contiguous()
+            if name.startswith("lin"):
+                packed[name] = wc.reshape(-1).to(device)
+            elif wc.dim() == 4:
+                packed[name] = pack(wc)
+                # backward-data operand: W'[ci, co, ky, kx] = W[co, ci, 2-ky, 2-kx]; conv1_1's 3 input channels are padded to 32 rows
+                wt = wc.flip(2, 3).permute(1, 0, 2, 3).contiguous()
+                if wt.shape[0] == 3:
+                    wt = torch.cat([wt, torch.zeros(29, *wt.shape[1:])], 0).contiguous()
+                packed[name + ".T"] = pack(wt)
+            else:
+                packed[name] = wc.to(device)
+        self._pack_cache = (str(device), packed)
+        return packed
+
+    def _plans_for(self, V, R, device):
+        key = (V, R, str(device))
+        if key not in self._plans:
+            s = _LpipsPlan(self, V, R, device).build_forward()
+            fwd = _LpipsPlan(self, V, R, device, (s.zero.off, s.misc.off + s.ws_bytes + 256, s.ws_bytes)).build_forward()
+            s = _LpipsPlan(self, V, R, device, fwd=fwd).build_backward()
+            bwd = _LpipsPlan(self, V, R, device, (s.zero.off + 256, s.misc.off + s.ws_bytes + 256, s.ws_bytes), fwd=fwd).build_backward()
+            self._plans[key] = (fwd, bwd)
+        return self._plans[key]
+
+    def forward(self, in0, in1, retPerLayer=False, normalize=False):
+        if retPerLayer:
+            raise NotImplementedError("retPerLayer is not used by the reference")
+        _lib.require_cuda(in0, in1)
+        if in0.shape != in1.shape or in0.dim() != 4 or in0.shape[1] != 3 or in0.shape[2] != in0.shape[3] or in0.shape[2] % 16:
+            raise RuntimeError(f"LPIPS: expected two [B, 3, R, R] images with R % 16 == 0, got {tuple(in0.shape)}, {tuple(in1.shape)}")
+        if normalize:
+            in0, in1 = 2 * in0 - 1, 2 * in1 - 1
+        return _LpipsFn.apply(self, in0.float().contiguous(), in1.detach().float().contiguous())
+
+
+class PerceptualLoss(nn.Module):
+    """external/external_utils.py:11-50."""
+
+    def __init__(self, net='vgg', device='cuda:0'):
+        super().__init__()
+        self.model = LPIPS(net=net, verbose=False).to(device)
+        self.device = device
+
+    def get_device(self, default_device=None):
+        try:
+            return next(self.parameters()).device
+        except StopIteration:
+            return default_device
+
+    def __call__(self, pred, target, normalize=True):
+        if pred.shape[1] != 3:
+            pred, target = pred.permute(0, 3, 1, 2), target.permute(0, 3, 1, 2)
+        if normalize:
+            target, pred = 2 * target - 1, 2 * pred - 1
+        return self.model.forward(pred.to(self.device).float(), target.to(self.device)).to(self.device)
