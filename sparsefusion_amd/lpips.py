@@ -159,6 +159,7 @@ class LPIPS(nn.Module):
         self.conv_waves_target = 1024
         self.lazy_consumers = 0
         self.ss_total = 0
+        self.lds_conv_min_blocks = 96
         self._pack_cache, self._plans, self._serial = None, {}, 0
 
     conv_tiling = Unet.conv_tiling

@@ -245,13 +245,21 @@ class _Plan:
             self.need(self.ws_owner)                          # the workspace is about to be overwritten
             self.ws_bytes = max(self.ws_bytes, groups * M * n_frags * 16 * 4)
             ws = self.ws_ptr
+        tile = WM * 16 + WN
+        # large-M layers (VAE, VGG, B >= 4): the LDS-tiled kernel, 128 pixels x 128 (or 64) channels per workgroup
+        lds_min = getattr(self.u, "lds_conv_min_blocks", 0)
+        if lds_min and not pixshuf and n_frags >= 4:
+            bnf = 8 if n_frags > 4 else 4
+            blocks = ((m_frags + 7) // 8) * ((n_frags + bnf - 1) // bnf)
+            if blocks >= lds_min:
+                tile, groups, ws = 256 + bnf, 1, 0
         defer = bool(defer and not relu and groups > 1 and not accum and not pixshuf and co_off == 0 and ldc == Cout == out.C and M == out.rows
                      and (self.u.lazy_consumers & 1))
         bias, res = self.wptr(bname) if bname else 0, resid.ptr if resid else 0
         self.op(OP_CONV, (1 if x_f32 else 0) | (2 if pixshuf else 0) | (4 if accum else 0) | (8 if defer else 0) |
                 (16 if upsampled else 0) | (32 if relu else 0),
                 p=(x.ptr, w_ptr if w_ptr is not None else self.wptr(wname), bias, out.ptr, res, ws),
-                i=(B, H, W, x.C, Ho, Wo, Cout, ldc, co_off, k, k, stride, pad, groups, WM * 16 + WN))
+                i=(B, H, W, x.C, Ho, Wo, Cout, ldc, co_off, k, k, stride, pad, groups, tile))
         if defer:
             out.lazy = ("splitk", ws, bias, res, groups, n_frags * 16)
             self.ws_owner = out
@@ -538,6 +546,7 @@ class Unet(nn.Module):
                 off += shape[0]
         self.ss_total = off
         self.conv_waves_target = 1024       # waves wanted per conv launch (4 per CU) before split-K stops
+        self.lds_conv_min_blocks = 96       # use k_conv_lds when a layer has at least this many 128 x 128 output tiles
         self.lazy_consumers = 3             # bit 0: split-K reductions, bit 1: gated residuals are materialised by their first consumer
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches
         self._pack_cache = None

@@ -271,6 +271,7 @@ class AutoencoderKL(nn.Module):
         self.conv_waves_target = 1024
         self.lazy_consumers = 0                # VAE convs are large-M: no split-K partials worth deferring
         self.ss_total = 0
+        self.lds_conv_min_blocks = 96
         self._pack_cache, self._plans = None, {}
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)

@@ -91,6 +91,61 @@ def test_conv_igemm(case):
     assert out.cpu()[..., :co_off].abs().max() == 0 and out.cpu()[..., co_off + Cout:].abs().max() == 0
 
 
+LDS_CASES = [
+    # B, H, Cin, Cout, k, stride, pad, bnf, a_f32, resid, relu, ups
+    (1, 64, 128, 128, 3, 1, 1, 8, False, True, False, False),     # VAE-like 3x3
+    (2, 32, 64, 64, 3, 1, 1, 4, True, False, True, False),        # VGG conv1_2-like: fp32 A, ReLU epilogue, 4 n-frags
+    (1, 32, 3, 64, 3, 1, 1, 4, True, False, True, False),         # Cin 3 padded to 32: KS = 9 is odd -> padded last stage
+    (1, 40, 96, 200, 3, 1, 1, 8, False, False, False, False),     # ragged: M = 1600 (12.5 tiles), Cout = 200 (12.5 frags)
+    (1, 64, 128, 128, 3, 2, 0, 8, True, False, False, False),     # VAE Downsample: stride 2, pad right/bottom only
+    (1, 32, 128, 128, 3, 1, 1, 8, True, False, False, True),      # VAE Upsample: nearest x2 folded into the addressing
+    (3, 16, 256, 384, 1, 1, 0, 8, False, True, False, False),     # 1x1, odd batch
+]
+
+
+@pytest.mark.parametrize("case", LDS_CASES)
+def test_conv_lds_tiled(case):
+    """k_conv_lds (tile code 256 + n-fragments per workgroup): same contract as k_conv_igemm without split-K."""
+    B, H, Cin, Cout, k, stride, pad, bnf, a_f32, use_res, relu, ups = case
+    g = torch.Generator().manual_seed(Cin + Cout + k + H)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    wp, cpad = _pack_conv(w)
+    xh = torch.zeros(B, H, H, cpad)
+    xh[..., :Cin] = x.permute(0, 2, 3, 1)
+    xd = xh.to(DEV) if a_f32 else xh.to(torch.bfloat16).to(DEV)
+    Hin = 2 * H if ups else H                                         # logical input size seen by the conv
+    if stride == 2:
+        Ho = Hin // 2                                                 # asymmetric (0,1,0,1) padding: explicit output size
+    else:
+        Ho = (Hin + 2 * pad - k) // stride + 1
+    ldc, co_off = Cout + 8, 4
+    out = torch.zeros(B, Ho, Ho, ldc, device=DEV)
+    res = torch.randn(B, Ho, Ho, ldc, generator=g).to(DEV) if use_res else None
+    flags = (1 if a_f32 else 0) | (16 if ups else 0) | (32 if relu else 0)
+    _run([_op(1, flags, p=(xd, wp, bias.to(DEV), out, res, None),
+              i=(B, Hin, Hin, cpad, Ho, Ho, Cout, ldc, co_off, k, k, stride, pad, 1, 256 + bnf))])
+    xr = bf(x)
+    if ups:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    if stride == 2:
+        xr = F.pad(xr, (0, 1, 0, 1))
+    ref = F.conv2d(xr, bf(w), bias, stride=stride, padding=pad).permute(0, 2, 3, 1)
+    if use_res:
+        ref = ref + res.cpu()[..., co_off:co_off + Cout]
+    if relu:
+        ref = F.relu(ref)
+    got = out.cpu()[..., co_off:co_off + Cout]
+    assert torch.allclose(got, ref, rtol=2e-4, atol=2e-4), (got - ref).abs().max()
+    assert out.cpu()[..., :co_off].abs().max() == 0 and out.cpu()[..., co_off + Cout:].abs().max() == 0
+    # accumulate flag: a second launch adds onto the first result
+    if not relu and not use_res:
+        _run([_op(1, flags | 4, p=(xd, wp, bias.to(DEV), out, None, None),
+                  i=(B, Hin, Hin, cpad, Ho, Ho, Cout, ldc, co_off, k, k, stride, pad, 1, 256 + bnf))])
+        assert torch.allclose(out.cpu()[..., co_off:co_off + Cout], 2 * ref, rtol=4e-4, atol=4e-4)
+
+
 def test_conv_accumulates_and_pixel_shuffle():
     g = torch.Generator().manual_seed(3)
     B, H, C = 2, 8, 128
