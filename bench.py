@@ -134,12 +134,16 @@ class HotPath:
 
 
 def time_region(fn, iters):
+    """GPU-side milliseconds per call (events on the current stream, which is the stream the plans launch on)."""
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    t = time.time()
+    e0.record()
     for _ in range(iters):
         fn()
+    e1.record()
     torch.cuda.synchronize()
-    return (time.time() - t) / iters * 1e3
+    return e0.elapsed_time(e1) / iters
 
 
 def unet_roofline(hp):
@@ -311,14 +315,14 @@ def main():
                        "parallelism": "view-sharded replicas x%d, RCCL all-gather(latents) + all-reduce(NGP grads)" % world},
         }
         # component timings + roofline of the dominant kernel (after the timed region)
+        lp_a, lp_b = torch.rand(1, 3, 256, 256, device=dev, requires_grad=True), torch.rand(1, 3, 256, 256, device=dev)
         res["breakdown_ms"] = {
             "ngp_render_fwd": round(time_region(lambda: hp.render(hp.rays_novel[0]), 5), 3),
             "unet_eval_wall": round(time_region(lambda: hp.unet.forward_with_cond_scale(
                 torch.zeros(1, 4, 32, 32, device=dev), torch.zeros(1, device=dev), cond_images=hp.features[:1]), 10), 3),
             "vae_encode": round(time_region(lambda: hp.vae.encode(torch.zeros(1, 3, 256, 256, device=dev)), 5), 3),
             "vae_decode": round(time_region(lambda: hp.vae.decode(torch.zeros(1, 4, 32, 32, device=dev)), 5), 3),
-            "lpips_fwd_bwd": round(time_region(lambda: hp.percep(torch.rand(1, 3, 256, 256, device=dev, requires_grad=True),
-                                                                 torch.rand(1, 3, 256, 256, device=dev)).sum().backward(), 5), 3),
+            "lpips_fwd_bwd": round(time_region(lambda: hp.percep(lp_a, lp_b).sum().backward(), 5), 3),
         }
         res["roofline"] = unet_roofline(hp)
         if world == 1 and not args.no_cpu_baseline:
