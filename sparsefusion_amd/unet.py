@@ -251,6 +251,8 @@ class _Plan:
         if lds_min and not pixshuf and n_frags >= 4:
             bnf = 8 if n_frags > 4 else 4
             blocks = ((m_frags + 7) // 8) * ((n_frags + bnf - 1) // bnf)
+            if bnf == 8 and blocks < 256:                     # fewer tiles than CUs: halve the channel tile instead of idling CUs
+                bnf, blocks = 4, ((m_frags + 7) // 8) * ((n_frags + 3) // 4)
             if blocks >= lds_min:
                 tile, groups, ws = 256 + bnf, 1, 0
         defer = bool(defer and not relu and groups > 1 and not accum and not pixshuf and co_off == 0 and ldc == Cout == out.C and M == out.rows
