@@ -708,7 +708,7 @@ class Unet(nn.Module):
                 self._run_plan(plan)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (RCCL watchdog) may touch HIP meanwhile
                     self._run_plan(plan)
                 plan.graph = g
             plan.graph.replay()
