@@ -1175,11 +1175,16 @@ extern "C" int sf_plan_run(const sf_op* ops, uint32_t n_ops, void* stream) {
 extern "C" int sf_plan_profile(const sf_op* ops, uint32_t n_ops, void* stream, float* h_ms) {
   hipStream_t st = (hipStream_t)stream;
   hipEvent_t* ev = new hipEvent_t[n_ops + 1];
-  for (uint32_t k = 0; k <= n_ops; ++k) hipEventCreate(&ev[k]);
-  int rc = plan_run_impl(ops, n_ops, st, ev);
+  uint32_t made = 0;
+  int rc = SF_OK;
+  for (; made <= n_ops; ++made)
+    if (hipEventCreate(&ev[made]) != hipSuccess) { rc = SF_ERR_LAUNCH; break; }
+  if (rc == SF_OK) rc = plan_run_impl(ops, n_ops, st, ev);
+  else snprintf(sf_err_buf, sizeof(sf_err_buf), "plan_profile: hipEventCreate failed");
   if (rc == SF_OK && hipEventSynchronize(ev[n_ops]) != hipSuccess) rc = SF_ERR_LAUNCH;
-  for (uint32_t k = 0; k < n_ops && rc == SF_OK; ++k) hipEventElapsedTime(&h_ms[k], ev[k], ev[k + 1]);
-  for (uint32_t k = 0; k <= n_ops; ++k) hipEventDestroy(ev[k]);
+  for (uint32_t k = 0; k < n_ops && rc == SF_OK; ++k)
+    if (hipEventElapsedTime(&h_ms[k], ev[k], ev[k + 1]) != hipSuccess) rc = SF_ERR_LAUNCH;
+  for (uint32_t k = 0; k < made; ++k) (void)hipEventDestroy(ev[k]);
   delete[] ev;
   return rc;
 }
