@@ -64,7 +64,8 @@ class HotPath:
         ngp.encoder.embeddings.data.uniform_(-0.5, 0.5)           # "trained-like" table, semi-transparent scene
         ngp.sigma_net.net[2].bias.data[0] = -3.0
         self.ngp = ngp.to(device).train()
-        self.optim = torch.optim.Adam(self.ngp.get_params(lr=5e-4))
+        from sparsefusion_amd.optim import FusedAdam
+        self.optim = FusedAdam(self.ngp.get_params(lr=5e-4))              # torch.optim.Adam arithmetic, one launch per step
         unet = Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2),
                     layer_attns=(False, False, False, True), layer_cross_attns=(False, False, False, False),
                     cond_images_channels=256, attn_pool_text=False)

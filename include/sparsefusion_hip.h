@@ -234,6 +234,31 @@ typedef struct {
   float f[4];
 } sf_op;
 
+/* ------------------------------------------------------------------------ */
+/* Multi-tensor Adam: replaces the two torch.optim.Adam.step() calls of every */
+/* distillation iteration (sparsefusion/distillation.py:165,246,352) by one    */
+/* launch each. torch.optim.Adam arithmetic, amsgrad/weight_decay off.         */
+/* ------------------------------------------------------------------------ */
+#define SF_ADAM_MAX_TENSORS 16
+typedef struct {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  uint64_t n;
+  float step_size;          /* lr / (1 - beta1^step), per tensor (per param group) */
+  float pad_;
+} sf_adam_tensor;
+typedef struct {
+  sf_adam_tensor t[SF_ADAM_MAX_TENSORS];
+  uint32_t chunk_start[SF_ADAM_MAX_TENSORS];   /* filled by the library */
+  uint32_t n_tensors;
+  float beta1, beta2, eps;
+  float bias_correction2_sqrt;                 /* sqrt(1 - beta2^step) */
+  float one_minus_beta1, one_minus_beta2;      /* computed in double by the caller */
+} sf_adam_args;
+int sf_adam_multi(const sf_adam_args* args, void* stream);
+
 int sf_plan_run(const sf_op* ops, uint32_t n_ops, void* stream);
 /* sf_plan_run with a HIP event before every op on the launch stream; h_ms[n_ops] (host) gets per-op
  * elapsed milliseconds.  Synchronises; measurement aid for bench.py (per-kernel roofline). */

@@ -32,6 +32,20 @@ class SfNgpFieldGrad(C.Structure):
                 ("g_w1", C.c_void_p), ("g_b1", C.c_void_p), ("g_w2", C.c_void_p), ("g_b2", C.c_void_p)]
 
 
+SF_ADAM_MAX_TENSORS = 16
+
+
+class SfAdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("n", C.c_uint64), ("step_size", C.c_float), ("pad_", C.c_float)]
+
+
+class SfAdamArgs(C.Structure):
+    _fields_ = [("t", SfAdamTensor * SF_ADAM_MAX_TENSORS), ("chunk_start", C.c_uint32 * SF_ADAM_MAX_TENSORS),
+                ("n_tensors", C.c_uint32), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("bias_correction2_sqrt", C.c_float), ("one_minus_beta1", C.c_float), ("one_minus_beta2", C.c_float)]
+
+
 class SfOp(C.Structure):
     _fields_ = [("type", C.c_int32), ("flags", C.c_int32), ("p", C.c_void_p * 12),
                 ("i", C.c_int32 * 16), ("f", C.c_float * 4)]
@@ -61,6 +75,7 @@ SIGNATURES = {
                                 C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "sf_composite_rays": (C.c_int, [u32, u32, C.c_float, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                     c_f32p, C.c_void_p]),
+    "sf_adam_multi": (C.c_int, [C.POINTER(SfAdamArgs), C.c_void_p]),
     "sf_ngp_density": (C.c_int, [C.POINTER(SfNgpField), c_f32p, u32, c_f32p, c_f32p, C.c_void_p]),
     "sf_ngp_render_forward": (C.c_int, [C.POINTER(SfNgpField), c_f32p, c_f32p, c_f32p, u32, u32, C.c_float,
                                         c_f32p, c_f32p, c_f32p, u32, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p,

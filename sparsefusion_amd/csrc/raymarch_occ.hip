@@ -341,13 +341,12 @@ __global__ __launch_bounds__(256) void k_composite_train_bwd(const float* __rest
   const float* dl = deltas + (size_t)offset * 2;
   float* gs = grad_sigmas + offset;
   float* gc = grad_rgbs + (size_t)offset * 3;
-  float T = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f, ws = 0.0f;
+  float T = 1.0f, r = 0.0f, g = 0.0f, b = 0.0f;
   for (uint32_t step = 0; step < num_steps; ++step) {
     const float c0 = cl[step * 3], c1 = cl[step * 3 + 1], c2 = cl[step * 3 + 2], dlt = dl[step * 2];
     const float alpha = 1.0f - __expf(-sg[step] * dlt);
     const float weight = alpha * T;
     r = fmaf(weight, c0, r); g = fmaf(weight, c1, g); b = fmaf(weight, c2, b);
-    ws += weight;
     T *= 1.0f - alpha;
     gc[step * 3] = g0 * weight; gc[step * 3 + 1] = g1 * weight; gc[step * 3 + 2] = g2 * weight;
     // d image / d sigma_i = delta_i * (T_{i+1} * c_i - (C_final - C_{<=i})); the weights_sum term likewise
