@@ -221,3 +221,103 @@ def reference_vae(cfg):
 
     m.encode_mode, m.decode = encode_mode, decode
     return m
+
+
+# ---------------------------------------------------------------------------------------------
+# EFT (row E1): the reference module itself imports on CPU once its third-party imports are stubbed
+# ---------------------------------------------------------------------------------------------
+class PinholeCameras:
+    """Minimal stand-in for pytorch3d's PerspectiveCameras: the two methods sparsefusion/eft.py calls
+    (`transform_points_ndc` :239, `get_camera_center` :316) and `__len__`.  World -> view is X_cam = X_world R + T
+    (row vectors, the pytorch3d convention), NDC = focal * (x, y) / z + principal point.  pytorch3d itself is
+    absent and unpinned (ENVIRONMENT.md:42): the tests use this class on BOTH sides, so the convention cancels."""
+
+    def __init__(self, R, T, focal, principal=None):
+        self.R, self.T = R.float(), T.float()                       # [NC,3,3], [NC,3]
+        self.focal = focal.float()                                  # [NC,2]
+        self.principal = torch.zeros_like(self.focal) if principal is None else principal.float()
+
+    def __len__(self):
+        return self.R.shape[0]
+
+    def to(self, device):
+        return PinholeCameras(self.R.to(device), self.T.to(device), self.focal.to(device), self.principal.to(device))
+
+    def get_camera_center(self):
+        return -torch.bmm(self.T[:, None], self.R.transpose(1, 2))[:, 0]          # C = -T R^T
+
+    def transform_points_ndc(self, pts):
+        p = pts.expand(len(self), -1, -1) if pts.shape[0] == 1 else pts
+        cam = torch.bmm(p, self.R) + self.T[:, None]
+        z = cam[..., 2:3]
+        xy = cam[..., :2] / z * self.focal[:, None] + self.principal[:, None]
+        return torch.cat([xy, 1.0 / z], -1)
+
+
+def _resnet18_stub():
+    """torchvision.models.resnet18 (torchvision 0.12, ENVIRONMENT.md) restated with torch.nn so that the reference's
+    `getattr(torchvision.models, 'resnet18')(pretrained=True)` (eft.py:99) constructs; weights are random here."""
+    import torch.nn as nn
+
+    class BasicBlock(nn.Module):
+        def __init__(self, cin, cout, stride):
+            super().__init__()
+            self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+            self.bn1 = nn.BatchNorm2d(cout)
+            self.relu = nn.ReLU(inplace=True)
+            self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(cout)
+            self.downsample = None
+            if stride != 1 or cin != cout:
+                self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+        def forward(self, x):
+            idt = x if self.downsample is None else self.downsample(x)
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.bn2(self.conv2(out))
+            return self.relu(out + idt)
+
+    class ResNet18(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+            self.bn1 = nn.BatchNorm2d(64)
+            self.relu = nn.ReLU(inplace=True)
+            self.maxpool = nn.MaxPool2d(3, 2, 1)
+            self.layer1 = nn.Sequential(BasicBlock(64, 64, 1), BasicBlock(64, 64, 1))
+            self.layer2 = nn.Sequential(BasicBlock(64, 128, 2), BasicBlock(128, 128, 1))
+            self.layer3 = nn.Sequential(BasicBlock(128, 256, 2), BasicBlock(256, 256, 1))
+            self.layer4 = nn.Sequential(BasicBlock(256, 512, 2), BasicBlock(512, 512, 1))
+            self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+            self.fc = nn.Linear(512, 1000)
+
+    return lambda pretrained=False, **kw: ResNet18()
+
+
+def reference_eft(**kwargs):
+    """The reference's EpipolarFeatureTransformer (sparsefusion/eft.py:55) with the arguments of utils/load_model.py:33."""
+    install()
+    import collections
+    tv = sys.modules["torchvision"]
+    if not hasattr(tv, "models"):
+        tv.models = _stub("torchvision.models", resnet18=_resnet18_stub())
+    RayBundle = collections.namedtuple("RayBundle", ["origins", "directions", "lengths", "xys"])
+
+    def ray_bundle_to_ray_points(rb):
+        return rb.origins[..., None, :] + rb.lengths[..., :, None] * rb.directions[..., None, :]
+
+    for name in ("pytorch3d", "pytorch3d.renderer", "pytorch3d.renderer.cameras", "pytorch3d.renderer.implicit",
+                 "pytorch3d.renderer.implicit.utils", "skimage", "skimage.metrics"):
+        if name not in sys.modules:
+            _stub(name)
+    sys.modules["pytorch3d.renderer"].RayBundle = RayBundle
+    sys.modules["pytorch3d.renderer"].ray_bundle_to_ray_points = ray_bundle_to_ray_points
+    sys.modules["pytorch3d.renderer.cameras"].PerspectiveCameras = PinholeCameras
+    sys.modules["pytorch3d.renderer.implicit.utils"]._validate_ray_bundle_variables = lambda *a, **k: None
+    sys.modules["pytorch3d.renderer.implicit.utils"].ray_bundle_variables_to_ray_points = \
+        lambda o, d, l: o[..., None, :] + l[..., :, None] * d[..., None, :]
+    sys.modules["skimage"].metrics = sys.modules["skimage.metrics"]
+    from sparsefusion.eft import EpipolarFeatureTransformer
+    kw = dict(use_r=True, encoder='resnet18', return_features=True, remove_unused_layers=False)
+    kw.update(kwargs)
+    return EpipolarFeatureTransformer(**kw), RayBundle
