@@ -221,7 +221,8 @@ enum {
   SF_OP_TIME_EMB = 9,  /* learned sinusoidal embedding of log-snr           */
   SF_OP_SPLITK_REDUCE = 10, /* stand-alone reduction of deferred split-K partials */
   SF_OP_POOL = 11,     /* 2x2 max pooling fwd / bwd (LPIPS-VGG)             */
-  SF_OP_LPIPS = 12     /* LPIPS per-layer head fwd / bwd                    */
+  SF_OP_LPIPS = 12,    /* LPIPS per-layer head fwd / bwd                    */
+  SF_OP_EFT = 13       /* EFT pre-pass: resize, grid-sample gather, harmonic embedding, short-sequence attention, softmax pooling */
 };
 
 /* One op = one or two kernel launches.  Interpretation of p[]/i[]/f[] per op type is

@@ -197,6 +197,7 @@ int sf_plan_extra_op(const sf_op* opp, void* stream) {
   switch (op.type) {
     case SF_OP_POOL: {
       const int B = op.i[0], H = op.i[1], W = op.i[2], C = op.i[3];
+      if (op.flags == 2) return sf_plan_eft_op(opp, stream);          // 3x3 / 2 stem pooling (eft_ops.hip)
       if ((H | W) & 1 || C % 4) SF_FAIL(SF_ERR_INVALID, "pool: H, W must be even and C a multiple of 4");
       const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
       if (op.flags == 0) {

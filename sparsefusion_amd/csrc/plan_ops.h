@@ -3,3 +3,4 @@
 #include "sf_common.h"
 
 int sf_plan_extra_op(const sf_op* op, void* stream);
+int sf_plan_eft_op(const sf_op* op, void* stream);

@@ -61,7 +61,7 @@ __device__ __forceinline__ float wave_max(float v) {
 //   flags: 1 = A is f32, 2 = epilogue SiLU + PixelShuffle(2) (no split-K), 4 = accumulate into out (out += ...),
 //          8 = split-K partials stay in the workspace; the consumer reduces them (LazySrc mode 1),
 //          16 = the input is a nearest x2 upsampling of a stored [B, H/2, W/2, Cin] map (H, W = upsampled dims),
-//          32 = ReLU in the epilogue (after bias / residual / accumulate)
+//          32 = ReLU, 64 = GELU(erf) in the epilogue (after bias / residual / accumulate)
 // No atomics: with groups == 1 every output element is owned by one wave (plain store / read-modify-write);
 // with groups > 1 each K-slice group stores its partial tile to the workspace and k_splitk_reduce sums them
 // (fp32 L2 atomics top out at ~25 G lane-ops/s on MI355X, which made the atomic split-K epilogue 10x the
@@ -74,7 +74,7 @@ struct ConvArgs {
   int accum, npad;
   int B, H, W, Cin, Ho, Wo, Cout, ldc, co_off, kh, kw, stride, pad, groups;
   int KS, cchunks, m_frags, n_frags, m_tiles, n_tiles, steps_per_wave;
-  int pixshuf, ups, relu;
+  int pixshuf, ups, relu;   // relu: 0 none, 1 ReLU, 2 GELU (erf)
 };
 
 template <int WM, int WN, bool A_FP32>
@@ -258,7 +258,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
           const long o = (long)m * a.ldc + a.co_off + n;
           if (a.resid) v += a.resid[o];
           if (a.accum) v += a.out[o];
-          if (a.relu) v = fmaxf(v, 0.0f);
+          if (a.relu == 1) v = fmaxf(v, 0.0f);
+          else if (a.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
           a.out[o] = v;
         }
       }
@@ -279,7 +280,8 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
     const long o = (long)m * ldc + co_off + n;
     if (resid) v += resid[o];
     if (accum) v += out[o];
-    if (relu) v = fmaxf(v, 0.0f);
+    if (relu == 1) v = fmaxf(v, 0.0f);
+    else if (relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
     out[o] = v;
   }
 }
@@ -905,7 +907,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_lds(ConvArgs a) {
         float v = acc[i][n][r] + bv;
         if (a.resid) v += a.resid[o];
         if (a.accum) v += a.out[o];
-        if (a.relu) v = fmaxf(v, 0.0f);
+        if (a.relu == 1) v = fmaxf(v, 0.0f);
+        else if (a.relu == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
         a.out[o] = v;
       }
     }
@@ -933,7 +936,7 @@ static int run_conv(const sf_op& op, hipStream_t st) {
   const int WM = tile / 16, WN = tile % 16;
   a.pixshuf = (op.flags & 2) ? 1 : 0;
   a.ups = (op.flags & 16) ? 1 : 0;
-  a.relu = (op.flags & 32) ? 1 : 0;
+  a.relu = (op.flags & 32) ? 1 : ((op.flags & 64) ? 2 : 0);
   if (a.ups && ((a.H | a.W) & 1)) SF_FAIL(SF_ERR_INVALID, "conv: upsampled input dims must be even");
   if (a.Cin % 32) SF_FAIL(SF_ERR_INVALID, "conv: Cin_pad must be a multiple of 32");
   if (a.pixshuf && a.groups != 1) SF_FAIL(SF_ERR_INVALID, "conv: pixel-shuffle epilogue cannot be split-K");
@@ -1153,6 +1156,7 @@ static int plan_run_impl(const sf_op* ops, uint32_t n_ops, hipStream_t st, hipEv
         break;
       case SF_OP_POOL:
       case SF_OP_LPIPS: rc = sf_plan_extra_op(&op, st); break;
+      case SF_OP_EFT: rc = sf_plan_eft_op(&op, st); break;
       default: SF_FAIL(SF_ERR_INVALID, "plan: unknown op type %d at %u", op.type, k);
     }
     if (rc) {

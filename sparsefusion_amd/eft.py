@@ -1,0 +1,381 @@
+"""Epipolar Feature Transformer (EFT) forward on the HIP op plan -- the view-conditioned feature pre-pass (row E1).
+
+Mirrors `EpipolarFeatureTransformer` of sparsefusion/eft.py:55-525 as constructed by utils/load_model.py:33
+(`use_r=True, encoder='resnet18', return_features=True`): same constructor keywords, the same 278 state-dict keys,
+`encode(input_cameras, input_images)`, `forward(ray_bundle, input_cameras=, input_rgb=) -> (rgb [N,3], f3 [N,256], 0)`,
+`batched_forward(ray_bundle, n_batches=, ...)` as called through `renderer_feat` at sparsefusion/distillation.py:100-109.
+Inference only (the pre-pass runs under torch.no_grad()).
+
+What runs where: the camera object (pytorch3d `PerspectiveCameras` in the reference; anything with
+`transform_points_ndc` / `get_camera_center`) and the ray arithmetic in front of it stay torch -- a few elementwise ops on
+[NC, N*D, 3] tensors.  Everything else is the library: resnet18 trunk as implicit-GEMM convs with BatchNorm folded
+into the packed weights, 3x3/2 max-pool, align-corners resize of the four pyramid levels into one 512-channel NHWC map,
+the grid_sample gather straight into the T1 input rows, harmonic embeddings, every Linear of the 12 encoder layers on
+the MFMA conv kernels (GELU / ReLU / residual in the epilogue), single-head attention over the 2-6 views or the 20 depths
+as strided rows of ONE matrix (no 'nc (n d) -> d (nc n)' permutes: only the attention kernel knows which rows form a
+sequence), LayerNorm, and the two softmax poolings with the colour head fused into the last one.
+The input columns of the three `pre` Linears are re-ordered so that the 256/512-wide blocks start 16-byte aligned; the
+weight columns are permuted identically at pack time, which leaves the product unchanged.  No CPU fallback."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .unet import OP_ELTWISE, OP_MEMSET, Unet, _Node, _Plan, _T
+
+OP_POOL, OP_EFT = 11, 13
+RAY_DIM, DEPTH_DIM = 78, 13                     # HarmonicEmbedding(6): (2*6+1) * {6, 1}
+
+
+def _resnet_spec(out, p, cin, cout, stride):
+    def bn(q, c):
+        return [(q + ".weight", (c,)), (q + ".bias", (c,)), (q + ".running_mean", (c,)), (q + ".running_var", (c,)),
+                (q + ".num_batches_tracked", ())]
+    out += [(p + ".conv1.weight", (cout, cin, 3, 3))] + bn(p + ".bn1", cout) + [(p + ".conv2.weight", (cout, cout, 3, 3))] + \
+        bn(p + ".bn2", cout)
+    if stride != 1 or cin != cout:
+        out += [(p + ".downsample.0.weight", (cout, cin, 1, 1))] + bn(p + ".downsample.1", cout)
+
+
+def eft_param_spec(remove_unused_layers=False):
+    """(name, shape) in the registration order of the reference module (eft.py:83-146; torchvision resnet18)."""
+    e = "encoder_model"
+    spec = [(e + ".conv1.weight", (64, 3, 7, 7))]
+    spec += [(e + ".bn1." + k, s) for k, s in (("weight", (64,)), ("bias", (64,)), ("running_mean", (64,)), ("running_var", (64,)),
+                                               ("num_batches_tracked", ()))]
+    cin = 64
+    for layer, cout, stride in ((1, 64, 1), (2, 128, 2), (3, 256, 2), (4, 512, 2)):
+        if layer == 4 and remove_unused_layers:
+            break
+        _resnet_spec(spec, f"{e}.layer{layer}.0", cin, cout, stride)
+        _resnet_spec(spec, f"{e}.layer{layer}.1", cout, cout, 1)
+        cin = cout
+    if not remove_unused_layers:
+        spec += [(e + ".fc.weight", (1000, 512)), (e + ".fc.bias", (1000,))]
+    for t, d_in in (("t1", RAY_DIM + DEPTH_DIM + 515), ("t2", 2 * RAY_DIM + DEPTH_DIM + 256), ("t3", 2 * RAY_DIM + 256)):
+        spec += [(f"{t}.pre.0.weight", (256, d_in)), (f"{t}.pre.0.bias", (256,))]
+        for i in range(4):
+            p = f"{t}.encoder.layers.{i}"
+            spec += [(p + ".self_attn.in_proj_weight", (768, 256)), (p + ".self_attn.in_proj_bias", (768,)),
+                     (p + ".self_attn.out_proj.weight", (256, 256)), (p + ".self_attn.out_proj.bias", (256,)),
+                     (p + ".linear1.weight", (256, 256)), (p + ".linear1.bias", (256,)),
+                     (p + ".linear2.weight", (256, 256)), (p + ".linear2.bias", (256,)),
+                     (p + ".norm1.weight", (256,)), (p + ".norm1.bias", (256,)), (p + ".norm2.weight", (256,)), (p + ".norm2.bias", (256,))]
+        if t == "t2":
+            spec += [("t2_attn.weight", (1, 256)), ("t2_attn.bias", (1,))]
+    spec += [("t3_attn.weight", (1, 256)), ("t3_attn.bias", (1,)), ("color_layer.0.weight", (3, 256)), ("color_layer.0.bias", (3,))]
+    return spec
+
+
+def _i64(v):
+    return (v & 0xffffffff) - (1 << 32) if (v & 0xffffffff) >= (1 << 31) else (v & 0xffffffff), v >> 32
+
+
+class _EftPlan(_Plan):
+    def eft_op(self, sub, p, ints, f=()):
+        self.op(OP_EFT, sub, p=p, i=ints, f=f)
+
+    # ---- encoder: resnet18 trunk -> 512-channel pyramid at half resolution (eft.py:173-206)
+    def build_encoder(self, NC, R):
+        self.op(OP_MEMSET, 0, p=(self.zero.buf.data_ptr() if self.zero.buf is not None else 1,), i=(0,))
+        memset_op = self.ops[-1]
+        e = "encoder_model"
+        HW = R * R
+        self.x_in = self.f32(NC, 3 * HW)
+        xin = self.f32(NC * HW, 32, HW)
+        self.op(OP_ELTWISE, 2, p=(0, self.x_in.ptr, 0, xin.ptr), i=(NC, HW, 0, 3, 32))
+        H = R // 2
+        x0 = self.zf32(NC * H * H, 64, H * H)
+        self.conv(xin, True, R, R, e + ".conv1.weight", e + ".conv1.fbias", x0, 64, 0, 64, 7, 2, 3, relu=True)
+        Hp = (H - 1) // 2 + 1
+        x = self.f32(NC * Hp * Hp, 64, Hp * Hp)
+        self.op(OP_POOL, 2, p=(x0.ptr, 0, 0, x.ptr), i=(NC, H, H, 64))
+        latents, Hc = [(x0, H)], Hp
+        for layer, cout, stride in ((1, 64, 1), (2, 128, 2), (3, 256, 2)):
+            for blk in (0, 1):
+                p = f"{e}.layer{layer}.{blk}"
+                s = stride if blk == 0 else 1
+                Ho = (Hc + 2 - 3) // s + 1
+                idt = x
+                if (p + ".downsample.0.weight") in self.w:
+                    idt = self.zf32(NC * Ho * Ho, cout, Ho * Ho)
+                    self.conv(x, True, Hc, Hc, p + ".downsample.0.weight", p + ".downsample.0.fbias", idt, cout, 0, cout, 1, s, 0)
+                h = self.zf32(NC * Ho * Ho, cout, Ho * Ho)
+                self.conv(x, True, Hc, Hc, p + ".conv1.weight", p + ".conv1.fbias", h, cout, 0, cout, 3, s, 1, relu=True)
+                y = self.zf32(NC * Ho * Ho, cout, Ho * Ho)
+                self.conv(h, True, Ho, Ho, p + ".conv2.weight", p + ".conv2.fbias", y, cout, 0, cout, 3, 1, 1, resid=idt, relu=True)
+                x, Hc = y, Ho
+            latents.append((x, Hc))
+        self.latent = self.f32(NC * H * H, 512, H * H)
+        co = 0
+        for t, Ht in latents:                                      # F.interpolate(..., bilinear, align_corners=True) + cat (:193-202)
+            self.eft_op(0, (t.ptr, 0, 0, self.latent.ptr), (NC, Ht, Ht, t.C, H, H, 512, co))
+            co += t.C
+        self.Hf = H
+        memset_op.i[0] = (self.zero.off + 3) // 4
+        self.op_array = (_lib.SfOp * len(self.ops))(*self.ops)
+        if self.misc.buf is not None:
+            self.x_view = self.tview(self.x_in)
+            self.latent_view = self.tview(self.latent).view(NC, H, H, 512)
+        return self
+
+    # ---- transformer pieces (eft.py:19-52; nn.TransformerEncoderLayer(256, 1, 256), post-norm, ReLU)
+    def linear(self, x, M, wname, bname, out, cout, resid=None, act=0):
+        self.conv(x, True, 1, M, wname, bname, out, cout, 0, cout, 1, batch=1, resid=resid, relu=(act == 1), gelu=(act == 2))
+
+    def encoder_layer(self, p, x, M, S, stride, gmul):
+        qkv = self.zf32(M, 768)
+        self.linear(x, M, p + ".self_attn.in_proj_weight", p + ".self_attn.in_proj_bias", qkv, 768)
+        att = self.f32(M, 256)
+        self.eft_op(3, (qkv.ptr, 0, 0, att.ptr), _i64(M // S) + (S,) + _i64(stride) + _i64(gmul), (1.0 / math.sqrt(256.0),))
+        y = self.zf32(M, 256)
+        self.linear(att, M, p + ".self_attn.out_proj.weight", p + ".self_attn.out_proj.bias", y, 256, resid=x)
+        x1 = self.f32(M, 256)
+        self.ln(y, p + ".norm1.weight", p + ".norm1.bias", x1, 256, M, out_f32=True)
+        h = self.zf32(M, 256)
+        self.linear(x1, M, p + ".linear1.weight", p + ".linear1.bias", h, 256, act=1)
+        y2 = self.zf32(M, 256)
+        self.linear(h, M, p + ".linear2.weight", p + ".linear2.bias", y2, 256, resid=x1)
+        x2 = self.f32(M, 256)
+        self.ln(y2, p + ".norm2.weight", p + ".norm2.bias", x2, 256, M, out_f32=True)
+        return x2
+
+    def transformer(self, t, w_in, K, M, S, stride, gmul):
+        x = self.zf32(M, 256)
+        self.linear(_T(w_in.ptr, M, K), M, t + ".pre.0.weight", t + ".pre.0.bias", x, 256, act=2)
+        for i in range(4):
+            x = self.encoder_layer(f"{t}.encoder.layers.{i}", x, M, S, stride, gmul)
+        return x
+
+    def harmonic(self, src, out, rows, dim, ldo, co, div=1, mod=1 << 40, mul=1, add=0):
+        self.eft_op(2, (src.ptr, 0, 0, out.ptr), _i64(rows) + (dim, ldo, co) + _i64(div) + _i64(mod) + _i64(mul) + _i64(add))
+
+    def copy_cols(self, src, out, rows, C, ldo, co):
+        self.eft_op(0, (src.ptr, 0, 0, out.ptr), (1, 1, rows, C, 1, rows, ldo, co))     # same-size "resize" = strided copy
+
+    # ---- forward for N rays x D depths against NC encoded views (eft.py:351-452)
+    def build_forward(self, NC, N, D, enc, Hi):
+        P, M = N * D, NC * N * D
+        self.xy, self.ref_src = self.f32(NC * P, 2), self.f32(M, 6)
+        self.q_src, self.depth_src = self.f32(N, 6), self.f32(P, 1)
+        K1, K2, K3 = 608, 448, 416                              # 606 / 425 / 412 padded to a multiple of 32
+        self.t1_in, self.t2_in, self.t3_in = self.f32(M, K1), self.f32(M, K2), self.f32(NC * N, K3)
+        # T1 input columns: [features 512 | rgb 3 | reference Pluecker 78 | depth 13 | pad]
+        self.eft_op(1, (enc.latent.ptr, self.images_ptr, self.xy.ptr, self.t1_in.ptr),
+                    (NC,) + _i64(P) + (enc.Hf, enc.Hf, 512, Hi, Hi, K1, 0))
+        self.harmonic(self.ref_src, self.t1_in, M, 6, K1, 515)
+        self.harmonic(self.depth_src, self.t1_in, M, 1, K1, 515 + RAY_DIM, mod=P)
+        f1 = self.transformer("t1", self.t1_in, K1, M, NC, P, 1)                    # sequence = views: rows g + s * (N*D)
+        # T2 input columns: [f1 256 | query Pluecker 78 | reference Pluecker 78 | depth 13 | pad]
+        self.copy_cols(f1, self.t2_in, M, 256, K2, 0)
+        self.harmonic(self.q_src, self.t2_in, M, 6, K2, 256, div=D, mod=N)
+        self.harmonic(self.ref_src, self.t2_in, M, 6, K2, 256 + RAY_DIM)
+        self.harmonic(self.depth_src, self.t2_in, M, 1, K2, 256 + 2 * RAY_DIM, mod=P)
+        f2 = self.transformer("t2", self.t2_in, K2, M, D, 1, D)                     # sequence = depths: rows g*D + s
+        f2p = self.f32(NC * N, 256)
+        self.eft_op(4, (f2.ptr, self.wptr("t2_attn.weight"), self.wptr("t2_attn.bias"), f2p.ptr),
+                    _i64(NC * N) + (D,) + _i64(1) + _i64(D))
+        # T3 input columns: [f2 256 | query Pluecker 78 | reference Pluecker at depth D//2 78 | pad]
+        self.copy_cols(f2p, self.t3_in, NC * N, 256, K3, 0)
+        self.harmonic(self.q_src, self.t3_in, NC * N, 6, K3, 256, mod=N)
+        self.harmonic(self.ref_src, self.t3_in, NC * N, 6, K3, 256 + RAY_DIM, mul=D, add=D // 2)
+        f3 = self.transformer("t3", self.t3_in, K3, NC * N, NC, N, 1)               # sequence = views: rows g + s * N
+        self.f3, self.rgb = self.f32(N, 256), self.f32(N, 3)
+        self.eft_op(4, (f3.ptr, self.wptr("t3_attn.weight"), self.wptr("t3_attn.bias"), self.f3.ptr,
+                        self.wptr("color_layer.0.weight"), self.wptr("color_layer.0.bias"), self.rgb.ptr),
+                    _i64(N) + (NC,) + _i64(N) + _i64(1))
+        self.op_array = (_lib.SfOp * len(self.ops))(*self.ops)
+        if self.misc.buf is not None:
+            for name in ("xy", "ref_src", "q_src", "depth_src", "f3", "rgb"):
+                setattr(self, name + "_view", self.tview(getattr(self, name)))
+            for t in (self.t1_in, self.t2_in, self.t3_in):         # the pad columns are never written again
+                self.tview(t).zero_()
+        return self
+
+
+class EpipolarFeatureTransformer(nn.Module):
+    def __init__(self, use_r=True, n_harmonic_functions=6, conv_dims=(32,), return_features=False, encoder='lite',
+                 remove_unused_layers=True, in_dim=3, out_dim=3, out_sigmoid=True, omega0=1.0, verbose=False):
+        super().__init__()
+        if not (use_r and encoder == 'resnet18' and return_features and in_dim == 3 and out_dim == 3 and out_sigmoid
+                and n_harmonic_functions == 6 and omega0 == 1.0):
+            raise NotImplementedError("sparsefusion_amd EFT covers the configuration of utils/load_model.py:33 only: "
+                                      "use_r=True, encoder='resnet18', return_features=True (6 octaves, omega0 = 1)")
+        self.use_r, self.return_features, self.encoder, self.in_dim = use_r, return_features, encoder, in_dim
+        self.conv_dims, self.encoder_num_layers, self.feat_size = 'default', 4, 512
+        g = torch.Generator().manual_seed(0)
+        for name, shape in eft_param_spec(remove_unused_layers):
+            self._add(name, shape, g)
+        self.input_bbox = self.input_cameras = self.input_images = self.encoder_latent = None
+        self.conv_waves_target, self.lazy_consumers, self.ss_total, self.lds_conv_min_blocks = 1024, 0, 0, 96
+        self._pack_cache, self._plans, self._enc = None, {}, None
+
+    conv_tiling = Unet.conv_tiling
+
+    def _add(self, dotted, shape, g):
+        parts = dotted.split(".")
+        node = self
+        for p in parts[:-1]:
+            if p not in node._modules:
+                node.add_module(p, _Node())
+            node = node._modules[p]
+        leaf = parts[-1]
+        if leaf in ("running_mean", "running_var", "num_batches_tracked"):
+            t = {"running_mean": torch.zeros(shape), "running_var": torch.ones(shape)}.get(leaf, torch.tensor(0))
+            node.register_buffer(leaf, t)
+            return
+        if len(shape) == 1:
+            t = torch.ones(shape) if leaf == "weight" else torch.zeros(shape)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            t = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+        node.register_parameter(leaf, nn.Parameter(t, requires_grad=False))
+
+    def get_config(self):
+        return {'model': 'patch_nerf', 'conv_dims': self.conv_dims, 'encoder': self.encoder}
+
+    def invalidate(self):
+        self._pack_cache, self._plans, self._enc = None, {}, None
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.invalidate()
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self.invalidate()
+        return r
+
+    # ---- packing: BatchNorm folded into the conv, `pre` Linears with re-ordered, padded input columns
+    def _packed(self, device):
+        if self._pack_cache is not None and self._pack_cache[0] == str(device):
+            return self._pack_cache[1]
+        lib = _lib.lib()
+        sd = {k: v.detach().float().cpu() for k, v in self.state_dict().items()}
+        packed = {}
+
+        def pack(w4):
+            w4 = w4.contiguous()
+            co, ci, kh, kw = w4.shape
+            cpad = (ci + 31) // 32 * 32
+            buf = torch.empty(lib.sf_conv_packed_elems(co, cpad, kh, kw), dtype=torch.int16)
+            _lib.check(lib.sf_conv_pack_weights(w4.data_ptr(), co, ci, cpad, kh, kw, buf.data_ptr()), "pack")
+            return buf.to(device)
+
+        def fold(conv, bn):
+            s = sd[bn + ".weight"] / torch.sqrt(sd[bn + ".running_var"] + 1e-5)
+            packed[conv + ".weight"] = pack(sd[conv + ".weight"] * s[:, None, None, None])
+            packed[conv + ".fbias"] = (sd[bn + ".bias"] - sd[bn + ".running_mean"] * s).contiguous().to(device)
+
+        e = "encoder_model"
+        fold(e + ".conv1", e + ".bn1")
+        for layer in (1, 2, 3):
+            for blk in (0, 1):
+                p = f"{e}.layer{layer}.{blk}"
+                fold(p + ".conv1", p + ".bn1")
+                fold(p + ".conv2", p + ".bn2")
+                if (p + ".downsample.0.weight") in sd:
+                    fold(p + ".downsample.0", p + ".downsample.1")
+        R, Dd = RAY_DIM, DEPTH_DIM
+        # reference column order -> plan column order (see _EftPlan.build_forward)
+        perm = {"t1": list(range(R + Dd, R + Dd + 515)) + list(range(0, R)) + list(range(R, R + Dd)),          # [ref|depth|feat+rgb]
+                "t2": list(range(2 * R + Dd, 2 * R + Dd + 256)) + list(range(0, 2 * R + Dd)),                   # [q|ref|depth|f1]
+                "t3": list(range(2 * R, 2 * R + 256)) + list(range(0, 2 * R))}                                  # [q|ref|f2]
+        for name, w in sd.items():
+            if name.startswith(e) or name.endswith("num_batches_tracked"):
+                continue
+            if name.endswith(".pre.0.weight"):
+                w = w[:, perm[name[:2]]]
+            if w.dim() == 2 and name not in ("t2_attn.weight", "t3_attn.weight", "color_layer.0.weight"):
+                packed[name] = pack(w.reshape(w.shape[0], w.shape[1], 1, 1))
+            else:
+                packed[name] = w.reshape(-1).contiguous().to(device)
+        self._pack_cache = (str(device), packed)
+        return packed
+
+    # ---- reference API
+    @torch.no_grad()
+    def encode(self, input_cameras, input_images, input_bbox=None):
+        """eft.py:155-207.  input_images [NC, 3, H, W] (or channels-last) -> (input_images, encoder_latent [NC, 512, H/2, W/2])."""
+        if input_images is None:
+            return None, None
+        if input_images.shape[1] != self.in_dim:
+            input_images = input_images.permute(0, 3, 1, 2)
+        _lib.require_cuda(input_images)
+        if input_bbox is not None:
+            pass        # the reference computes an in-box mask and then discards it (eft.py:264-284: `ep_bool = ones_like`)
+        images = input_images.float().contiguous()
+        NC, _, H, W = images.shape
+        if H != W or H % 32:
+            raise RuntimeError(f"EFT encode: square inputs with side % 32 == 0 expected, got {H}x{W}")
+        key = ("enc", NC, H, str(images.device))
+        if key not in self._plans:
+            s = _EftPlan(self, NC, images.device).build_encoder(NC, H)
+            self._plans[key] = _EftPlan(self, NC, images.device, (s.zero.off + 256, s.misc.off + s.ws_bytes + 256, s.ws_bytes)
+                                        ).build_encoder(NC, H)
+        plan = self._plans[key]
+        plan.x_view.copy_(images.reshape(NC, -1))
+        _lib.check(_lib.lib().sf_plan_run(plan.op_array, len(plan.ops), _lib.stream_ptr()), "eft encoder plan")
+        self._enc = plan
+        self.input_images, self.input_cameras, self.input_bbox = images, input_cameras, input_bbox
+        self.encoder_latent = plan.latent_view.permute(0, 3, 1, 2)
+        return self.input_images, self.encoder_latent
+
+    @torch.no_grad()
+    def forward(self, ray_bundle, return_intermediates=False, **kwargs):
+        """eft.py:351-452 with return_features=True: -> (rgb [N, 3], f3 [N, 256], 0)."""
+        if return_intermediates:
+            raise NotImplementedError("return_intermediates is not used by the distillation pre-pass")
+        if kwargs.get('input_cameras') is not None:
+            self.encode(kwargs['input_cameras'], kwargs['input_rgb'], kwargs.get('input_bbox'))
+        if self._enc is None:
+            raise RuntimeError("EFT.forward before encode(): no input views")
+        o = ray_bundle.origins.reshape(-1, 3).float()
+        d = ray_bundle.directions.reshape(-1, 3).float()
+        lengths = ray_bundle.lengths.reshape(o.shape[0], -1).float()
+        _lib.require_cuda(o, d, lengths)
+        N, D = lengths.shape
+        NC, cams, enc = len(self.input_cameras), self.input_cameras, self._enc
+        key = ("fwd", NC, N, D, id(enc))
+        if key not in self._plans:
+            def make(sizing=None):
+                pl = _EftPlan(self, NC, o.device, sizing)
+                pl.images_ptr = self.input_images.data_ptr()
+                return pl.build_forward(NC, N, D, enc, self.input_images.shape[-1])
+            s = make()
+            self._plans[key] = make((s.zero.off + 256, s.misc.off + s.ws_bytes + 256, s.ws_bytes))
+        plan = self._plans[key]
+        if plan.images_ptr != self.input_images.data_ptr():
+            raise RuntimeError("EFT: the encoded input images were replaced; call encode() again")
+        # ray geometry in torch (the camera object is the caller's): eft.py:373-381, :239-246, :316-332
+        xyz = o[:, None, :] + lengths[:, :, None] * d[:, None, :]
+        dn = torch.nn.functional.normalize(d, dim=-1)
+        plan.q_src_view.copy_(torch.cat((dn, torch.cross(o, dn, dim=-1)), -1))
+        plan.xy_view.copy_(cams.transform_points_ndc(xyz.reshape(1, -1, 3))[..., :2].reshape(NC * N * D, 2))
+        centers = cams.get_camera_center()[:, None, None, :].expand(NC, N, D, 3)
+        in_dirs = torch.nn.functional.normalize(xyz[None] - centers, dim=-1)
+        plan.ref_src_view.copy_(torch.cat((in_dirs, torch.cross(centers, in_dirs, dim=-1)), -1).reshape(-1, 6))
+        plan.depth_src_view.copy_(lengths.reshape(-1, 1))
+        _lib.check(_lib.lib().sf_plan_run(plan.op_array, len(plan.ops), _lib.stream_ptr()), "eft forward plan")
+        return plan.rgb_view.clone(), plan.f3_view.clone(), 0
+
+    @torch.no_grad()
+    def batched_forward(self, ray_bundle, n_batches=32, return_intermediates=False, **kwargs):
+        """eft.py:454-525: rays in `n_batches` chunks (rays are independent: chunking only bounds memory)."""
+        if return_intermediates:
+            raise NotImplementedError("return_intermediates is not used by the distillation pre-pass")
+        if kwargs.get('input_cameras') is not None:
+            self.encode(kwargs['input_cameras'], kwargs['input_rgb'])
+        n_pts = ray_bundle.lengths.shape[-1]
+        spatial = list(ray_bundle.origins.shape[:-1])
+        o, d = ray_bundle.origins.reshape(-1, 3), ray_bundle.directions.reshape(-1, 3)
+        lengths = ray_bundle.lengths.reshape(-1, n_pts)
+        outs = []
+        for idx in torch.chunk(torch.arange(o.shape[0], device=o.device), n_batches):
+            outs.append(self.forward(type(ray_bundle)(o[idx], d[idx], lengths[idx], None)))
+        rgb = torch.cat([t[0] for t in outs], 0).view(*spatial, -1)
+        f3 = torch.cat([t[1] for t in outs], 0).view(*spatial, -1)
+        return rgb, f3, 0

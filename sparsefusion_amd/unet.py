@@ -226,7 +226,7 @@ class _Plan:
 
     # -------- op emitters
     def conv(self, x, x_f32, H, W, wname, bname, out, ldc, co_off, Cout, k, stride=1, pad=0, resid=None, pixshuf=False,
-             defer=False, w_ptr=None, batch=None, out_hw=None, upsampled=False, relu=False):
+             defer=False, w_ptr=None, batch=None, out_hw=None, upsampled=False, relu=False, gelu=False):
         """One implicit-GEMM launch.  `w_ptr` replaces the named weight by a device-packed B operand (attention),
         `batch` overrides the plan batch (per-sample GEMMs), `out_hw` the output size (asymmetric padding),
         `upsampled` makes (H, W) the dims of a nearest-x2 view of the stored [H/2, W/2] input."""
@@ -255,11 +255,11 @@ class _Plan:
                 bnf, blocks = 4, ((m_frags + 7) // 8) * ((n_frags + 3) // 4)
             if blocks >= lds_min:
                 tile, groups, ws = 256 + bnf, 1, 0
-        defer = bool(defer and not relu and groups > 1 and not accum and not pixshuf and co_off == 0 and ldc == Cout == out.C and M == out.rows
+        defer = bool(defer and not relu and not gelu and groups > 1 and not accum and not pixshuf and co_off == 0 and ldc == Cout == out.C and M == out.rows
                      and (self.u.lazy_consumers & 1))
         bias, res = self.wptr(bname) if bname else 0, resid.ptr if resid else 0
         self.op(OP_CONV, (1 if x_f32 else 0) | (2 if pixshuf else 0) | (4 if accum else 0) | (8 if defer else 0) |
-                (16 if upsampled else 0) | (32 if relu else 0),
+                (16 if upsampled else 0) | (32 if relu else 0) | (64 if gelu else 0),
                 p=(x.ptr, w_ptr if w_ptr is not None else self.wptr(wname), bias, out.ptr, res, ws),
                 i=(B, H, W, x.C, Ho, Wo, Cout, ldc, co_off, k, k, stride, pad, groups, tile))
         if defer:
