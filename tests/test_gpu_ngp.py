@@ -263,6 +263,29 @@ def test_render_full_size_properties(golden):
     assert psnr(got["image"][0].cpu(), ref["image"]) > 50.0
 
 
+def test_render_batched_eval_sizes(golden):
+    """BASELINE config 4 renders 512^2 at evaluation time through render_batched (renderer_df.py:681-717): chunks of
+    max_ray_batch rays must reproduce the single-launch result bit for bit (rays are independent; eval sampling is
+    deterministic), also for a ragged last chunk, and stay finite at 262 144 rays."""
+    p = params_from_cfg(golden["teacher"]["cfg"])
+    net = _net(p).eval()
+    kw = dict(perturb=False, bg_color=1, shading='albedo', **{k: v for k, v in vars(net.opt).items() if k != 'max_ray_batch'})
+    o, d = ngp_ref.circle_rays(256, view=5)
+    o, d = o[None].to(DEV), d[None].to(DEV)
+    whole = net.render_batched(o, d, batched=False, **kw)
+    chunks = net.render_batched(o, d, batched=True, max_ray_batch=128 * 128, **kw)
+    ragged = net.render_batched(o, d, batched=True, max_ray_batch=10007, **kw)
+    for k in ("image", "depth", "weights_sum"):
+        a = whole[k].reshape(chunks[k].shape)
+        assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(chunks[k])), k
+        assert torch.equal(torch.nan_to_num(a), torch.nan_to_num(ragged[k])), k
+    assert not whole["image"].requires_grad
+    o5, d5 = ngp_ref.circle_rays(512, view=9)
+    big = net.render_batched(o5[None].to(DEV), d5[None].to(DEV), batched=True, max_ray_batch=128 * 128, **kw)
+    assert big["image"].shape == (1, 512 * 512, 3) and bool(torch.isfinite(big["image"]).all())
+    assert 0.0 <= float(big["weights_sum"].min()) and float(big["weights_sum"].max()) <= 1 + 1e-5
+
+
 def test_render_rng_stream_matches_reference_order():
     """With no injected noise `run` draws randn(3), rand(N,T), rand(N,T) in the reference's order."""
     from sparsefusion_amd.nerf import NeRFNetwork, get_default_torch_ngp_opt
