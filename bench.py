@@ -308,7 +308,9 @@ def main():
             "value": round(world * args.views_per_gpu / (ms_per_step * 1e-3), 4), "unit": "views/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16 MFMA operands / f32 accumulate (UNet); f32 (NGP render)", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: single MI355X, 256^2 hydrant-like synthetic scene, 2 input views, "
+            "config": {"workload": ("BASELINE configs[1]: single MI355X" if args.views_per_gpu == 1 and world == 1 else
+                                    "BASELINE configs[3]-style view sharding: %d GPU(s) x %d novel views per step" % (world, args.views_per_gpu)) +
+                                   ", 256^2 hydrant-like synthetic scene, 2 input views, "
                                    "32x32 latent UNet (400.68M params, B=%d per GPU) + NGP render 128x128 rays x (64+64) samples; "
                                    "SD-VAE encode 256^2 -> 32x32x4 and decode back (83.65M params) and LPIPS-VGG16 fwd+bwd at 256^2 every step; "
                                    "max_thres=%.2f" % (args.views_per_gpu, args.max_thres),
