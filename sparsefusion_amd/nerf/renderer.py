@@ -166,38 +166,36 @@ class NeRFRenderer(nn.Module):
 
     @torch.no_grad()
     def update_extra_state(self, decay=0.95, S=128, noise=None):
-        """EMA update of the cascaded density grid and its bitfield, and of the mean sample count
-        (renderer_df.py:586-638).  `noise(like) -> U[0,1)` tensor injects the per-cascade jitter that the reference
-        draws with torch.rand_like."""
+        """EMA update of the cascaded density grid, its bitfield and the mean sample count (renderer_df.py:586-638).
+
+        The grid is stored in Morton order, so every cell of a cascade is visited in storage order: cell coordinates
+        come from ONE morton3D_invert of arange(H^3) and the queried densities are written back contiguously (the
+        reference walks the grid in x-major blocks of S^3 and scatters through morton3D; same cells, same jitter law).
+        `noise(like) -> U[0,1)` injects the per-cascade jitter in the REFERENCE's x-major cell order (tests); by default it
+        is drawn directly in storage order."""
         if not self.cuda_ray:
             return
         from .. import raymarching
-        dev = self.density_bitfield.device
-        tmp_grid = -torch.ones_like(self.density_grid)
-        rng = noise if noise is not None else torch.rand_like
-        axis = torch.arange(self.grid_size, dtype=torch.int32, device=dev).split(S)
-        for xs in axis:
-            for ys in axis:
-                for zs in axis:
-                    xx, yy, zz = torch.meshgrid(xs, ys, zs, indexing='ij')
-                    coords = torch.cat([xx.reshape(-1, 1), yy.reshape(-1, 1), zz.reshape(-1, 1)], dim=-1)
-                    indices = raymarching.morton3D(coords).long()
-                    xyzs = 2 * coords.float() / (self.grid_size - 1) - 1
-                    for cas in range(self.cascade):
-                        bound = min(2 ** cas, self.bound)
-                        half_grid_size = bound / self.grid_size
-                        cas_xyzs = xyzs * (bound - half_grid_size)
-                        cas_xyzs += (rng(cas_xyzs) * 2 - 1) * half_grid_size
-                        tmp_grid[cas, indices] = self.density(cas_xyzs)['sigma'].reshape(-1).detach()
-        valid_mask = self.density_grid >= 0
-        self.density_grid[valid_mask] = torch.maximum(self.density_grid[valid_mask] * decay, tmp_grid[valid_mask])
-        self.mean_density = torch.mean(self.density_grid[valid_mask]).item()
+        H, dev = self.grid_size, self.density_bitfield.device
+        coords = raymarching.morton3D_invert(torch.arange(H ** 3, dtype=torch.int32, device=dev))      # [H^3, 3] of cell (x, y, z)
+        xyzs = 2 * coords.float() / (H - 1) - 1
+        xmajor = (coords[:, 0].long() * H + coords[:, 1].long()) * H + coords[:, 2].long() if noise is not None else None
+        tmp_grid = torch.empty_like(self.density_grid)
+        for cas in range(self.cascade):
+            bound = min(2 ** cas, self.bound)
+            half_cell = bound / H
+            u = noise(xyzs)[xmajor] if noise is not None else torch.rand_like(xyzs)
+            pts = xyzs * (bound - half_cell) + (u * 2 - 1) * half_cell
+            tmp_grid[cas] = self.density(pts)['sigma'].reshape(-1)
+        valid = self.density_grid >= 0                                    # cells never marked invalid (< 0) take the EMA / max rule
+        self.density_grid[valid] = torch.maximum(self.density_grid[valid] * decay, tmp_grid[valid])
+        self.mean_density = torch.mean(self.density_grid[valid]).item()
         self.iter_density += 1
-        density_thresh = min(self.mean_density, self.density_thresh)
-        self.density_bitfield = raymarching.packbits(self.density_grid, density_thresh, self.density_bitfield)
-        total_step = min(16, self.local_step)
-        if total_step > 0:
-            self.mean_count = int(self.step_counter[:total_step, 0].sum().item() / total_step)
+        self.density_bitfield = raymarching.packbits(self.density_grid, min(self.mean_density, self.density_thresh),
+                                                     self.density_bitfield)
+        rounds = min(16, self.local_step)                                 # point budget of the next rounds = mean of the last ones
+        if rounds > 0:
+            self.mean_count = int(self.step_counter[:rounds, 0].sum().item() / rounds)
         self.local_step = 0
 
     def _table(self, T, device):
