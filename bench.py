@@ -214,6 +214,36 @@ def unet_roofline(hp):
             "unet_eval_weight_stream_GBs": round(801.4e6 / (total_ms * 1e-3) / 1e9, 1)}
 
 
+def lds_conv_roofline(hp):
+    """MFMA-bound companion of `roofline`: the LDS-tiled large-M convs (k_conv_lds) of one SD-VAE decode, event-timed per op
+    on the launch stream; FLOPs are the algorithmic 2*M*N*K of each layer (padding and out-of-image taps not counted)."""
+    import ctypes as C
+    from sparsefusion_amd import _lib
+    from sparsefusion_amd.unet import OP_CONV
+    hp.vae.decode(torch.zeros(1, 4, 32, 32, device=hp.dev))
+    plan = hp.vae._plan("dec", 1, hp.dev)
+    ms = (C.c_float * len(plan.ops))()
+    lib = _lib.lib()
+    acc = np.zeros(len(plan.ops))
+    for it in range(4):
+        _lib.check(lib.sf_plan_profile(plan.op_array, len(plan.ops), _lib.stream_ptr(), ms))
+        if it:
+            acc += np.array(list(ms))
+    acc /= 3
+    flops, t, n = 0.0, 0.0, 0
+    for o, m in zip(plan.ops, acc):
+        if o.type == OP_CONV and o.i[14] >= 256:                   # tile code 256 + n-fragments = k_conv_lds
+            B, Cin, Ho, Wo, Cout, k = o.i[0], o.i[3], o.i[4], o.i[5], o.i[6], o.i[9]
+            flops += 2.0 * B * Ho * Wo * Cout * Cin * k * k
+            t += float(m)
+            n += 1
+    if not n:
+        return None
+    achieved = flops / (t * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "k_conv_lds (SD-VAE decode, %d layers)" % n, "achieved": round(achieved, 1), "peak": 2500.0,
+            "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4), "gflop": round(flops / 1e9, 1), "ms": round(t, 3)}
+
+
 def cpu_baseline(max_thres):
     """The CPU oracle (a port: the reference has no CPU path for its CUDA kernels) timed on this host, on a
     bounded sample of the same workload, scaled to one step."""
@@ -328,6 +358,7 @@ def main():
             "lpips_fwd_bwd": round(time_region(lambda: hp.percep(lp_a, lp_b).sum().backward(), 5), 3),
         }
         res["roofline"] = unet_roofline(hp)
+        res["roofline_mfma"] = lds_conv_roofline(hp)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.max_thres)
         print(json.dumps(res))
