@@ -687,8 +687,6 @@ class Unet(nn.Module):
     def forward(self, x, time, *, cond_images=None, cond_drop_prob=0., **unsupported):
         if cond_images is None:
             raise AssertionError("you requested to condition on an image on the unet, but the conditioning image is not supplied")
-        if cond_drop_prob != 0.:
-            raise NotImplementedError("conditioning dropout is a training feature; sampling uses cond_drop_prob=0 (cond_scale=1)")
         for k, v in unsupported.items():
             if v is not None:
                 raise NotImplementedError(f"Unet.forward argument '{k}' is not supported")
@@ -699,6 +697,12 @@ class Unet(nn.Module):
             'the number of channels on the conditioning image you are passing in does not match'
         if cond_images.shape[-1] != self.image_size:        # resize_image_to: nearest (imagen_pytorch.py:150-165)
             cond_images = torch.nn.functional.interpolate(cond_images, self.image_size, mode='nearest')
+        if cond_drop_prob != 0.:                            # conditioning dropout: the image condition is zeroed per sample
+            if cond_drop_prob >= 1.:                        # (prob_mask_like + `cond_images * keep_mask`, :1499-1503)
+                keep = torch.zeros(B, dtype=torch.bool, device=x.device)
+            else:
+                keep = torch.zeros(B, device=x.device).float().uniform_(0, 1) < (1 - cond_drop_prob)
+            cond_images = cond_images * keep.view(B, 1, 1, 1)
         plan = self._plan(B, x.device)
         plan.x_view.copy_(x.reshape(B, -1))
         plan.t_view.copy_(time.reshape(-1).expand(B).reshape(B, 1))
@@ -721,6 +725,9 @@ class Unet(nn.Module):
         _lib.check(_lib.lib().sf_plan_run(plan.op_array, len(plan.ops), _lib.stream_ptr()), "unet plan")
 
     def forward_with_cond_scale(self, *args, cond_scale=1., **kwargs):
-        if cond_scale != 1:
-            raise NotImplementedError("classifier-free guidance (cond_scale != 1) is not used by the distillation path")
-        return self.forward(*args, **kwargs)
+        """imagen_pytorch.py:1456-1468: classifier-free guidance = a second eval with the condition dropped."""
+        logits = self.forward(*args, **kwargs)
+        if cond_scale == 1:
+            return logits
+        null_logits = self.forward(*args, cond_drop_prob=1., **kwargs)
+        return null_logits + (logits - null_logits) * cond_scale

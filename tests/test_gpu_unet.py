@@ -83,9 +83,16 @@ def test_unet_state_dict_roundtrip_and_errors():
     net = _unet("small")
     sd = net.state_dict()
     assert set(sd.keys()) == set(dict(spec("small")).keys())
-    with pytest.raises(NotImplementedError):
-        net.forward_with_cond_scale(torch.zeros(1, 4, 32, 32, device=DEV), torch.zeros(1, device=DEV),
-                                    cond_images=torch.zeros(1, 60, 32, 32, device=DEV), cond_scale=2.0)
+    # classifier-free guidance (imagen_pytorch.py:1456-1468): null branch = the image condition zeroed (:1499-1503)
+    sdd = state("small")
+    x, ls, cond = inputs(CONFIGS["small"], 2, 9)
+    with torch.no_grad():
+        lo = unet_ref.unet_forward(sdd, x, ls, cond)
+        nu = unet_ref.unet_forward(sdd, x, ls, torch.zeros_like(cond))
+    y = net.forward_with_cond_scale(x.to(DEV), ls.to(DEV), cond_images=cond.to(DEV), cond_scale=2.5).cpu()
+    assert rel_err(y, nu + (lo - nu) * 2.5) < 2 * TOL_REL
+    y1 = net.forward(x.to(DEV), ls.to(DEV), cond_images=cond.to(DEV), cond_drop_prob=1.).cpu()
+    assert rel_err(y1, nu) < TOL_REL
     with pytest.raises(RuntimeError):
         net.forward(torch.zeros(1, 4, 32, 32), torch.zeros(1), cond_images=torch.zeros(1, 60, 32, 32))   # CPU tensors
 
