@@ -305,11 +305,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    backend = os.environ.get("SF_BENCH_BACKEND", "nccl")         # "gloo": dry-run of the multi-rank path on fewer GPUs than ranks
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)             # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)         # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     hp = HotPath(dev, rank, world, args.max_thres, args.views_per_gpu)
     for _ in range(args.warmup):
