@@ -76,6 +76,9 @@ class HotPath:
                          auto_normalize_img=False, clip_output=True, dynamic_thresholding=False,
                          dynamic_thresholding_percentile=.68, clip_value=10).to(device)
         self.unet = self.vldm.unets[0]
+        # plain plan replay and hipGraph replay take the same time (the GPU, not the host, is the bottleneck: DESIGN.md 4);
+        # with RCCL in the process the capture is one more thing that can go wrong, so multi-rank runs skip it
+        self.unet.use_hip_graph = (world == 1)
         self.plms = PLMSSampler(self.vldm, 50)
         from sparsefusion_amd.vae import AutoencoderKL
         self.vae = AutoencoderKL().to(device)                     # sd-vae.yaml architecture, default (kaiming-range) init

@@ -7,6 +7,8 @@ dev = torch.device("cuda:0")
 unet = Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2), layer_attns=(False, False, False, True),
             layer_cross_attns=(False,) * 4, cond_images_channels=256, attn_pool_text=False).to(dev)
 for k, v in os.environ.items():
+    if k == "SF_WAVES":
+        unet.conv_waves_target = int(v)
     if k == "SF_LAZY":
         unet.lazy_consumers = int(v)
 x, ls, cond = torch.randn(B, 4, 32, 32, device=dev), torch.zeros(B, device=dev), torch.randn(B, 256, 32, 32, device=dev)
