@@ -1,0 +1,123 @@
+"""Planner invariants checked WITHOUT a GPU: every model's static launch plan is built in sizing mode (fake device
+pointers) and its op list is audited -- operand presence, alignment contracts of the kernels, op-code agreement with the
+C header, lazy tensors all consumed.  Guards the host logic of unet.py / vae.py / lpips.py / eft.py."""
+import re
+import os
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPU = torch.device("cpu")
+
+
+def _header_enum():
+    txt = open(os.path.join(ROOT, "include", "sparsefusion_hip.h")).read()
+    return {m.group(1): int(m.group(2)) for m in re.finditer(r"(SF_OP_[A-Z_0-9]+)\s*=\s*(\d+)", txt)}
+
+
+def test_op_codes_match_header():
+    from sparsefusion_amd import unet, lpips, eft
+    e = _header_enum()
+    assert (unet.OP_CONV, unet.OP_GN_ACT, unet.OP_LN, unet.OP_GEMV, unet.OP_ATTN, unet.OP_GCA_POOL, unet.OP_ELTWISE, unet.OP_MEMSET,
+            unet.OP_TIME_EMB, unet.OP_SPLITK_REDUCE) == tuple(e[k] for k in (
+                "SF_OP_CONV", "SF_OP_GN_ACT", "SF_OP_LN", "SF_OP_GEMV", "SF_OP_ATTN", "SF_OP_GCA_POOL", "SF_OP_ELTWISE", "SF_OP_MEMSET",
+                "SF_OP_TIME_EMB", "SF_OP_SPLITK_REDUCE"))
+    assert (lpips.OP_POOL, lpips.OP_LPIPS, eft.OP_POOL, eft.OP_EFT) == (e["SF_OP_POOL"], e["SF_OP_LPIPS"], e["SF_OP_POOL"], e["SF_OP_EFT"])
+    assert sorted(e.values()) == list(range(1, len(e) + 1))                      # dense, no duplicates
+
+
+def _audit(ops, name, sized=False):
+    from sparsefusion_amd import unet
+    n_conv = 0
+    for k, o in enumerate(ops):
+        where = f"{name} op {k} type {o.type}"
+        if o.type == unet.OP_CONV:
+            n_conv += 1
+            B, H, W, Cin, Ho, Wo, Cout, ldc, co_off, kh, kw, stride, pad, groups, tile = list(o.i)[:15]
+            assert o.p[0] and o.p[1] and o.p[3], where
+            assert Cin % 32 == 0 and Cin > 0 and Cout > 0 and ldc >= co_off + (Cout if not o.flags & 2 else Cout // 4), where
+            assert groups >= 1 and kh == kw and stride in (1, 2), where
+            if groups > 1:
+                assert o.p[5] or not sized, where + ": split-K without workspace"
+                assert not (o.flags & 2), where + ": pixel shuffle cannot be split-K"
+            if tile >= 256:                                                     # k_conv_lds contract
+                assert groups == 1 and not (o.flags & (2 | 8)) and tile - 256 in (4, 8), where
+            else:
+                assert tile // 16 in (1, 2, 4) and tile % 16 in (1, 2, 4), where
+            if o.flags & 8:
+                assert groups > 1 and not (o.flags & (4 | 32 | 64)), where + ": deferred reduce only for plain split-K"
+        elif o.type == unet.OP_GN_ACT:
+            B, HW, C1, C2, _, lazy, lgroups, npad, G = list(o.i)[:9]
+            G = G or 8
+            assert o.p[0] and o.p[2] and o.p[3] and o.p[5] and o.p[7], where
+            assert (C1 + C2) % (4 * G) == 0 and C1 % 4 == 0, where
+            if lazy == 1:
+                assert (o.p[8] or not sized) and lgroups >= 1 and npad % 4 == 0, where       # p[8] = the split-K workspace
+            if lazy == 2:
+                assert o.p[8] and o.p[9], where
+        elif o.type == unet.OP_LN:
+            assert o.p[0] and o.p[1] and o.p[3] and o.i[1] % 64 == 0 and o.i[1] <= 2048, where
+        elif o.type == unet.OP_GEMV:
+            assert o.p[0] and o.p[1] and o.p[3] and 1 <= o.i[0] <= 8 and o.i[3] % 8 == 0, where
+    return n_conv
+
+
+def test_unet_plan_invariants():
+    from sparsefusion_amd.unet import Unet, _Plan
+    net = Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2), layer_attns=(False, False, False, True),
+               layer_cross_attns=(False,) * 4, cond_images_channels=256, attn_pool_text=False)
+    for B in (1, 4):
+        for lazy in (0, 3):
+            net.lazy_consumers = lazy
+            plan = _Plan(net, B, CPU).build()
+            assert _audit(plan.ops, f"unet B={B} lazy={lazy}") == 95              # conv / linear layers per eval
+            assert plan.ws_owner is None or plan.ws_owner.lazy is None             # nothing left un-materialised
+            assert plan.zero.off > 0 and plan.misc.off > plan.zero.off
+    # second pass with real arenas (host memory stands in for HBM): pointers are now real, the workspace exists
+    s = _Plan(net, 1, CPU).build()
+    sized = _Plan(net, 1, CPU, (s.zero.off, s.misc.off + s.ws_bytes + 256, s.ws_bytes)).build()
+    assert _audit(sized.ops, "unet sized", sized=True) == 95 and len(sized.ops) == len(s.ops)
+    lo, hi = sized.misc.buf.data_ptr(), sized.misc.buf.data_ptr() + sized.misc.buf.numel()
+    for o in sized.ops:                                                            # every activation operand lies inside an arena
+        if o.type == 1:
+            assert lo <= o.p[3] < hi and lo <= o.p[0] < hi
+    # the lazy plan drops launches but never changes the set of convs
+    net.lazy_consumers = 3
+    lazy_ops = len(_Plan(net, 1, CPU).build().ops)
+    net.lazy_consumers = 0
+    assert lazy_ops < len(_Plan(net, 1, CPU).build().ops)
+
+
+def test_vae_lpips_eft_plan_invariants():
+    from sparsefusion_amd.vae import AutoencoderKL, _VaePlan
+    from sparsefusion_amd.lpips import LPIPS, _LpipsPlan
+    from sparsefusion_amd.eft import EpipolarFeatureTransformer, _EftPlan
+    vae = AutoencoderKL()
+    assert _audit(_VaePlan(vae, "enc", 1, CPU).build().ops, "vae enc") == 34
+    assert _audit(_VaePlan(vae, "dec", 2, CPU).build().ops, "vae dec") == 42 + 2       # two per-sample attention GEMM pairs more
+    lp = LPIPS()
+    fwd = _LpipsPlan(lp, 1, 256, CPU).build_forward()
+    assert _audit(fwd.ops, "lpips fwd") == 13
+    bwd = _LpipsPlan(lp, 1, 256, CPU, fwd=fwd).build_backward()
+    assert _audit(bwd.ops, "lpips bwd") == 13
+    eft = EpipolarFeatureTransformer(use_r=True, encoder='resnet18', return_features=True, remove_unused_layers=False)
+    enc = _EftPlan(eft, 6, CPU).build_encoder(6, 256)
+    assert _audit(enc.ops, "eft enc") == 1 + 2 * 6 + 2                              # conv1, 6 BasicBlocks, 2 downsample convs
+    f = _EftPlan(eft, 6, CPU)
+    f.images_ptr = 1
+    f.build_forward(6, 1024, 20, enc, 256)
+    assert _audit(f.ops, "eft fwd") == 3 * (1 + 4 * 4)                              # 3 x (pre + 4 layers x (qkv, out, ff1, ff2))
+
+
+def test_lds_conv_selection_rule():
+    """Large-M layers switch to the LDS-tiled kernel by tile count; small-M UNet layers at B = 1 never do."""
+    from sparsefusion_amd.unet import OP_CONV, Unet, _Plan
+    from sparsefusion_amd.vae import AutoencoderKL, _VaePlan
+    net = Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2), layer_attns=(False, False, False, True),
+               layer_cross_attns=(False,) * 4, cond_images_channels=256, attn_pool_text=False)
+    assert all(o.i[14] < 256 for o in _Plan(net, 1, CPU).build().ops if o.type == OP_CONV)
+    assert any(o.i[14] >= 256 for o in _Plan(net, 16, CPU).build().ops if o.type == OP_CONV)
+    dec = _VaePlan(AutoencoderKL(), "dec", 1, CPU).build()
+    big = [o for o in dec.ops if o.type == OP_CONV and o.i[4] >= 128]
+    assert big and all(o.i[14] >= 256 or o.i[6] < 64 for o in big)                 # every wide 128^2 / 256^2 conv is LDS-tiled
