@@ -236,6 +236,11 @@ def test_gemv(M, N, K, in_silu, act):
     ref = F.linear(F.silu(xin) if in_silu else xin, bf(w), b)
     ref = F.silu(ref) if act == 1 else torch.sigmoid(ref) if act == 2 else ref
     assert torch.allclose(y.cpu()[:, :N], ref, rtol=1e-4, atol=1e-4)
+    # rows are independent: every row evaluated alone (M = 1 launch) gives the same bits as inside the M-row launch
+    for m in range(M):
+        y1 = torch.zeros(1, N + 2, device=DEV)
+        _run([_op(4, (1 if in_silu else 0) | (act << 1), p=(x[m:m + 1].contiguous().to(DEV), wp, b.to(DEV), y1), i=(1, N, K, Kp, K + 3, N + 2))])
+        assert torch.equal(y1.cpu()[0, :N], y.cpu()[m, :N]), m
 
 
 def test_attention_core_self_and_cross():
