@@ -537,22 +537,25 @@ __global__ __launch_bounds__(256) void k_gemv(const float* __restrict__ x, const
 // ATTN: softmax(q k^T) v for 16 queries, head dim 64, <= 24 keys built from up to 3 segments.
 //   p[0] q f32 [B*16, ldq] (head h at column h*64), p[1] out bf16 [B*16, 512]
 //   segment s (s = 0..2): p[2+2s] keys, p[3+2s] values (f32); i[4+4s..] = rows, row_stride, batch_stride, head_stride
-//   i[0] = B, i[1] = heads, i[2] = ldq ; f[0] = q scale.   One 64-thread workgroup per (b, head).
+//   i[0] = B, i[1] = heads, i[2] = ldq ; f[0] = q scale.   One 256-thread workgroup per (b, head).
 // ---------------------------------------------------------------------------------------------
 struct AttnSeg { const float* k; const float* v; int rows, row_stride, batch_stride, head_stride; };
-__global__ __launch_bounds__(64) void k_attn16(const float* __restrict__ q, __bf16* __restrict__ out, AttnSeg s0, AttnSeg s1,
-                                               AttnSeg s2, int heads, int ldq, float scale) {
+__global__ __launch_bounds__(256) void k_attn16(const float* __restrict__ q, __bf16* __restrict__ out, AttnSeg s0, AttnSeg s1,
+                                                AttnSeg s2, int heads, int ldq, float scale) {
+  // 4 waves per (b, head): the kernel is a chain of dependent phases (load, q.k, softmax, p.v), so the only lever is to make
+  // every phase short -- rows of q / k / v are fetched by different waves at once, the 16 x J scores and the 16 output rows
+  // are spread over all 256 lanes
   __shared__ float sq[16][65];
   __shared__ float sk[24][65];
   __shared__ float sv[24][65];
   __shared__ float sim[16][25];
-  const int b = blockIdx.x / heads, h = blockIdx.x % heads, t = threadIdx.x;
-  for (int i = 0; i < 16; ++i) sq[i][t] = q[((long)b * 16 + i) * ldq + h * 64 + t] * scale;
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads, t = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = wv; i < 16; i += 4) sq[i][t] = q[((long)b * 16 + i) * ldq + h * 64 + t] * scale;
   const AttnSeg segs[3] = {s0, s1, s2};
   int J = 0;
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
-    for (int r = 0; r < segs[s].rows; ++r) {
+    for (int r = wv; r < segs[s].rows; r += 4) {
       const long off = (long)b * segs[s].batch_stride + (long)r * segs[s].row_stride + (long)h * segs[s].head_stride + t;
       sk[J + r][t] = segs[s].k[off];
       sv[J + r][t] = segs[s].v[off];
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(64) void k_attn16(const float* __restrict__ q, __bf
     J += segs[s].rows;
   }
   __syncthreads();
-  for (int e = t; e < 16 * J; e += 64) {
+  for (int e = threadIdx.x; e < 16 * J; e += 256) {
     const int i = e / J, j = e - i * J;
     float a = 0.0f;
 #pragma unroll 8
@@ -568,16 +571,17 @@ __global__ __launch_bounds__(64) void k_attn16(const float* __restrict__ q, __bf
     sim[i][j] = a;
   }
   __syncthreads();
-  if (t < 16) {
+  if (threadIdx.x < 16) {
+    const int i = threadIdx.x;
     float mx = -INFINITY;
-    for (int j = 0; j < J; ++j) mx = fmaxf(mx, sim[t][j]);
+    for (int j = 0; j < J; ++j) mx = fmaxf(mx, sim[i][j]);
     float den = 0.0f;
-    for (int j = 0; j < J; ++j) { const float e = expf(sim[t][j] - mx); sim[t][j] = e; den += e; }
+    for (int j = 0; j < J; ++j) { const float e = expf(sim[i][j] - mx); sim[i][j] = e; den += e; }
     const float inv = 1.0f / den;
-    for (int j = 0; j < J; ++j) sim[t][j] *= inv;
+    for (int j = 0; j < J; ++j) sim[i][j] *= inv;
   }
   __syncthreads();
-  for (int i = 0; i < 16; ++i) {
+  for (int i = wv; i < 16; i += 4) {
     float a = 0.0f;
     for (int j = 0; j < J; ++j) a = fmaf(sim[i][j], sv[j][t], a);
     out[((long)b * 16 + i) * (heads * 64) + h * 64 + t] = (__bf16)a;
@@ -1061,7 +1065,7 @@ static int run_attn(const sf_op& op, hipStream_t st) {
     J += s[k].rows;
   }
   if (J < 1 || J > 24) SF_FAIL(SF_ERR_INVALID, "attn: 1..24 keys");
-  k_attn16<<<op.i[0] * op.i[1], 64, 0, st>>>((const float*)op.p[0], (__bf16*)op.p[1], s[0], s[1], s[2], op.i[1], op.i[2], op.f[0]);
+  k_attn16<<<op.i[0] * op.i[1], 256, 0, st>>>((const float*)op.p[0], (__bf16*)op.p[1], s[0], s[1], s[2], op.i[1], op.i[2], op.f[0]);
   SF_CHECK_LAUNCH("attn16");
   return SF_OK;
 }
