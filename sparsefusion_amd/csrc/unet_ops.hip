@@ -628,10 +628,13 @@ __global__ __launch_bounds__(256) void k_gca_logits_wg(float* __restrict__ h, co
 // grid (B, ceil(HW/32)): every workgroup re-derives the softmax normaliser from the <=1024 logits, then
 // accumulates its 32 pixels for ALL channels (coalesced along C) and adds into the pre-zeroed pooled[b][:].
 __global__ __launch_bounds__(256) void k_gca_pool(const float* __restrict__ h, const float* __restrict__ logit,
-                                                  float* __restrict__ pooled, int HW, int C, int chunks) {
+                                                  float* __restrict__ pooled, int HW, int C, int chunks, int csplit) {
   __shared__ float red[8];
   __shared__ float e[32];
-  const int b = blockIdx.x / chunks, pc = blockIdx.x % chunks;
+  // grid = (b, pixel chunk, channel slab of 256): small maps (4x4, 8x8) have one or two pixel chunks only, the channel
+  // slabs are what gives them enough workgroups to finish in one short phase
+  const int cs = blockIdx.x % csplit, bp = blockIdx.x / csplit;
+  const int b = bp / chunks, pc = bp % chunks;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const float* lg = logit + (long)b * HW;
   float mx = -INFINITY;
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(256) void k_gca_pool(const float* __restrict__ h, c
   const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
   const int np = min(32, HW - p0);
   const float* hb = h + ((long)b * HW + p0) * C;
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = cs * 256 + threadIdx.x; c < C; c += 256 * csplit) {
     float a = 0.0f;
     for (int p = 0; p < np; ++p) a = fmaf(e[p], hb[(long)p * C + c], a);
     atomic_add_f32(pooled + (long)b * C + c, a * inv);
@@ -1083,7 +1086,9 @@ static int run_gca_pool(const sf_op& op, hipStream_t st) {
                                                       (float*)op.p[4], B * HW, C, lz);
   SF_CHECK_LAUNCH("gca_logits");
   const int chunks = (HW + 31) / 32;
-  k_gca_pool<<<B * chunks, 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[4], (float*)op.p[3], HW, C, chunks);
+  const int csplit = chunks < 8 ? (C + 255) / 256 : 1;
+  k_gca_pool<<<B * chunks * csplit, 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[4], (float*)op.p[3], HW, C, chunks,
+                                                  csplit);
   SF_CHECK_LAUNCH("gca_pool");
   return SF_OK;
 }
