@@ -1026,7 +1026,12 @@ static int run_gn(const sf_op& op, hipStream_t st) {
   } else {
     // a lazy split-K source multiplies the loads per chunk by `groups`: one chunk per thread then
     const int per_block = lz.mode == 1 ? 256 : GN_CHUNKS_PER_BLOCK;
-    const int slices = (chunks + per_block - 1) / per_block;
+    int slices = (chunks + per_block - 1) / per_block;
+    // small maps: a (b, group) has too few chunks to fill its workgroup slice-wise -- aim for >= 128 workgroups in total,
+    // down to one chunk per thread
+    const int want = 128 / (B * G), max_slices = (chunks + 255) / 256;
+    if (slices < want) slices = want < max_slices ? want : max_slices;
+    if (slices < 1) slices = 1;
     k_gn_stats<<<B * G * slices, 256, 0, st>>>((float*)op.p[0], (const float*)op.p[1], (double*)op.p[7], HW, C1, C2, slices,
                                                op.f[1], lz, G);
   }
