@@ -482,7 +482,10 @@ __global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in,
 //   p[0] x f32 (row stride ldx), p[1] W bf16 [N][Kp] (Kp = K padded to 8), p[2] bias f32 or NULL, p[3] y f32 (row stride ldy)
 //   i = M, N, K, Kp, ldx, ldy ; flags: bit0 SiLU on input, bits 1-2 output act (0 none, 1 SiLU, 2 sigmoid)
 // ---------------------------------------------------------------------------------------------
-#define GEMV_ROWS 4    // output rows per wave: 4 independent 16-byte weight loads in flight per lane and step
+// GEMV_ROWS output rows per wave = that many independent 16-byte weight loads in flight per lane and step: 4 for the long
+// layers (the 33 792-row time-MLP GEMV streams 72 MB), 1 for the short ones (N <= 2048: gca nets, time tokens), which are a
+// single latency-bound phase and want as many workgroups as they have rows.
+template <int GEMV_ROWS>
 __global__ __launch_bounds__(256) void k_gemv(const float* __restrict__ x, const __bf16* __restrict__ W,
                                               const float* __restrict__ bias, float* __restrict__ y, int M, int N, int K,
                                               int Kp, int ldx, int ldy, int in_silu, int out_act) {
@@ -1056,9 +1059,12 @@ static int run_ln(const sf_op& op, hipStream_t st) {
 static int run_gemv(const sf_op& op, hipStream_t st) {
   const int M = op.i[0], N = op.i[1];
   if (M > 8) SF_FAIL(SF_ERR_INVALID, "gemv: at most 8 rows");
-  k_gemv<<<sf_div_up(N, 4 * GEMV_ROWS), 256, 0, st>>>((const float*)op.p[0], (const __bf16*)op.p[1], (const float*)op.p[2],
-                                                     (float*)op.p[3], M, N, op.i[2], op.i[3], op.i[4], op.i[5], op.flags & 1,
-                                                     (op.flags >> 1) & 3);
+  if (N <= 2048)
+    k_gemv<1><<<sf_div_up(N, 4), 256, 0, st>>>((const float*)op.p[0], (const __bf16*)op.p[1], (const float*)op.p[2], (float*)op.p[3], M,
+                                              N, op.i[2], op.i[3], op.i[4], op.i[5], op.flags & 1, (op.flags >> 1) & 3);
+  else
+    k_gemv<4><<<sf_div_up(N, 16), 256, 0, st>>>((const float*)op.p[0], (const __bf16*)op.p[1], (const float*)op.p[2], (float*)op.p[3], M,
+                                               N, op.i[2], op.i[3], op.i[4], op.i[5], op.flags & 1, (op.flags >> 1) & 3);
   SF_CHECK_LAUNCH("gemv");
   return SF_OK;
 }
