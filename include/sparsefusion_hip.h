@@ -222,7 +222,10 @@ enum {
   SF_OP_SPLITK_REDUCE = 10, /* stand-alone reduction of deferred split-K partials */
   SF_OP_POOL = 11,     /* 2x2 max pooling fwd / bwd (LPIPS-VGG)             */
   SF_OP_LPIPS = 12,    /* LPIPS per-layer head fwd / bwd                    */
-  SF_OP_EFT = 13       /* EFT pre-pass: resize, grid-sample gather, harmonic embedding, short-sequence attention, softmax pooling */
+  SF_OP_EFT = 13,      /* EFT pre-pass: resize, grid-sample gather, harmonic embedding, short-sequence attention, softmax pooling */
+  SF_OP_FCONV = 14,    /* [GroupNorm | LayerNorm] (+scale/shift, SiLU) fused into the conv's A-operand prologue (Block, :641-662) */
+  SF_OP_SLOTS = 15,    /* (sum, sum of squares) slots of a tensor for the next fused GroupNorm; optional gate*h + residual first */
+  SF_OP_GCA = 16       /* fused GlobalContext stages (imagen_pytorch.py:916-941) */
 };
 
 /* One op = one or two kernel launches.  Interpretation of p[]/i[]/f[] per op type is
@@ -230,9 +233,9 @@ enum {
 typedef struct {
   int32_t type;
   int32_t flags;
-  void* p[12];
-  int32_t i[16];
-  float f[4];
+  void* p[24];
+  int32_t i[32];
+  float f[8];
 } sf_op;
 
 /* ------------------------------------------------------------------------ */

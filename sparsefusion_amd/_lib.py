@@ -47,8 +47,8 @@ class SfAdamArgs(C.Structure):
 
 
 class SfOp(C.Structure):
-    _fields_ = [("type", C.c_int32), ("flags", C.c_int32), ("p", C.c_void_p * 12),
-                ("i", C.c_int32 * 16), ("f", C.c_float * 4)]
+    _fields_ = [("type", C.c_int32), ("flags", C.c_int32), ("p", C.c_void_p * 24),
+                ("i", C.c_int32 * 32), ("f", C.c_float * 8)]
 
 
 # name -> (restype, argtypes); mirrors include/sparsefusion_hip.h one to one.

@@ -1,0 +1,102 @@
+// Host-side decoding of the fused ops (SF_OP_FCONV / SF_OP_SLOTS): operand checks, tile geometry, LDS layout.
+// Shared by the gfx950 launchers (unet_fused.hip) and the CPU kernel-logic harness (tests/hostemu/fused_emu.cpp).
+//
+// SF_OP_FCONV operands
+//   p: 0 s1.p  1 s1.a  2 s1.b  3 s1.r  4 s1.slots  5 s2.p  6 s2.slots  7 packed weights  8 bias  9 out  10 resid
+//      11 split-K slabs (S > 1)  12 slots_out  13 gamma / LN gain  14 beta / LN bias  15 scale_shift
+//   i: 0 B  1 H  2 W  3 C1  4 C2  5 Cout  6 ldc  7 co_off  8 k (1 | 3)  9 s1.mode  10 s1.groups  11 s1.npad
+//      12 norm (FNORM_*)  13 G  14 TR (image rows per tile)  15 WM  16 WN  17 S (input-channel slices)  18 ss_stride
+//   flags: 1 SiLU after the norm, 2 GELU before the LayerNorm, 4 accumulate into out
+//   f: 0 eps  1 s1.scale  2 s2.scale
+// SF_OP_SLOTS operands
+//   p: 0 x (or h)  1 gate [B, C] or null  2 res  3 out (gate mode)  4 slots ;  i: 0 M  1 C  2 HW
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/sparsefusion_hip.h"
+#include "fused_kernels.h"
+
+#define SF_LDS_MAX 163840
+
+static inline int fconv_pix_stride(int Cs) {
+  const int raw = Cs * 2;
+  return raw + ((32 - raw % 256) + 256) % 256;      // stride = 32 (mod 256): conflict-free 16-byte fragment reads
+}
+
+// Returns 0 on success; on failure writes a message to err.
+static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, uint32_t& grid, uint32_t& lds_bytes, char* err,
+                              size_t errn) {
+#define FC_FAIL(...) do { snprintf(err, errn, __VA_ARGS__); return 1; } while (0)
+  a.s1.p = (float*)op.p[0]; a.s1.a = (const float*)op.p[1]; a.s1.b = (const float*)op.p[2]; a.s1.r = (const float*)op.p[3];
+  a.s1.slots = (const float*)op.p[4];
+  a.s2.p = (float*)op.p[5]; a.s2.a = a.s2.b = a.s2.r = nullptr; a.s2.slots = (const float*)op.p[6];
+  a.w = (const bf16x8*)op.p[7]; a.bias = (const float*)op.p[8]; a.out = (float*)op.p[9]; a.resid = (const float*)op.p[10];
+  a.ws = (float*)op.p[11]; a.slots_out = (float*)op.p[12];
+  a.gamma = (const float*)op.p[13]; a.beta = (const float*)op.p[14]; a.ss = (const float*)op.p[15];
+  a.B = op.i[0]; a.H = op.i[1]; a.W = op.i[2];
+  a.s1.C = op.i[3]; a.s2.C = op.i[4]; a.C = a.s1.C + a.s2.C;
+  a.Cout = op.i[5]; a.ldc = op.i[6]; a.co_off = op.i[7]; a.k = op.i[8];
+  a.s1.mode = op.i[9]; a.s1.groups = op.i[10]; a.s1.npad = op.i[11];
+  a.s2.mode = 0; a.s2.groups = 0; a.s2.npad = 0;
+  a.norm = op.i[12]; a.G = op.i[13] > 0 ? op.i[13] : 8; a.TR = op.i[14];
+  WM = op.i[15]; WN = op.i[16];
+  a.S = op.i[17] > 0 ? op.i[17] : 1;
+  a.ss_stride = op.i[18];
+  a.silu = (op.flags & 1) ? 1 : 0; a.pre_gelu = (op.flags & 2) ? 1 : 0; a.accum = (op.flags & 4) ? 1 : 0;
+  a.eps = op.f[0]; a.s1.scale = op.f[1]; a.s2.scale = op.f[2];
+  if (!a.s1.p || !a.w || a.B < 1 || a.H < 1 || a.W < 1) FC_FAIL("fconv: missing operand");
+  if (a.k != 1 && a.k != 3) FC_FAIL("fconv: k must be 1 or 3 (stride 1, same padding)");
+  if (a.W & (a.W - 1)) FC_FAIL("fconv: W must be a power of two");
+  if (a.C % 32 || a.s1.C % 32 || a.s1.C <= 0 || a.s2.C < 0) FC_FAIL("fconv: channel counts must be multiples of 32");
+  if (a.s2.C && !a.s2.p) FC_FAIL("fconv: second source missing");
+  if (a.TR < 1 || a.H % a.TR || a.TR * a.W != 16 * WM) FC_FAIL("fconv: tile of %d rows x %d != 16*WM (WM=%d)", a.TR, a.W, WM);
+  if (!((WM == 1 || WM == 2) && (WN == 1 || WN == 2))) FC_FAIL("fconv: unsupported wave tile %dx%d", WM, WN);
+  a.cchunks = a.C / 32;
+  if (a.cchunks % a.S) FC_FAIL("fconv: %d chunks do not split into %d slices", a.cchunks, a.S);
+  a.cps = a.cchunks / a.S;
+  a.KS = a.k * a.k * a.cchunks;
+  a.M = a.B * a.H * a.W;
+  a.mt_per_img = a.H / a.TR;
+  a.n_frags = (a.Cout + 15) / 16;
+  a.n_tiles = (a.n_frags + WN - 1) / WN;
+  a.npad = a.n_frags * 16;
+  if (a.s1.mode < 0 || a.s1.mode > 2) FC_FAIL("fconv: unknown lazy mode %d", a.s1.mode);
+  if (a.s1.mode == 1 && (!a.s1.a || a.s1.groups < 1 || a.s1.npad % 4)) FC_FAIL("fconv: bad split-K source");
+  if (a.s1.mode == 2 && (!a.s1.a || !a.s1.b || !a.s1.r)) FC_FAIL("fconv: gated source needs h, gate and res");
+  if (a.s1.mode && a.s1.scale != 1.0f) FC_FAIL("fconv: lazy sources are unscaled");
+  if (a.s1.mode && (a.s1.p == a.s1.a || a.s1.p == a.s1.r)) FC_FAIL("fconv: a lazy source must materialise into its own buffer");
+  const int Cs = a.cps * 32;
+  if (a.norm == FNORM_GN_SELF || a.norm == FNORM_GN_SLOTS) {
+    if (!a.gamma || !a.beta || a.C % a.G) FC_FAIL("fconv: GroupNorm parameters missing");
+    const int Cg = a.C / a.G;
+    if (Cs % Cg || Cs / Cg > 8 || Cg % 4) FC_FAIL("fconv: a slice must hold 1..8 whole groups (Cs=%d Cg=%d)", Cs, Cg);
+    if (a.norm == FNORM_GN_SELF && a.TR != a.H) FC_FAIL("fconv: GN_SELF needs the whole image in the tile");
+    if (a.norm == FNORM_GN_SLOTS) {
+      if (!a.s1.slots || (a.s2.C && !a.s2.slots)) FC_FAIL("fconv: GN_SLOTS without slots");
+      if (Cg % 16 || (a.H * a.W) % 16 || a.s1.mode == 1) FC_FAIL("fconv: GN_SLOTS geometry");
+    }
+  } else if (a.norm == FNORM_LN) {
+    if (a.S != 1 || a.k != 1 || !a.gamma || a.s2.C) FC_FAIL("fconv: LayerNorm prologue needs S=1, k=1, one source, a gain");
+  } else if (a.norm != FNORM_NONE) {
+    FC_FAIL("fconv: unknown norm %d", a.norm);
+  }
+  if (a.S > 1) {
+    if (!a.ws || a.accum || a.slots_out) FC_FAIL("fconv: split-K slices write slabs only");
+  } else {
+    if (!a.out) FC_FAIL("fconv: output missing");
+    if (a.slots_out && (a.Cout % 16 || a.ldc % 16 || a.co_off % 16)) FC_FAIL("fconv: slots need 16-aligned channels");
+  }
+  a.pix_stride = fconv_pix_stride(Cs);
+  const int h = a.k >> 1;
+  const uint32_t frame = (uint32_t)(a.TR + 2 * h) * (a.W + 2 * h) * a.pix_stride;
+  a.red_off = (int)frame;
+  a.tab_off = a.red_off + 4096 * WM * WN;
+  a.misc_off = a.tab_off + 2 * Cs * 4;
+  lds_bytes = a.misc_off + 640;
+  if (lds_bytes > SF_LDS_MAX) FC_FAIL("fconv: tile needs %u bytes of LDS", lds_bytes);
+  const int MT = a.B * a.mt_per_img;
+  a.xcd_map = (a.n_tiles % 8 == 0 && MT > 1) ? 1 : 0;
+  grid = (uint32_t)a.S * MT * a.n_tiles;
+  return 0;
+#undef FC_FAIL
+}

@@ -4,3 +4,4 @@
 
 int sf_plan_extra_op(const sf_op* op, void* stream);
 int sf_plan_eft_op(const sf_op* op, void* stream);
+int sf_plan_fused_op(const sf_op* op, void* stream);

@@ -1,0 +1,80 @@
+// Device-side vocabulary of the fused UNet kernels (gfx950): vector types, the MFMA tile op, wave reductions.
+// Built two ways: by hipcc for gfx950 (the product), and by the host clang with -DSF_HOST_EMU for the kernel-logic
+// tests of tests/hostemu (one OS thread per lane; test infrastructure, never shipped or timed).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#ifdef SF_HOST_EMU
+#include "hip_emu.h"
+#define SF_KERNEL(...)
+#define SF_DEV inline
+#define SF_DYN_LDS(name) char* name = hipemu::dyn_smem()
+#define SF_SHARED static
+static inline void sf_sync() { hipemu::syncthreads(); }
+template <class T>
+static inline T sf_shfl_xor(T v, int m) { return hipemu::shfl_xor(v, m); }
+static inline float sf_exp(float v) { return expf(v); }
+static inline float sf_rsqrt(float v) { return 1.0f / sqrtf(v); }
+// D = A (16 x 32, rows = lane & 15) * B (32 x 16, cols = lane & 15) + C; see tests/hostemu/hip_emu.h for the layout
+static inline f32x4 sf_mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  hipemu::WaveState* w = hipemu::t_wave;
+  const int lane = hipemu::t_lane;
+  static thread_local int dummy;
+  (void)dummy;
+  struct Pair { bf16x8 a, b; };
+  static Pair xa[64][64];                       // [wave slot][lane]; one workgroup alive at a time, <= 64 waves
+  const int ws = (int)(threadIdx.x >> 6);
+  xa[ws][lane].a = a;
+  xa[ws][lane].b = b;
+  w->bar.wait();
+  f32x4 d = c;
+  const int n = lane & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int m = 4 * (lane >> 4) + r;
+    float acc = 0.0f;
+    for (int kb = 0; kb < 4; ++kb)
+      for (int j = 0; j < 8; ++j) acc += (float)xa[ws][kb * 16 + m].a[j] * (float)xa[ws][kb * 16 + n].b[j];
+    d[r] += acc;
+  }
+  w->bar.wait();
+  return d;
+}
+#else
+#include <hip/hip_runtime.h>
+#define SF_KERNEL(...) __global__ __launch_bounds__(__VA_ARGS__)
+#define SF_DEV __device__ __forceinline__
+#define SF_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define SF_SHARED __shared__
+SF_DEV void sf_sync() { __syncthreads(); }
+template <class T>
+SF_DEV T sf_shfl_xor(T v, int m) { return __shfl_xor(v, m, 64); }
+SF_DEV float sf_exp(float v) { return __expf(v); }
+SF_DEV float sf_rsqrt(float v) { return rsqrtf(v); }
+SF_DEV f32x4 sf_mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+#endif
+
+SF_DEV float sf_silu(float v) { return v / (1.0f + sf_exp(-v)); }
+SF_DEV float sf_sigmoid(float v) { return 1.0f / (1.0f + sf_exp(-v)); }
+SF_DEV float sf_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+
+SF_DEV float sf_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += sf_shfl_xor(v, o);
+  return v;
+}
+SF_DEV float sf_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, sf_shfl_xor(v, o));
+  return v;
+}
+// sum over aligned groups of `width` lanes (width = power of two <= 64)
+SF_DEV float sf_group_sum(float v, int width) {
+  for (int o = width >> 1; o > 0; o >>= 1) v += sf_shfl_xor(v, o);
+  return v;
+}
+SF_DEV bf16x8 sf_zero8() { return bf16x8{0, 0, 0, 0, 0, 0, 0, 0}; }

@@ -1,0 +1,56 @@
+// gfx950 launchers of the fused UNet ops (kernels: fused_kernels.h / fused_gca.h; operand decoding: fused_host.h).
+#include "sf_common.h"
+#include "plan_ops.h"
+#include "fused_host.h"
+
+// Dynamic LDS above 64 KiB must be enabled per kernel AND per device (a process may drive several GPUs).
+template <class K>
+static int allow_big_lds(K kernel, uint32_t bytes, unsigned& device_mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "hipGetDevice failed");
+  if (dev < 32 && (device_mask & (1u << dev))) return SF_OK;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_MAX) != hipSuccess)
+    SF_FAIL(SF_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
+  if (dev < 32) device_mask |= 1u << dev;
+  return SF_OK;
+}
+
+template <int WM, int WN, int D>
+static int launch_fconv(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStream_t st) {
+  static unsigned mask = 0;
+  if (int rc = allow_big_lds(k_conv_fused<WM, WN, D>, lds, mask)) return rc;
+  k_conv_fused<WM, WN, D><<<grid, 256, lds, st>>>(a);
+  SF_CHECK_LAUNCH("conv_fused");
+  return SF_OK;
+}
+
+static int run_fconv(const sf_op& op, hipStream_t st) {
+  FConvArgs a;
+  int WM, WN;
+  uint32_t grid, lds;
+  if (fconv_setup(op, a, WM, WN, grid, lds, sf_err_buf, sizeof(sf_err_buf))) return SF_ERR_INVALID;
+  if (WM == 1 && WN == 1) return launch_fconv<1, 1, 12>(a, grid, lds, st);
+  if (WM == 1 && WN == 2) return launch_fconv<1, 2, 8>(a, grid, lds, st);
+  if (WM == 2 && WN == 1) return launch_fconv<2, 1, 12>(a, grid, lds, st);
+  return launch_fconv<2, 2, 8>(a, grid, lds, st);
+}
+
+static int run_slots(const sf_op& op, hipStream_t st) {
+  const int M = op.i[0], C = op.i[1], HW = op.i[2];
+  if (M % 16 || C % 16 || !op.p[0] || !op.p[4] || (op.p[1] && (!op.p[2] || !op.p[3])))
+    SF_FAIL(SF_ERR_INVALID, "slots: M, C must be multiples of 16; gate mode needs res and out");
+  const uint32_t waves = (uint32_t)(M / 16) * (C / 16);
+  k_slots<<<sf_div_up(waves, 4), 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], (float*)op.p[3],
+                                                (float*)op.p[4], M, C, HW);
+  SF_CHECK_LAUNCH("slots");
+  return SF_OK;
+}
+
+int sf_plan_fused_op(const sf_op* op, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  switch (op->type) {
+    case SF_OP_FCONV: return run_fconv(*op, st);
+    case SF_OP_SLOTS: return run_slots(*op, st);
+    default: SF_FAIL(SF_ERR_INVALID, "fused: unknown op type %d", op->type);
+  }
+}

@@ -1177,6 +1177,9 @@ static int plan_run_impl(const sf_op* ops, uint32_t n_ops, hipStream_t st, hipEv
       case SF_OP_POOL:
       case SF_OP_LPIPS: rc = sf_plan_extra_op(&op, st); break;
       case SF_OP_EFT: rc = sf_plan_eft_op(&op, st); break;
+      case SF_OP_FCONV:
+      case SF_OP_SLOTS:
+      case SF_OP_GCA: rc = sf_plan_fused_op(&op, st); break;
       default: SF_FAIL(SF_ERR_INVALID, "plan: unknown op type %d at %u", op.type, k);
     }
     if (rc) {

@@ -19,6 +19,9 @@ import torch.nn as nn
 from . import _lib
 
 OP_CONV, OP_GN_ACT, OP_LN, OP_GEMV, OP_ATTN, OP_GCA_POOL, OP_ELTWISE, OP_MEMSET, OP_TIME_EMB, OP_SPLITK_REDUCE = range(1, 11)
+OP_FCONV, OP_SLOTS, OP_GCA = 14, 15, 16
+FNORM_NONE, FNORM_GN_SELF, FNORM_GN_SLOTS, FNORM_LN = range(4)      # csrc/fused_kernels.h
+LDS_MAX = 163840
 SKIP_SCALE = 2 ** -0.5            # scale_skip_connection (imagen_pytorch.py:1283)
 
 
@@ -150,13 +153,16 @@ class _Arena:
 
 class _T:
     """A planned activation: device pointer + logical shape [B, HW, C] (NHWC) or [rows, C]."""
-    __slots__ = ("ptr", "rows", "C", "HW", "lazy")
+    __slots__ = ("ptr", "rows", "C", "HW", "lazy", "slots")
 
     def __init__(self, ptr, rows, C, HW=None):
         self.ptr, self.rows, self.C, self.HW = ptr, rows, C, HW
         # lazy: None, or how the first consumer must materialise the tensor (csrc/unet_ops.hip LazySrc):
-        #   ("splitk", ws, bias, resid, groups, npad)   or   ("gate", h, gate, res)
+        #   ("splitk", ws, bias, resid, groups, npad, ws index)   or   ("gate", h, gate, res)
         self.lazy = None
+        # slots: device pointer of the [rows/16][C/16][2] (sum, sum of squares) table of the materialised values that a
+        # GroupNorm-fused conv reads its statistics from (csrc/fused_kernels.h), or None
+        self.slots = None
 
 
 class _Plan:
@@ -170,9 +176,38 @@ class _Plan:
             self.zero, self.misc = _Arena(sizing[0], device), _Arena(sizing[1], device)
         self.w = unet._packed(device)
         self.written = set()                 # (ptr, channel offset) of conv outputs that already hold data
-        self.ws_bytes = 0                    # split-K workspace demand (max over ops; ops run serially)
-        self.ws_ptr = self.misc.alloc(sizing[2]) if sizing is not None else 0
-        self.ws_owner = None                 # tensor whose un-reduced split-K partials currently live in the workspace
+        # two split-K workspaces (max demand over the ops that use each; ops run serially): a fused conv reads its input's
+        # slabs from one while it writes its own partial tiles to the other
+        self.ws_need = [0, 0]
+        self.ws_ptrs = [self.misc.alloc(sizing[2]) if sizing is not None else 0,
+                        self.misc.alloc(sizing[3]) if sizing is not None and len(sizing) > 3 and sizing[3] else 0]
+        self.ws_owners = [None, None]        # tensors whose un-reduced split-K partials currently live in each workspace
+
+    @property
+    def ws_bytes(self):
+        return self.ws_need[0]
+
+    @property
+    def ws2_bytes(self):
+        return self.ws_need[1]
+
+    @property
+    def ws_owner(self):
+        return next((o for o in self.ws_owners if o is not None and o.lazy is not None), None)
+
+    def acquire_ws(self, nbytes, avoid=()):
+        """Index of a workspace the op being emitted may overwrite: a free one if possible, never one that holds the
+        partials of a tensor in `avoid` (an input of that op); a workspace owned by another tensor is reduced first."""
+        for i in sorted(range(2), key=lambda j: (self.ws_owners[j] is not None and self.ws_owners[j].lazy is not None, j)):
+            o = self.ws_owners[i]
+            if o is not None and o.lazy is not None:
+                if any(o is t for t in avoid):
+                    continue
+                self.need(o)
+            self.ws_need[i] = max(self.ws_need[i], nbytes)
+            self.ws_owners[i] = None
+            return i
+        raise AssertionError("no split-K workspace available")
 
     # -------- allocation helpers
     def zf32(self, rows, C, HW=None):        # conv outputs: first writer stores, later writers accumulate
@@ -205,9 +240,9 @@ class _Plan:
             return t
         lz, t.lazy = t.lazy, None
         if lz[0] == "splitk":
-            _, ws, bias, resid, groups, npad = lz
+            _, ws, bias, resid, groups, npad, wi = lz
             self.op(OP_SPLITK_REDUCE, 0, p=(ws, bias, resid, t.ptr), i=(t.rows, t.C, npad, groups))
-            self.ws_owner = None
+            self.ws_owners[wi] = None
         else:
             _, h, gate, res = lz
             self.op(OP_ELTWISE, 1, p=(h, gate, res, t.ptr), i=(self.B, t.HW, t.C))
@@ -220,7 +255,7 @@ class _Plan:
             return (0, 0, 0), (0, 0, 0)
         lz, t.lazy = t.lazy, None
         if lz[0] == "splitk":
-            self.ws_owner = None
+            self.ws_owners[lz[6]] = None
             return (lz[1], lz[2], lz[3]), (1, lz[4], lz[5])
         return (lz[1], lz[2], lz[3]), (2, 0, 0)
 
@@ -240,11 +275,10 @@ class _Plan:
         WM, WN, groups = self.u.conv_tiling(m_frags, n_frags, KS, pixshuf)
         accum = (out.ptr, co_off) in self.written
         self.written.add((out.ptr, co_off))
-        ws = 0
+        ws, wi = 0, 0
         if groups > 1:
-            self.need(self.ws_owner)                          # the workspace is about to be overwritten
-            self.ws_bytes = max(self.ws_bytes, groups * M * n_frags * 16 * 4)
-            ws = self.ws_ptr
+            wi = self.acquire_ws(groups * M * n_frags * 16 * 4)   # a workspace about to be overwritten is reduced first
+            ws = self.ws_ptrs[wi]
         tile = WM * 16 + WN
         # large-M layers (VAE, VGG, B >= 4): the LDS-tiled kernel, 128 pixels x 128 (or 64) channels per workgroup
         lds_min = getattr(self.u, "lds_conv_min_blocks", 0)
@@ -263,8 +297,9 @@ class _Plan:
                 p=(x.ptr, w_ptr if w_ptr is not None else self.wptr(wname), bias, out.ptr, res, ws),
                 i=(B, H, W, x.C, Ho, Wo, Cout, ldc, co_off, k, k, stride, pad, groups, tile))
         if defer:
-            out.lazy = ("splitk", ws, bias, res, groups, n_frags * 16)
-            self.ws_owner = out
+            out.lazy = ("splitk", ws, bias, res, groups, n_frags * 16, wi)
+            self.ws_owners[wi] = out
+        out.slots = None
         return Ho, Wo
 
     def gn_act(self, x, skip, gname, ss_ptr, out, raw=None, silu=True, groups=8, eps=1e-5):
@@ -304,8 +339,157 @@ class _Plan:
                 i += list(s[2:])
         self.op(OP_ATTN, 0, p=p, i=i, f=(scale,))
 
+
+    # -------- fused GroupNorm / LayerNorm -> conv ops (csrc/fused_kernels.h)
+    def fused_geometry(self, H, C, Cout, norm, k):
+        """(TR, WM, WN, S) of a k_conv_fused launch on an H x H map, or None when the layer does not fit the kernel."""
+        B = self.B
+        if not getattr(self.u, "fused", False) or H not in (4, 8, 16, 32) or C % 32 or Cout % 16:
+            return None
+        TR, WM = {4: (4, 1), 8: (2, 1), 16: (1, 1), 32: (1, 2)}[H]
+        n_frags = Cout // 16
+        MT = B * (H // TR)
+        S = 1
+        if norm in (FNORM_GN_SELF, FNORM_GN_SLOTS):
+            if C % 8:
+                return None
+            Cg = C // 8
+            if Cg % 4 or (norm == FNORM_GN_SLOTS and Cg % 16):
+                return None
+            if norm == FNORM_GN_SELF:
+                if H != 4:
+                    return None
+                ok = [d for d in (1, 2, 4, 8) if (C // 32) % d == 0 and (C // d) % Cg == 0]
+                S = next((d for d in ok if MT * n_frags * d >= 256), ok[-1])
+        WN = 2 if (n_frags % 2 == 0 and MT * (n_frags // 2) * S >= 256) else 1
+        Cs = C // S
+        stride = Cs * 2 + ((32 - (Cs * 2) % 256) + 256) % 256
+        h = k // 2
+        lds = (TR + 2 * h) * (H + 2 * h) * stride + 4096 * WM * WN + 2 * Cs * 4 + 640
+        if lds > LDS_MAX:
+            return None
+        return TR, WM, WN, S
+
+    def ensure_slots(self, t):
+        """Make `t` a materialised tensor with a (sum, sum of squares) slot table (one launch when it has none)."""
+        if t.slots is not None and t.lazy is None:
+            return t
+        assert t.rows % 16 == 0 and t.C % 16 == 0
+        slots = self.misc.alloc(t.rows // 16 * (t.C // 16) * 2 * 4)
+        if t.lazy is not None and t.lazy[0] == "gate" and t.lazy[3] and t.lazy[3] != t.ptr:
+            _, h, gate, res = t.lazy
+            t.lazy = None
+            self.op(OP_SLOTS, 0, p=(h, gate, res, t.ptr, slots), i=(t.rows, t.C, t.HW))
+        else:
+            self.need(t)
+            self.op(OP_SLOTS, 0, p=(t.ptr, 0, 0, 0, slots), i=(t.rows, t.C, t.HW or t.rows))
+        t.slots = slots
+        return t
+
+    def fconv(self, x, skip, H, wname, bname, out, Cout, k, norm, geom, gname=None, ss_ptr=0, silu=True, resid=None,
+              want_slots=False, pre_gelu=False, beta_name=None, ldc=None, co_off=0):
+        """One k_conv_fused launch: out = conv_k(act(norm(concat(x, skip * 2^-1/2)))).  With S > 1 input-channel slices the
+        output stays a lazy split-K tensor (slabs + bias + resid) that the next fused conv / GroupNorm / gca pass reduces."""
+        TR, WM, WN, S = geom
+        B = self.B
+        C1, C2 = x.C, (skip.C if skip else 0)
+        self.need(skip)
+        self.need(resid)
+        if norm == FNORM_GN_SLOTS:
+            self.ensure_slots(x)
+            if skip:
+                self.ensure_slots(skip)
+        ldc = ldc or Cout
+        accum = (out.ptr, co_off) in self.written
+        n_frags = (Cout + 15) // 16
+        ws, wi = 0, 0
+        if S > 1:                                               # before x's slabs are released: never write the workspace we read
+            assert not accum and ldc == Cout and co_off == 0
+            wi = self.acquire_ws(S * x.rows * n_frags * 16 * 4, avoid=(x,))
+            ws = self.ws_ptrs[wi]
+        else:
+            self.written.add((out.ptr, co_off))
+        lp, li = (0, 0, 0), (0, 0, 0)
+        if x.lazy is not None:
+            if x.lazy[0] == "gate" and (not x.lazy[3] or x.lazy[3] == x.ptr):
+                self.need(x)                                    # res lives in the target buffer: only a one-reader kernel may do that
+            else:
+                lp, li = self.take_lazy(x, ("splitk", "gate"))
+        slots_out = 0
+        if want_slots and S == 1:
+            if out.slots is None:
+                out.slots = self.misc.alloc(out.rows // 16 * (ldc // 16) * 2 * 4)
+            slots_out = out.slots
+        bias, res = (self.wptr(bname) if bname else 0), (resid.ptr if resid else 0)
+        gam = self.wptr(gname + ".weight") if norm in (FNORM_GN_SELF, FNORM_GN_SLOTS) else (self.wptr(gname) if gname else 0)
+        bet = self.wptr(gname + ".bias") if norm in (FNORM_GN_SELF, FNORM_GN_SLOTS) else (self.wptr(beta_name) if beta_name else 0)
+        self.op(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0),
+                p=(x.ptr, lp[0], lp[1], lp[2], x.slots or 0, skip.ptr if skip else 0, (skip.slots or 0) if skip else 0,
+                   self.wptr(wname), 0 if S > 1 else bias, out.ptr, 0 if S > 1 else res, ws, slots_out, gam, bet, ss_ptr),
+                i=(B, H, H, C1, C2, Cout, ldc, co_off, k, li[0], li[1], li[2], norm, 8, TR, WM, WN, S, self.u.ss_total),
+                f=(1e-5, 1.0, SKIP_SCALE))
+        if S > 1:
+            out.lazy = ("splitk", ws, bias, res, S, n_frags * 16, wi)
+            self.ws_owners[wi] = out
+            out.slots = None
+
+    def resnet_fused(self, name, x, skip, cout, H, gca=False, cross=False):
+        """ResnetBlock (imagen_pytorch.py:665-729) with both GroupNorms inside their convs: 2 launches (+ res_conv, + gca)
+        instead of 6-10.  Returns None when a layer of the block does not fit the fused kernel."""
+        B, HW = self.B, H * H
+        cin = x.C + (skip.C if skip else 0)
+        rows = B * HW
+        norm = FNORM_GN_SELF if H == 4 else FNORM_GN_SLOTS
+        g1 = self.fused_geometry(H, cin, cout, norm, 3)
+        g2 = self.fused_geometry(H, cout, cout, norm, 3)
+        gr = self.fused_geometry(H, cin, cout, FNORM_NONE, 1) if cin != cout else g1
+        if g1 is None or g2 is None or gr is None or x.C % 32 or rows % 16:
+            return None
+        slots = norm == FNORM_GN_SLOTS
+        h = self.zf32(rows, cout, HW)
+        self.fconv(x, skip, H, f"{name}.block1.project.weight", f"{name}.block1.project.bias", h, cout, 3, norm, g1,
+                   gname=f"{name}.block1.groupnorm", want_slots=slots)
+        rc = None
+        if cin != cout:                                             # res_conv reads the raw concat (x is materialised now)
+            rc = self.zf32(rows, cout, HW)
+            self.fconv(x, skip, H, f"{name}.res_conv.weight", f"{name}.res_conv.bias", rc, cout, 1, FNORM_NONE, gr, silu=False)
+        if cross:
+            h = self.cross_attention(f"{name}.cross_attn.fn", h)
+        ss_ptr = self.ss.ptr + self.u.ss_offset[name] * 4
+        w2, b2, gn2 = f"{name}.block2.project.weight", f"{name}.block2.project.bias", f"{name}.block2.groupnorm"
+        res = rc if rc is not None else x
+        out = self.zf32(rows, cout, HW)
+        if not gca:
+            self.fconv(h, None, H, w2, b2, out, cout, 3, norm, g2, gname=gn2, ss_ptr=ss_ptr, resid=res, want_slots=slots)
+            return out
+        h2 = self.zf32(rows, cout, HW)
+        self.fconv(h, None, H, w2, b2, h2, cout, 3, norm, g2, gname=gn2, ss_ptr=ss_ptr)
+        gate = self.gca_gate(name, h2, cout)
+        out.lazy = ("gate", h2.ptr, gate.ptr, res.ptr)
+        return out
+
+    def gca_gate(self, name, h2, cout):
+        """GlobalContext gate of h2 (imagen_pytorch.py:916-941): softmax-pooled context -> two 1x1 convs -> sigmoid."""
+        B, HW = self.B, h2.HW
+        pooled = _T(self.zero.alloc(B * cout * 4), B, cout)        # accumulated with atomics: zeroed per eval
+        hid = self.f32(B, max(3, cout // 2))
+        gate = self.f32(B, cout)
+        logits = self.f32(B, HW)
+        lp, li = self.take_lazy(h2, ("splitk",))
+        self.op(OP_GCA_POOL, 0, p=(h2.ptr, self.wptr(f"{name}.gca.to_k.weight"), self.wptr(f"{name}.gca.to_k.bias"), pooled.ptr,
+                                   logits.ptr, 0, 0, 0) + lp, i=(B, HW, cout) + li)
+        self.gemv(pooled.ptr, B, cout, f"{name}.gca.net.0.weight", f"{name}.gca.net.0.bias", hid.ptr, hid.C, hid.C, cout,
+                  out_act=1)
+        self.gemv(hid.ptr, B, hid.C, f"{name}.gca.net.2.weight", f"{name}.gca.net.2.bias", gate.ptr, cout, cout, hid.C,
+                  out_act=2)
+        return gate
+
     # -------- blocks
     def resnet(self, name, x, skip, cout, H, gca=False, cross=False):
+        if getattr(self.u, "fused", False):
+            y = self.resnet_fused(name, x, skip, cout, H, gca, cross)
+            if y is not None:
+                return y
         B, HW = self.B, H * H
         cin = x.C + (skip.C if skip else 0)
         rows = B * HW
@@ -550,6 +734,7 @@ class Unet(nn.Module):
         self.conv_waves_target = 1024       # waves wanted per conv launch (4 per CU) before split-K stops
         self.lds_conv_min_blocks = 96       # use k_conv_lds when a layer has at least this many 128 x 128 output tiles
         self.lazy_consumers = 3             # bit 0: split-K reductions, bit 1: gated residuals are materialised by their first consumer
+        self.fused = True                   # GroupNorm inside the conv launches (k_conv_fused) wherever the layer fits
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches
         self._pack_cache = None
         self._plans = {}
@@ -678,7 +863,8 @@ class Unet(nn.Module):
         key = (B, str(device))
         if key not in self._plans:
             sizing = _Plan(self, B, device).build()
-            plan = _Plan(self, B, device, (sizing.zero.off, sizing.misc.off + sizing.ws_bytes + 256, sizing.ws_bytes)).build()
+            plan = _Plan(self, B, device, (sizing.zero.off, sizing.misc.off + sizing.ws_bytes + sizing.ws2_bytes + 512,
+                                           sizing.ws_bytes, sizing.ws2_bytes)).build()
             self._plans[key] = plan
         return self._plans[key]
 

@@ -1,0 +1,171 @@
+"""Shared cases of the fused UNet kernels (sparsefusion_amd/csrc/fused_kernels.h): the same op descriptors run either on
+CPU threads (backend "emu": tests/hostemu, kernel logic without a GPU) or through the C ABI on the GPU (backend "gpu":
+sf_plan_run), and are compared with a plain torch fp32 reference of the same op on bf16-rounded operands
+(GroupNorm / LayerNorm -> scale/shift -> SiLU -> conv, external/imagen_pytorch.py:641-662)."""
+import torch
+import torch.nn.functional as F
+
+from hostemu import fused
+from sparsefusion_amd import _lib
+
+OP_FCONV, OP_SLOTS, OP_GCA = 14, 15, 16
+NONE, GN_SELF, GN_SLOTS, LN = 0, 1, 2, 3
+
+
+def bf(x):
+    return x.to(torch.bfloat16).float()
+
+
+def rel(a, b):
+    return float((a - b).norm() / b.norm().clamp(min=1e-20))
+
+
+def slots_of(x, M, C):
+    """[M/16][C/16][2] (sum, sum of squares) over 16-pixel x 16-channel blocks of an NHWC [M, C] tensor."""
+    t = x.reshape(M // 16, 16, C // 16, 16).permute(0, 2, 1, 3).reshape(M // 16, C // 16, 256)
+    return torch.stack([t.sum(-1), (t * t).sum(-1)], -1).contiguous()
+
+
+def nhwc(x, B, H, W):      # [M, C] -> NCHW
+    return x.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def to_rows(x):            # NCHW -> [M, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def run_ops(ops, backend):
+    if backend == "emu":
+        fused.run(ops)
+    else:
+        arr = (_lib.SfOp * len(ops))(*ops)
+        _lib.check(_lib.lib().sf_plan_run(arr, len(ops), _lib.stream_ptr()), "plan")
+        torch.cuda.synchronize()
+
+
+def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, silu=True, ss=True, accum=False, resid=False,
+                  slots=True, pre_gelu=False, ln_bias=False, seed=0, G=8, scale2=2 ** -0.5, tol=4e-3):
+    dev = "cpu" if backend == "emu" else "cuda:0"
+    d = lambda t: None if t is None else t.to(dev)
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    M, HW, C = B * H * W, H * W, C1 + C2
+    TR = 16 * WM // W
+    # ---- source 1 (possibly lazy) and source 2
+    if lazy == 1:
+        groups, npad = 3, C1 + 16
+        ws = rn(groups, M, npad) * 0.5
+        bias1, r1 = rn(C1), rn(M, C1)
+        x1 = ws[:, :, :C1].sum(0) + bias1 + r1
+        s1 = dict(p=d(torch.full((M, C1), float("nan"))), a=d(ws), b=d(bias1), r=d(r1), mode=1, groups=groups, npad=npad)
+    elif lazy == 2:
+        hh, gate, r1 = rn(M, C1), torch.sigmoid(rn(B, C1)), rn(M, C1)
+        x1 = hh * gate.repeat_interleave(HW, 0) + r1
+        s1 = dict(p=d(torch.full((M, C1), float("nan"))), a=d(hh), b=d(gate), r=d(r1), mode=2, groups=0, npad=0)
+    else:
+        x1 = rn(M, C1) * 1.5 + 0.3
+        s1 = dict(p=d(x1.clone()), a=None, b=None, r=None, mode=0, groups=0, npad=0)
+    x2 = rn(M, C2) if C2 else None
+    xc = torch.cat([x1, x2 * scale2], 1) if C2 else x1
+    # ---- reference
+    gamma, beta = rn(C) * 0.5 + 1, rn(C) * 0.2
+    ssv = rn(B, 2 * C) * 0.3 if (ss and norm in (GN_SELF, GN_SLOTS)) else None
+    if norm in (GN_SELF, GN_SLOTS):
+        y = F.group_norm(nhwc(xc, B, H, W), G, gamma, beta, eps=1e-5)
+        if ssv is not None:
+            y = y * (ssv[:, :C, None, None] + 1) + ssv[:, C:, None, None]
+    elif norm == LN:
+        u = F.gelu(xc) if pre_gelu else xc
+        mean, var = u.mean(1, keepdim=True), u.var(1, unbiased=False, keepdim=True)
+        y = nhwc((u - mean) * (var + 1e-5).rsqrt() * gamma + (beta if ln_bias else 0), B, H, W)
+    else:
+        y = nhwc(xc, B, H, W)
+    if silu:
+        y = F.silu(y)
+    w = rn(Cout, C, k, k) / (C * k * k) ** 0.5
+    bias = rn(Cout)
+    ref = to_rows(F.conv2d(bf(y), bf(w), None, padding=k // 2))
+    # ---- op
+    ldc, co_off = Cout + 32, 16
+    out0 = rn(M, ldc)
+    out = d(out0.clone())
+    res = rn(M, ldc) if resid else None
+    res_d = d(res)
+    wp = d(fused.pack_conv_weights(w))
+    wsl = d(torch.full((S, M, (Cout + 15) // 16 * 16), float("nan"))) if S > 1 else None
+    slots_out = d(torch.full((M // 16, ldc // 16, 2), float("nan"))) if (slots and S == 1 and Cout % 16 == 0) else None
+    sl1 = d(slots_of(x1, M, C1)) if norm == GN_SLOTS else None
+    sl2 = d(slots_of(x2, M, C2)) if (norm == GN_SLOTS and C2) else None
+    x2_d, bias_d, gamma_d, ssv_d = d(x2), d(bias), d(gamma), d(ssv)
+    beta_d = d(beta) if (norm != LN or ln_bias) else None
+    op = fused.mkop(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0),
+                    p=(s1["p"], s1["a"], s1["b"], s1["r"], sl1, x2_d, sl2, wp, bias_d, out, res_d, wsl, slots_out, gamma_d, beta_d, ssv_d),
+                    i=(B, H, W, C1, C2, Cout, ldc, co_off, k, s1["mode"], s1["groups"], s1["npad"], norm, G, TR, WM, WN, S, 2 * C),
+                    f=(1e-5, 1.0, scale2))
+    run_ops([op], backend)
+    out = out.cpu()
+    if S > 1:
+        got = wsl.cpu()[:, :, :Cout].sum(0)
+        want = ref
+    else:
+        got = out[:, co_off:co_off + Cout]
+        want = ref + bias
+        if resid:
+            want = want + res[:, co_off:co_off + Cout]
+        if accum:
+            want = want + out0[:, co_off:co_off + Cout]
+        # columns outside [co_off, co_off + Cout) are untouched
+        assert torch.equal(out[:, :co_off], out0[:, :co_off]) and torch.equal(out[:, co_off + Cout:], out0[:, co_off + Cout:])
+    assert torch.isfinite(got).all()
+    e = rel(got, want)
+    assert e < tol, f"conv mismatch rel {e}"
+    if lazy:
+        assert torch.allclose(s1["p"].cpu(), x1, atol=1e-5), "lazy source not materialised correctly"
+    if slots_out is not None:
+        sl = slots_of(out[:, co_off:co_off + Cout].contiguous(), M, Cout)
+        got_sl = slots_out.cpu()[:, co_off // 16:co_off // 16 + Cout // 16]
+        assert torch.allclose(got_sl, sl, rtol=1e-4, atol=2e-3), "output slots wrong"
+    return e
+
+
+def run_slots_case(backend):
+    dev = "cpu" if backend == "emu" else "cuda:0"
+    g = torch.Generator().manual_seed(9)
+    M, C, HW = 64, 48, 32
+    h, gate, res = torch.randn(M, C, generator=g), torch.rand(2, C, generator=g), torch.randn(M, C, generator=g)
+    hd, gd, rd = h.to(dev), gate.to(dev), res.to(dev)
+    out, sl = torch.zeros(M, C, device=dev), torch.zeros(M // 16, C // 16, 2, device=dev)
+    run_ops([fused.mkop(OP_SLOTS, p=(hd, gd, rd, out, sl), i=(M, C, HW))], backend)
+    x = h * gate.repeat_interleave(HW, 0) + res
+    assert torch.allclose(out.cpu(), x, atol=1e-6) and torch.allclose(sl.cpu(), slots_of(x, M, C), rtol=1e-5, atol=1e-4)
+    sl2, xd = torch.zeros_like(sl), x.to(dev)
+    run_ops([fused.mkop(OP_SLOTS, p=(xd, None, None, None, sl2), i=(M, C, HW))], backend)
+    assert torch.allclose(sl2.cpu(), slots_of(x, M, C), rtol=1e-5, atol=1e-4)
+
+
+# name -> kwargs of run_conv_case; small enough for the CPU-thread emulator, and every kernel path is in here
+CONV_CASES = {
+    # the 4x4 level: whole image per tile, input-channel slices, lazy split-K source, partial slabs out
+    "gn_self_sliced_lazy_splitk_4x4": dict(B=2, H=4, W=4, C1=64, C2=0, Cout=48, k=3, norm=GN_SELF, WM=1, WN=1, S=2, lazy=1),
+    "gn_self_concat_gate_lazy_4x4": dict(B=1, H=4, W=4, C1=64, C2=64, Cout=32, k=3, norm=GN_SELF, WM=1, WN=2, S=4, lazy=2, seed=1),
+    # 8x8 level: 2-row tiles with halo rows from neighbouring tiles, statistics from producer slots, final epilogue + slots
+    "gn_slots_concat_8x8": dict(B=1, H=8, W=8, C1=128, C2=128, Cout=32, k=3, norm=GN_SLOTS, WM=1, WN=1, resid=True, seed=2),
+    # 32-pixel rows (WM = 2), 2 n-fragments per tile, accumulate mode
+    "gn_slots_wide_rows_wm2_wn2": dict(B=2, H=4, W=32, C1=128, C2=0, Cout=64, k=3, norm=GN_SLOTS, WM=2, WN=2, accum=True, seed=3),
+    # XCD-aware tile order (8 n-tiles)
+    "gn_slots_xcd_map_16x16": dict(B=1, H=16, W=16, C1=128, C2=0, Cout=128, k=3, norm=GN_SLOTS, WM=1, WN=1, ss=False, seed=4),
+    "raw_1x1_concat_res_conv": dict(B=1, H=8, W=8, C1=64, C2=32, Cout=40, k=1, norm=NONE, WM=1, WN=1, silu=False, slots=False, seed=5),
+    "layernorm_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=1, silu=False, seed=6),
+    "gelu_layernorm_bias_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=2, silu=False, pre_gelu=True,
+                                       ln_bias=True, seed=6),
+}
+# the UNet's own layer shapes (B = 1): GPU only
+CONV_CASES_FULL = {
+    "unet_4x4_1024_s4": dict(B=1, H=4, W=4, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=1, seed=10),
+    "unet_4x4_2048_s4_gate": dict(B=1, H=4, W=4, C1=1024, C2=1024, Cout=1024, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=2, seed=11),
+    "unet_8x8_1536": dict(B=1, H=8, W=8, C1=1024, C2=512, Cout=1024, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=12),
+    "unet_16x16_768": dict(B=1, H=16, W=16, C1=512, C2=256, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=2, resid=True, seed=13),
+    "unet_32x32_512": dict(B=1, H=32, W=32, C1=256, C2=256, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=14),
+    "unet_32x32_res_conv": dict(B=1, H=32, W=32, C1=256, C2=256, Cout=256, k=1, norm=NONE, WM=2, WN=2, silu=False, seed=15),
+    "unet_b4_4x4": dict(B=4, H=4, W=4, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SELF, WM=1, WN=1, S=1, seed=16),
+}

@@ -1,0 +1,47 @@
+// CPU harness for the fused UNet kernels (sparsefusion_amd/csrc/fused_kernels.h): the SAME kernel source, compiled
+// by the host clang with one OS thread per lane (hip_emu.h), driven by the SAME op decoding as the gfx950 launchers
+// (fused_host.h).  Test infrastructure only -- checks kernel logic (indexing, LDS layout, fragment order, lazy
+// sources, statistics) on a GPU-less machine; the product path is unet_fused.hip on the GPU.
+#ifndef SF_HOST_EMU
+#define SF_HOST_EMU
+#endif
+#define HIPEMU_IMPLEMENTATION
+#include "hip_emu.h"
+#include "../../sparsefusion_amd/csrc/fused_host.h"
+
+template <int WM, int WN, int D>
+static void emu_fconv(const FConvArgs& a, uint32_t grid, uint32_t lds) {
+  hipemu::launch(grid, 256, lds, [&] { k_conv_fused<WM, WN, D>(a); });
+}
+
+extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
+  err[0] = 0;
+  if (op->type == SF_OP_FCONV) {
+    FConvArgs a;
+    int WM, WN;
+    uint32_t grid, lds;
+    if (fconv_setup(*op, a, WM, WN, grid, lds, err, (size_t)errn)) return 1;
+    if (WM == 1 && WN == 1) emu_fconv<1, 1, 12>(a, grid, lds);
+    else if (WM == 1 && WN == 2) emu_fconv<1, 2, 8>(a, grid, lds);
+    else if (WM == 2 && WN == 1) emu_fconv<2, 1, 12>(a, grid, lds);
+    else emu_fconv<2, 2, 8>(a, grid, lds);
+    return 0;
+  }
+  if (op->type == SF_OP_SLOTS) {
+    const int M = op->i[0], C = op->i[1], HW = op->i[2];
+    if (M % 16 || C % 16 || !op->p[0] || !op->p[4]) { snprintf(err, errn, "slots: bad operands"); return 1; }
+    const uint32_t waves = (uint32_t)(M / 16) * (C / 16);
+    hipemu::launch((waves + 3) / 4, 256, 0, [&] {
+      k_slots((const float*)op->p[0], (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], (float*)op->p[4], M, C, HW);
+    });
+    return 0;
+  }
+  snprintf(err, errn, "emu: op type %d not supported", op->type);
+  return 1;
+}
+
+extern "C" int emu_plan_run(const sf_op* ops, uint32_t n, char* err, int errn) {
+  for (uint32_t k = 0; k < n; ++k)
+    if (int rc = emu_run_op(&ops[k], err, errn)) return rc;
+  return 0;
+}

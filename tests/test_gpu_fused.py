@@ -1,0 +1,19 @@
+"""GPU parity of the fused UNet ops through the C ABI (sf_plan_run): the cases of tests/fused_cases.py -- the small ones
+the CPU-thread emulator also runs, and the UNet's own layer shapes -- against a torch fp32 reference on bf16-rounded
+operands (tolerance 4e-3 relative L2: same operand rounding, different summation order)."""
+import pytest
+
+import fused_cases as fc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", sorted(fc.CONV_CASES) + sorted(fc.CONV_CASES_FULL))
+def test_fused_conv_on_gpu(name):
+    kw = fc.CONV_CASES.get(name) or fc.CONV_CASES_FULL[name]
+    e = fc.run_conv_case("gpu", **kw)
+    print(f"{name}: rel {e:.2e}")
+
+
+def test_slots_kernel_and_gate_on_gpu():
+    fc.run_slots_case("gpu")

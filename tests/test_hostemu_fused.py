@@ -1,0 +1,50 @@
+"""Kernel-logic tests of the fused UNet kernels (sparsefusion_amd/csrc/fused_kernels.h) on CPU threads: the product's
+kernel source is compiled by the host clang with one OS thread per lane (tests/hostemu/hip_emu.h) and compared with a
+plain torch fp32 reference of the same op on bf16-rounded operands (cases: tests/fused_cases.py).  The GPU launch path
+runs the same cases in tests/test_gpu_fused.py."""
+import os
+
+import pytest
+import torch
+
+import fused_cases as fc
+from hostemu import fused
+
+pytestmark = pytest.mark.skipif(not fused.available(), reason="host clang not found")
+
+
+@pytest.mark.parametrize("name", sorted(fc.CONV_CASES))
+def test_fused_conv_on_cpu_threads(name):
+    fc.run_conv_case("emu", **fc.CONV_CASES[name])
+
+
+def test_slots_kernel_and_gate():
+    fc.run_slots_case("emu")
+
+
+@pytest.mark.skipif(not os.environ.get("SF_SLOW_TESTS"), reason="minutes of CPU-thread emulation: set SF_SLOW_TESTS=1")
+@pytest.mark.parametrize("dim", [64, 128])
+def test_whole_fused_plan_against_oracle(dim):
+    """The complete fused launch plan of a dim-64 (mixed fused / first-round ops) and a dim-128 (every block fused) UNet,
+    interpreted on the CPU (hostemu/plan_interp.py), against the fp32 oracle: planner wiring, workspaces, lazy tensors."""
+    from oracle import unet_ref
+    from sparsefusion_amd.unet import Unet, _Plan, unet_param_spec
+    from hostemu import plan_interp
+    cfg = dict(dim=dim, dim_mults=(1, 2, 4, 4), num_resnet_blocks=2, layer_attns=(False, False, False, True),
+               cond_images_channels=28, channels=4)
+    net = Unet(**cfg, layer_cross_attns=(False,) * 4, attn_pool_text=False)
+    sd = unet_ref.init_state(unet_param_spec(dim, (1, 2, 4, 4), net.nres, net.attns, 28, 4, net.cond_dim), seed=0)
+    net.load_state_dict(sd, strict=True)
+    cpu = torch.device("cpu")
+    s = _Plan(net, 1, cpu).build()
+    plan = _Plan(net, 1, cpu, (s.zero.off, s.misc.off + s.ws_bytes + s.ws2_bytes + 512, s.ws_bytes, s.ws2_bytes)).build()
+    g = torch.Generator().manual_seed(5)
+    x, cond = torch.randn(1, 4, 32, 32, generator=g), torch.randn(1, 28, 32, 32, generator=g)
+    ls = unet_ref.log_snr(torch.tensor([0.37]))
+    plan.misc.buf.view(torch.float32)[:] = float("nan")               # a read of an unwritten activation would show
+    plan.x_view.copy_(x.reshape(1, -1)); plan.t_view.copy_(ls.reshape(1, 1)); plan.cond_view.copy_(cond.reshape(1, -1))
+    plan_interp.run_plan(plan.ops)
+    y = plan.out_view.clone().view(1, 4, 32, 32)
+    with torch.no_grad():
+        y_ref = unet_ref.unet_forward(sd, x, ls, cond)
+    assert torch.isfinite(y).all() and fc.rel(y, y_ref) < 2e-2

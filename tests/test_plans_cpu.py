@@ -56,6 +56,32 @@ def _audit(ops, name, sized=False):
                 assert (o.p[8] or not sized) and lgroups >= 1 and npad % 4 == 0, where       # p[8] = the split-K workspace
             if lazy == 2:
                 assert o.p[8] and o.p[9], where
+        elif o.type == unet.OP_FCONV:
+            n_conv += 1
+            B, H, W, C1, C2, Cout, ldc, co_off, k, lmode, lgroups, npad, norm, G, TR, WM, WN, S = list(o.i)[:18]
+            C = C1 + C2
+            assert o.p[0] and o.p[7] and (o.p[9] or S > 1), where
+            assert C % 32 == 0 and C1 % 32 == 0 and k in (1, 3) and TR * W == 16 * WM and H % TR == 0, where
+            assert (C // 32) % S == 0 and WM in (1, 2) and WN in (1, 2), where
+            if S > 1:
+                assert (o.p[11] or not sized) and not (o.flags & 4) and not o.p[12], where + ": sliced convs write slabs only"
+            if norm in (unet.FNORM_GN_SELF, unet.FNORM_GN_SLOTS):
+                Cg = C // G
+                assert o.p[13] and o.p[14] and (C // S) % Cg == 0 and (C // S) // Cg <= 8, where
+                if norm == unet.FNORM_GN_SELF:
+                    assert TR == H, where
+                else:
+                    assert o.p[4] and (o.p[6] or not C2) and Cg % 16 == 0 and lmode != 1, where + ": slot statistics"
+            if lmode:
+                assert (o.p[1] or not sized) and (lmode == 1 or (o.p[2] and o.p[3])) and o.p[3] != o.p[0] and o.p[1] != o.p[0], where
+            if lmode == 1 and S > 1 and sized:
+                assert o.p[1] != o.p[11], where + ": a conv must not overwrite the slabs it reads"
+            h = k // 2
+            Cs = C // S
+            stride = Cs * 2 + ((32 - (Cs * 2) % 256) + 256) % 256
+            assert (TR + 2 * h) * (W + 2 * h) * stride + 4096 * WM * WN + 8 * Cs + 640 <= unet.LDS_MAX, where
+        elif o.type == unet.OP_SLOTS:
+            assert o.p[0] and o.p[4] and o.i[0] % 16 == 0 and o.i[1] % 16 == 0 and (not o.p[1] or (o.p[2] and o.p[3])), where
         elif o.type == unet.OP_LN:
             assert o.p[0] and o.p[1] and o.p[3] and o.i[1] % 64 == 0 and o.i[1] <= 2048, where
         elif o.type == unet.OP_GEMV:
@@ -64,25 +90,35 @@ def _audit(ops, name, sized=False):
 
 
 def test_unet_plan_invariants():
+    from sparsefusion_amd import unet as unet_mod
     from sparsefusion_amd.unet import Unet, _Plan
     net = Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2), layer_attns=(False, False, False, True),
                layer_cross_attns=(False,) * 4, cond_images_channels=256, attn_pool_text=False)
-    for B in (1, 4):
-        for lazy in (0, 3):
-            net.lazy_consumers = lazy
-            plan = _Plan(net, B, CPU).build()
-            assert _audit(plan.ops, f"unet B={B} lazy={lazy}") == 95              # conv / linear layers per eval
-            assert plan.ws_owner is None or plan.ws_owner.lazy is None             # nothing left un-materialised
-            assert plan.zero.off > 0 and plan.misc.off > plan.zero.off
-    # second pass with real arenas (host memory stands in for HBM): pointers are now real, the workspace exists
+    for fused in (False, True):
+        net.fused = fused
+        for B in (1, 4):
+            for lazy in (0, 3):
+                net.lazy_consumers = lazy
+                plan = _Plan(net, B, CPU).build()
+                assert _audit(plan.ops, f"unet B={B} lazy={lazy} fused={fused}") == 95   # conv / linear layers per eval
+                assert plan.ws_owner is None or plan.ws_owner.lazy is None             # nothing left un-materialised
+                assert plan.zero.off > 0 and plan.misc.off > plan.zero.off
+                if fused:                                                              # GroupNorm lives inside the convs now
+                    assert sum(o.type == unet_mod.OP_GN_ACT for o in plan.ops) == 0
+                    assert sum(o.type == unet_mod.OP_FCONV for o in plan.ops) >= 54
+    # second pass with real arenas (host memory stands in for HBM): pointers are now real, the workspaces exist
+    net.lazy_consumers = 3
     s = _Plan(net, 1, CPU).build()
-    sized = _Plan(net, 1, CPU, (s.zero.off, s.misc.off + s.ws_bytes + 256, s.ws_bytes)).build()
+    sized = _Plan(net, 1, CPU, (s.zero.off, s.misc.off + s.ws_bytes + s.ws2_bytes + 512, s.ws_bytes, s.ws2_bytes)).build()
     assert _audit(sized.ops, "unet sized", sized=True) == 95 and len(sized.ops) == len(s.ops)
     lo, hi = sized.misc.buf.data_ptr(), sized.misc.buf.data_ptr() + sized.misc.buf.numel()
     for o in sized.ops:                                                            # every activation operand lies inside an arena
         if o.type == 1:
             assert lo <= o.p[3] < hi and lo <= o.p[0] < hi
+        if o.type == unet_mod.OP_FCONV:
+            assert lo <= o.p[0] < hi and (lo <= o.p[9] < hi) and (not o.p[11] or lo <= o.p[11] < hi)
     # the lazy plan drops launches but never changes the set of convs
+    net.fused = False
     net.lazy_consumers = 3
     lazy_ops = len(_Plan(net, 1, CPU).build().ops)
     net.lazy_consumers = 0
@@ -116,6 +152,7 @@ def test_lds_conv_selection_rule():
     from sparsefusion_amd.vae import AutoencoderKL, _VaePlan
     net = Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2), layer_attns=(False, False, False, True),
                layer_cross_attns=(False,) * 4, cond_images_channels=256, attn_pool_text=False)
+    net.fused = False                                                             # the first-round plan (fused convs never use it)
     assert all(o.i[14] < 256 for o in _Plan(net, 1, CPU).build().ops if o.type == OP_CONV)
     assert any(o.i[14] >= 256 for o in _Plan(net, 16, CPU).build().ops if o.type == OP_CONV)
     dec = _VaePlan(AutoencoderKL(), "dec", 1, CPU).build()
