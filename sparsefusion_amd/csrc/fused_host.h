@@ -4,6 +4,7 @@
 // SF_OP_FCONV operands
 //   p: 0 s1.p  1 s1.a  2 s1.b  3 s1.r  4 s1.slots  5 s2.p  6 s2.slots  7 packed weights  8 bias  9 out  10 resid
 //      11 split-K slabs (S > 1)  12 slots_out  13 gamma / LN gain  14 beta / LN bias  15 scale_shift
+//      16 debug: [grid][8] int64 phase timestamps (100 MHz), normally null
 //   i: 0 B  1 H  2 W  3 C1  4 C2  5 Cout  6 ldc  7 co_off  8 k (1 | 3)  9 s1.mode  10 s1.groups  11 s1.npad
 //      12 norm (FNORM_*)  13 G  14 TR (image rows per tile)  15 WM  16 WN  17 S (input-channel slices)  18 ss_stride
 //   flags: 1 SiLU after the norm, 2 GELU before the LayerNorm, 4 accumulate into out
@@ -17,6 +18,21 @@
 #include "fused_kernels.h"
 
 #define SF_LDS_MAX 163840
+#define SF_FCONV_WAVES 8          /* waves per k_conv_fused workgroup */
+
+// The instantiated variants of k_conv_fused: (WM, WN, D, NORM, LAZY); everything the planner emits (unet.py::fused_geometry).
+#define SF_FCONV_VARIANTS(X) \
+  X(1, 1, 12, FNORM_GN_SELF, 0) \
+  X(1, 1, 12, FNORM_GN_SELF, 1) \
+  X(1, 1, 12, FNORM_GN_SELF, 2) \
+  X(1, 1, 12, FNORM_GN_SLOTS, 0) \
+  X(1, 2, 8, FNORM_GN_SLOTS, 0) \
+  X(2, 2, 8, FNORM_GN_SLOTS, 0) \
+  X(1, 1, 12, FNORM_NONE, 0) \
+  X(1, 2, 8, FNORM_NONE, 0) \
+  X(2, 2, 8, FNORM_NONE, 0) \
+  X(1, 1, 12, FNORM_LN, 0) \
+  X(1, 2, 8, FNORM_LN, 0)
 
 static inline int fconv_pix_stride(int Cs) {
   const int raw = Cs * 2;
@@ -32,6 +48,7 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   a.s2.p = (float*)op.p[5]; a.s2.a = a.s2.b = a.s2.r = nullptr; a.s2.slots = (const float*)op.p[6];
   a.w = (const bf16x8*)op.p[7]; a.bias = (const float*)op.p[8]; a.out = (float*)op.p[9]; a.resid = (const float*)op.p[10];
   a.ws = (float*)op.p[11]; a.slots_out = (float*)op.p[12];
+  a.dbg = (long long*)op.p[16];
   a.gamma = (const float*)op.p[13]; a.beta = (const float*)op.p[14]; a.ss = (const float*)op.p[15];
   a.B = op.i[0]; a.H = op.i[1]; a.W = op.i[2];
   a.s1.C = op.i[3]; a.s2.C = op.i[4]; a.C = a.s1.C + a.s2.C;
@@ -86,11 +103,20 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
     if (!a.out) FC_FAIL("fconv: output missing");
     if (a.slots_out && (a.Cout % 16 || a.ldc % 16 || a.co_off % 16)) FC_FAIL("fconv: slots need 16-aligned channels");
   }
+  if (a.norm == FNORM_GN_SELF && (a.H * a.W * (Cs / 4) > 4096)) FC_FAIL("fconv: GN_SELF tile exceeds the register-resident prologue");
+  a.logW = 0;
+  while ((1 << a.logW) < a.W) ++a.logW;
+  auto mk = [](uint32_t d) { FDiv f; f.d = d ? d : 1; f.magic = (uint32_t)(0x100000000ull / f.d) + 1u; return f; };
+  a.d_cs4 = mk(Cs / 4);
+  a.d_cg = mk((a.norm == FNORM_GN_SELF || a.norm == FNORM_GN_SLOTS) ? a.C / a.G : 1);
+  a.d_cps = mk(a.cps);
+  a.d_tc = mk((Cs / 4) < SF_FCONV_WAVES * 64 ? (Cs / 4) : SF_FCONV_WAVES * 64);
+  a.d_ncf = mk((a.norm == FNORM_GN_SLOTS) ? (a.C / a.G) / 16 : 1);
   a.pix_stride = fconv_pix_stride(Cs);
   const int h = a.k >> 1;
   const uint32_t frame = (uint32_t)(a.TR + 2 * h) * (a.W + 2 * h) * a.pix_stride;
   a.red_off = (int)frame;
-  a.tab_off = a.red_off + 4096 * WM * WN;
+  a.tab_off = a.red_off + 1024 * SF_FCONV_WAVES * WM * WN;
   a.misc_off = a.tab_off + 2 * Cs * 4;
   lds_bytes = a.misc_off + 640;
   if (lds_bytes > SF_LDS_MAX) FC_FAIL("fconv: tile needs %u bytes of LDS", lds_bytes);

@@ -20,6 +20,10 @@
 #pragma once
 #include "sf_dev.h"
 
+// n / d for small n (< 2^20) by one multiply: magic = floor(2^32 / d) + 1 (exact for the index ranges used here)
+struct FDiv { uint32_t d, magic; };
+SF_DEV uint32_t fdiv(uint32_t n, FDiv f) { return f.d == 1 ? n : (uint32_t)(((uint64_t)n * f.magic) >> 32); }
+
 enum { FNORM_NONE = 0, FNORM_GN_SELF = 1, FNORM_GN_SLOTS = 2, FNORM_LN = 3 };
 
 // fp32 NHWC source [M = B*HW, C].  mode 0: plain at p.  mode 1: v = b[c] + sum_g a[g][m][c (ld npad)] (+ r[m][c]).
@@ -49,17 +53,21 @@ struct FConvArgs {
   float eps;
   int B, H, W, C, Cout, ldc, co_off, k;
   int TR, S, cps, cchunks, KS, n_frags, n_tiles, mt_per_img, npad, M;
-  int pix_stride, xcd_map;
+  int pix_stride, xcd_map, logW;
+  FDiv d_ncf;                            // 16-channel fragments per group
+  FDiv d_cs4, d_cg, d_cps, d_tc;         // Cs/4, channels per group, chunks per slice, min(Cs/4, threads)
   int red_off, tab_off, misc_off;    // LDS byte offsets
+  long long* dbg;                    // optional [grid][8] phase timestamps (tools/fconv_phases.py), null in production
 };
 
+template <int MODE>
 SF_DEV f32x4 fsrc_load4(const FSrc& s, int M, int HW, long m, int c) {
   f32x4 v;
-  if (s.mode == 1) {
+  if (MODE == 1) {
     v = s.b ? *reinterpret_cast<const f32x4*>(s.b + c) : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int g = 0; g < s.groups; ++g) v += *reinterpret_cast<const f32x4*>(s.a + ((long)g * M + m) * s.npad + c);
     if (s.r) v += *reinterpret_cast<const f32x4*>(s.r + m * s.C + c);
-  } else if (s.mode == 2) {
+  } else if (MODE == 2) {
     const f32x4 hv = *reinterpret_cast<const f32x4*>(s.a + m * s.C + c);
     const f32x4 gv = *reinterpret_cast<const f32x4*>(s.b + (m / HW) * s.C + c);
     const f32x4 rv = *reinterpret_cast<const f32x4*>(s.r + m * s.C + c);
@@ -70,21 +78,28 @@ SF_DEV f32x4 fsrc_load4(const FSrc& s, int M, int HW, long m, int c) {
   return v;
 }
 
-// value of the (virtual) concat at pixel row m, concat channel c (c % 4 == 0); materialises lazy s1 elements when `own`
-SF_DEV f32x4 fconv_load(const FConvArgs& a, long m, int c, bool own) {
+// raw (unscaled) value of the (virtual) concat at pixel row m, concat channel c (c % 4 == 0); LAZY = mode of source 1
+template <int LAZY>
+SF_DEV f32x4 fconv_value(const FConvArgs& a, long m, int c) {
   const int HW = a.H * a.W;
-  if (c < a.s1.C) {
-    f32x4 v = fsrc_load4(a.s1, a.M, HW, m, c);
-    if (own && a.s1.mode) *reinterpret_cast<f32x4*>(a.s1.p + m * a.s1.C + c) = v;
-    return v * a.s1.scale;
-  }
-  return fsrc_load4(a.s2, a.M, HW, m, c - a.s1.C) * a.s2.scale;
+  if (c < a.s1.C) return fsrc_load4<LAZY>(a.s1, a.M, HW, m, c);
+  return *reinterpret_cast<const f32x4*>(a.s2.p + m * a.s2.C + (c - a.s1.C));
 }
 
-template <int WM, int WN, int D>
-SF_KERNEL(256) void k_conv_fused(FConvArgs a) {
+template <int N>
+struct FConst { static constexpr int value = N; };
+
+// NORM / LAZY (normalisation kind, lazy mode of source 1) are compile-time: one straight-line prologue per variant
+// (the all-in-one version was 49 k instructions and spilled 190 SGPRs).  NW = waves per workgroup: the prologue is VALU
+// and latency bound (SiLU per element, one workgroup per CU because of the LDS frame), so it wants 2 waves per SIMD;
+// the same 8 waves then split K eight ways and keep 8 x D KiB of weight fragments in flight per CU.
+template <int WM, int WN, int D, int NORM, int LAZY, int NW>
+SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
+  constexpr int NT = NW * 64;
   SF_DYN_LDS(lds);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#define FC_STAMP(k) do { if (a.dbg && tid == 0) a.dbg[(long)blockIdx.x * 8 + (k)] = sf_clock(); } while (0)
+  FC_STAMP(0);
   // ---- which tile
   const int MT = a.B * a.mt_per_img;
   const int tiles = MT * a.n_tiles;
@@ -109,7 +124,7 @@ SF_KERNEL(256) void k_conv_fused(FConvArgs a) {
 
   // ---- weight stream: this wave's k-steps [k0, k1) of the slice-local list (tap-major, then 32-channel chunk)
   const int KSl = a.k * a.k * a.cps;
-  const int spw = (KSl + 3) >> 2;
+  const int spw = (KSl + NW - 1) / NW;
   const int k0 = wave * spw;
   const int k1 = (KSl < k0 + spw) ? KSl : (k0 + spw);
   const bf16x8* wbase[WN];
@@ -120,24 +135,27 @@ SF_KERNEL(256) void k_conv_fused(FConvArgs a) {
     wbase[ni] = a.w + ((long)nf * a.KS + s * a.cps) * 64 + lane;
   }
   auto wload = [&](int j, int ni) -> bf16x8 {
-    if (j > KSl - 1) j = KSl - 1;
-    const int tap = j / a.cps, ccl = j - tap * a.cps;
+    const int tap = (int)fdiv((uint32_t)j, a.d_cps), ccl = j - tap * a.cps;
     return wbase[ni][(long)(tap * a.cchunks + ccl) * 64];
   };
   bf16x8 fb[D][WN];
+  auto prefetch_weights = [&]() {          // fill the ring: the HBM / L2 weight stream runs under the rest of the prologue
 #pragma unroll
-  for (int u = 0; u < D; ++u)
+    for (int u = 0; u < D; ++u)
+      if (k0 + u < k1) {
 #pragma unroll
-    for (int ni = 0; ni < WN; ++ni) fb[u][ni] = wload(k0 + u, ni);
+        for (int ni = 0; ni < WN; ++ni) fb[u][ni] = wload(k0 + u, ni);
+      }
+  };
 
   float* tabA = reinterpret_cast<float*>(lds + a.tab_off);
   float* tabB = tabA + Cs;
-  float* misc = reinterpret_cast<float*>(lds + a.misc_off);      // [0..7] block-reduction scratch, [8..] group / row statistics
+  float* misc = reinterpret_cast<float*>(lds + a.misc_off);      // [0..15] group sums, [16..] group / row (mean, rstd)
 
   // ---- (a) zero the frame pixels outside the image (conv zero padding); 8 threads per pixel
   if (h) {
     const int npix = FR * FW;
-    for (int q = tid >> 3; q < npix; q += 32) {
+    for (int q = tid >> 3; q < npix; q += NT / 8) {
       const int fr = q / FW, fx = q - fr * FW;
       const int r = row0 - h + fr, x = fx - h;
       if (r < 0 || r >= a.H || x < 0 || x >= a.W) {
@@ -147,93 +165,14 @@ SF_KERNEL(256) void k_conv_fused(FConvArgs a) {
     }
   }
 
-  // ---- (b) normalisation parameters
-  const int Cg = (a.norm == FNORM_GN_SELF || a.norm == FNORM_GN_SLOTS) ? a.C / a.G : 1;
-  if (a.norm == FNORM_GN_SELF) {
-    // the tile holds all HW pixels of image b and the slice holds whole groups: statistics from the data
-    const int ngs = Cs / Cg, Cg4 = Cg >> 2, cnt = HW * Cg4;
-    for (int gi = 0; gi < ngs; ++gi) {
-      float sm = 0.0f, sq = 0.0f;
-      for (int i = tid; i < cnt; i += 256) {
-        const int p = i / Cg4, c = c0 + gi * Cg + (i - p * Cg4) * 4;
-        const f32x4 v = fconv_load(a, mb + p, c, false);
-        sm += (v[0] + v[1]) + (v[2] + v[3]);
-        sq = fmaf(v[0], v[0], sq); sq = fmaf(v[1], v[1], sq); sq = fmaf(v[2], v[2], sq); sq = fmaf(v[3], v[3], sq);
-      }
-      sm = sf_wave_sum(sm);
-      sq = sf_wave_sum(sq);
-      if (lane == 0) { misc[wave] = sm; misc[4 + wave] = sq; }
-      sf_sync();
-      if (tid == 0) {
-        const double n = (double)HW * Cg;
-        const double mean = ((double)misc[0] + misc[1] + misc[2] + misc[3]) / n;
-        double var = ((double)misc[4] + misc[5] + misc[6] + misc[7]) / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        misc[8 + 2 * gi] = (float)mean;
-        misc[9 + 2 * gi] = sf_rsqrt((float)var + a.eps);
-      }
-      sf_sync();
-    }
-  } else if (a.norm == FNORM_GN_SLOTS) {
-    // 32 lanes per group sum the producer's (sum, sum of squares) slots of image b
-    const int ngs = Cs / Cg, gi = tid >> 5, li = tid & 31;
-    const int n_mf = HW >> 4, n_cf = Cg >> 4, cnt = n_mf * n_cf;
-    const int cf1 = a.s1.C >> 4, cf2 = a.s2.C >> 4;
-    float sm = 0.0f, sq = 0.0f;
-    if (gi < ngs) {
-      for (int i = li; i < cnt; i += 32) {
-        const int mf = i / n_cf, cfa = ((c0 + gi * Cg) >> 4) + (i - mf * n_cf);
-        const long mfg = (long)b * n_mf + mf;
-        if (cfa < cf1) {
-          const float* sl = a.s1.slots + (mfg * cf1 + cfa) * 2;
-          sm += sl[0] * a.s1.scale;
-          sq += sl[1] * a.s1.scale * a.s1.scale;
-        } else {
-          const float* sl = a.s2.slots + (mfg * cf2 + (cfa - cf1)) * 2;
-          sm += sl[0] * a.s2.scale;
-          sq += sl[1] * a.s2.scale * a.s2.scale;
-        }
-      }
-    }
-    sm = sf_group_sum(sm, 32);
-    sq = sf_group_sum(sq, 32);
-    if (li == 0 && gi < ngs) {
-      const double n = (double)HW * Cg;
-      const double mean = (double)sm / n;
-      double var = (double)sq / n - mean * mean;
-      if (var < 0.0) var = 0.0;
-      misc[8 + 2 * gi] = (float)mean;
-      misc[9 + 2 * gi] = sf_rsqrt((float)var + a.eps);
-    }
-    sf_sync();
-  } else if (a.norm == FNORM_LN) {
-    // per-row statistics over all C channels (S == 1, k == 1): 256 / rows threads per row, two passes like nn.LayerNorm
-    const int rows = 16 * WM, tpr = 256 / rows;
-    const int row = tid / tpr, part = tid - row * tpr;
-    const long m = mb + (long)row0 * a.W + row;
-    float sm = 0.0f;
-    for (int c4 = part; c4 < Cs4; c4 += tpr) {
-      f32x4 v = fconv_load(a, m, c4 * 4, false);
-      if (a.pre_gelu) { v[0] = sf_gelu(v[0]); v[1] = sf_gelu(v[1]); v[2] = sf_gelu(v[2]); v[3] = sf_gelu(v[3]); }
-      sm += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-    const float mean = sf_group_sum(sm, tpr) / (float)Cs;
-    float sq = 0.0f;
-    for (int c4 = part; c4 < Cs4; c4 += tpr) {
-      f32x4 v = fconv_load(a, m, c4 * 4, false);
-      if (a.pre_gelu) { v[0] = sf_gelu(v[0]); v[1] = sf_gelu(v[1]); v[2] = sf_gelu(v[2]); v[3] = sf_gelu(v[3]); }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { const float d = v[j] - mean; sq = fmaf(d, d, sq); }
-    }
-    const float rstd = sf_rsqrt(sf_group_sum(sq, tpr) / (float)Cs + a.eps);
-    if (part == 0) { misc[8 + 2 * row] = mean; misc[9 + 2 * row] = rstd; }
-    sf_sync();
-  }
-  if (a.norm == FNORM_GN_SELF || a.norm == FNORM_GN_SLOTS) {
-    // per-channel affine of this (image, slice): y = v * A + B  ==  ((v - mean) * rstd * gamma + beta) * (scale + 1) + shift
-    for (int cl = tid; cl < Cs; cl += 256) {
-      const int c = c0 + cl, gi = cl / Cg;
-      const float mean = misc[8 + 2 * gi], rstd = misc[9 + 2 * gi];
+  constexpr bool gn = NORM == FNORM_GN_SELF || NORM == FNORM_GN_SLOTS;
+  const int Cg = gn ? a.C / a.G : 1;
+  // per-channel affine of this (image, slice) from the group statistics in misc[16 + 2g], misc[17 + 2g]:
+  //   y = v * A + B  ==  ((v - mean) * rstd * gamma + beta) * (scale + 1) + shift
+  auto build_table = [&]() {
+    for (int cl = tid; cl < Cs; cl += NT) {
+      const int c = c0 + cl, gi = (int)fdiv((uint32_t)cl, a.d_cg);
+      const float mean = misc[16 + 2 * gi], rstd = misc[17 + 2 * gi];
       float A = rstd * a.gamma[c], Bv = a.beta[c] - mean * A;
       if (a.ss) {
         const float sc = a.ss[(long)b * a.ss_stride + c] + 1.0f, sh = a.ss[(long)b * a.ss_stride + a.C + c];
@@ -243,51 +182,255 @@ SF_KERNEL(256) void k_conv_fused(FConvArgs a) {
       tabA[cl] = A;
       tabB[cl] = Bv;
     }
-    sf_sync();
-  }
-
-  // ---- (c) stage the in-image frame rows: fp32 -> normalise -> activate -> bf16 [frame pixel][channel]
-  {
-    const int per_row = a.W * Cs4, cnt = FR * per_row;
-    for (int i = tid; i < cnt; i += 256) {
-      const int fr = i / per_row, rem = i - fr * per_row;
-      const int x = rem / Cs4, c4 = rem - x * Cs4;
-      const int r = row0 - h + fr;
-      if (r < 0 || r >= a.H) continue;
-      const int cl = c4 * 4;
-      const long m = mb + (long)r * a.W + x;
-      const bool own = (nt == 0) && fr >= h && fr < h + a.TR;
-      f32x4 v = fconv_load(a, m, c0 + cl, own);
-      if (a.norm == FNORM_GN_SELF || a.norm == FNORM_GN_SLOTS) {
-        const f32x4 A = *reinterpret_cast<const f32x4*>(tabA + cl), Bv = *reinterpret_cast<const f32x4*>(tabB + cl);
+  };
+  // normalise / activate one float4 of channels [cl, cl+4) and store it as bf16 at frame pixel fp.  (A, Bv) = the
+  // thread's slice of the affine table (GroupNorm) or (gain, bias) (LayerNorm): loop invariants of the callers.
+  auto finish = [&](f32x4 v, int fp, int cl, int row, const f32x4& A, const f32x4& Bv) {
+    if (gn) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], A[j], Bv[j]);
-      } else if (a.norm == FNORM_LN) {
-        const int row = (fr - h) * a.W + x;
-        const float mean = misc[8 + 2 * row], rstd = misc[9 + 2 * row];
-        const f32x4 g = *reinterpret_cast<const f32x4*>(a.gamma + c0 + cl);
+      for (int j = 0; j < 4; ++j) v[j] = fmaf(v[j], A[j], Bv[j]);
+    } else if (NORM == FNORM_LN) {
+      const float mean = misc[16 + 2 * row], rstd = misc[17 + 2 * row];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float u = a.pre_gelu ? sf_gelu(v[j]) : v[j];
-          v[j] = (u - mean) * rstd * g[j];
-        }
-        if (a.beta) {
-          const f32x4 be = *reinterpret_cast<const f32x4*>(a.beta + c0 + cl);
-          v += be;
-        }
+      for (int j = 0; j < 4; ++j) {
+        const float u = a.pre_gelu ? sf_gelu(v[j]) : v[j];
+        v[j] = fmaf((u - mean) * rstd, A[j], Bv[j]);
       }
-      if (a.silu) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = sf_silu(v[j]);
-      }
-      bf16x4 o;
-      o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
-      *reinterpret_cast<bf16x4*>(lds + (long)(fr * FW + x + h) * a.pix_stride + cl * 2) = o;
     }
+    if (a.silu) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = sf_silu_fast(v[j]);
+    }
+    bf16x4 o;
+    o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+    *reinterpret_cast<bf16x4*>(lds + (long)fp * a.pix_stride + cl * 2) = o;
+  };
+  auto affine_of = [&](int cl, f32x4& A, f32x4& Bv) {
+    A = f32x4{1.f, 1.f, 1.f, 1.f};
+    Bv = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (gn) {
+      A = *reinterpret_cast<const f32x4*>(tabA + cl);
+      Bv = *reinterpret_cast<const f32x4*>(tabB + cl);
+    } else if (NORM == FNORM_LN) {
+      A = *reinterpret_cast<const f32x4*>(a.gamma + c0 + cl);
+      if (a.beta) Bv = *reinterpret_cast<const f32x4*>(a.beta + c0 + cl);
+    }
+  };
+
+  if (NORM == FNORM_GN_SELF) {
+    // ---- (b1) the 4x4 level: the tile holds all HW pixels of image b and the slice holds whole groups.  Every element is
+    // loaded ONCE into registers (issued before the weight ring, so one round trip covers the whole prologue), group sums
+    // meet in LDS, then the registers are normalised straight into the frame.
+    constexpr int NV = 4096 / NT;
+    const int cnt = HW * Cs4;
+    f32x4 v[NV];
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int i = tid + u * NT;
+      if (i < cnt) {
+        const int p = (int)fdiv((uint32_t)i, a.d_cs4), c4 = i - p * Cs4;
+        v[u] = fconv_value<LAZY>(a, mb + p, c0 + c4 * 4);
+      }
+    }
+    prefetch_weights();
+    FC_STAMP(1);
+    if (tid < 16) misc[tid] = 0.0f;
+    sf_sync();
+    int cur = -1;
+    float sm = 0.0f, sq = 0.0f;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int i = tid + u * NT;
+      if (i < cnt) {
+        const int p = (int)fdiv((uint32_t)i, a.d_cs4), c4 = i - p * Cs4;
+        const int gi = (int)fdiv((uint32_t)(c4 * 4), a.d_cg);
+        const float sc = (c0 + c4 * 4 < a.s1.C) ? a.s1.scale : a.s2.scale;
+        if (gi != cur) {
+          if (cur >= 0) { sf_lds_add(misc + 2 * cur, sm); sf_lds_add(misc + 2 * cur + 1, sq); }
+          cur = gi; sm = 0.0f; sq = 0.0f;
+        }
+        const f32x4 w = v[u] * sc;
+        sm += (w[0] + w[1]) + (w[2] + w[3]);
+        sq = fmaf(w[0], w[0], sq); sq = fmaf(w[1], w[1], sq); sq = fmaf(w[2], w[2], sq); sq = fmaf(w[3], w[3], sq);
+      }
+    }
+    if (cur >= 0) { sf_lds_add(misc + 2 * cur, sm); sf_lds_add(misc + 2 * cur + 1, sq); }
+    sf_sync();
+    if (tid < Cs / Cg) {
+      const double n = (double)HW * Cg;
+      const double mean = (double)misc[2 * tid] / n;
+      double var = (double)misc[2 * tid + 1] / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      misc[16 + 2 * tid] = (float)mean;
+      misc[17 + 2 * tid] = sf_rsqrt((float)var + a.eps);
+    }
+    sf_sync();
+    build_table();
+    sf_sync();
+    FC_STAMP(2);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int i = tid + u * NT;
+      if (i < cnt) {
+        const int p = (int)fdiv((uint32_t)i, a.d_cs4), c4 = i - p * Cs4;
+        const int py = p >> a.logW, px = p - (py << a.logW);
+        const int c = c0 + c4 * 4;
+        if (nt == 0 && LAZY && c < a.s1.C) *reinterpret_cast<f32x4*>(a.s1.p + (mb + p) * a.s1.C + c) = v[u];
+        f32x4 A, Bv;
+        affine_of(c4 * 4, A, Bv);
+        finish(v[u] * (c < a.s1.C ? a.s1.scale : a.s2.scale), (py + h) * FW + px + h, c4 * 4, 0, A, Bv);
+      }
+    }
+  } else {
+    // ---- (b2) statistics from the producer's slots (GroupNorm on large maps) or from the rows themselves (LayerNorm)
+    if (NORM == FNORM_GN_SLOTS) {
+      // one wave per group sums the (sum, sum of squares) slots of image b: 4 independent slot loads in flight per lane
+      const int ngs = Cs / Cg;
+      const int n_mf = HW >> 4, n_cf = (Cg >> 4) > 0 ? (Cg >> 4) : 1, cnt = n_mf * n_cf;
+      const int cf1 = a.s1.C >> 4, cf2 = a.s2.C >> 4;
+      for (int gi = wave; gi < ngs; gi += NW) {
+        float sm = 0.0f, sq = 0.0f;
+        for (int i0 = lane; i0 < cnt; i0 += 256) {
+          float ps[4], pq[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            int i = i0 + u * 64;
+            const bool live = i < cnt;
+            if (!live) i = cnt - 1;
+            const int mf = (int)fdiv((uint32_t)i, a.d_ncf), cfa = ((c0 + gi * Cg) >> 4) + (i - mf * n_cf);
+            const long mfg = (long)b * n_mf + mf;
+            const bool first = cfa < cf1;
+            const float* base = first ? a.s1.slots : a.s2.slots;
+            const long off = first ? (mfg * cf1 + cfa) : (mfg * cf2 + (cfa - cf1));
+            const f32x2 sl = *reinterpret_cast<const f32x2*>(base + off * 2);
+            const float sc = live ? (first ? a.s1.scale : a.s2.scale) : 0.0f;
+            ps[u] = sl[0] * sc;
+            pq[u] = sl[1] * sc * sc;
+          }
+          sm += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+          sq += (pq[0] + pq[1]) + (pq[2] + pq[3]);
+        }
+        sm = sf_wave_sum(sm);
+        sq = sf_wave_sum(sq);
+        if (lane == 0) {
+          const double n = (double)HW * Cg;
+          const double mean = (double)sm / n;
+          double var = (double)sq / n - mean * mean;
+          if (var < 0.0) var = 0.0;
+          misc[16 + 2 * gi] = (float)mean;
+          misc[17 + 2 * gi] = sf_rsqrt((float)var + a.eps);
+        }
+      }
+      prefetch_weights();
+      FC_STAMP(1);
+      sf_sync();
+      build_table();
+      sf_sync();
+    } else if (NORM == FNORM_LN) {
+      // per-row statistics over all C channels (S == 1, k == 1): NT / rows threads per row, two passes like nn.LayerNorm,
+      // each pass in batches of 8 independent loads
+      prefetch_weights();
+      FC_STAMP(1);
+      const int rows = 16 * WM, tpr = NT / rows;
+      const int row = tid / tpr, part = tid - row * tpr;
+      const long m = mb + (long)row0 * a.W + row;
+      float sm = 0.0f;
+      for (int c4 = part; c4 < Cs4; c4 += 8 * tpr) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int cc = c4 + u * tpr;
+          v[u] = fconv_value<LAZY>(a, m, (cc < Cs4 ? cc : Cs4 - 1) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (c4 + u * tpr < Cs4) {
+            if (a.pre_gelu) { v[u][0] = sf_gelu(v[u][0]); v[u][1] = sf_gelu(v[u][1]); v[u][2] = sf_gelu(v[u][2]); v[u][3] = sf_gelu(v[u][3]); }
+            sm += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+          }
+      }
+      const float mean = sf_group_sum(sm, tpr) / (float)Cs;
+      float sq = 0.0f;
+      for (int c4 = part; c4 < Cs4; c4 += 8 * tpr) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int cc = c4 + u * tpr;
+          v[u] = fconv_value<LAZY>(a, m, (cc < Cs4 ? cc : Cs4 - 1) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (c4 + u * tpr < Cs4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float d = (a.pre_gelu ? sf_gelu(v[u][j]) : v[u][j]) - mean;
+              sq = fmaf(d, d, sq);
+            }
+          }
+      }
+      const float rstd = sf_rsqrt(sf_group_sum(sq, tpr) / (float)Cs + a.eps);
+      if (part == 0) { misc[16 + 2 * row] = mean; misc[17 + 2 * row] = rstd; }
+      sf_sync();
+    } else {
+      prefetch_weights();
+      FC_STAMP(1);
+    }
+    FC_STAMP(2);
+    // ---- (c) stage the in-image frame rows: fp32 -> normalise -> activate -> bf16 [frame pixel][channel].
+    // Thread layout: TC = min(Cs/4, NT) threads span the slice's float4 channel chunks (coalesced rows), NT / TC pixel
+    // lanes; a thread keeps ONE channel chunk, so its affine (A, B) lives in registers and the per-element index math
+    // is a shift and a mask.  Batches of U independent pixel loads are issued before the first one is used (a
+    // dependent load per trip costs a full L2 / HBM round trip; the per-element SiLU makes the rest VALU bound).
+    auto stage = [&](auto uc) {
+      constexpr int U = decltype(uc)::value;
+      const int TC = Cs4 < NT ? Cs4 : NT;
+      const int ppp = NT / TC;
+      const int tp = (int)fdiv((uint32_t)tid, a.d_tc), tcx = tid - tp * TC;
+      const int npx = FR << a.logW;
+      for (int cb = 0; cb < Cs4; cb += TC) {
+        const int c4 = cb + tcx;
+        const bool cact = tp < ppp && c4 < Cs4;
+        const int cl = (c4 < Cs4 ? c4 : Cs4 - 1) * 4, c = c0 + cl;
+        const bool first = c < a.s1.C;
+        const float scale = first ? a.s1.scale : a.s2.scale;
+        f32x4 A, Bv;
+        affine_of(cl, A, Bv);
+        for (int p0 = tp; p0 < npx; p0 += ppp * U) {
+          f32x4 v[U];
+          int fpx[U];
+          long mx[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            int pi = p0 + u * ppp;
+            const bool live = pi < npx;
+            if (!live) pi = npx - 1;
+            const int fr = pi >> a.logW, x = pi & (a.W - 1);
+            const int r = row0 - h + fr;
+            const bool in = live && cact && r >= 0 && r < a.H;
+            const int rc = r < 0 ? 0 : (r >= a.H ? a.H - 1 : r);
+            mx[u] = mb + ((long)rc << a.logW) + x;
+            // fpx < 0: nothing to store; bit 30: this workgroup owns the element (materialises a lazy source)
+            fpx[u] = in ? ((fr * FW + x + h) | ((nt == 0 && fr >= h && fr < h + a.TR) ? (1 << 30) : 0)) : -1;
+            v[u] = fconv_value<LAZY>(a, mx[u], c);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (fpx[u] < 0) continue;
+            if (LAZY && (fpx[u] >> 30) && first) *reinterpret_cast<f32x4*>(a.s1.p + mx[u] * a.s1.C + c) = v[u];
+            const int fp = fpx[u] & 0x3fffffff;
+            finish(v[u] * scale, fp, cl, NORM == FNORM_LN ? (fp - h) : 0, A, Bv);
+          }
+        }
+      }
+    };
+    if (LAZY == 1) stage(FConst<4>());
+    else stage(FConst<8>());
   }
   sf_sync();
+  FC_STAMP(3);
 
-  // ---- main loop
+  // ---- main loop: per k-step WM A fragments (16-byte LDS reads of shifted pixels, fetched one step ahead), WN weight
+  // fragments from the ring, WM x WN MFMAs; the ring slot is refilled D steps ahead
   f32x4 acc[WM][WN];
 #pragma unroll
   for (int mi = 0; mi < WM; ++mi)
@@ -297,38 +440,53 @@ SF_KERNEL(256) void k_conv_fused(FConvArgs a) {
 #pragma unroll
   for (int mi = 0; mi < WM; ++mi) {
     const int p = mi * 16 + (lane & 15);
-    const int ty = p / a.W, tx = p - ty * a.W;
+    const int ty = p >> a.logW, tx = p - (ty << a.logW);
     abase[mi] = (ty * FW + tx) * a.pix_stride + (lane >> 4) * 16;
+  }
+  auto aoff = [&](int j) -> int {
+    const int tap = (int)fdiv((uint32_t)j, a.d_cps), ccl = j - tap * a.cps;
+    const int ky = (a.k == 3) ? (tap >= 6 ? 2 : (tap >= 3 ? 1 : 0)) : 0, kx = tap - ky * a.k;
+    return (ky * FW + kx) * a.pix_stride + ccl * 64;
+  };
+  bf16x8 fa[WM];
+  if (k0 < k1) {
+    const int toff = aoff(k0);
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8*>(lds + abase[mi] + toff);
   }
   for (int j0 = k0; j0 < k1; j0 += D) {
 #pragma unroll
     for (int u = 0; u < D; ++u) {
       const int j = j0 + u;
       if (j < k1) {
-        const int tap = j / a.cps, ccl = j - tap * a.cps;
-        const int ky = tap / a.k, kx = tap - ky * a.k;
-        const int toff = (ky * FW + kx) * a.pix_stride + ccl * 64;
-        bf16x8 fa[WM];
+        bf16x8 fn[WM];
+        const int toff = aoff(j + 1 < k1 ? j + 1 : j);
 #pragma unroll
-        for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8*>(lds + abase[mi] + toff);
+        for (int mi = 0; mi < WM; ++mi) fn[mi] = *reinterpret_cast<const bf16x8*>(lds + abase[mi] + toff);
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
           for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = sf_mfma16(fa[mi], fb[u][ni], acc[mi][ni]);
+        if (j + D < k1) {
 #pragma unroll
-        for (int ni = 0; ni < WN; ++ni) fb[u][ni] = wload(j + D, ni);     // refill the ring slot just consumed
+          for (int ni = 0; ni < WN; ++ni) fb[u][ni] = wload(j + D, ni);     // refill the ring slot just consumed
+        }
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) fa[mi] = fn[mi];
       }
     }
   }
 
-  // ---- epilogue: the 4 K-slices of the workgroup meet in LDS
+  FC_STAMP(4);
+  // ---- epilogue: the NW K-slices of the workgroup meet in LDS
+  constexpr int F = WM * WN;
   float* red = reinterpret_cast<float*>(lds + a.red_off);         // [wave][frag][r][lane]
 #pragma unroll
   for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
     for (int ni = 0; ni < WN; ++ni)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[((wave * (WM * WN) + mi * WN + ni) * 4 + r) * 64 + lane] = acc[mi][ni][r];
+      for (int r = 0; r < 4; ++r) red[((wave * F + mi * WN + ni) * 4 + r) * 64 + lane] = acc[mi][ni][r];
   sf_sync();
   const long m0 = mb + (long)row0 * a.W;
 #pragma unroll
@@ -336,14 +494,17 @@ SF_KERNEL(256) void k_conv_fused(FConvArgs a) {
 #pragma unroll
     for (int ni = 0; ni < WN; ++ni) {
       const int f = mi * WN + ni;
-      if ((f & 3) != wave) continue;
+      if ((f % NW) != wave) continue;
       const int nf = nt * WN + ni;
       if (nf >= a.n_frags) continue;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int idx = (f * 4 + r) * 64 + lane;
-        v[r] = (red[idx] + red[idx + WM * WN * 256]) + (red[idx + 2 * WM * WN * 256] + red[idx + 3 * WM * WN * 256]);
+        float sacc = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sacc += red[idx + w * F * 256];
+        v[r] = sacc;
       }
       const int n = nf * 16 + (lane & 15);
       const long mrow = m0 + mi * 16 + (lane >> 4) * 4;
@@ -377,6 +538,8 @@ SF_KERNEL(256) void k_conv_fused(FConvArgs a) {
       }
     }
   }
+  FC_STAMP(5);
+#undef FC_STAMP
 }
 
 // (sum, sum of squares) slots of an fp32 NHWC tensor [M, C], one wave per 16 pixels x 16 channels; with `gate` the

@@ -8,6 +8,7 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 #ifdef SF_HOST_EMU
 #include "hip_emu.h"
@@ -19,13 +20,23 @@ static inline void sf_sync() { hipemu::syncthreads(); }
 template <class T>
 static inline T sf_shfl_xor(T v, int m) { return hipemu::shfl_xor(v, m); }
 static inline float sf_exp(float v) { return expf(v); }
+static inline void sf_lds_add(float* p, float v) {
+  uint32_t* u = reinterpret_cast<uint32_t*>(p);
+  uint32_t old = __atomic_load_n(u, __ATOMIC_RELAXED), neu;
+  do {
+    float f;
+    memcpy(&f, &old, 4);
+    f += v;
+    memcpy(&neu, &f, 4);
+  } while (!__atomic_compare_exchange_n(u, &old, neu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+}
 static inline float sf_rsqrt(float v) { return 1.0f / sqrtf(v); }
+static inline float sf_rcp(float v) { return 1.0f / v; }
+static inline long long sf_clock() { return 0; }
 // D = A (16 x 32, rows = lane & 15) * B (32 x 16, cols = lane & 15) + C; see tests/hostemu/hip_emu.h for the layout
 static inline f32x4 sf_mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   hipemu::WaveState* w = hipemu::t_wave;
   const int lane = hipemu::t_lane;
-  static thread_local int dummy;
-  (void)dummy;
   struct Pair { bf16x8 a, b; };
   static Pair xa[64][64];                       // [wave slot][lane]; one workgroup alive at a time, <= 64 waves
   const int ws = (int)(threadIdx.x >> 6);
@@ -54,11 +65,16 @@ SF_DEV void sf_sync() { __syncthreads(); }
 template <class T>
 SF_DEV T sf_shfl_xor(T v, int m) { return __shfl_xor(v, m, 64); }
 SF_DEV float sf_exp(float v) { return __expf(v); }
+SF_DEV void sf_lds_add(float* p, float v) { atomicAdd(p, v); }
 SF_DEV float sf_rsqrt(float v) { return rsqrtf(v); }
+SF_DEV float sf_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+SF_DEV long long sf_clock() { return (long long)wall_clock64(); }      // 100 MHz constant clock
 SF_DEV f32x4 sf_mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 #endif
 
 SF_DEV float sf_silu(float v) { return v / (1.0f + sf_exp(-v)); }
+// SiLU with the hardware reciprocal (1 ulp) instead of an IEEE division: the operand is rounded to bf16 right after
+SF_DEV float sf_silu_fast(float v) { return v * sf_rcp(1.0f + sf_exp(-v)); }
 SF_DEV float sf_sigmoid(float v) { return 1.0f / (1.0f + sf_exp(-v)); }
 SF_DEV float sf_gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
 

@@ -15,11 +15,11 @@ static int allow_big_lds(K kernel, uint32_t bytes, unsigned& device_mask) {
   return SF_OK;
 }
 
-template <int WM, int WN, int D>
+template <int WM, int WN, int D, int NORM, int LAZY>
 static int launch_fconv(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStream_t st) {
   static unsigned mask = 0;
-  if (int rc = allow_big_lds(k_conv_fused<WM, WN, D>, lds, mask)) return rc;
-  k_conv_fused<WM, WN, D><<<grid, 256, lds, st>>>(a);
+  if (int rc = allow_big_lds(k_conv_fused<WM, WN, D, NORM, LAZY, SF_FCONV_WAVES>, lds, mask)) return rc;
+  k_conv_fused<WM, WN, D, NORM, LAZY, SF_FCONV_WAVES><<<grid, SF_FCONV_WAVES * 64, lds, st>>>(a);
   SF_CHECK_LAUNCH("conv_fused");
   return SF_OK;
 }
@@ -29,10 +29,11 @@ static int run_fconv(const sf_op& op, hipStream_t st) {
   int WM, WN;
   uint32_t grid, lds;
   if (fconv_setup(op, a, WM, WN, grid, lds, sf_err_buf, sizeof(sf_err_buf))) return SF_ERR_INVALID;
-  if (WM == 1 && WN == 1) return launch_fconv<1, 1, 12>(a, grid, lds, st);
-  if (WM == 1 && WN == 2) return launch_fconv<1, 2, 8>(a, grid, lds, st);
-  if (WM == 2 && WN == 1) return launch_fconv<2, 1, 12>(a, grid, lds, st);
-  return launch_fconv<2, 2, 8>(a, grid, lds, st);
+#define SF_TRY(wm, wn, d, nm_, lz_) \
+  if (WM == wm && WN == wn && a.norm == nm_ && a.s1.mode == lz_) return launch_fconv<wm, wn, d, nm_, lz_>(a, grid, lds, st);
+  SF_FCONV_VARIANTS(SF_TRY)
+#undef SF_TRY
+  SF_FAIL(SF_ERR_INVALID, "fconv: no kernel variant for tile %dx%d norm %d lazy %d", WM, WN, a.norm, a.s1.mode);
 }
 
 static int run_slots(const sf_op& op, hipStream_t st) {

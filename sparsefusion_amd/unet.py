@@ -11,6 +11,7 @@ forward is a static list of ~330 kernel launches (an "op plan") built once per b
 pre-packed bf16 weights and two device arenas, replayed by ONE C call (`sf_plan_run`).  See
 DESIGN.md section 4 for the dataflow and the fusion map."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -349,7 +350,14 @@ class _Plan:
         TR, WM = {4: (4, 1), 8: (2, 1), 16: (1, 1), 32: (1, 2)}[H]
         n_frags = Cout // 16
         MT = B * (H // TR)
-        S = 1
+        h = k // 2
+
+        def lds_bytes(S_, WN_):
+            Cs = C // S_
+            stride = Cs * 2 + ((32 - (Cs * 2) % 256) + 256) % 256
+            return (TR + 2 * h) * (H + 2 * h) * stride + 8192 * WM * WN_ + 2 * Cs * 4 + 640
+
+        cand = [1]
         if norm in (FNORM_GN_SELF, FNORM_GN_SLOTS):
             if C % 8:
                 return None
@@ -359,15 +367,13 @@ class _Plan:
             if norm == FNORM_GN_SELF:
                 if H != 4:
                     return None
-                ok = [d for d in (1, 2, 4, 8) if (C // 32) % d == 0 and (C // d) % Cg == 0]
-                S = next((d for d in ok if MT * n_frags * d >= 256), ok[-1])
-        WN = 2 if (n_frags % 2 == 0 and MT * (n_frags // 2) * S >= 256) else 1
-        Cs = C // S
-        stride = Cs * 2 + ((32 - (Cs * 2) % 256) + 256) % 256
-        h = k // 2
-        lds = (TR + 2 * h) * (H + 2 * h) * stride + 4096 * WM * WN + 2 * Cs * 4 + 640
-        if lds > LDS_MAX:
+                # input-channel slices of whole groups: enough of them to give every CU a workgroup and to fit the LDS
+                cand = [d for d in (1, 2, 4, 8) if (C // 32) % d == 0 and (C // d) % Cg == 0]
+        cand = [d for d in cand if lds_bytes(d, 1) <= LDS_MAX]
+        if not cand:
             return None
+        S = next((d for d in cand if MT * n_frags * d >= 256), cand[-1])
+        WN = 2 if (n_frags % 2 == 0 and MT * (n_frags // 2) * S >= 256 and lds_bytes(S, 2) <= LDS_MAX and norm != FNORM_GN_SELF) else 1
         return TR, WM, WN, S
 
     def ensure_slots(self, t):
@@ -734,7 +740,8 @@ class Unet(nn.Module):
         self.conv_waves_target = 1024       # waves wanted per conv launch (4 per CU) before split-K stops
         self.lds_conv_min_blocks = 96       # use k_conv_lds when a layer has at least this many 128 x 128 output tiles
         self.lazy_consumers = 3             # bit 0: split-K reductions, bit 1: gated residuals are materialised by their first consumer
-        self.fused = True                   # GroupNorm inside the conv launches (k_conv_fused) wherever the layer fits
+        # GroupNorm inside the conv launches (k_conv_fused) wherever the layer fits; SF_UNET_FUSED=0 = the first-round plan (A/B runs)
+        self.fused = os.environ.get("SF_UNET_FUSED", "1") != "0"
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches
         self._pack_cache = None
         self._plans = {}

@@ -9,9 +9,9 @@
 #include "hip_emu.h"
 #include "../../sparsefusion_amd/csrc/fused_host.h"
 
-template <int WM, int WN, int D>
+template <int WM, int WN, int D, int NORM, int LAZY>
 static void emu_fconv(const FConvArgs& a, uint32_t grid, uint32_t lds) {
-  hipemu::launch(grid, 256, lds, [&] { k_conv_fused<WM, WN, D>(a); });
+  hipemu::launch(grid, SF_FCONV_WAVES * 64, lds, [&] { k_conv_fused<WM, WN, D, NORM, LAZY, SF_FCONV_WAVES>(a); });
 }
 
 extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
@@ -21,11 +21,12 @@ extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
     int WM, WN;
     uint32_t grid, lds;
     if (fconv_setup(*op, a, WM, WN, grid, lds, err, (size_t)errn)) return 1;
-    if (WM == 1 && WN == 1) emu_fconv<1, 1, 12>(a, grid, lds);
-    else if (WM == 1 && WN == 2) emu_fconv<1, 2, 8>(a, grid, lds);
-    else if (WM == 2 && WN == 1) emu_fconv<2, 1, 12>(a, grid, lds);
-    else emu_fconv<2, 2, 8>(a, grid, lds);
-    return 0;
+#define SF_TRY(wm, wn, d, nm_, lz_) \
+    if (WM == wm && WN == wn && a.norm == nm_ && a.s1.mode == lz_) { emu_fconv<wm, wn, d, nm_, lz_>(a, grid, lds); return 0; }
+    SF_FCONV_VARIANTS(SF_TRY)
+#undef SF_TRY
+    snprintf(err, errn, "fconv: no kernel variant for tile %dx%d norm %d lazy %d", WM, WN, a.norm, a.s1.mode);
+    return 1;
   }
   if (op->type == SF_OP_SLOTS) {
     const int M = op->i[0], C = op->i[1], HW = op->i[2];

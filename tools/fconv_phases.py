@@ -1,0 +1,25 @@
+"""Phase breakdown of k_conv_fused on the UNet's own layer shapes: per-workgroup timestamps (100 MHz clock) taken inside the
+kernel (FConvArgs.dbg) -> microseconds spent in weight-prefetch issue, statistics, staging, main loop, epilogue."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+import fused_cases as fc
+
+names = sys.argv[1:] or sorted(fc.CONV_CASES_FULL)
+for name in names:
+    kw = dict(fc.CONV_CASES_FULL[name])
+    if kw.get("accum"):
+        continue
+    dbg = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda:0")
+    wall = fc.run_conv_case("gpu", **kw, dbg=dbg, reps=20)
+    d = dbg.view(-1, 8).cpu()
+    d = d[d[:, 5] != 0].double()
+    t0 = d[:, 0].min()
+    ph = (d[:, 1:6] - d[:, 0:5]) / 100.0                      # us per phase per workgroup
+    start = (d[:, 0] - t0) / 100.0
+    end = (d[:, 5] - t0) / 100.0
+    print(f"{name:28s} WGs {d.shape[0]:4d}  wall/launch {wall * 1e6:6.1f} us  kernel span {float(end.max()):6.2f} us  "
+          f"WG start spread {float(start.max()):5.2f}")
+    for k, lab in enumerate(["prefetch-issue", "statistics", "staging", "main loop", "epilogue"]):
+        print(f"      {lab:15s} mean {float(ph[:, k].mean()):6.2f}  max {float(ph[:, k].max()):6.2f}")

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sparsefusion_amd import _lib
 from sparsefusion_amd.unet import Unet
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-NAMES = {1: "CONV", 2: "GN_ACT", 3: "LN", 4: "GEMV", 5: "ATTN", 6: "GCA_POOL", 7: "ELTWISE", 8: "MEMSET", 9: "TIME_EMB"}
+NAMES = {14: "FCONV", 15: "SLOTS", 16: "GCA", 10: "SPLITK_RED", 1: "CONV", 2: "GN_ACT", 3: "LN", 4: "GEMV", 5: "ATTN", 6: "GCA_POOL", 7: "ELTWISE", 8: "MEMSET", 9: "TIME_EMB"}
 dev = torch.device("cuda:0")
 unet = Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2), layer_attns=(False, False, False, True),
             layer_cross_attns=(False,) * 4, cond_images_channels=256, attn_pool_text=False).to(dev)
