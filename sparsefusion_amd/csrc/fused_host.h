@@ -5,6 +5,7 @@
 //   p: 0 s1.p  1 s1.a  2 s1.b  3 s1.r  4 s1.slots  5 s2.p  6 s2.slots  7 packed weights  8 bias  9 out  10 resid
 //      11 split-K slabs (S > 1)  12 slots_out  13 gamma / LN gain  14 beta / LN bias  15 scale_shift
 //      16 debug: [grid][8] int64 phase timestamps (100 MHz), normally null
+//      17 GlobalContext to_k weight [Cout]  18 partial context logits [S * n_frags][M]   (both or neither)
 //   i: 0 B  1 H  2 W  3 C1  4 C2  5 Cout  6 ldc  7 co_off  8 k (1 | 3)  9 s1.mode  10 s1.groups  11 s1.npad
 //      12 norm (FNORM_*)  13 G  14 TR (image rows per tile)  15 WM  16 WN  17 S (input-channel slices)  18 ss_stride
 //   flags: 1 SiLU after the norm, 2 GELU before the LayerNorm, 4 accumulate into out
@@ -16,6 +17,7 @@
 #include <stdio.h>
 #include "../../include/sparsefusion_hip.h"
 #include "fused_kernels.h"
+#include "fused_gca.h"
 
 #define SF_LDS_MAX 163840
 #define SF_FCONV_WAVES 8          /* waves per k_conv_fused workgroup */
@@ -49,6 +51,8 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   a.w = (const bf16x8*)op.p[7]; a.bias = (const float*)op.p[8]; a.out = (float*)op.p[9]; a.resid = (const float*)op.p[10];
   a.ws = (float*)op.p[11]; a.slots_out = (float*)op.p[12];
   a.dbg = (long long*)op.p[16];
+  a.wk = (const float*)op.p[17]; a.logit_part = (float*)op.p[18];
+  if ((a.wk == nullptr) != (a.logit_part == nullptr)) FC_FAIL("fconv: context logits need both to_k weight and the partial buffer");
   a.gamma = (const float*)op.p[13]; a.beta = (const float*)op.p[14]; a.ss = (const float*)op.p[15];
   a.B = op.i[0]; a.H = op.i[1]; a.W = op.i[2];
   a.s1.C = op.i[3]; a.s2.C = op.i[4]; a.C = a.s1.C + a.s2.C;
@@ -125,4 +129,45 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   grid = (uint32_t)a.S * MT * a.n_tiles;
   return 0;
 #undef FC_FAIL
+}
+
+// SF_OP_GCA operands (flags = stage)
+//   1 POOL  p: 0 h2  1 split-K slabs or null  2 conv bias or null  3 logit_part  4 part_pool  5 part_ms
+//           i: 0 M  1 C  2 HW  3 CH (pixels per chunk)  4 chunks per image  5 nparts  6 groups  7 npad
+//   2 NET0  p: 0 part_pool  1 part_ms  2 W0 bf16 [HID][Kp]  3 b0  4 hid ;  i: 0 B  1 C  2 Kp  3 HID  4 chunks
+//   3 GATE  p: 0 h2  1 res  2 hid  3 W2 bf16 [C][Kp2]  4 b2  5 out  6 slots or null ;  i: 0 M  1 C  2 HW  3 HID  4 Kp2
+static inline int gca_setup(const sf_op& op, GcaPoolArgs& pa, GcaNetArgs& na, GcaGateArgs& ga, uint32_t& grid, char* err, size_t errn) {
+#define GC_FAIL(...) do { snprintf(err, errn, __VA_ARGS__); return 1; } while (0)
+  if (op.flags == 1) {
+    pa.h2 = (float*)op.p[0]; pa.ws = (const float*)op.p[1]; pa.bias = (const float*)op.p[2];
+    pa.logit_part = (const float*)op.p[3]; pa.part_pool = (float*)op.p[4]; pa.part_ms = (float*)op.p[5];
+    pa.M = op.i[0]; pa.C = op.i[1]; pa.HW = op.i[2]; pa.CH = op.i[3]; pa.chunks = op.i[4]; pa.nparts = op.i[5];
+    pa.groups = op.i[6]; pa.npad = op.i[7];
+    if (!pa.h2 || !pa.logit_part || !pa.part_pool || !pa.part_ms) GC_FAIL("gca pool: missing operand");
+    if (pa.C % 64 || pa.CH < 1 || pa.CH > 128 || pa.CH * pa.chunks != pa.HW || pa.M % pa.HW || pa.nparts < 1)
+      GC_FAIL("gca pool: C %% 64, 1 <= CH <= 128, CH * chunks == HW required");
+    if (pa.ws && (pa.groups < 1 || pa.npad % 4)) GC_FAIL("gca pool: bad split-K source");
+    grid = (uint32_t)(pa.M / pa.HW) * pa.chunks * (pa.C / 64);
+    return 0;
+  }
+  if (op.flags == 2) {
+    na.part_pool = (const float*)op.p[0]; na.part_ms = (const float*)op.p[1]; na.W0 = (const __bf16*)op.p[2];
+    na.b0 = (const float*)op.p[3]; na.hid = (float*)op.p[4];
+    na.B = op.i[0]; na.C = op.i[1]; na.Kp = op.i[2]; na.HID = op.i[3]; na.chunks = op.i[4];
+    if (!na.part_pool || !na.part_ms || !na.W0 || !na.b0 || !na.hid) GC_FAIL("gca net0: missing operand");
+    if (na.C > 2048 || na.C % 8 || na.Kp < na.C || na.chunks < 1 || na.chunks > 8) GC_FAIL("gca net0: C <= 2048, 1..8 chunks");
+    grid = (uint32_t)na.B * ((na.HID + 15) / 16);
+    return 0;
+  }
+  if (op.flags == 3) {
+    ga.h2 = (const float*)op.p[0]; ga.res = (const float*)op.p[1]; ga.hid = (const float*)op.p[2];
+    ga.W2 = (const __bf16*)op.p[3]; ga.b2 = (const float*)op.p[4]; ga.out = (float*)op.p[5]; ga.slots = (float*)op.p[6];
+    ga.M = op.i[0]; ga.C = op.i[1]; ga.HW = op.i[2]; ga.HID = op.i[3]; ga.Kp2 = op.i[4];
+    if (!ga.h2 || !ga.res || !ga.hid || !ga.W2 || !ga.b2 || !ga.out) GC_FAIL("gca gate: missing operand");
+    if (ga.M % 16 || ga.C % 16 || ga.HW % 16 || ga.Kp2 % 8 || ga.Kp2 < ga.HID) GC_FAIL("gca gate: 16-aligned M, C, HW required");
+    grid = ((uint32_t)(ga.M / 16) * (ga.C / 16) + 3) / 4;
+    return 0;
+  }
+  GC_FAIL("gca: unknown stage %d", op.flags);
+#undef GC_FAIL
 }

@@ -57,6 +57,8 @@ struct FConvArgs {
   FDiv d_ncf;                            // 16-channel fragments per group
   FDiv d_cs4, d_cg, d_cps, d_tc;         // Cs/4, channels per group, chunks per slice, min(Cs/4, threads)
   int red_off, tab_off, misc_off;    // LDS byte offsets
+  const float* wk;                   // GlobalContext to_k weight [Cout] or null: the epilogue also emits partial context logits
+  float* logit_part;                 //   logit_part[(s * n_frags + n_frag) * M + m] = sum over the fragment's 16 channels of value * wk
   long long* dbg;                    // optional [grid][8] phase timestamps (tools/fconv_phases.py), null in production
 };
 
@@ -169,18 +171,35 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
   const int Cg = gn ? a.C / a.G : 1;
   // per-channel affine of this (image, slice) from the group statistics in misc[16 + 2g], misc[17 + 2g]:
   //   y = v * A + B  ==  ((v - mean) * rstd * gamma + beta) * (scale + 1) + shift
-  auto build_table = [&]() {
-    for (int cl = tid; cl < Cs; cl += NT) {
-      const int c = c0 + cl, gi = (int)fdiv((uint32_t)cl, a.d_cg);
-      const float mean = misc[16 + 2 * gi], rstd = misc[17 + 2 * gi];
-      float A = rstd * a.gamma[c], Bv = a.beta[c] - mean * A;
-      if (a.ss) {
-        const float sc = a.ss[(long)b * a.ss_stride + c] + 1.0f, sh = a.ss[(long)b * a.ss_stride + a.C + c];
-        A *= sc;
-        Bv = Bv * sc + sh;
+  // gamma / beta / scale / shift are fetched into registers NOW (their global round trip runs under the statistics)
+  constexpr int TABN = 4;                                          // Cs <= 2048 channels per slice at NT = 512
+  float tg[TABN], tb[TABN], tsc[TABN], tsh[TABN];
+  if (gn) {
+#pragma unroll
+    for (int k = 0; k < TABN; ++k) {
+      const int cl = tid + k * NT;
+      tg[k] = 1.0f; tb[k] = 0.0f; tsc[k] = 1.0f; tsh[k] = 0.0f;
+      if (cl < Cs) {
+        tg[k] = a.gamma[c0 + cl];
+        tb[k] = a.beta[c0 + cl];
+        if (a.ss) {
+          tsc[k] = a.ss[(long)b * a.ss_stride + c0 + cl] + 1.0f;
+          tsh[k] = a.ss[(long)b * a.ss_stride + a.C + c0 + cl];
+        }
       }
-      tabA[cl] = A;
-      tabB[cl] = Bv;
+    }
+  }
+  auto build_table = [&]() {
+#pragma unroll
+    for (int k = 0; k < TABN; ++k) {
+      const int cl = tid + k * NT;
+      if (cl < Cs) {
+        const int gi = (int)fdiv((uint32_t)cl, a.d_cg);
+        const float mean = misc[16 + 2 * gi], rstd = misc[17 + 2 * gi];
+        const float A = rstd * tg[k];
+        tabA[cl] = A * tsc[k];
+        tabB[cl] = (tb[k] - mean * A) * tsc[k] + tsh[k];
+      }
     }
   };
   // normalise / activate one float4 of channels [cl, cl+4) and store it as bf16 at frame pixel fp.  (A, Bv) = the
@@ -288,10 +307,12 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
       const int ngs = Cs / Cg;
       const int n_mf = HW >> 4, n_cf = (Cg >> 4) > 0 ? (Cg >> 4) : 1, cnt = n_mf * n_cf;
       const int cf1 = a.s1.C >> 4, cf2 = a.s2.C >> 4;
+      bool ring = false;
       for (int gi = wave; gi < ngs; gi += NW) {
         float sm = 0.0f, sq = 0.0f;
         for (int i0 = lane; i0 < cnt; i0 += 256) {
-          float ps[4], pq[4];
+          f32x2 sl[4];
+          float sc[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             int i = i0 + u * 64;
@@ -302,13 +323,15 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
             const bool first = cfa < cf1;
             const float* base = first ? a.s1.slots : a.s2.slots;
             const long off = first ? (mfg * cf1 + cfa) : (mfg * cf2 + (cfa - cf1));
-            const f32x2 sl = *reinterpret_cast<const f32x2*>(base + off * 2);
-            const float sc = live ? (first ? a.s1.scale : a.s2.scale) : 0.0f;
-            ps[u] = sl[0] * sc;
-            pq[u] = sl[1] * sc * sc;
+            sl[u] = *reinterpret_cast<const f32x2*>(base + off * 2);
+            sc[u] = live ? (first ? a.s1.scale : a.s2.scale) : 0.0f;
           }
-          sm += (ps[0] + ps[1]) + (ps[2] + ps[3]);
-          sq += (pq[0] + pq[1]) + (pq[2] + pq[3]);
+          if (!ring) { prefetch_weights(); ring = true; }            // behind the first slot loads, ahead of their use
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            sm = fmaf(sl[u][0], sc[u], sm);
+            sq = fmaf(sl[u][1], sc[u] * sc[u], sq);
+          }
         }
         sm = sf_wave_sum(sm);
         sq = sf_wave_sum(sq);
@@ -321,7 +344,10 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
           misc[17 + 2 * gi] = sf_rsqrt((float)var + a.eps);
         }
       }
-      prefetch_weights();
+      if (!ring) prefetch_weights();
+      FC_STAMP(1);
+      sf_sync();
+      build_table();      prefetch_weights();
       FC_STAMP(1);
       sf_sync();
       build_table();
@@ -478,9 +504,26 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
   }
 
   FC_STAMP(4);
-  // ---- epilogue: the NW K-slices of the workgroup meet in LDS
+  // ---- epilogue: the NW K-slices of the workgroup meet in LDS; wave f finalises fragment f and fetches what it needs
+  // for that (bias, residual, previous contents) BEFORE the reduction barrier
   constexpr int F = WM * WN;
   float* red = reinterpret_cast<float*>(lds + a.red_off);         // [wave][frag][r][lane]
+  const long m0 = mb + (long)row0 * a.W;
+  const int my_mi = wave / WN, my_ni = wave - my_mi * WN;         // fragment of this wave (waves >= F only contribute partials)
+  const int my_nf = nt * WN + my_ni;
+  const bool fin = wave < F && my_nf < a.n_frags;
+  const int n = my_nf * 16 + (lane & 15);
+  const long mrow = m0 + my_mi * 16 + (lane >> 4) * 4;
+  float bv = 0.0f, rv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (fin && a.S == 1 && n < a.Cout) {
+    if (a.bias) bv = a.bias[n];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long o = (mrow + r) * a.ldc + a.co_off + n;
+      if (a.resid) rv[r] = a.resid[o];
+      if (a.accum) rv[r] += a.out[o];
+    }
+  }
 #pragma unroll
   for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
@@ -488,41 +531,36 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[((wave * F + mi * WN + ni) * 4 + r) * 64 + lane] = acc[mi][ni][r];
   sf_sync();
-  const long m0 = mb + (long)row0 * a.W;
+  if (fin) {
+    const int f = wave;
+    float v[4];
 #pragma unroll
-  for (int mi = 0; mi < WM; ++mi) {
+    for (int r = 0; r < 4; ++r) {
+      const int idx = (f * 4 + r) * 64 + lane;
+      float sacc = 0.0f;
 #pragma unroll
-    for (int ni = 0; ni < WN; ++ni) {
-      const int f = mi * WN + ni;
-      if ((f % NW) != wave) continue;
-      const int nf = nt * WN + ni;
-      if (nf >= a.n_frags) continue;
-      float v[4];
+      for (int w = 0; w < NW; ++w) sacc += red[idx + w * F * 256];
+      v[r] = sacc;
+    }
+    if (a.logit_part) {                      // bias terms are the same for every pixel: they cancel in the softmax
+      const float wkv = n < a.Cout ? a.wk[n] : 0.0f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int idx = (f * 4 + r) * 64 + lane;
-        float sacc = 0.0f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) sacc += red[idx + w * F * 256];
-        v[r] = sacc;
+        float lp = v[r] * wkv;
+        lp += sf_shfl_xor(lp, 1); lp += sf_shfl_xor(lp, 2); lp += sf_shfl_xor(lp, 4); lp += sf_shfl_xor(lp, 8);
+        if ((lane & 15) == 0) a.logit_part[((long)s * a.n_frags + my_nf) * a.M + mrow + r] = lp;
       }
-      const int n = nf * 16 + (lane & 15);
-      const long mrow = m0 + mi * 16 + (lane >> 4) * 4;
-      if (a.S > 1) {
+    }
+    if (a.S > 1) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.ws[((long)s * a.M + mrow + r) * a.npad + n] = v[r];
-        continue;
-      }
+      for (int r = 0; r < 4; ++r) a.ws[((long)s * a.M + mrow + r) * a.npad + n] = v[r];
+    } else {
       float sm = 0.0f, sq = 0.0f;
       if (n < a.Cout) {
-        const float bv = a.bias ? a.bias[n] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const long o = (mrow + r) * a.ldc + a.co_off + n;
-          float y = v[r] + bv;
-          if (a.resid) y += a.resid[o];
-          if (a.accum) y += a.out[o];
-          a.out[o] = y;
+          const float y = v[r] + bv + rv[r];
+          a.out[(mrow + r) * a.ldc + a.co_off + n] = y;
           sm += y;
           sq = fmaf(y, y, sq);
         }
@@ -531,7 +569,7 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
         sm = sf_wave_sum(sm);
         sq = sf_wave_sum(sq);
         if (lane == 0) {
-          float* sl = a.slots_out + (((m0 >> 4) + mi) * (long)(a.ldc >> 4) + (a.co_off >> 4) + nf) * 2;
+          float* sl = a.slots_out + (((m0 >> 4) + my_mi) * (long)(a.ldc >> 4) + (a.co_off >> 4) + my_nf) * 2;
           sl[0] = sm;
           sl[1] = sq;
         }

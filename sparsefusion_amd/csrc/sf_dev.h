@@ -19,6 +19,8 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 static inline void sf_sync() { hipemu::syncthreads(); }
 template <class T>
 static inline T sf_shfl_xor(T v, int m) { return hipemu::shfl_xor(v, m); }
+template <class T>
+static inline T sf_shfl(T v, int src) { return hipemu::shfl_xor(v, (src ^ hipemu::t_lane) & 63); }
 static inline float sf_exp(float v) { return expf(v); }
 static inline void sf_lds_add(float* p, float v) {
   uint32_t* u = reinterpret_cast<uint32_t*>(p);
@@ -64,6 +66,8 @@ static inline f32x4 sf_mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 SF_DEV void sf_sync() { __syncthreads(); }
 template <class T>
 SF_DEV T sf_shfl_xor(T v, int m) { return __shfl_xor(v, m, 64); }
+template <class T>
+SF_DEV T sf_shfl(T v, int src) { return __shfl(v, src, 64); }
 SF_DEV float sf_exp(float v) { return __expf(v); }
 SF_DEV void sf_lds_add(float* p, float v) { atomicAdd(p, v); }
 SF_DEV float sf_rsqrt(float v) { return rsqrtf(v); }

@@ -47,11 +47,25 @@ static int run_slots(const sf_op& op, hipStream_t st) {
   return SF_OK;
 }
 
+static int run_gca(const sf_op& op, hipStream_t st) {
+  GcaPoolArgs pa;
+  GcaNetArgs na;
+  GcaGateArgs ga;
+  uint32_t grid;
+  if (gca_setup(op, pa, na, ga, grid, sf_err_buf, sizeof(sf_err_buf))) return SF_ERR_INVALID;
+  if (op.flags == 1) k_gca_pool<<<grid, 256, 0, st>>>(pa);
+  else if (op.flags == 2) k_gca_net0<<<grid, 256, 0, st>>>(na);
+  else k_gca_gate<<<grid, 256, 0, st>>>(ga);
+  SF_CHECK_LAUNCH("gca");
+  return SF_OK;
+}
+
 int sf_plan_fused_op(const sf_op* op, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   switch (op->type) {
     case SF_OP_FCONV: return run_fconv(*op, st);
     case SF_OP_SLOTS: return run_slots(*op, st);
+    case SF_OP_GCA: return run_gca(*op, st);
     default: SF_FAIL(SF_ERR_INVALID, "fused: unknown op type %d", op->type);
   }
 }

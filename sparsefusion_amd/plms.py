@@ -74,7 +74,17 @@ class PLMSSampler():
         img = image if max_thres >= .99 else x_noisy
         tl = times.tolist()
 
+        # the UNet's time path depends on the step only: one table for the whole trajectory (Unet.time_table), every
+        # eval then replays the body of the plan (classifier-free guidance, cond_scale != 1, keeps the generic path)
+        fast = cond_scale == 1 and hasattr(unet, "begin_sampling") and len(tl) > 1
+        if fast:
+            eval_times = list(dict.fromkeys(tl[:-1] + [tl[1]]))     # every step's t, plus t_next of the first (improved Euler)
+            row_of = {t: k for k, t in enumerate(eval_times)}
+            ctx = unet.begin_sampling(cond_images, torch.stack([alpha_cosine_log_snr(_f(t)) for t in eval_times]).to(dev))
+
         def eps_model(x, t):
+            if fast:
+                return unet.eval_prepared(ctx, x, row_of[t]).clone()
             ls = torch.full((B,), float(alpha_cosine_log_snr(_f(t))), dtype=torch.float32, device=dev)
             return unet.forward_with_cond_scale(x, ls, cond_images=cond_images, cond_scale=cond_scale)
 

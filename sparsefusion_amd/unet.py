@@ -311,7 +311,7 @@ class _Plan:
         self.op(OP_GN_ACT, 0 if silu else 1,
                 p=(x.ptr, skip.ptr if skip else 0, self.wptr(gname + ".weight"), self.wptr(gname + ".bias"), ss_ptr, out.ptr,
                    raw.ptr if raw else 0, stats) + lp,
-                i=(self.B, x.HW, C1, C2, self.u.ss_total) + li + (groups,), f=(eps, SKIP_SCALE))
+                i=(self.B, x.HW, C1, C2, getattr(self.u, "tb_stride", 0)) + li + (groups,), f=(eps, SKIP_SCALE))
 
     def ln(self, x, gname, bname, out, C, rows, eps=1e-5, gelu=False, out_f32=False, resid=None):
         self.need(x)
@@ -393,7 +393,7 @@ class _Plan:
         return t
 
     def fconv(self, x, skip, H, wname, bname, out, Cout, k, norm, geom, gname=None, ss_ptr=0, silu=True, resid=None,
-              want_slots=False, pre_gelu=False, beta_name=None, ldc=None, co_off=0):
+              want_slots=False, pre_gelu=False, beta_name=None, ldc=None, co_off=0, logit=None):
         """One k_conv_fused launch: out = conv_k(act(norm(concat(x, skip * 2^-1/2)))).  With S > 1 input-channel slices the
         output stays a lazy split-K tensor (slabs + bias + resid) that the next fused conv / GroupNorm / gca pass reduces."""
         TR, WM, WN, S = geom
@@ -431,8 +431,9 @@ class _Plan:
         bet = self.wptr(gname + ".bias") if norm in (FNORM_GN_SELF, FNORM_GN_SLOTS) else (self.wptr(beta_name) if beta_name else 0)
         self.op(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0),
                 p=(x.ptr, lp[0], lp[1], lp[2], x.slots or 0, skip.ptr if skip else 0, (skip.slots or 0) if skip else 0,
-                   self.wptr(wname), 0 if S > 1 else bias, out.ptr, 0 if S > 1 else res, ws, slots_out, gam, bet, ss_ptr),
-                i=(B, H, H, C1, C2, Cout, ldc, co_off, k, li[0], li[1], li[2], norm, 8, TR, WM, WN, S, self.u.ss_total),
+                   self.wptr(wname), 0 if S > 1 else bias, out.ptr, 0 if S > 1 else res, ws, slots_out, gam, bet, ss_ptr, 0,
+                   logit[0] if logit else 0, logit[1] if logit else 0),
+                i=(B, H, H, C1, C2, Cout, ldc, co_off, k, li[0], li[1], li[2], norm, 8, TR, WM, WN, S, self.u.tb_stride),
                 f=(1e-5, 1.0, SKIP_SCALE))
         if S > 1:
             out.lazy = ("splitk", ws, bias, res, S, n_frags * 16, wi)
@@ -469,10 +470,41 @@ class _Plan:
             self.fconv(h, None, H, w2, b2, out, cout, 3, norm, g2, gname=gn2, ss_ptr=ss_ptr, resid=res, want_slots=slots)
             return out
         h2 = self.zf32(rows, cout, HW)
+        if cout % 64 == 0 and cout <= 2048 and HW % 16 == 0:
+            # fused GlobalContext: conv2's epilogue leaves partial context logits, then pool -> net0 -> gate (+ residual, + slots)
+            nparts = g2[3] * (cout // 16)
+            lpart = self.f32(nparts, rows)
+            self.fconv(h, None, H, w2, b2, h2, cout, 3, norm, g2, gname=gn2, ss_ptr=ss_ptr,
+                       logit=(self.wptr(f"{name}.gca.to_k.weight"), lpart.ptr))
+            self.gca_fused(name, h2, cout, res, out, lpart, nparts, slots)
+            return out
         self.fconv(h, None, H, w2, b2, h2, cout, 3, norm, g2, gname=gn2, ss_ptr=ss_ptr)
         gate = self.gca_gate(name, h2, cout)
         out.lazy = ("gate", h2.ptr, gate.ptr, res.ptr)
         return out
+
+    def gca_fused(self, name, h2, cout, res, out, lpart, nparts, want_slots):
+        """GlobalContext + gated residual in three launches (csrc/fused_gca.h): out = h2 * gca(h2) + res, materialised, with
+        its statistics slots when the consumer is a slot-GroupNorm conv."""
+        B, HW, rows = self.B, h2.HW, h2.rows
+        chunks = min(8, HW // 16)
+        CH = HW // chunks
+        hidc = max(3, cout // 2)
+        part_pool, part_ms, hid = self.f32(B * chunks, cout), self.f32(B * chunks, 2), self.f32(B, hidc)
+        ws = bias = groups = npad = 0
+        if h2.lazy is not None:
+            assert h2.lazy[0] == "splitk" and not h2.lazy[3]
+            _, ws, bias, _, groups, npad, wi = h2.lazy
+            h2.lazy = None
+            self.ws_owners[wi] = None
+        self.need(res)
+        self.op(OP_GCA, 1, p=(h2.ptr, ws, bias, lpart.ptr, part_pool.ptr, part_ms.ptr), i=(rows, cout, HW, CH, chunks, nparts, groups, npad))
+        self.op(OP_GCA, 2, p=(part_pool.ptr, part_ms.ptr, self.wptr(f"{name}.gca.net.0.weight"), self.wptr(f"{name}.gca.net.0.bias"),
+                              hid.ptr), i=(B, cout, (cout + 7) // 8 * 8, hidc, chunks))
+        if want_slots:
+            out.slots = self.misc.alloc(rows // 16 * (cout // 16) * 2 * 4)
+        self.op(OP_GCA, 3, p=(h2.ptr, res.ptr, hid.ptr, self.wptr(f"{name}.gca.net.2.weight"), self.wptr(f"{name}.gca.net.2.bias"),
+                              out.ptr, out.slots or 0), i=(rows, cout, HW, hidc, (hidc + 7) // 8 * 8))
 
     def gca_gate(self, name, h2, cout):
         """GlobalContext gate of h2 (imagen_pytorch.py:916-941): softmax-pooled context -> two 1x1 convs -> sigmoid."""
@@ -557,11 +589,10 @@ class _Plan:
         self.ln(h, f"{name}.norm.g", None, xn, d, rows)
         q = self.zf32(rows, inner)
         self.conv(xn, False, 1, rows // B, f"{name}.to_q.weight", None, q, inner, 0, inner, 1)
-        kv = self.f32(2 * B, inner * 2)
-        self.gemv(self.c.ptr, 2 * B, self.u.cond_dim, f"{name}.to_kv.weight", None, kv.ptr, inner * 2, inner * 2, self.u.cond_dim)
         att = self.bf16(rows, inner)
         nk = self.wptr(f"{name}.null_kv")
-        segs = [(nk, nk + dh * 4, 1, 0, 0, 0), (kv.ptr, kv.ptr + inner * 4, 2, inner * 2, 2 * inner * 2, dh)]
+        kvp = self.tb.ptr + self.u.tb_off[name] * 4            # k/v of the 2 time tokens: computed by emit_time (time-only)
+        segs = [(nk, nk + dh * 4, 1, 0, 0, 0), (kvp, kvp + inner * 4, 2, inner * 2, self.u.tb_stride, dh)]
         self.attn(q, att, segs, heads, inner, dh ** -0.5)
         return self._attn_out(name, att, h, d, rows)
 
@@ -577,11 +608,8 @@ class _Plan:
         self.conv(xn, False, 1, rows // B, f"{name}.to_kv.weight", None, kv, 2 * dh, 0, 2 * dh, 1)
         segs = []
         if context:
-            cn, ckv = self.f32(2 * B, self.u.cond_dim), self.f32(2 * B, 2 * dh)
-            self.ln(self.c, f"{name}.to_context.0.weight", f"{name}.to_context.0.bias", cn, self.u.cond_dim, 2 * B, out_f32=True)
-            self.gemv(cn.ptr, 2 * B, self.u.cond_dim, f"{name}.to_context.1.weight", f"{name}.to_context.1.bias", ckv.ptr,
-                      2 * dh, 2 * dh, self.u.cond_dim)
-            segs.append((ckv.ptr, ckv.ptr + dh * 4, 2, 2 * dh, 2 * 2 * dh, 0))
+            ckvp = self.tb.ptr + self.u.tb_off[name] * 4
+            segs.append((ckvp, ckvp + dh * 4, 2, 2 * dh, self.u.tb_stride, 0))
         nk = self.wptr(f"{name}.null_kv")
         tok = rows // B
         segs += [(nk, nk + dh * 4, 1, 0, 0, 0), (kv.ptr, kv.ptr + dh * 4, tok, 2 * dh, tok * 2 * dh, 0)]
@@ -603,6 +631,34 @@ class _Plan:
         self.conv(xn3, False, 1, rows // B, f"{name}.layers.0.1.4.weight", None, x2, d, 0, d, 1, resid=x1)
         return x2
 
+    # -------- time path (imagen_pytorch.py:1175-1190, :1514-1604) + the context projections that depend on it alone
+    def emit_time(self, rows, tb_ptr, t_ptr):
+        """Ops that fill `rows` time-block rows (u.tb_stride floats each, layout u.tb_off) from `rows` log-snr values."""
+        u = self.u
+        st = u.tb_stride
+        half = u.learned_sinu_pos_emb_dim // 2
+        heads, dh = u.attn_heads, u.attn_dim_head
+        four, hid, t = self.f32(rows, 2 * half + 1), self.f32(rows, u.tdim), self.f32(rows, u.tdim)
+        tok = self.f32(rows, 2 * u.cond_dim)
+        self.op(OP_TIME_EMB, 0, p=(t_ptr, self.wptr("to_time_hiddens.0.weights"), 0, four.ptr), i=(rows, half))
+        self.gemv(four.ptr, rows, four.C, "to_time_hiddens.1.weight", "to_time_hiddens.1.bias", hid.ptr, u.tdim, u.tdim, four.C, out_act=1)
+        self.gemv(hid.ptr, rows, u.tdim, "to_time_cond.0.weight", "to_time_cond.0.bias", t.ptr, u.tdim, u.tdim, u.tdim)
+        self.gemv(hid.ptr, rows, u.tdim, "to_time_tokens.0.weight", "to_time_tokens.0.bias", tok.ptr, 2 * u.cond_dim, 2 * u.cond_dim, u.tdim)
+        c = self.f32(2 * rows, u.cond_dim)                 # the 2 time tokens of every row, norm_cond applied
+        self.ln(tok, "norm_cond.weight", "norm_cond.bias", c, u.cond_dim, 2 * rows, out_f32=True)
+        # all 27 time_mlp outputs in one GEMV (SiLU -> Linear)
+        self.gemv(t.ptr, rows, u.tdim, "__time_mlps__.weight", "__time_mlps__.bias", tb_ptr, st, u.ss_total, u.tdim, in_silu=True)
+        for name, off in u.tb_off.items():
+            if name.endswith(".cross_attn.fn"):            # CrossAttention.to_kv(context) (:731-805)
+                n_out, src, wname, bname = 2 * heads * dh, c, f"{name}.to_kv.weight", None
+            else:                                          # Attention.to_context = LayerNorm + Linear (:480-566)
+                src = self.f32(2 * rows, u.cond_dim)
+                self.ln(c, f"{name}.to_context.0.weight", f"{name}.to_context.0.bias", src, u.cond_dim, 2 * rows, out_f32=True)
+                n_out, wname, bname = 2 * dh, f"{name}.to_context.1.weight", f"{name}.to_context.1.bias"
+            for tk in range(2):                            # token tk of every row -> its k|v slot of that row's block
+                self.gemv(src.ptr + tk * u.cond_dim * 4, rows, 2 * u.cond_dim, wname, bname, tb_ptr + (off + tk * n_out) * 4, st,
+                          n_out, u.cond_dim)
+
     # -------- whole network
     def build(self):
         u, B = self.u, self.B
@@ -612,23 +668,14 @@ class _Plan:
         cpad = (cin0 + 31) // 32 * 32
         self.x_in, self.t_in = self.f32(B, u.channels * HW), self.f32(B, 1)
         self.cond_in = self.f32(B, u.cond_images_channels * HW)
+        self.tb = self.f32(B, u.tb_stride)
+        self.ss = self.tb
+        self.emit_time(B, self.tb.ptr, self.t_in.ptr)
+        self.n_time_ops = len(self.ops)                   # a sampler replays ops[n_time_ops:] after gathering its table row
         self.op(OP_MEMSET, 0, p=(self.zero.buf.data_ptr() if self.zero.buf is not None else 1,), i=(0,))   # size patched below
         memset_op = self.ops[-1]
         xin = self.f32(B * HW, cpad, HW)
         self.op(OP_ELTWISE, 2, p=(self.cond_in.ptr, self.x_in.ptr, 0, xin.ptr), i=(B, HW, u.cond_images_channels, u.channels, cpad))
-        # time path (imagen_pytorch.py:1175-1190, :1514-1604)
-        half = u.learned_sinu_pos_emb_dim // 2
-        four, hid, t = self.f32(B, 2 * half + 1), self.f32(B, u.tdim), self.f32(B, u.tdim)
-        tok = self.f32(B, 2 * u.cond_dim)
-        self.op(OP_TIME_EMB, 0, p=(self.t_in.ptr, self.wptr("to_time_hiddens.0.weights"), 0, four.ptr), i=(B, half))
-        self.gemv(four.ptr, B, four.C, "to_time_hiddens.1.weight", "to_time_hiddens.1.bias", hid.ptr, u.tdim, u.tdim, four.C, out_act=1)
-        self.gemv(hid.ptr, B, u.tdim, "to_time_cond.0.weight", "to_time_cond.0.bias", t.ptr, u.tdim, u.tdim, u.tdim)
-        self.gemv(hid.ptr, B, u.tdim, "to_time_tokens.0.weight", "to_time_tokens.0.bias", tok.ptr, 2 * u.cond_dim, 2 * u.cond_dim, u.tdim)
-        self.c = self.f32(2 * B, u.cond_dim)
-        self.ln(tok, "norm_cond.weight", "norm_cond.bias", self.c, u.cond_dim, 2 * B, out_f32=True)
-        self.ss = self.f32(B, u.ss_total)                 # all 27 time_mlp outputs in one GEMV (SiLU -> Linear)
-        self.gemv(t.ptr, B, u.tdim, "__time_mlps__.weight", "__time_mlps__.bias", self.ss.ptr, u.ss_total, u.ss_total, u.tdim,
-                  in_silu=True)
         # init conv: CrossEmbedLayer k = 3 / 7 / 15 into channel slices (:1017-1042)
         x = self.zf32(B * HW, u.dim, HW)
         co = 0
@@ -678,8 +725,13 @@ class _Plan:
         self.out = self.f32(B, u.channels * HW)
         self.op(OP_ELTWISE, 3, p=(o.ptr, 0, 0, self.out.ptr), i=(B, HW, u.channels, u.channels))
         memset_op.i[0] = (self.zero.off + 3) // 4
+        if self.zero.off == 0:                          # nothing accumulates with atomics in this plan: no memset launch
+            self.ops.remove(memset_op)
         self.op_array = (_lib.SfOp * len(self.ops))(*self.ops)
+        body = self.ops[self.n_time_ops:]
+        self.body_array = (_lib.SfOp * len(body))(*body)
         if self.misc.buf is not None:
+            self.tb_view = self.tview(self.tb)
             self.x_view, self.t_view = self.tview(self.x_in), self.tview(self.t_in)
             self.cond_view, self.out_view = self.tview(self.cond_in), self.tview(self.out)
         return self
@@ -688,6 +740,20 @@ class _Plan:
         """torch view of a planned fp32 buffer of the misc arena (static input / output staging)."""
         off = t.ptr - self.misc.buf.data_ptr()
         return self.misc.buf[off:off + t.rows * t.C * 4].view(torch.float32).view(t.rows, t.C)
+
+
+class _TimePlan(_Plan):
+    """The time path alone, for T time steps at once: one table row per step (Unet.time_table)."""
+
+    def build(self):
+        T = self.B
+        self.t_in = self.f32(T, 1)
+        self.table = self.f32(T, self.u.tb_stride)
+        self.emit_time(T, self.table.ptr, self.t_in.ptr)
+        self.op_array = (_lib.SfOp * len(self.ops))(*self.ops)
+        if self.misc.buf is not None:
+            self.t_view, self.table_view = self.tview(self.t_in), self.tview(self.table)
+        return self
 
 
 class Unet(nn.Module):
@@ -737,6 +803,18 @@ class Unet(nn.Module):
                 self.ss_offset[name[:-len(".time_mlp.1.weight")]] = off
                 off += shape[0]
         self.ss_total = off
+        # "time block": everything of one eval that depends on the time ONLY, one row per batch element --
+        # [all (scale, shift) pairs | per attention-with-context: k/v of the 2 time tokens | per cross-attention: k/v of the 2 time
+        # tokens].  A sampler evaluates it once per trajectory for all its time steps (`time_table`), the eval gathers one row.
+        self.tb_off = {}
+        for name, shape in spec:
+            if name.endswith(".to_context.1.weight"):
+                self.tb_off[name[:-len(".to_context.1.weight")]] = off
+                off += 2 * shape[0]
+            elif name.endswith(".cross_attn.fn.to_kv.weight"):
+                self.tb_off[name[:-len(".to_kv.weight")]] = off
+                off += 2 * shape[0]
+        self.tb_stride = (off + 63) // 64 * 64
         self.conv_waves_target = 1024       # waves wanted per conv launch (4 per CU) before split-K stops
         self.lds_conv_min_blocks = 96       # use k_conv_lds when a layer has at least this many 128 x 128 output tiles
         self.lazy_consumers = 3             # bit 0: split-K reductions, bit 1: gated residuals are materialised by their first consumer
@@ -914,8 +992,65 @@ class Unet(nn.Module):
         return plan.out_view.clone().view(B, self.channels, self.image_size, self.image_size)
 
     @staticmethod
-    def _run_plan(plan):
-        _lib.check(_lib.lib().sf_plan_run(plan.op_array, len(plan.ops), _lib.stream_ptr()), "unet plan")
+    def _run_plan(plan, body_only=False):
+        if body_only:
+            _lib.check(_lib.lib().sf_plan_run(plan.body_array, len(plan.ops) - plan.n_time_ops, _lib.stream_ptr()), "unet plan")
+        else:
+            _lib.check(_lib.lib().sf_plan_run(plan.op_array, len(plan.ops), _lib.stream_ptr()), "unet plan")
+
+    # ---- sampler fast path: the time path is evaluated once per trajectory, the eval replays the body only
+    def _time_plan(self, T, device):
+        key = ("time", T, str(device))
+        if key not in self._plans:
+            sizing = _TimePlan(self, T, device).build()
+            self._plans[key] = _TimePlan(self, T, device, (sizing.zero.off, sizing.misc.off + 512, 0, 0)).build()
+        return self._plans[key]
+
+    @torch.no_grad()
+    def time_table(self, log_snrs):
+        """[T, tb_stride] time-block rows for T log-snr values: time MLPs, every ResnetBlock's (scale, shift), and the k/v of the
+        time tokens of every attention that sees them (external/imagen_pytorch.py:1514-1604) -- everything that depends on
+        the time alone.  One call per sampler trajectory replaces ~14 launches and a 72 MB weight read in each eval."""
+        _lib.require_cuda(log_snrs)
+        T = log_snrs.numel()
+        plan = self._time_plan(T, log_snrs.device)
+        plan.t_view.copy_(log_snrs.reshape(T, 1))
+        _lib.check(_lib.lib().sf_plan_run(plan.op_array, len(plan.ops), _lib.stream_ptr()), "unet time plan")
+        return plan.table_view.clone()
+
+    @torch.no_grad()
+    def begin_sampling(self, cond_images, log_snrs):
+        """Prepare a trajectory: time table for `log_snrs` [T] + the (fixed) conditioning image.  Returns the context for
+        `eval_prepared`.  Same numerics as `forward` (same kernels, same operands), fewer launches per eval."""
+        _lib.require_cuda(cond_images)
+        B = cond_images.shape[0]
+        if cond_images.shape[-1] != self.image_size:
+            cond_images = torch.nn.functional.interpolate(cond_images, self.image_size, mode='nearest')
+        plan = self._plan(B, cond_images.device)
+        plan.cond_view.copy_(cond_images.reshape(B, -1))
+        return {"plan": plan, "table": self.time_table(log_snrs), "B": B}
+
+    @torch.no_grad()
+    def eval_prepared(self, ctx, x, row):
+        """eps = unet(x, time = log_snrs[row]) for a context of `begin_sampling`.  `x` may be ctx['plan'].x_view itself (a
+        sampler that writes its latents there saves the copy).  Returns a VIEW of the plan's output buffer: consume or clone
+        it before the next eval."""
+        plan, B = ctx["plan"], ctx["B"]
+        if x.data_ptr() != plan.x_view.data_ptr():
+            plan.x_view.copy_(x.reshape(B, -1))
+        plan.tb_view.copy_(ctx["table"][row].expand(B, -1))
+        if self.use_hip_graph and not torch.cuda.is_current_stream_capturing():
+            if getattr(plan, "body_graph", None) is None:
+                self._run_plan(plan, True)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._run_plan(plan, True)
+                plan.body_graph = g
+            plan.body_graph.replay()
+        else:
+            self._run_plan(plan, True)
+        return plan.out_view.view(B, self.channels, self.image_size, self.image_size)
 
     def forward_with_cond_scale(self, *args, cond_scale=1., **kwargs):
         """imagen_pytorch.py:1456-1468: classifier-free guidance = a second eval with the condition dropped."""

@@ -44,7 +44,7 @@ def run_ops(ops, backend):
 
 
 def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, silu=True, ss=True, accum=False, resid=False,
-                  slots=True, pre_gelu=False, ln_bias=False, seed=0, G=8, scale2=2 ** -0.5, tol=4e-3, dbg=None, reps=1):
+                  slots=True, pre_gelu=False, ln_bias=False, seed=0, G=8, scale2=2 ** -0.5, tol=4e-3, dbg=None, reps=1, logits=False):
     dev = "cpu" if backend == "emu" else "cuda:0"
     d = lambda t: None if t is None else t.to(dev)
     g = torch.Generator().manual_seed(seed)
@@ -98,8 +98,12 @@ def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, 
     sl2 = d(slots_of(x2, M, C2)) if (norm == GN_SLOTS and C2) else None
     x2_d, bias_d, gamma_d, ssv_d = d(x2), d(bias), d(gamma), d(ssv)
     beta_d = d(beta) if (norm != LN or ln_bias) else None
+    n_frags = (Cout + 15) // 16
+    wk = rn(Cout) if logits else None
+    wk_d = d(wk)
+    lpart = d(torch.full((S * n_frags, M), float("nan"))) if logits else None
     op = fused.mkop(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0),
-                    p=(s1["p"], s1["a"], s1["b"], s1["r"], sl1, x2_d, sl2, wp, bias_d, out, res_d, wsl, slots_out, gamma_d, beta_d, ssv_d, dbg),
+                    p=(s1["p"], s1["a"], s1["b"], s1["r"], sl1, x2_d, sl2, wp, bias_d, out, res_d, wsl, slots_out, gamma_d, beta_d, ssv_d, dbg, wk_d, lpart),
                     i=(B, H, W, C1, C2, Cout, ldc, co_off, k, s1["mode"], s1["groups"], s1["npad"], norm, G, TR, WM, WN, S, 2 * C),
                     f=(1e-5, 1.0, scale2))
     run_ops([op], backend)
@@ -126,6 +130,10 @@ def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, 
     assert e < tol, f"conv mismatch rel {e}"
     if lazy:
         assert torch.allclose(s1["p"].cpu(), x1, atol=1e-5), "lazy source not materialised correctly"
+    if logits:                                           # partial context logits: per-pixel sums equal value . wk (bias excluded when sliced)
+        assert not (accum or resid)                      # the GlobalContext input is the bare conv output (bias is pixel-constant)
+        val = got if S > 1 else out[:, co_off:co_off + Cout] - bias
+        assert torch.allclose(lpart.cpu().sum(0), val @ wk, rtol=1e-3, atol=2e-3), "context logits wrong"
     if slots_out is not None:
         sl = slots_of(out[:, co_off:co_off + Cout].contiguous(), M, Cout)
         got_sl = slots_out.cpu()[:, co_off // 16:co_off // 16 + Cout // 16]
@@ -148,17 +156,68 @@ def run_slots_case(backend):
     assert torch.allclose(sl2.cpu(), slots_of(x, M, C), rtol=1e-5, atol=1e-4)
 
 
+def run_gca_case(backend, B, H, C, lazy=False, seed=0):
+    """k_gca_pool -> k_gca_net0 -> k_gca_gate against GlobalContext + gated residual (imagen_pytorch.py:916-941, :727-729)."""
+    dev = "cpu" if backend == "emu" else "cuda:0"
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    HW, M, HID = H * H, B * H * H, max(3, C // 2)
+    h2, res, wk = rn(M, C), rn(M, C), rn(C) * 0.3
+    W0, b0, W2, b2 = rn(HID, C) / C ** 0.5, rn(HID) * 0.1, rn(C, HID) / HID ** 0.5, rn(C) * 0.1
+    sm = torch.softmax((h2 @ wk).view(B, HW), 1)
+    pooled = (sm[:, :, None] * h2.view(B, HW, C)).sum(1)
+    hid = F.silu(pooled @ bf(W0).t() + b0)
+    gate = torch.sigmoid(hid @ bf(W2).t() + b2)
+    want = h2 * gate.repeat_interleave(HW, 0) + res
+    nparts = C // 16
+    lpart = (h2 * wk).view(M, nparts, 16).sum(-1).t().contiguous() + 3.0       # a per-pixel-constant shift must not matter
+    chunks = min(8, HW // 16)
+    CH = HW // chunks
+    Kp, Kp2 = (C + 7) // 8 * 8, (HID + 7) // 8 * 8
+    dv = lambda t: t.to(dev)
+    if lazy:
+        groups, npad = 3, C + 16
+        ws = rn(groups, M, npad)
+        bias = rn(C)
+        ws[0, :, :C] = h2 - ws[1:, :, :C].sum(0) - bias
+        h2_d, ws_d, bias_d = dv(torch.full((M, C), float("nan"))), dv(ws), dv(bias)
+    else:
+        groups = npad = 0
+        h2_d, ws_d, bias_d = dv(h2), None, None
+    lp_d, res_d = dv(lpart), dv(res)
+    part_pool, part_ms = torch.zeros(B * chunks, C, device=dev), torch.zeros(B * chunks, 2, device=dev)
+    W0p = dv(F.pad(W0, (0, Kp - C)).to(torch.bfloat16).contiguous())
+    W2p = dv(F.pad(W2, (0, Kp2 - HID)).to(torch.bfloat16).contiguous())
+    b0_d, b2_d = dv(b0), dv(b2)
+    hid_d, out = torch.zeros(B, HID, device=dev), torch.zeros(M, C, device=dev)
+    slots = torch.zeros(M // 16, C // 16, 2, device=dev)
+    ops = [fused.mkop(OP_GCA, 1, p=(h2_d, ws_d, bias_d, lp_d, part_pool, part_ms), i=(M, C, HW, CH, chunks, nparts, groups, npad)),
+           fused.mkop(OP_GCA, 2, p=(part_pool, part_ms, W0p, b0_d, hid_d), i=(B, C, Kp, HID, chunks)),
+           fused.mkop(OP_GCA, 3, p=(h2_d, res_d, hid_d, W2p, b2_d, out, slots), i=(M, C, HW, HID, Kp2))]
+    run_ops(ops, backend)
+    assert torch.allclose(hid_d.cpu(), hid, rtol=2e-4, atol=2e-5), "hidden vector wrong"
+    assert torch.allclose(out.cpu(), want, rtol=2e-4, atol=2e-4), "gated residual wrong"
+    assert torch.allclose(slots.cpu(), slots_of(want, M, C), rtol=1e-4, atol=2e-3)
+    if lazy:
+        assert torch.allclose(h2_d.cpu(), h2, atol=1e-5)
+
+
+GCA_CASES = {"4x4_lazy": dict(B=2, H=4, C=128, lazy=True), "8x8": dict(B=1, H=8, C=64, seed=1), "16x16": dict(B=1, H=16, C=64, seed=2)}
+GCA_CASES_FULL = {"unet_4x4": dict(B=1, H=4, C=1024, lazy=True, seed=3), "unet_8x8": dict(B=1, H=8, C=1024, seed=4),
+                  "unet_32x32": dict(B=1, H=32, C=256, seed=5), "unet_b4_16x16": dict(B=4, H=16, C=512, seed=6)}
+
+
 # name -> kwargs of run_conv_case; small enough for the CPU-thread emulator, and every kernel path is in here
 CONV_CASES = {
     # the 4x4 level: whole image per tile, input-channel slices, lazy split-K source, partial slabs out
-    "gn_self_sliced_lazy_splitk_4x4": dict(B=2, H=4, W=4, C1=64, C2=0, Cout=48, k=3, norm=GN_SELF, WM=1, WN=1, S=2, lazy=1),
+    "gn_self_sliced_lazy_splitk_4x4": dict(B=2, H=4, W=4, C1=64, C2=0, Cout=48, k=3, norm=GN_SELF, WM=1, WN=1, S=2, lazy=1, logits=True),
     "gn_self_concat_gate_lazy_4x4": dict(B=1, H=4, W=4, C1=64, C2=64, Cout=32, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=2, seed=1),
     # 8x8 level: 2-row tiles with halo rows from neighbouring tiles, statistics from producer slots, final epilogue + slots
     "gn_slots_concat_8x8": dict(B=1, H=8, W=8, C1=128, C2=128, Cout=32, k=3, norm=GN_SLOTS, WM=1, WN=1, resid=True, seed=2),
     # 32-pixel rows (WM = 2), 2 n-fragments per tile, accumulate mode
     "gn_slots_wide_rows_wm2_wn2": dict(B=2, H=4, W=32, C1=128, C2=0, Cout=64, k=3, norm=GN_SLOTS, WM=2, WN=2, accum=True, seed=3),
     # XCD-aware tile order (8 n-tiles)
-    "gn_slots_xcd_map_16x16": dict(B=1, H=16, W=16, C1=128, C2=0, Cout=128, k=3, norm=GN_SLOTS, WM=1, WN=1, ss=False, seed=4),
+    "gn_slots_xcd_map_16x16": dict(B=1, H=16, W=16, C1=128, C2=0, Cout=128, k=3, norm=GN_SLOTS, WM=1, WN=1, ss=False, seed=4, logits=True),
     "raw_1x1_concat_res_conv": dict(B=1, H=8, W=8, C1=64, C2=32, Cout=40, k=1, norm=NONE, WM=1, WN=1, silu=False, slots=False, seed=5),
     "layernorm_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=1, silu=False, seed=6),
     "gelu_layernorm_bias_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=2, silu=False, pre_gelu=True,

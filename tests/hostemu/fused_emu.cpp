@@ -37,6 +37,17 @@ extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
     });
     return 0;
   }
+  if (op->type == SF_OP_GCA) {
+    GcaPoolArgs pa;
+    GcaNetArgs na;
+    GcaGateArgs ga;
+    uint32_t grid;
+    if (gca_setup(*op, pa, na, ga, grid, err, (size_t)errn)) return 1;
+    if (op->flags == 1) hipemu::launch(grid, 256, 0, [&] { k_gca_pool(pa); });
+    else if (op->flags == 2) hipemu::launch(grid, 256, 0, [&] { k_gca_net0(na); });
+    else hipemu::launch(grid, 256, 0, [&] { k_gca_gate(ga); });
+    return 0;
+  }
   snprintf(err, errn, "emu: op type %d not supported", op->type);
   return 1;
 }

@@ -17,3 +17,8 @@ def test_fused_conv_on_gpu(name):
 
 def test_slots_kernel_and_gate_on_gpu():
     fc.run_slots_case("gpu")
+
+
+@pytest.mark.parametrize("name", sorted({**fc.GCA_CASES, **fc.GCA_CASES_FULL}))
+def test_gca_chain_on_gpu(name):
+    fc.run_gca_case("gpu", **({**fc.GCA_CASES, **fc.GCA_CASES_FULL})[name])

@@ -79,6 +79,23 @@ def test_lazy_consumers_do_not_change_the_result(B):
         assert r < TOL_REL and c > TOL_COS
 
 
+def test_sampler_fast_path_equals_forward():
+    """Unet.begin_sampling / eval_prepared (time table once per trajectory + plan body per eval) is the same computation as
+    Unet.forward: same kernels on the same operands, so the outputs agree to fp32 round-off."""
+    name = "canonical"
+    net = _unet(name)
+    g = torch.Generator().manual_seed(77)
+    for B in (1, 2):
+        x = torch.randn(B, 4, 32, 32, generator=g).to(DEV)
+        cond = torch.randn(B, 256, 32, 32, generator=g).to(DEV)
+        ls = unet_ref.log_snr(torch.tensor([0.9, 0.5, 0.1, 0.02])).to(DEV)
+        ctx = net.begin_sampling(cond, ls)
+        for row in (2, 0, 3):
+            y_fast = net.eval_prepared(ctx, x, row).clone()
+            y_full = net.forward(x, ls[row].expand(B), cond_images=cond)
+            assert torch.allclose(y_fast, y_full, rtol=1e-5, atol=1e-6), (B, row, rel_err(y_fast.cpu(), y_full.cpu()))
+
+
 def test_unet_state_dict_roundtrip_and_errors():
     net = _unet("small")
     sd = net.state_dict()
@@ -120,6 +137,13 @@ def test_plms_sampler_matches_reference_golden(max_thres, evals):
         return orig(*a, **k)
 
     unet.forward_with_cond_scale = counting
+    orig_prepared = unet.eval_prepared
+
+    def counting_prepared(*a, **k):                      # the sampler's fast path (time table + plan body) is an eval too
+        calls[0] += 1
+        return orig_prepared(*a, **k)
+
+    unet.eval_prepared = counting_prepared
     img, xn, nz, acp = PLMSSampler(vldm, 50).sample(lat.to(DEV), cond_images=cond.to(DEV), use_tqdm=False, return_noise=True,
                                                     max_thres=max_thres, noises=noises)
     assert calls[0] == evals

@@ -48,3 +48,8 @@ def test_whole_fused_plan_against_oracle(dim):
     with torch.no_grad():
         y_ref = unet_ref.unet_forward(sd, x, ls, cond)
     assert torch.isfinite(y).all() and fc.rel(y, y_ref) < 2e-2
+
+
+@pytest.mark.parametrize("name", sorted(fc.GCA_CASES))
+def test_gca_chain_on_cpu_threads(name):
+    fc.run_gca_case("emu", **(fc.GCA_CASES)[name])

@@ -9,6 +9,11 @@ unet = Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2
             layer_cross_attns=(False,) * 4, cond_images_channels=256, attn_pool_text=False).to(dev)
 unet.use_hip_graph = False
 x, ls, cond = torch.randn(B, 4, 32, 32, device=dev), torch.zeros(B, device=dev), torch.randn(B, 256, 32, 32, device=dev)
-for _ in range(N):
-    unet.forward(x, ls, cond_images=cond)
+if len(sys.argv) > 3 and sys.argv[3] == "full":      # the stand-alone forward (time path inside every eval)
+    for _ in range(N):
+        unet.forward(x, ls, cond_images=cond)
+else:                                                 # what the PLMS sampler runs: time table once, plan body per eval
+    ctx = unet.begin_sampling(cond, torch.linspace(-3, 3, 8, device=dev))
+    for k in range(N):
+        unet.eval_prepared(ctx, x, k % 8)
 torch.cuda.synchronize()
