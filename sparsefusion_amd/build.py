@@ -63,6 +63,23 @@ def build(verbose=True, force=False):
     return LIB
 
 
+def build_timing(verbose=True):
+    """libsf_fused_timing.so: unet_fused.hip with in-kernel phase timestamps (-DSF_FCONV_TIMING), a measurement aid for
+    tools/fconv_phases.py -- never loaded by the package."""
+    out = os.path.join(HERE, "libsf_fused_timing.so")
+    srcs = [os.path.join(CSRC, f) for f in ("unet_fused.hip", "core.hip")]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
+        return out
+    cmd = [HIPCC] + FLAGS + ["-DSF_FCONV_TIMING", "-shared", "-o", out] + srcs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    if "--timing" in sys.argv:
+        print(build_timing())
     print(LIB)

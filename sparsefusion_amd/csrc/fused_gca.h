@@ -21,23 +21,40 @@ struct GcaPoolArgs {
   int M, C, HW, CH, chunks, nparts, groups, npad;
 };
 
-// grid = B * chunks * (C / 64); 256 threads = 16 channel float4 lanes x 16 pixel lanes
+// grid = B * chunks * (C / 64); 256 threads = 16 channel float4 lanes x 16 pixel lanes.
+// Every phase issues its loads as one independent batch: a dependent load per loop trip costs an L2 / fabric round trip
+// (~0.5 us), and the first version of this kernel spent 30 us summing 256 logit parts one after the other.
 SF_KERNEL(256) void k_gca_pool(GcaPoolArgs a) {
   SF_SHARED float e[128];
-  SF_SHARED float red[16][68];
+  SF_SHARED float red[16][132];
   const int tid = threadIdx.x, lane = tid & 63;
   const int cslabs = a.C >> 6;
   const int cs = blockIdx.x % cslabs, bc = blockIdx.x / cslabs;      // bc = image * chunks + chunk
   const int b = bc / a.chunks, ch = bc - b * a.chunks;
   const long m0 = (long)b * a.HW + (long)ch * a.CH;
-  // (1) logits of the chunk's pixels: 2 threads per pixel (CH <= 128), each sums half of the parts
+  // (1) logits of the chunk's pixels: CH (power of two, 16..128) pixels x PL = 256 / CH part lanes
   {
-    const int p = tid >> 1, half = tid & 1;
+    const int p = tid & (a.CH - 1), pl = tid / a.CH, PL = 256 / a.CH;
     float l = 0.0f;
-    if (p < a.CH)
-      for (int k = half; k < a.nparts; k += 2) l += a.logit_part[(long)k * a.M + m0 + p];
-    l += sf_shfl_xor(l, 1);
-    if (p < a.CH && half == 0) e[p] = l;
+    for (int k0 = pl; k0 < a.nparts; k0 += 8 * PL) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + u * PL;
+        t[u] = a.logit_part[(long)(k < a.nparts ? k : a.nparts - 1) * a.M + m0 + p];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + u * PL < a.nparts) l += t[u];
+    }
+    red[pl][p] = l;
+  }
+  sf_sync();
+  if (tid < a.CH) {
+    const int PL = 256 / a.CH;
+    float l = 0.0f;
+    for (int k = 0; k < PL; ++k) l += red[k][tid];
+    e[tid] = l;
   }
   sf_sync();
   // (2) chunk-local softmax numerators
@@ -55,18 +72,30 @@ SF_KERNEL(256) void k_gca_pool(GcaPoolArgs a) {
   const int c4 = tid & 15, pl = tid >> 4;
   const int c = cs * 64 + c4 * 4;
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int p = pl; p < a.CH; p += 16) {
-    const long m = m0 + p;
-    f32x4 v;
-    if (a.ws) {
-      v = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int g = 0; g < a.groups; ++g) v += *reinterpret_cast<const f32x4*>(a.ws + ((long)g * a.M + m) * a.npad + c);
-      *reinterpret_cast<f32x4*>(a.h2 + m * a.C + c) = v;
-    } else {
-      v = *reinterpret_cast<const f32x4*>(a.h2 + m * a.C + c);
+  const f32x4 bvec = (a.ws && a.bias) ? *reinterpret_cast<const f32x4*>(a.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int p0 = pl; p0 < a.CH; p0 += 64) {   // 4 pixels per thread and trip, all their loads in flight together
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * 16;
+      const long m = m0 + (p < a.CH ? p : a.CH - 1);
+      if (a.ws) {
+        v[u] = bvec;
+        for (int g = 0; g < a.groups; ++g) v[u] += *reinterpret_cast<const f32x4*>(a.ws + ((long)g * a.M + m) * a.npad + c);
+      } else {
+        v[u] = *reinterpret_cast<const f32x4*>(a.h2 + m * a.C + c);
+      }
     }
-    acc += v * e[p];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * 16;
+      if (p < a.CH) {
+        if (a.ws) *reinterpret_cast<f32x4*>(a.h2 + (m0 + p) * a.C + c) = v[u];
+        acc += v[u] * e[p];
+      }
+    }
   }
+  sf_sync();
 #pragma unroll
   for (int j = 0; j < 4; ++j) red[pl][c4 * 4 + j] = acc[j];
   sf_sync();
@@ -94,37 +123,52 @@ SF_KERNEL(256) void k_gca_net0(GcaNetArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rb = (a.HID + 15) / 16;
   const int b = blockIdx.x / rb, r0 = (blockIdx.x - b * rb) * 16;
-  if (tid == 0) {                                         // online-softmax merge weights of the chunks
-    float M = -INFINITY;
-    for (int j = 0; j < a.chunks; ++j) M = fmaxf(M, a.part_ms[((long)b * a.chunks + j) * 2]);
-    float Z = 0.0f;
-    for (int j = 0; j < a.chunks; ++j) {
-      const float w = sf_exp(a.part_ms[((long)b * a.chunks + j) * 2] - M);
-      wgt[j] = w;
-      Z += w * a.part_ms[((long)b * a.chunks + j) * 2 + 1];
+  // this wave's 4 weight rows: C <= 2048 -> at most 4 x 16-byte loads per row and lane, all issued before anything waits
+  bf16x8 w[4][4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = r0 + wave * 4 + rr;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int k = lane * 8 + it * 512;
+      w[rr][it] = (r < a.HID && k < a.C) ? *reinterpret_cast<const bf16x8*>(a.W0 + (long)r * a.Kp + k) : sf_zero8();
     }
-    const float inv = 1.0f / Z;
-    for (int j = 0; j < a.chunks; ++j) wgt[j] *= inv;
+  }
+  if (wave == 0) {                                        // online-softmax merge weights of the chunks (lanes = chunks)
+    const bool on = lane < a.chunks;
+    const float mj = on ? a.part_ms[((long)b * a.chunks + lane) * 2] : -INFINITY;
+    const float sj = on ? a.part_ms[((long)b * a.chunks + lane) * 2 + 1] : 0.0f;
+    const float M = sf_wave_max(mj);
+    const float wj = on ? sf_exp(mj - M) : 0.0f;
+    const float Z = sf_wave_sum(wj * sj);
+    if (on) wgt[lane] = wj / Z;
   }
   sf_sync();
   for (int c = tid; c < a.C; c += 256) {
+    float pj[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pj[j] = a.part_pool[((long)b * a.chunks + (j < a.chunks ? j : a.chunks - 1)) * a.C + c];
     float s = 0.0f;
-    for (int j = 0; j < a.chunks; ++j) s = fmaf(wgt[j], a.part_pool[((long)b * a.chunks + j) * a.C + c], s);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < a.chunks) s = fmaf(wgt[j], pj[j], s);
     pooled[c] = s;
   }
   sf_sync();
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     const int r = r0 + wave * 4 + rr;
-    if (r >= a.HID) break;                                // wave-uniform
     float acc = 0.0f;
-    for (int k = lane * 8; k < a.C; k += 512) {
-      const bf16x8 w = *reinterpret_cast<const bf16x8*>(a.W0 + (long)r * a.Kp + k);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc = fmaf((float)w[j], pooled[k + j], acc);
+    for (int it = 0; it < 4; ++it) {
+      const int k = lane * 8 + it * 512;
+      if (k < a.C) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = fmaf((float)w[rr][it][j], pooled[k + j], acc);
+      }
     }
     acc = sf_wave_sum(acc);
-    if (lane == 0) a.hid[(long)b * a.HID + r] = sf_silu(acc + a.b0[r]);
+    if (lane == 0 && r < a.HID) a.hid[(long)b * a.HID + r] = sf_silu(acc + a.b0[r]);
   }
 }
 
@@ -146,26 +190,49 @@ SF_KERNEL(256) void k_gca_gate(GcaGateArgs a) {
   if (gw >= (a.M >> 4) * CF) return;
   const int mf = gw / CF, cf = gw - mf * CF;
   const int b = (mf * 16) / a.HW;
-  // gate of channel cf*16 + (lane & 15): the 4 lanes with equal (lane & 15) split the hidden dimension
+  // the tile's own operands first (independent of the gate): lane -> pixel (lane >> 2), channels cf*16 + (lane & 3)*4 .. +3
+  const long m = (long)mf * 16 + (lane >> 2);
+  const int c = cf * 16 + (lane & 3) * 4;
+  const f32x4 hv = *reinterpret_cast<const f32x4*>(a.h2 + m * a.C + c);
+  const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + m * a.C + c);
+  // gate of channel cf*16 + (lane & 15): the 4 lanes with equal (lane & 15) split the hidden dimension; HID <= 1024
+  // -> at most 4 trips of 8 k-steps, each trip's 8 weight + 16 hidden-vector loads in flight together
   const int ch = cf * 16 + (lane & 15), q = lane >> 4;
+  const float bias = a.b2[ch];
   float g = 0.0f;
-  for (int k = q * 8; k < a.HID; k += 32) {
-    const bf16x8 w = *reinterpret_cast<const bf16x8*>(a.W2 + (long)ch * a.Kp2 + k);
+  for (int k0 = q * 8; k0 < a.HID; k0 += 256) {
+    bf16x8 w[8];
+    f32x4 h0[8], h1[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (k + j < a.HID) g = fmaf((float)w[j], a.hid[(long)b * a.HID + k + j], g);
+    for (int u = 0; u < 8; ++u) {
+      int k = k0 + u * 32;
+      if (k + 8 > a.Kp2) k = 0;                            // clamped, masked below
+      w[u] = *reinterpret_cast<const bf16x8*>(a.W2 + (long)ch * a.Kp2 + k);
+      int kh = k0 + u * 32;
+      if (kh + 8 > a.HID) kh = a.HID >= 8 ? a.HID - 8 : 0;
+      h0[u] = *reinterpret_cast<const f32x4*>(a.hid + (long)b * a.HID + kh);
+      h1[u] = *reinterpret_cast<const f32x4*>(a.hid + (long)b * a.HID + kh + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + u * 32;
+      if (k + 8 <= a.HID) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g = fmaf((float)w[u][j], h0[u][j], g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g = fmaf((float)w[u][4 + j], h1[u][j], g);
+      } else {
+        for (int j = 0; j < 8; ++j)
+          if (k + j < a.HID) g = fmaf((float)(reinterpret_cast<const __bf16*>(a.W2)[(long)ch * a.Kp2 + k + j]), a.hid[(long)b * a.HID + k + j], g);
+      }
+    }
   }
   g += sf_shfl_xor(g, 16);
   g += sf_shfl_xor(g, 32);
-  g = sf_sigmoid(g + a.b2[ch]);                           // lanes l, l+16, l+32, l+48 hold the gate of channel cf*16 + (l & 15)
-  // the tile: lane -> pixel (lane >> 2), channels cf*16 + (lane & 3)*4 .. +3; fetch those 4 gates from their owner lanes
-  const long m = (long)mf * 16 + (lane >> 2);
-  const int c = cf * 16 + (lane & 3) * 4;
+  g = sf_sigmoid(g + bias);                               // lanes l, l+16, l+32, l+48 hold the gate of channel cf*16 + (l & 15)
   f32x4 gv;
 #pragma unroll
   for (int j = 0; j < 4; ++j) gv[j] = sf_shfl(g, (lane & 3) * 4 + j);
-  const f32x4 hv = *reinterpret_cast<const f32x4*>(a.h2 + m * a.C + c);
-  const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + m * a.C + c);
   const f32x4 v = hv * gv + rv;
   *reinterpret_cast<f32x4*>(a.out + m * a.C + c) = v;
   if (a.slots) {

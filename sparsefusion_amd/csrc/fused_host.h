@@ -144,8 +144,8 @@ static inline int gca_setup(const sf_op& op, GcaPoolArgs& pa, GcaNetArgs& na, Gc
     pa.M = op.i[0]; pa.C = op.i[1]; pa.HW = op.i[2]; pa.CH = op.i[3]; pa.chunks = op.i[4]; pa.nparts = op.i[5];
     pa.groups = op.i[6]; pa.npad = op.i[7];
     if (!pa.h2 || !pa.logit_part || !pa.part_pool || !pa.part_ms) GC_FAIL("gca pool: missing operand");
-    if (pa.C % 64 || pa.CH < 1 || pa.CH > 128 || pa.CH * pa.chunks != pa.HW || pa.M % pa.HW || pa.nparts < 1)
-      GC_FAIL("gca pool: C %% 64, 1 <= CH <= 128, CH * chunks == HW required");
+    if (pa.C % 64 || pa.CH < 16 || pa.CH > 128 || (pa.CH & (pa.CH - 1)) || pa.CH * pa.chunks != pa.HW || pa.M % pa.HW || pa.nparts < 1)
+      GC_FAIL("gca pool: C %% 64, CH a power of two in 16..128, CH * chunks == HW required");
     if (pa.ws && (pa.groups < 1 || pa.npad % 4)) GC_FAIL("gca pool: bad split-K source");
     grid = (uint32_t)(pa.M / pa.HW) * pa.chunks * (pa.C / 64);
     return 0;
@@ -164,7 +164,7 @@ static inline int gca_setup(const sf_op& op, GcaPoolArgs& pa, GcaNetArgs& na, Gc
     ga.W2 = (const __bf16*)op.p[3]; ga.b2 = (const float*)op.p[4]; ga.out = (float*)op.p[5]; ga.slots = (float*)op.p[6];
     ga.M = op.i[0]; ga.C = op.i[1]; ga.HW = op.i[2]; ga.HID = op.i[3]; ga.Kp2 = op.i[4];
     if (!ga.h2 || !ga.res || !ga.hid || !ga.W2 || !ga.b2 || !ga.out) GC_FAIL("gca gate: missing operand");
-    if (ga.M % 16 || ga.C % 16 || ga.HW % 16 || ga.Kp2 % 8 || ga.Kp2 < ga.HID) GC_FAIL("gca gate: 16-aligned M, C, HW required");
+    if (ga.M % 16 || ga.C % 16 || ga.HW % 16 || ga.Kp2 % 8 || ga.Kp2 < ga.HID || ga.HID > 1024 || ga.HID < 8) GC_FAIL("gca gate: 16-aligned M, C, HW and 8 <= HID <= 1024 required");
     grid = ((uint32_t)(ga.M / 16) * (ga.C / 16) + 3) / 4;
     return 0;
   }

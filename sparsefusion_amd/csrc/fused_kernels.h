@@ -100,7 +100,11 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
   constexpr int NT = NW * 64;
   SF_DYN_LDS(lds);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef SF_FCONV_TIMING      // tools/fconv_phases.py builds its own instrumented copy; a maybe-executed store would make every
 #define FC_STAMP(k) do { if (a.dbg && tid == 0) a.dbg[(long)blockIdx.x * 8 + (k)] = sf_clock(); } while (0)
+#else                       // later s_waitcnt conservative, so the product has no trace of it
+#define FC_STAMP(k) do { } while (0)
+#endif
   FC_STAMP(0);
   // ---- which tile
   const int MT = a.B * a.mt_per_img;
@@ -141,13 +145,17 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
     return wbase[ni][(long)(tap * a.cchunks + ccl) * 64];
   };
   bf16x8 fb[D][WN];
-  auto prefetch_weights = [&]() {          // fill the ring: the HBM / L2 weight stream runs under the rest of the prologue
+  // fill the ring: the HBM / L2 weight stream runs under the rest of the prologue.  The loads are UNCONDITIONAL (indices
+  // clamped into the wave's range): loads under a branch keep the compiler from counting what is in flight, and every
+  // later s_waitcnt then drains the whole queue.
+  const int klast = k1 > k0 ? k1 - 1 : (k0 < KSl ? k0 : KSl - 1);
+  auto prefetch_weights = [&]() {
 #pragma unroll
-    for (int u = 0; u < D; ++u)
-      if (k0 + u < k1) {
+    for (int u = 0; u < D; ++u) {
+      const int j = k0 + u < k1 ? k0 + u : klast;
 #pragma unroll
-        for (int ni = 0; ni < WN; ++ni) fb[u][ni] = wload(k0 + u, ni);
-      }
+      for (int ni = 0; ni < WN; ++ni) fb[u][ni] = wload(j, ni);
+    }
   };
 
   float* tabA = reinterpret_cast<float*>(lds + a.tab_off);
@@ -175,18 +183,15 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
   constexpr int TABN = 4;                                          // Cs <= 2048 channels per slice at NT = 512
   float tg[TABN], tb[TABN], tsc[TABN], tsh[TABN];
   if (gn) {
+    const float* ssrow = a.ss ? a.ss + (long)b * a.ss_stride : a.gamma;      // any valid address when there is no scale / shift
+    const int shoff = a.ss ? a.C : 0;
 #pragma unroll
     for (int k = 0; k < TABN; ++k) {
-      const int cl = tid + k * NT;
-      tg[k] = 1.0f; tb[k] = 0.0f; tsc[k] = 1.0f; tsh[k] = 0.0f;
-      if (cl < Cs) {
-        tg[k] = a.gamma[c0 + cl];
-        tb[k] = a.beta[c0 + cl];
-        if (a.ss) {
-          tsc[k] = a.ss[(long)b * a.ss_stride + c0 + cl] + 1.0f;
-          tsh[k] = a.ss[(long)b * a.ss_stride + a.C + c0 + cl];
-        }
-      }
+      const int cl = tid + k * NT, cc = c0 + (cl < Cs ? cl : Cs - 1);
+      tg[k] = a.gamma[cc];
+      tb[k] = a.beta[cc];
+      tsc[k] = ssrow[cc];
+      tsh[k] = ssrow[shoff + cc];
     }
   }
   auto build_table = [&]() {
@@ -196,9 +201,9 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
       if (cl < Cs) {
         const int gi = (int)fdiv((uint32_t)cl, a.d_cg);
         const float mean = misc[16 + 2 * gi], rstd = misc[17 + 2 * gi];
-        const float A = rstd * tg[k];
-        tabA[cl] = A * tsc[k];
-        tabB[cl] = (tb[k] - mean * A) * tsc[k] + tsh[k];
+        const float A = rstd * tg[k], sc = a.ss ? tsc[k] + 1.0f : 1.0f, sh = a.ss ? tsh[k] : 0.0f;
+        tabA[cl] = A * sc;
+        tabB[cl] = (tb[k] - mean * A) * sc + sh;
       }
     }
   };
@@ -419,6 +424,8 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
         const int cl = (c4 < Cs4 ? c4 : Cs4 - 1) * 4, c = c0 + cl;
         const bool first = c < a.s1.C;
         const float scale = first ? a.s1.scale : a.s2.scale;
+        const float* srcp = first ? a.s1.p + c : a.s2.p + (c - a.s1.C);      // plain sources: one unconditional load per element
+        const long srcld = first ? a.s1.C : a.s2.C;
         f32x4 A, Bv;
         affine_of(cl, A, Bv);
         for (int p0 = tp; p0 < npx; p0 += ppp * U) {
@@ -437,7 +444,8 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
             mx[u] = mb + ((long)rc << a.logW) + x;
             // fpx < 0: nothing to store; bit 30: this workgroup owns the element (materialises a lazy source)
             fpx[u] = in ? ((fr * FW + x + h) | ((nt == 0 && fr >= h && fr < h + a.TR) ? (1 << 30) : 0)) : -1;
-            v[u] = fconv_value<LAZY>(a, mx[u], c);
+            if (LAZY == 0) v[u] = *reinterpret_cast<const f32x4*>(srcp + mx[u] * srcld);
+            else v[u] = fconv_value<LAZY>(a, mx[u], c);
           }
 #pragma unroll
           for (int u = 0; u < U; ++u) {

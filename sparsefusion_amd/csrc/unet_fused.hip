@@ -69,3 +69,6 @@ int sf_plan_fused_op(const sf_op* op, void* stream) {
     default: SF_FAIL(SF_ERR_INVALID, "fused: unknown op type %d", op->type);
   }
 }
+
+// C entry for the instrumented build of this file (libsf_fused_timing.so, -DSF_FCONV_TIMING; tools/fconv_phases.py)
+extern "C" int sf_fused_op_run(const sf_op* op, void* stream) { return sf_plan_fused_op(op, stream); }

@@ -34,9 +34,17 @@ def to_rows(x):            # NCHW -> [M, C]
     return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
 
 
+TIMING_LIB = None          # tools/fconv_phases.py: the instrumented build of unet_fused.hip (libsf_fused_timing.so)
+
+
 def run_ops(ops, backend):
     if backend == "emu":
         fused.run(ops)
+    elif TIMING_LIB is not None:
+        for o in ops:
+            if TIMING_LIB.sf_fused_op_run(_lib.C.byref(o), _lib.stream_ptr()):
+                raise RuntimeError("timing lib: op failed")
+        torch.cuda.synchronize()
     else:
         arr = (_lib.SfOp * len(ops))(*ops)
         _lib.check(_lib.lib().sf_plan_run(arr, len(ops), _lib.stream_ptr()), "plan")

@@ -81,7 +81,9 @@ def test_lazy_consumers_do_not_change_the_result(B):
 
 def test_sampler_fast_path_equals_forward():
     """Unet.begin_sampling / eval_prepared (time table once per trajectory + plan body per eval) is the same computation as
-    Unet.forward: same kernels on the same operands, so the outputs agree to fp32 round-off."""
+    Unet.forward: same kernels on the same operands.  Not bit-identical: the GroupNorm statistics of the 4x4 level meet
+    through LDS float atomics whose order varies from launch to launch, and a last-ulp difference there decorrelates the
+    bf16 roundings downstream -- two runs of the SAME path differ by the same amount, so the bound is the bf16 one."""
     name = "canonical"
     net = _unet(name)
     g = torch.Generator().manual_seed(77)
@@ -93,7 +95,9 @@ def test_sampler_fast_path_equals_forward():
         for row in (2, 0, 3):
             y_fast = net.eval_prepared(ctx, x, row).clone()
             y_full = net.forward(x, ls[row].expand(B), cond_images=cond)
-            assert torch.allclose(y_fast, y_full, rtol=1e-5, atol=1e-6), (B, row, rel_err(y_fast.cpu(), y_full.cpu()))
+            assert rel_err(y_fast.cpu(), y_full.cpu()) < TOL_REL, (B, row, rel_err(y_fast.cpu(), y_full.cpu()))
+            y_again = net.forward(x, ls[row].expand(B), cond_images=cond)
+            print(f"B={B} row={row}: fast vs full {rel_err(y_fast.cpu(), y_full.cpu()):.2e}, full vs full {rel_err(y_again.cpu(), y_full.cpu()):.2e}")
 
 
 def test_unet_state_dict_roundtrip_and_errors():

@@ -4,7 +4,12 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
+import ctypes as C
 import fused_cases as fc
+from sparsefusion_amd import build
+
+fc.TIMING_LIB = C.CDLL(build.build_timing(verbose=False))
+fc.TIMING_LIB.sf_fused_op_run.restype = C.c_int
 
 names = sys.argv[1:] or sorted(fc.CONV_CASES_FULL)
 for name in names:
