@@ -34,6 +34,7 @@
   X(1, 2, 8, FNORM_NONE, 0) \
   X(2, 2, 8, FNORM_NONE, 0) \
   X(1, 1, 12, FNORM_LN, 0) \
+  X(1, 1, 12, FNORM_LN, 1) \
   X(1, 2, 8, FNORM_LN, 0)
 
 static inline int fconv_pix_stride(int Cs) {

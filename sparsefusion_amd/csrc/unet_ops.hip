@@ -540,11 +540,11 @@ __global__ __launch_bounds__(256) void k_gemv(const float* __restrict__ x, const
 // ATTN: softmax(q k^T) v for 16 queries, head dim 64, <= 24 keys built from up to 3 segments.
 //   p[0] q f32 [B*16, ldq] (head h at column h*64), p[1] out bf16 [B*16, 512]
 //   segment s (s = 0..2): p[2+2s] keys, p[3+2s] values (f32); i[4+4s..] = rows, row_stride, batch_stride, head_stride
-//   i[0] = B, i[1] = heads, i[2] = ldq ; f[0] = q scale.   One 256-thread workgroup per (b, head).
+//   i[0] = B, i[1] = heads, i[2] = ldq ; f[0] = q scale ; flags: 1 = fp32 output.   One 256-thread workgroup per (b, head).
 // ---------------------------------------------------------------------------------------------
 struct AttnSeg { const float* k; const float* v; int rows, row_stride, batch_stride, head_stride; };
-__global__ __launch_bounds__(256) void k_attn16(const float* __restrict__ q, __bf16* __restrict__ out, AttnSeg s0, AttnSeg s1,
-                                                AttnSeg s2, int heads, int ldq, float scale) {
+__global__ __launch_bounds__(256) void k_attn16(const float* __restrict__ q, void* __restrict__ out, AttnSeg s0, AttnSeg s1,
+                                                AttnSeg s2, int heads, int ldq, float scale, int out_f32) {
   // 4 waves per (b, head): the kernel is a chain of dependent phases (load, q.k, softmax, p.v), so the only lever is to make
   // every phase short -- rows of q / k / v are fetched by different waves at once, the 16 x J scores and the 16 output rows
   // are spread over all 256 lanes
@@ -587,7 +587,9 @@ __global__ __launch_bounds__(256) void k_attn16(const float* __restrict__ q, __b
   for (int i = wv; i < 16; i += 4) {
     float a = 0.0f;
     for (int j = 0; j < J; ++j) a = fmaf(sim[i][j], sv[j][t], a);
-    out[((long)b * 16 + i) * (heads * 64) + h * 64 + t] = (__bf16)a;
+    const long o = ((long)b * 16 + i) * (heads * 64) + h * 64 + t;
+    if (out_f32) reinterpret_cast<float*>(out)[o] = a;          // consumed by a fused linear (fp32 A operand prologue)
+    else reinterpret_cast<__bf16*>(out)[o] = (__bf16)a;
   }
 }
 
@@ -1079,7 +1081,7 @@ static int run_attn(const sf_op& op, hipStream_t st) {
     J += s[k].rows;
   }
   if (J < 1 || J > 24) SF_FAIL(SF_ERR_INVALID, "attn: 1..24 keys");
-  k_attn16<<<op.i[0] * op.i[1], 256, 0, st>>>((const float*)op.p[0], (__bf16*)op.p[1], s[0], s[1], s[2], op.i[1], op.i[2], op.f[0]);
+  k_attn16<<<op.i[0] * op.i[1], 256, 0, st>>>((const float*)op.p[0], op.p[1], s[0], s[1], s[2], op.i[1], op.i[2], op.f[0], op.flags & 1);
   SF_CHECK_LAUNCH("attn16");
   return SF_OK;
 }

@@ -328,7 +328,7 @@ class _Plan:
                     p=(x_ptr + m0 * ldx * 4, self.wptr(wname), self.wptr(bname) if bname else 0, y_ptr + m0 * ldy * 4),
                     i=(mm, N, K, Kp, ldx, ldy))
 
-    def attn(self, q, out, segs, heads, ldq, scale):
+    def attn(self, q, out, segs, heads, ldq, scale, out_f32=False):
         p = [q.ptr, out.ptr]
         i = [self.B, heads, ldq, 0]
         for s in (segs + [None] * 3)[:3]:
@@ -338,7 +338,7 @@ class _Plan:
             else:
                 p += [s[0], s[1]]
                 i += list(s[2:])
-        self.op(OP_ATTN, 0, p=p, i=i, f=(scale,))
+        self.op(OP_ATTN, 1 if out_f32 else 0, p=p, i=i, f=(scale,))
 
 
     # -------- fused GroupNorm / LayerNorm -> conv ops (csrc/fused_kernels.h)
@@ -580,8 +580,56 @@ class _Plan:
         self.ln(o, f"{name}.to_out.1.g", None, y, d, rows, out_f32=True, resid=x)
         return y
 
+    # ---- attention on the fused linear (k_conv_fused k = 1: LayerNorm in the prologue, no split-K reduce launches)
+    def lin_geometry(self, x, N, norm):
+        """Geometry of a fused linear on a 4x4 token map, or None (the first-round ops then run)."""
+        if x.HW != 16 or x.rows != self.B * 16:
+            return None
+        return self.fused_geometry(4, x.C, N, norm, 1)
+
+    def attention_fused(self, name, x, context, cross):
+        """x + Attention(x) with 4 launches: [LayerNorm + q (| k | v) projection], the 16-query attention core, the output
+        projection, [LayerNorm + residual]  (imagen_pytorch.py:480-566, :731-805).  None when the shapes do not fit."""
+        B, d, rows = self.B, x.C, x.rows
+        heads, dh = self.u.attn_heads, self.u.attn_dim_head
+        inner = heads * dh
+        nq = inner if cross else inner + 2 * dh
+        g1, g2 = self.lin_geometry(x, nq, FNORM_LN), None
+        if g1 is None or d % 32:
+            return None
+        att = _T(self.misc.alloc(rows * inner * 4), rows, inner, 16)
+        g2 = self.lin_geometry(att, d, FNORM_NONE)
+        if g2 is None:
+            return None
+        if x.lazy is not None and x.lazy[0] != "splitk":
+            self.need(x)
+        qkv = self.zf32(rows, nq, 16)
+        self.fconv(x, None, 4, f"{name}.to_q.weight" if cross else f"{name}.__qkv__", None, qkv, nq, 1, FNORM_LN, g1,
+                   gname=f"{name}.norm.g", silu=False)
+        nk = self.wptr(f"{name}.null_kv")
+        segs = []
+        if cross:                                              # keys = [null, the 2 time tokens] (time block)
+            kvp = self.tb.ptr + self.u.tb_off[name] * 4
+            segs = [(nk, nk + dh * 4, 1, 0, 0, 0), (kvp, kvp + inner * 4, 2, inner * 2, self.u.tb_stride, dh)]
+        else:
+            if context:
+                ckvp = self.tb.ptr + self.u.tb_off[name] * 4
+                segs.append((ckvp, ckvp + dh * 4, 2, 2 * dh, self.u.tb_stride, 0))
+            kp = qkv.ptr + inner * 4                           # one shared k/v head right of the 8 query heads
+            segs += [(nk, nk + dh * 4, 1, 0, 0, 0), (kp, kp + dh * 4, 16, nq, 16 * nq, 0)]
+        self.attn(qkv, att, segs, heads, nq, dh ** -0.5, out_f32=True)
+        o = self.zf32(rows, d, 16)
+        self.fconv(att, None, 4, f"{name}.to_out.0.weight", None, o, d, 1, FNORM_NONE, g2, silu=False)
+        y = self.f32(rows, d, x.HW)
+        self.ln(o, f"{name}.to_out.1.g", None, y, d, rows, out_f32=True, resid=x)
+        return y
+
     def cross_attention(self, name, h):
         """h + CrossAttention(h, context=c)  (imagen_pytorch.py:731-805; keys = [null, 2 time tokens])."""
+        if getattr(self.u, "fused", False):
+            y = self.attention_fused(name, h, False, True)
+            if y is not None:
+                return y
         B, d, rows = self.B, h.C, h.rows
         heads, dh = self.u.attn_heads, self.u.attn_dim_head
         inner = heads * dh
@@ -598,6 +646,10 @@ class _Plan:
 
     def self_attention(self, name, x, context):
         """x + Attention(x[, context=c])  (imagen_pytorch.py:480-566; one shared k/v head)."""
+        if getattr(self.u, "fused", False):
+            y = self.attention_fused(name, x, context, False)
+            if y is not None:
+                return y
         B, d, rows = self.B, x.C, x.rows
         heads, dh = self.u.attn_heads, self.u.attn_dim_head
         inner = heads * dh
@@ -621,6 +673,18 @@ class _Plan:
         B, d, rows = self.B, x.C, x.rows
         x1 = self.self_attention(f"{name}.layers.0.0.fn", x, True)
         hid = int(d * self.u.ff_mult)
+        if getattr(self.u, "fused", False):                      # ChanFeedForward with both ChanLayerNorms inside the 1x1 convs
+            ga, gb = self.lin_geometry(x1, hid, FNORM_LN), None
+            if ga is not None and hid % 32 == 0:
+                f1 = self.zf32(rows, hid, 16)
+                gb = self.lin_geometry(f1, d, FNORM_LN)
+            if ga is not None and gb is not None:
+                self.fconv(x1, None, 4, f"{name}.layers.0.1.1.weight", None, f1, hid, 1, FNORM_LN, ga,
+                           gname=f"{name}.layers.0.1.0.g", silu=False)
+                x2 = self.zf32(rows, d, x.HW)
+                self.fconv(f1, None, 4, f"{name}.layers.0.1.4.weight", None, x2, d, 1, FNORM_LN, gb,
+                           gname=f"{name}.layers.0.1.3.g", silu=False, pre_gelu=True, resid=x1)
+                return x2
         xn = self.bf16(rows, d)
         self.ln(x1, f"{name}.layers.0.1.0.g", None, xn, d, rows)
         f1 = self.zf32(rows, hid)
@@ -683,6 +747,20 @@ class _Plan:
             cw = u.spec_shapes[f"init_conv.convs.{i}.weight"][0]
             self.conv(xin, True, R, R, f"init_conv.convs.{i}.weight", f"init_conv.convs.{i}.bias", x, u.dim, co, cw, k, 1, k // 2)
             co += cw
+        self.n_init_ops = len(self.ops)
+        # Sampler variant of the init conv.  The conv is linear in its input channels and the conditioning image (256 of the
+        # 260 channels) is the same for every eval of a trajectory: `begin_sampling` runs the ops above once with x = 0 and
+        # keeps the result (bias included) in `base`; an eval then only convolves the 4 latent channels and adds `base`.
+        self.x0, self.base = x, self.f32(B * HW, u.dim, HW)
+        full_ops, full_written, self.ops, self.written = self.ops, self.written, [], set()
+        xin_x = self.f32(B * HW, 32, HW)
+        self.op(OP_ELTWISE, 2, p=(self.x_in.ptr, self.x_in.ptr, 0, xin_x.ptr), i=(B, HW, 0, u.channels, 32))
+        co = 0
+        for i, k in enumerate((3, 7, 15)):
+            cw = u.spec_shapes[f"init_conv.convs.{i}.weight"][0]
+            self.conv(xin_x, True, R, R, f"__init_x__.{i}", None, x, u.dim, co, cw, k, 1, k // 2, resid=self.base)
+            co += cw
+        self.init_x_ops, self.ops, self.written = self.ops, full_ops, full_written
         hiddens = []
         H = R
         n_lv = len(u.in_out)
@@ -728,12 +806,18 @@ class _Plan:
         if self.zero.off == 0:                          # nothing accumulates with atomics in this plan: no memset launch
             self.ops.remove(memset_op)
         self.op_array = (_lib.SfOp * len(self.ops))(*self.ops)
-        body = self.ops[self.n_time_ops:]
-        self.body_array = (_lib.SfOp * len(body))(*body)
+        n_init = self.n_init_ops - (1 if self.zero.off == 0 else 0)     # the memset op may just have been dropped
+        # sampler: [memset] + x-only init conv + everything after the init conv; begin_sampling: [memset] + full init conv
+        pre = [o for o in self.ops[self.n_time_ops:n_init] if o.type == OP_MEMSET]
+        body = pre + self.init_x_ops + self.ops[n_init:]
+        self.body_array, self.n_body_ops = (_lib.SfOp * len(body))(*body), len(body)
+        init = self.ops[self.n_time_ops:n_init]
+        self.init_array, self.n_init_run = (_lib.SfOp * len(init))(*init), len(init)
         if self.misc.buf is not None:
             self.tb_view = self.tview(self.tb)
             self.x_view, self.t_view = self.tview(self.x_in), self.tview(self.t_in)
             self.cond_view, self.out_view = self.tview(self.cond_in), self.tview(self.out)
+            self.x0_view, self.base_view = self.tview(self.x0), self.tview(self.base)
         return self
 
     def tview(self, t):
@@ -931,6 +1015,20 @@ class Unet(nn.Module):
                 packed[name] = self._gemv_pack(wc, device)
             else:
                 packed[name] = wc.reshape(-1).to(device)      # biases, gains, null_kv, sinusoid weights: fp32
+        for name in [k[:-len(".to_kv.weight")] for k in sd if k.endswith(".to_kv.weight") and ".cross_attn." not in k]:
+            wq, wkv = sd[name + ".to_q.weight"].float().cpu(), sd[name + ".to_kv.weight"].float().cpu()
+            w4 = torch.cat([wq, wkv], 0).contiguous()               # [8 heads * 64 | k 64 | v 64, d]: one fused projection
+            co, ci = w4.shape
+            if ci % 32 == 0:
+                buf = torch.empty(lib.sf_conv_packed_elems(co, ci, 1, 1), dtype=torch.int16)
+                _lib.check(lib.sf_conv_pack_weights(w4.data_ptr(), co, ci, ci, 1, 1, buf.data_ptr()), "pack qkv " + name)
+                packed[name + ".__qkv__"] = buf.to(device)
+        for i in range(3):                                      # latent-channel slices of the init conv (sampler path)
+            w4 = sd[f"init_conv.convs.{i}.weight"].float().cpu()[:, self.cond_images_channels:].contiguous()
+            co, ci, kh, kw = w4.shape
+            buf = torch.empty(lib.sf_conv_packed_elems(co, 32, kh, kw), dtype=torch.int16)
+            _lib.check(lib.sf_conv_pack_weights(w4.data_ptr(), co, ci, 32, kh, kw, buf.data_ptr()), "pack init x")
+            packed[f"__init_x__.{i}"] = buf.to(device)
         packed["__time_mlps__.weight"] = self._gemv_pack(torch.cat(tm_w, 0), device)
         packed["__time_mlps__.bias"] = torch.cat(tm_b, 0).to(device)
         self._pack_cache = (str(device), packed)
@@ -994,7 +1092,7 @@ class Unet(nn.Module):
     @staticmethod
     def _run_plan(plan, body_only=False):
         if body_only:
-            _lib.check(_lib.lib().sf_plan_run(plan.body_array, len(plan.ops) - plan.n_time_ops, _lib.stream_ptr()), "unet plan")
+            _lib.check(_lib.lib().sf_plan_run(plan.body_array, plan.n_body_ops, _lib.stream_ptr()), "unet plan")
         else:
             _lib.check(_lib.lib().sf_plan_run(plan.op_array, len(plan.ops), _lib.stream_ptr()), "unet plan")
 
@@ -1028,6 +1126,9 @@ class Unet(nn.Module):
             cond_images = torch.nn.functional.interpolate(cond_images, self.image_size, mode='nearest')
         plan = self._plan(B, cond_images.device)
         plan.cond_view.copy_(cond_images.reshape(B, -1))
+        plan.x_view.zero_()                                    # init conv of the conditioning image alone (+ bias) -> base
+        _lib.check(_lib.lib().sf_plan_run(plan.init_array, plan.n_init_run, _lib.stream_ptr()), "unet init conv")
+        plan.base_view.copy_(plan.x0_view)
         return {"plan": plan, "table": self.time_table(log_snrs), "B": B}
 
     @torch.no_grad()

@@ -147,7 +147,7 @@ def run_op(o):
     elif t == OP_ATTN:
         B, heads, ldq = i[0], i[1], i[2]
         q = f32(p[0], B * 16, ldq)
-        out = bf16(p[1], B * 16, heads * 64)
+        out = f32(p[1], B * 16, heads * 64) if fl & 1 else bf16(p[1], B * 16, heads * 64)
         for b in range(B):
             for hd in range(heads):
                 qq = q[b * 16:(b + 1) * 16, hd * 64:(hd + 1) * 64] * f[0]
@@ -160,7 +160,7 @@ def run_op(o):
                         vs.append(f32(p[3 + 2 * sgi] + off, 64))
                 K, V = torch.stack(ks), torch.stack(vs)
                 a = torch.softmax(qq @ K.t(), 1) @ V
-                out[b * 16:(b + 1) * 16, hd * 64:(hd + 1) * 64] = a.to(torch.bfloat16)
+                out[b * 16:(b + 1) * 16, hd * 64:(hd + 1) * 64] = a if fl & 1 else a.to(torch.bfloat16)
     elif t == OP_CONV:
         B, H, W, Cin, Ho, Wo, Cout, ldc, co_off, kh, kw, stride, pad, groups = [i[k] for k in range(14)]
         M = B * Ho * Wo

@@ -26,3 +26,14 @@ for graph in (True,):
     ms = (time.perf_counter() - t0) / n * 1e3
     plan = unet._plan(B, dev)
     print(f"B={B} graph={graph} lazy={unet.lazy_consumers} ops={len(plan.ops)} eval={ms:.3f} ms", flush=True)
+
+# the sampler path: time table + conditioning part of the init conv once per trajectory, plan body per eval
+ctx = unet.begin_sampling(cond, torch.linspace(-3, 3, 8, device=dev))
+for k in range(8):
+    unet.eval_prepared(ctx, x, k % 8)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for k in range(200):
+    unet.eval_prepared(ctx, x, k % 8)
+torch.cuda.synchronize()
+print(f"B={B} sampler path: body ops={plan.n_body_ops} eval={(time.perf_counter() - t0) / 200 * 1e3:.3f} ms (incl. the time-row copy)", flush=True)
