@@ -8,7 +8,7 @@
 //      17 GlobalContext to_k weight [Cout]  18 partial context logits [S * n_frags][M]   (both or neither)
 //   i: 0 B  1 H  2 W  3 C1  4 C2  5 Cout  6 ldc  7 co_off  8 k (1 | 3)  9 s1.mode  10 s1.groups  11 s1.npad
 //      12 norm (FNORM_*)  13 G  14 TR (image rows per tile)  15 WM  16 WN  17 S (input-channel slices)  18 ss_stride
-//   flags: 1 SiLU after the norm, 2 GELU before the LayerNorm, 4 accumulate into out
+//   flags: 1 SiLU after the norm, 2 GELU before the LayerNorm, 4 accumulate into out, 8 GELU on the final output
 //   f: 0 eps  1 s1.scale  2 s2.scale
 // SF_OP_SLOTS operands
 //   p: 0 x (or h)  1 gate [B, C] or null  2 res  3 out (gate mode)  4 slots ;  i: 0 M  1 C  2 HW
@@ -64,7 +64,7 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   WM = op.i[15]; WN = op.i[16];
   a.S = op.i[17] > 0 ? op.i[17] : 1;
   a.ss_stride = op.i[18];
-  a.silu = (op.flags & 1) ? 1 : 0; a.pre_gelu = (op.flags & 2) ? 1 : 0; a.accum = (op.flags & 4) ? 1 : 0;
+  a.silu = (op.flags & 1) ? 1 : 0; a.pre_gelu = (op.flags & 2) ? 1 : 0; a.accum = (op.flags & 4) ? 1 : 0; a.out_gelu = (op.flags & 8) ? 1 : 0;
   a.eps = op.f[0]; a.s1.scale = op.f[1]; a.s2.scale = op.f[2];
   if (!a.s1.p || !a.w || a.B < 1 || a.H < 1 || a.W < 1) FC_FAIL("fconv: missing operand");
   if (a.k != 1 && a.k != 3) FC_FAIL("fconv: k must be 1 or 3 (stride 1, same padding)");
@@ -99,11 +99,13 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
     }
   } else if (a.norm == FNORM_LN) {
     if (a.S != 1 || a.k != 1 || !a.gamma || a.s2.C) FC_FAIL("fconv: LayerNorm prologue needs S=1, k=1, one source, a gain");
+    if ((a.C / 4) * 16 * WM > 16 * SF_FCONV_WAVES * 64) FC_FAIL("fconv: LayerNorm row too long for the register-resident prologue (C <= 2048)");
+    if (a.s1.scale != 1.0f) FC_FAIL("fconv: LayerNorm source is unscaled");
   } else if (a.norm != FNORM_NONE) {
     FC_FAIL("fconv: unknown norm %d", a.norm);
   }
   if (a.S > 1) {
-    if (!a.ws || a.accum || a.slots_out) FC_FAIL("fconv: split-K slices write slabs only");
+    if (!a.ws || a.accum || a.slots_out || a.out_gelu) FC_FAIL("fconv: split-K slices write slabs only");
   } else {
     if (!a.out) FC_FAIL("fconv: output missing");
     if (a.slots_out && (a.Cout % 16 || a.ldc % 16 || a.co_off % 16)) FC_FAIL("fconv: slots need 16-aligned channels");

@@ -49,7 +49,7 @@ struct FConvArgs {
   const float* gamma;
   const float* beta;
   const float* ss;        // row b at ss + b*ss_stride: scale[C] then shift[C]; or null
-  int ss_stride, norm, silu, pre_gelu, accum, G;
+  int ss_stride, norm, silu, pre_gelu, accum, G, out_gelu;   // out_gelu: GELU(erf) on the final output (ChanFeedForward, :953-961)
   float eps;
   int B, H, W, C, Cout, ldc, co_off, k;
   int TR, S, cps, cchunks, KS, n_frags, n_tiles, mt_per_img, npad, M;
@@ -305,6 +305,56 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
         finish(v[u] * (c < a.s1.C ? a.s1.scale : a.s2.scale), (py + h) * FW + px + h, c4 * 4, 0, A, Bv);
       }
     }
+  } else if (NORM == FNORM_LN) {
+    // ---- (b1') LayerNorm over all C channels of each of the tile's 16*WM rows (S == 1, k == 1): NT / rows threads per
+    // row keep the whole row in registers -- one load round trip, two-pass statistics like nn.LayerNorm, then the
+    // registers are normalised straight into the frame.
+    constexpr int NVL = 16;                                 // C <= 2048 at 32 threads per row
+    const int rows = 16 * WM, tpr = NT / rows;
+    const int row = tid / tpr, part = tid - row * tpr;
+    const long m = mb + (long)row0 * a.W + row;
+    f32x4 v[NVL];
+#pragma unroll
+    for (int u = 0; u < NVL; ++u) {
+      const int c4 = part + u * tpr;
+      v[u] = fconv_value<LAZY>(a, m, (c4 < Cs4 ? c4 : Cs4 - 1) * 4);
+    }
+    prefetch_weights();
+    FC_STAMP(1);
+    float sm = 0.0f;
+#pragma unroll
+    for (int u = 0; u < NVL; ++u) {
+      if (part + u * tpr < Cs4) {
+        if (LAZY && nt == 0) *reinterpret_cast<f32x4*>(a.s1.p + m * a.s1.C + (part + u * tpr) * 4) = v[u];
+        if (a.pre_gelu) { v[u][0] = sf_gelu(v[u][0]); v[u][1] = sf_gelu(v[u][1]); v[u][2] = sf_gelu(v[u][2]); v[u][3] = sf_gelu(v[u][3]); }
+        sm += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+      }
+    }
+    const float mean = sf_group_sum(sm, tpr) / (float)Cs;
+    float sq = 0.0f;
+#pragma unroll
+    for (int u = 0; u < NVL; ++u)
+      if (part + u * tpr < Cs4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[u][j] - mean; sq = fmaf(d, d, sq); }
+      }
+    const float rstd = sf_rsqrt(sf_group_sum(sq, tpr) / (float)Cs + a.eps);
+    FC_STAMP(2);
+#pragma unroll
+    for (int u = 0; u < NVL; ++u) {
+      const int c4 = part + u * tpr;
+      if (c4 < Cs4) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(a.gamma + c4 * 4);
+        f32x4 y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = (v[u][j] - mean) * rstd * g[j];
+        if (a.beta) y += *reinterpret_cast<const f32x4*>(a.beta + c4 * 4);
+        if (a.silu) { y[0] = sf_silu_fast(y[0]); y[1] = sf_silu_fast(y[1]); y[2] = sf_silu_fast(y[2]); y[3] = sf_silu_fast(y[3]); }
+        bf16x4 o;
+        o[0] = (__bf16)y[0]; o[1] = (__bf16)y[1]; o[2] = (__bf16)y[2]; o[3] = (__bf16)y[3];
+        *reinterpret_cast<bf16x4*>(lds + (long)row * a.pix_stride + c4 * 8) = o;
+      }
+    }
   } else {
     // ---- (b2) statistics from the producer's slots (GroupNorm on large maps) or from the rows themselves (LayerNorm)
     if (NORM == FNORM_GN_SLOTS) {
@@ -356,51 +406,6 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
       FC_STAMP(1);
       sf_sync();
       build_table();
-      sf_sync();
-    } else if (NORM == FNORM_LN) {
-      // per-row statistics over all C channels (S == 1, k == 1): NT / rows threads per row, two passes like nn.LayerNorm,
-      // each pass in batches of 8 independent loads
-      prefetch_weights();
-      FC_STAMP(1);
-      const int rows = 16 * WM, tpr = NT / rows;
-      const int row = tid / tpr, part = tid - row * tpr;
-      const long m = mb + (long)row0 * a.W + row;
-      float sm = 0.0f;
-      for (int c4 = part; c4 < Cs4; c4 += 8 * tpr) {
-        f32x4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int cc = c4 + u * tpr;
-          v[u] = fconv_value<LAZY>(a, m, (cc < Cs4 ? cc : Cs4 - 1) * 4);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (c4 + u * tpr < Cs4) {
-            if (a.pre_gelu) { v[u][0] = sf_gelu(v[u][0]); v[u][1] = sf_gelu(v[u][1]); v[u][2] = sf_gelu(v[u][2]); v[u][3] = sf_gelu(v[u][3]); }
-            sm += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
-          }
-      }
-      const float mean = sf_group_sum(sm, tpr) / (float)Cs;
-      float sq = 0.0f;
-      for (int c4 = part; c4 < Cs4; c4 += 8 * tpr) {
-        f32x4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int cc = c4 + u * tpr;
-          v[u] = fconv_value<LAZY>(a, m, (cc < Cs4 ? cc : Cs4 - 1) * 4);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (c4 + u * tpr < Cs4) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float d = (a.pre_gelu ? sf_gelu(v[u][j]) : v[u][j]) - mean;
-              sq = fmaf(d, d, sq);
-            }
-          }
-      }
-      const float rstd = sf_rsqrt(sf_group_sum(sq, tpr) / (float)Cs + a.eps);
-      if (part == 0) { misc[16 + 2 * row] = mean; misc[17 + 2 * row] = rstd; }
       sf_sync();
     } else {
       prefetch_weights();
@@ -567,7 +572,8 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
       if (n < a.Cout) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float y = v[r] + bv + rv[r];
+          float y = v[r] + bv + rv[r];
+          if (a.out_gelu) y = sf_gelu(y);
           a.out[(mrow + r) * a.ldc + a.co_off + n] = y;
           sm += y;
           sq = fmaf(y, y, sq);

@@ -393,7 +393,7 @@ class _Plan:
         return t
 
     def fconv(self, x, skip, H, wname, bname, out, Cout, k, norm, geom, gname=None, ss_ptr=0, silu=True, resid=None,
-              want_slots=False, pre_gelu=False, beta_name=None, ldc=None, co_off=0, logit=None):
+              want_slots=False, pre_gelu=False, beta_name=None, ldc=None, co_off=0, logit=None, out_gelu=False):
         """One k_conv_fused launch: out = conv_k(act(norm(concat(x, skip * 2^-1/2)))).  With S > 1 input-channel slices the
         output stays a lazy split-K tensor (slabs + bias + resid) that the next fused conv / GroupNorm / gca pass reduces."""
         TR, WM, WN, S = geom
@@ -429,7 +429,8 @@ class _Plan:
         bias, res = (self.wptr(bname) if bname else 0), (resid.ptr if resid else 0)
         gam = self.wptr(gname + ".weight") if norm in (FNORM_GN_SELF, FNORM_GN_SLOTS) else (self.wptr(gname) if gname else 0)
         bet = self.wptr(gname + ".bias") if norm in (FNORM_GN_SELF, FNORM_GN_SLOTS) else (self.wptr(beta_name) if beta_name else 0)
-        self.op(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0),
+        assert not (out_gelu and S > 1)
+        self.op(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0) | (8 if out_gelu else 0),
                 p=(x.ptr, lp[0], lp[1], lp[2], x.slots or 0, skip.ptr if skip else 0, (skip.slots or 0) if skip else 0,
                    self.wptr(wname), 0 if S > 1 else bias, out.ptr, 0 if S > 1 else res, ws, slots_out, gam, bet, ss_ptr, 0,
                    logit[0] if logit else 0, logit[1] if logit else 0),
@@ -601,8 +602,7 @@ class _Plan:
         g2 = self.lin_geometry(att, d, FNORM_NONE)
         if g2 is None:
             return None
-        if x.lazy is not None and x.lazy[0] != "splitk":
-            self.need(x)
+        self.need(x)       # split-K slabs: one reduce launch beats re-reducing them in each of the projection's 40 workgroups
         qkv = self.zf32(rows, nq, 16)
         self.fconv(x, None, 4, f"{name}.to_q.weight" if cross else f"{name}.__qkv__", None, qkv, nq, 1, FNORM_LN, g1,
                    gname=f"{name}.norm.g", silu=False)
@@ -679,11 +679,12 @@ class _Plan:
                 f1 = self.zf32(rows, hid, 16)
                 gb = self.lin_geometry(f1, d, FNORM_LN)
             if ga is not None and gb is not None:
+                # GELU once, in ff1's epilogue (the 64 workgroups of ff2 would each redo it on the whole 16 x 2048 input)
                 self.fconv(x1, None, 4, f"{name}.layers.0.1.1.weight", None, f1, hid, 1, FNORM_LN, ga,
-                           gname=f"{name}.layers.0.1.0.g", silu=False)
+                           gname=f"{name}.layers.0.1.0.g", silu=False, out_gelu=True)
                 x2 = self.zf32(rows, d, x.HW)
                 self.fconv(f1, None, 4, f"{name}.layers.0.1.4.weight", None, x2, d, 1, FNORM_LN, gb,
-                           gname=f"{name}.layers.0.1.3.g", silu=False, pre_gelu=True, resid=x1)
+                           gname=f"{name}.layers.0.1.3.g", silu=False, resid=x1)
                 return x2
         xn = self.bf16(rows, d)
         self.ln(x1, f"{name}.layers.0.1.0.g", None, xn, d, rows)

@@ -52,7 +52,8 @@ def run_ops(ops, backend):
 
 
 def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, silu=True, ss=True, accum=False, resid=False,
-                  slots=True, pre_gelu=False, ln_bias=False, seed=0, G=8, scale2=2 ** -0.5, tol=4e-3, dbg=None, reps=1, logits=False):
+                  slots=True, pre_gelu=False, ln_bias=False, seed=0, G=8, scale2=2 ** -0.5, tol=4e-3, dbg=None, reps=1, logits=False,
+                  out_gelu=False):
     dev = "cpu" if backend == "emu" else "cuda:0"
     d = lambda t: None if t is None else t.to(dev)
     g = torch.Generator().manual_seed(seed)
@@ -110,7 +111,7 @@ def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, 
     wk = rn(Cout) if logits else None
     wk_d = d(wk)
     lpart = d(torch.full((S * n_frags, M), float("nan"))) if logits else None
-    op = fused.mkop(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0),
+    op = fused.mkop(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0) | (8 if out_gelu else 0),
                     p=(s1["p"], s1["a"], s1["b"], s1["r"], sl1, x2_d, sl2, wp, bias_d, out, res_d, wsl, slots_out, gamma_d, beta_d, ssv_d, dbg, wk_d, lpart),
                     i=(B, H, W, C1, C2, Cout, ldc, co_off, k, s1["mode"], s1["groups"], s1["npad"], norm, G, TR, WM, WN, S, 2 * C),
                     f=(1e-5, 1.0, scale2))
@@ -131,6 +132,8 @@ def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, 
             want = want + res[:, co_off:co_off + Cout]
         if accum:
             want = want + out0[:, co_off:co_off + Cout]
+        if out_gelu:
+            want = F.gelu(want)
         # columns outside [co_off, co_off + Cout) are untouched
         assert torch.equal(out[:, :co_off], out0[:, :co_off]) and torch.equal(out[:, co_off + Cout:], out0[:, co_off + Cout:])
     assert torch.isfinite(got).all()
@@ -227,7 +230,8 @@ CONV_CASES = {
     # XCD-aware tile order (8 n-tiles)
     "gn_slots_xcd_map_16x16": dict(B=1, H=16, W=16, C1=128, C2=0, Cout=128, k=3, norm=GN_SLOTS, WM=1, WN=1, ss=False, seed=4, logits=True),
     "raw_1x1_concat_res_conv": dict(B=1, H=8, W=8, C1=64, C2=32, Cout=40, k=1, norm=NONE, WM=1, WN=1, silu=False, slots=False, seed=5),
-    "layernorm_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=1, silu=False, seed=6),
+    "layernorm_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=1, silu=False, seed=6, out_gelu=True),
+    "layernorm_lazy_splitk_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=1, silu=False, lazy=1, seed=7),
     "gelu_layernorm_bias_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=2, silu=False, pre_gelu=True,
                                        ln_bias=True, seed=6),
 }
@@ -239,5 +243,7 @@ CONV_CASES_FULL = {
     "unet_16x16_768": dict(B=1, H=16, W=16, C1=512, C2=256, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=2, resid=True, seed=13),
     "unet_32x32_512": dict(B=1, H=32, W=32, C1=256, C2=256, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=14),
     "unet_32x32_res_conv": dict(B=1, H=32, W=32, C1=256, C2=256, Cout=256, k=1, norm=NONE, WM=2, WN=2, silu=False, seed=15),
+    "unet_ln_ff2_2048": dict(B=1, H=4, W=4, C1=2048, C2=0, Cout=1024, k=1, norm=LN, WM=1, WN=1, silu=False, pre_gelu=True, resid=True, seed=17),
+    "unet_ln_qkv_lazy": dict(B=1, H=4, W=4, C1=1024, C2=0, Cout=640, k=1, norm=LN, WM=1, WN=1, silu=False, lazy=1, seed=18),
     "unet_b4_4x4": dict(B=4, H=4, W=4, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SELF, WM=1, WN=1, S=1, seed=16),
 }
