@@ -67,6 +67,7 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   a.silu = (op.flags & 1) ? 1 : 0; a.pre_gelu = (op.flags & 2) ? 1 : 0; a.accum = (op.flags & 4) ? 1 : 0; a.out_gelu = (op.flags & 8) ? 1 : 0;
   a.eps = op.f[0]; a.s1.scale = op.f[1]; a.s2.scale = op.f[2];
   if (!a.s1.p || !a.w || a.B < 1 || a.H < 1 || a.W < 1) FC_FAIL("fconv: missing operand");
+  if ((long)a.B * a.H * a.W * (a.s1.C > a.s2.C ? a.s1.C : a.s2.C) >= (1L << 29)) FC_FAIL("fconv: source too large for 32-bit element offsets");
   if (a.k != 1 && a.k != 3) FC_FAIL("fconv: k must be 1 or 3 (stride 1, same padding)");
   if (a.W & (a.W - 1)) FC_FAIL("fconv: W must be a power of two");
   if (a.C % 32 || a.s1.C % 32 || a.s1.C <= 0 || a.s2.C < 0) FC_FAIL("fconv: channel counts must be multiples of 32");
@@ -121,7 +122,7 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   a.d_ncf = mk((a.norm == FNORM_GN_SLOTS) ? (a.C / a.G) / 16 : 1);
   a.pix_stride = fconv_pix_stride(Cs);
   const int h = a.k >> 1;
-  const uint32_t frame = (uint32_t)(a.TR + 2 * h) * (a.W + 2 * h) * a.pix_stride;
+  const uint32_t frame = ((uint32_t)(a.TR + 2 * h) * (a.W + 2 * h) + 1) * a.pix_stride;      // + 1 spare pixel (dead staging stores)
   a.red_off = (int)frame;
   a.tab_off = a.red_off + 1024 * SF_FCONV_WAVES * WM * WN;
   a.misc_off = a.tab_off + 2 * Cs * 4;

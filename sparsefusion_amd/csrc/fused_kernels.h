@@ -24,6 +24,9 @@
 struct FDiv { uint32_t d, magic; };
 SF_DEV uint32_t fdiv(uint32_t n, FDiv f) { return f.d == 1 ? n : (uint32_t)(((uint64_t)n * f.magic) >> 32); }
 
+#ifndef SF_STAGE_U
+#define SF_STAGE_U 8           // independent element loads in flight per thread while staging (plain sources)
+#endif
 enum { FNORM_NONE = 0, FNORM_GN_SELF = 1, FNORM_GN_SLOTS = 2, FNORM_LN = 3 };
 
 // fp32 NHWC source [M = B*HW, C].  mode 0: plain at p.  mode 1: v = b[c] + sum_g a[g][m][c (ld npad)] (+ r[m][c]).
@@ -221,9 +224,11 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
         v[j] = fmaf((u - mean) * rstd, A[j], Bv[j]);
       }
     }
-    if (a.silu) {
+    // a select, not a branch: the U elements of a staging batch must stay in one basic block to interleave
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = sf_silu_fast(v[j]);
+    for (int j = 0; j < 4; ++j) {
+      const float sv = sf_silu_fast(v[j]);
+      v[j] = a.silu ? sv : v[j];
     }
     bf16x4 o;
     o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
@@ -433,37 +438,39 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
         const long srcld = first ? a.s1.C : a.s2.C;
         f32x4 A, Bv;
         affine_of(cl, A, Bv);
+        // frame pixel pi = fr * W + x of an in-image row is source pixel M0 + pi: addresses are LINEAR in pi (the first
+        // version spent ~40 of its ~75 instructions per element on index arithmetic and was issue bound)
+        const int M0 = (int)mb + (row0 - h) * a.W;
+        const int pi_safe = h << a.logW;                                 // first own row: always inside the image
         for (int p0 = tp; p0 < npx; p0 += ppp * U) {
           f32x4 v[U];
-          int fpx[U];
-          long mx[U];
+          int fpx[U], mx[U];
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            int pi = p0 + u * ppp;
-            const bool live = pi < npx;
-            if (!live) pi = npx - 1;
-            const int fr = pi >> a.logW, x = pi & (a.W - 1);
+            const int pi = p0 + u * ppp;
+            const int fr = pi >> a.logW;
             const int r = row0 - h + fr;
-            const bool in = live && cact && r >= 0 && r < a.H;
-            const int rc = r < 0 ? 0 : (r >= a.H ? a.H - 1 : r);
-            mx[u] = mb + ((long)rc << a.logW) + x;
+            const bool in = pi < npx && cact && r >= 0 && r < a.H;
+            mx[u] = M0 + (in ? pi : pi_safe);
             // fpx < 0: nothing to store; bit 30: this workgroup owns the element (materialises a lazy source)
-            fpx[u] = in ? ((fr * FW + x + h) | ((nt == 0 && fr >= h && fr < h + a.TR) ? (1 << 30) : 0)) : -1;
-            if (LAZY == 0) v[u] = *reinterpret_cast<const f32x4*>(srcp + mx[u] * srcld);
+            fpx[u] = in ? ((pi + 2 * h * fr + h) | ((nt == 0 && fr >= h && fr < h + a.TR) ? (1 << 30) : 0)) : -1;
+            if (LAZY == 0) v[u] = *reinterpret_cast<const f32x4*>(srcp + mx[u] * (int)srcld);
             else v[u] = fconv_value<LAZY>(a, mx[u], c);
           }
+          // no branch per element: dead elements (rows outside the image, the tail of the last batch) are normalised
+          // like the others and land in a spare pixel behind the frame, so that the U dependent SiLU chains of a batch
+          // sit in ONE basic block and interleave (the chain exp -> add -> rcp -> mul is latency, not issue, bound)
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            if (fpx[u] < 0) continue;
-            if (LAZY && (fpx[u] >> 30) && first) *reinterpret_cast<f32x4*>(a.s1.p + mx[u] * a.s1.C + c) = v[u];
-            const int fp = fpx[u] & 0x3fffffff;
-            finish(v[u] * scale, fp, cl, NORM == FNORM_LN ? (fp - h) : 0, A, Bv);
+            if (LAZY && fpx[u] >= 0 && (fpx[u] >> 30) && first) *reinterpret_cast<f32x4*>(a.s1.p + (long)mx[u] * a.s1.C + c) = v[u];
+            const int fp = fpx[u] < 0 ? FR * FW : (fpx[u] & 0x3fffffff);
+            finish(v[u] * scale, fp, cl, 0, A, Bv);
           }
         }
       }
     };
     if (LAZY == 1) stage(FConst<4>());
-    else stage(FConst<8>());
+    else stage(FConst<SF_STAGE_U>());
   }
   sf_sync();
   FC_STAMP(3);

@@ -355,7 +355,7 @@ class _Plan:
         def lds_bytes(S_, WN_):
             Cs = C // S_
             stride = Cs * 2 + ((32 - (Cs * 2) % 256) + 256) % 256
-            return (TR + 2 * h) * (H + 2 * h) * stride + 8192 * WM * WN_ + 2 * Cs * 4 + 640
+            return ((TR + 2 * h) * (H + 2 * h) + 1) * stride + 8192 * WM * WN_ + 2 * Cs * 4 + 640
 
         cand = [1]
         if norm in (FNORM_GN_SELF, FNORM_GN_SLOTS):
