@@ -283,10 +283,11 @@ int sf_conv_pack_weights(const float* h_w, uint32_t Cout, uint32_t Cin,
 int sf_plms_update(const float* x, const float* eps, const float* noise,
                    const float* h_coef6, uint64_t n, float* x_prev, float* x0,
                    void* stream);
-/* e' = c0*e0 + c1*e1 + c2*e2 + c3*e3 (Adams-Bashforth combination, plms.py:137-152) */
+/* e' = c0*e0 + c1*e1 + c2*e2 + c3*e3 (Adams-Bashforth combination, plms.py:137-152);
+ * keep_e0 (or NULL) also receives a copy of e0 -- the history entry of this step. */
 int sf_plms_combine(const float* e0, const float* e1, const float* e2,
                     const float* e3, const float* h_c4, uint64_t n, float* out,
-                    void* stream);
+                    float* keep_e0, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1276,8 +1276,10 @@ __global__ __launch_bounds__(256) void k_plms_update(const float* __restrict__ x
 }
 __global__ __launch_bounds__(256) void k_plms_combine(const float* __restrict__ e0, const float* __restrict__ e1,
                                                       const float* __restrict__ e2, const float* __restrict__ e3, float c0,
-                                                      float c1, float c2, float c3, long n, float* __restrict__ out) {
+                                                      float c1, float c2, float c3, long n, float* __restrict__ out,
+                                                      float* __restrict__ keep) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    if (keep) keep[i] = e0[i];                   // the eps history entry of this step (saves the sampler a copy launch)
     float v = c0 * e0[i];
     if (e1) v += c1 * e1[i];
     if (e2) v += c2 * e2[i];
@@ -1297,11 +1299,11 @@ extern "C" int sf_plms_update(const float* x, const float* eps, const float* noi
 }
 
 extern "C" int sf_plms_combine(const float* e0, const float* e1, const float* e2, const float* e3, const float* h_c4,
-                               uint64_t n, float* out, void* stream) {
+                               uint64_t n, float* out, float* keep_e0, void* stream) {
   if (!e0 || !h_c4 || !out) SF_FAIL(SF_ERR_INVALID, "plms_combine: null argument");
   if (n == 0) return SF_OK;
   k_plms_combine<<<sf_grid_cap(sf_div_up(n, 256)), 256, 0, (hipStream_t)stream>>>(e0, e1, e2, e3, h_c4[0], h_c4[1], h_c4[2],
-                                                                                  h_c4[3], (long)n, out);
+                                                                                  h_c4[3], (long)n, out, keep_e0);
   SF_CHECK_LAUNCH("plms_combine");
   return SF_OK;
 }

@@ -69,6 +69,30 @@ def make_plms():
     torch.save(out, os.path.join(HERE, "plms_sample.pt"))
 
 
+def make_plms_canonical():
+    """Reference PLMSSampler.sample on the CANONICAL 400.68 M-parameter UNet at the distillation setting (max_thres = 0.5:
+    50 steps = 51 evals, B = 1, sparsefusion/distillation.py:304) -- the headline configuration of BASELINE.json."""
+    cfg = CONFIGS["canonical"]
+    vldm = ref_loader.reference_vldm(dict(cfg, layer_cross_attns=(False,) * 4, attn_pool_text=False)).eval()
+    unet = vldm.unets[0]
+    spec = [(k, tuple(v.shape)) for k, v in unet.state_dict().items()]
+    unet.load_state_dict(unet_ref.init_state(spec, seed=0), strict=True)
+    sampler = ref_loader.reference_plms(vldm, 50)
+    g = torch.Generator().manual_seed(13)
+    lat = 0.5 * torch.randn(1, 4, 32, 32, generator=g)
+    cond = torch.randn(1, cfg["cond_images_channels"], 32, 32, generator=g)
+    torch.manual_seed(79)
+    with torch.no_grad():
+        img, x_noisy, noise, acp = sampler.sample(lat.clone(), cond_images=cond, use_tqdm=False, return_noise=True, max_thres=0.5)
+    out = dict(B=1, input_seed=13, noise_seed=79, max_thres=0.5, img=img.clone(), x_noisy=x_noisy.clone(), noise=noise.clone(),
+               alpha_cumprod=acp.clone())
+    print("plms canonical", img.std().item(), acp)
+    torch.save(out, os.path.join(HERE, "plms_sample_canonical.pt"))
+
+
 if __name__ == "__main__":
-    make_unet()
-    make_plms()
+    if "--canonical-plms" in sys.argv:
+        make_plms_canonical()
+    else:
+        make_unet()
+        make_plms()

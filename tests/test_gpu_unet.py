@@ -159,8 +159,44 @@ def test_plms_sampler_matches_reference_golden(max_thres, evals):
     assert float(img.abs().max()) <= 10.0
 
 
-def test_plms_rng_draw_order_is_the_reference_one():
-    """Without injected noises the sampler draws randn tensors in the reference's order and count."""
+def test_plms_canonical_config_trajectory_matches_reference_golden():
+    """The headline configuration end to end: the reference's own PLMSSampler.sample on the 400.68 M-parameter UNet at
+    max_thres = 0.5 (50 steps = 51 evals, B = 1: sparsefusion/distillation.py:304, external/plms.py:54-119), golden from
+    tests/golden/make_golden_unet.py --canonical-plms.  51 chained bf16-operand evals: stated trajectory tolerance
+    relative L2 < 5e-2 and cosine > 0.998 (measured ~1.5e-2 / 0.9999)."""
+    from sparsefusion_amd.vldm import DDPM
+    from sparsefusion_amd.plms import PLMSSampler
+    r = torch.load(f"{GOLD}/plms_sample_canonical.pt")
+    unet = _unet("canonical")
+    vldm = DDPM(channels=4, unets=(unet,), conditional_encoder=None, conditional_embed_dim=None, image_sizes=(32,),
+                timesteps=500, cond_drop_prob=0.1, pred_objectives='noise', conditional=False, auto_normalize_img=False,
+                clip_output=True, dynamic_thresholding=False, dynamic_thresholding_percentile=.68, clip_value=10).to(DEV)
+    gg = torch.Generator().manual_seed(r["input_seed"])
+    lat = 0.5 * torch.randn(1, 4, 32, 32, generator=gg)
+    cond = torch.randn(1, 256, 32, 32, generator=gg)
+    torch.manual_seed(r["noise_seed"])
+    noises = [torch.randn(1, 4, 32, 32).to(DEV) for _ in range(unet_ref.plms_noise_count(r["max_thres"]))]
+    calls = [0]
+    orig = unet.eval_prepared
+
+    def counting(*a, **k):
+        calls[0] += 1
+        return orig(*a, **k)
+
+    unet.eval_prepared = counting
+    img, xn, nz, acp = PLMSSampler(vldm, 50).sample(lat.to(DEV), cond_images=cond.to(DEV), use_tqdm=False, return_noise=True,
+                                                    max_thres=r["max_thres"], noises=noises)
+    assert calls[0] == 51
+    assert torch.equal(nz.cpu(), r["noise"]) and torch.allclose(xn.cpu(), r["x_noisy"], atol=1e-5)
+    assert torch.allclose(acp.cpu(), r["alpha_cumprod"], atol=1e-6)
+    rr, cc = rel_err(img.cpu(), r["img"]), cosine(img.cpu(), r["img"])
+    print(f"plms canonical (51 evals) rel {rr:.3e} cos {cc:.6f}")
+    assert rr < 5e-2 and cc > 0.998 and float(img.abs().max()) <= 10.0
+
+
+def test_plms_internal_draws_match_injected_ones():
+    """Without injected noises the sampler draws the reference's number of gaussians (1 + 2n + 2) in ONE randn of the
+    whole trajectory and uses them in the reference's roles: injecting the same tensor slice by slice is the same run."""
     from sparsefusion_amd.vldm import DDPM
     from sparsefusion_amd.plms import PLMSSampler
     unet = _unet("small")
@@ -168,8 +204,8 @@ def test_plms_rng_draw_order_is_the_reference_one():
                 dynamic_thresholding=False, clip_value=10).to(DEV)
     lat, cond = torch.randn(1, 4, 32, 32, device=DEV), torch.randn(1, 60, 32, 32, device=DEV)
     torch.manual_seed(5)
-    noises = [torch.randn(1, 4, 32, 32, device=DEV) for _ in range(unet_ref.plms_noise_count(0.04))]
+    noises = list(torch.randn(unet_ref.plms_noise_count(0.04), 1, 4, 32, 32, device=DEV).unbind(0))
     a = PLMSSampler(vldm, 50).sample(lat, cond_images=cond, use_tqdm=False, return_noise=True, max_thres=0.04, noises=noises)
     torch.manual_seed(5)
     b = PLMSSampler(vldm, 50).sample(lat, cond_images=cond, use_tqdm=False, return_noise=True, max_thres=0.04)
-    assert torch.equal(a[2], b[2]) and rel_err(a[0].cpu(), b[0].cpu()) < 5e-3     # fp32 atomics order only
+    assert torch.equal(a[2], b[2]) and rel_err(a[0].cpu(), b[0].cpu()) < 2e-2     # eval-to-eval bf16 decorrelation only
