@@ -5,7 +5,7 @@ One "step" = one pass of the north-star hot path for one novel view per GPU, syn
   A  input-view NGP render (128x128 rays, 64+64 samples) fwd + bwd + Adam           distillation.py:185-247
   B  novel-view NGP render fwd -> x2 bilinear -> SD-VAE encode(.).mode() * z_scale -> PLMSSampler.sample(
      max_thres=0.5: 50 steps = 51 UNet evals at 32x32 latents, 256-ch view features) -> SD-VAE decode ->
-     (1-alpha_bar)*L1 + 1e-3*opacity -> bwd + Adam                                   distillation.py:262-352
+     (1-alpha_bar)*L1 + 1e-3*opacity + 1e-3*entropy -> bwd + Adam                    distillation.py:262-352
      + 0.1 * LPIPS-VGG(render, decoded)  (lambda_percep of itr > 1000, distillation.py:176-178,312-314)
 Everything runs on this repo's HIP path: NGP render, UNet/PLMS, the SD-VAE and the LPIPS
 term (row 2; VGG16 / lin weights are synthetic, the `lpips` package is not available).  fp32 everywhere except the
@@ -44,6 +44,12 @@ def pinhole_rays(n_side, view, n_views, device, radius=6.0, focal=2.0, elevation
     d = fwd[None, None] + (xx[..., None] * right[None, None] + yy[..., None] * up[None, None]) / focal
     d = d.reshape(1, -1, 3).contiguous()
     return eye.view(1, 1, 3).expand_as(d).contiguous().to(device), d.to(device)
+
+
+def entropy(sil):
+    """opacity entropy regulariser of the reference loss (sparsefusion/distillation.py:237-241, :337-341)."""
+    a = sil.clamp(1e-5, 1 - 1e-5)
+    return (-a * torch.log2(a) - (1 - a) * torch.log2(1 - a)).mean()
 
 
 def huber(x, y, scaling=0.1):
@@ -94,6 +100,13 @@ class HotPath:
         self.features = torch.randn(views, 256, 32, 32, generator=g).to(device)  # cached EFT features of the novel views
         self.flat_grads = None
 
+    def sampler_ctx(self):
+        """a prepared trajectory context (time table + conditioning part of the init conv) for timing single evals"""
+        if getattr(self, "_sctx", None) is None:
+            self._sctx = self.unet.begin_sampling(self.features[:1], torch.linspace(-3, 3, 4, device=self.dev))
+            self.sampler_x = torch.zeros(1, 4, 32, 32, device=self.dev)
+        return self._sctx
+
     def render(self, rays):
         o, d = rays
         out = self.ngp.render(o, d, staged=False, perturb=True, bg_color=0, ambient_ratio=1.0, shading='albedo',
@@ -111,7 +124,7 @@ class HotPath:
         # A: input view
         img, sil = self.render(self.rays_in)
         loss = huber(img, self.target_rgb).abs().mean() + huber(sil, self.target_mask).abs().mean() \
-            + 1e-3 * torch.sqrt(sil ** 2 + .01).mean()
+            + 1e-3 * torch.sqrt(sil ** 2 + .01).mean() + 1e-3 * entropy(sil)
         self.optim.zero_grad()
         loss.backward()
         self.sync_grads()
@@ -131,7 +144,7 @@ class HotPath:
             pred_img = ((self.vae.decode(pred_x0 / self.z_scale) + 1) * 0.5).clip(0.0, 1.0)   # distillation.py:309
         fusion = ((1 - acp).view(-1, 1, 1, 1) * (img256 - pred_img).abs()).mean()
         fusion = fusion + self.percep(img256, pred_img, normalize=True).mean() * self.lambda_percep      # :312-314
-        loss = fusion + 1e-3 * torch.sqrt(sil256 ** 2 + .01).mean()
+        loss = fusion + 1e-3 * torch.sqrt(sil256 ** 2 + .01).mean() + 1e-3 * entropy(sil256)
         loss.backward()
         self.sync_grads()
         self.optim.step()
@@ -150,37 +163,45 @@ def time_region(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
+def _op_weight_bytes(o):
+    """bf16 weight bytes one conv / linear op streams (each read once per eval)."""
+    from sparsefusion_amd.unet import OP_CONV, OP_FCONV
+    if o.type == OP_FCONV:
+        return 2 * o.i[5] * (o.i[3] + o.i[4]) * o.i[8] * o.i[8]
+    if o.type == OP_CONV:
+        return 2 * o.i[6] * o.i[3] * o.i[9] * o.i[10]
+    return 0
+
+
 def unet_roofline(hp):
-    """Per-op HIP-event timing of ONE UNet eval on its launch stream -> conv kernel roofline."""
+    """Per-op HIP-event timing of ONE UNet eval as the PLMS sampler runs it (plan body: the time path and the conditioning
+    half of the init conv are evaluated once per trajectory) on its launch stream -> roofline of the conv kernels."""
     import ctypes as C
     from sparsefusion_amd import _lib
-    from sparsefusion_amd.unet import OP_CONV
+    from sparsefusion_amd.unet import OP_CONV, OP_FCONV, OP_ELTWISE
     unet = hp.unet
-    plan = unet._plan(1, hp.dev)
-    ms = (C.c_float * len(plan.ops))()
+    ctx = unet.begin_sampling(hp.features[:1], torch.linspace(-3, 3, 4, device=hp.dev))
+    unet.eval_prepared(ctx, torch.zeros(1, 4, 32, 32, device=hp.dev), 0)
+    plan = ctx["plan"]
+    n_ops = plan.n_body_ops
+    ops = [plan.body_array[k] for k in range(n_ops)]
+    ms = (C.c_float * n_ops)()
     lib = _lib.lib()
-    acc = np.zeros(len(plan.ops))
+    acc = np.zeros(n_ops)
     reps = 5
     for it in range(reps + 1):
-        _lib.check(lib.sf_plan_profile(plan.op_array, len(plan.ops), _lib.stream_ptr(), ms))
+        _lib.check(lib.sf_plan_profile(plan.body_array, n_ops, _lib.stream_ptr(), ms))
         if it > 0:                                                 # first pass = warm-up, discarded
             acc += np.array(list(ms))
     acc /= reps
-    per_type = {}
-    for o, m in zip(plan.ops, acc):
-        per_type.setdefault(o.type, [0, 0.0])
-        per_type[o.type][0] += 1
-        per_type[o.type][1] += float(m)
-    n_conv, conv_ms = per_type[OP_CONV]
-    conv_params = sum(p.numel() for n, p in unet.named_parameters()
-                      if n.endswith(".weight") and (p.dim() == 4 and ".gca." not in n or
-                                                    any(s in n for s in (".to_q.", ".to_out.0.")) or
-                                                    (".to_kv." in n and ".cross_attn." not in n)))
-    conv_bytes = conv_params * 2                                   # bf16 weights, each read once per eval
-    achieved = conv_bytes / (conv_ms * 1e-3) / 1e9
+    conv = [(o, m) for o, m in zip(ops, acc) if o.type in (OP_CONV, OP_FCONV)]
+    fconv = [(o, m) for o, m in conv if o.type == OP_FCONV]
+    n_conv, conv_ms = len(conv), float(sum(m for _, m in conv))
+    conv_bytes = int(sum(_op_weight_bytes(o) for o, _ in conv))
+    fconv_bytes, fconv_ms = int(sum(_op_weight_bytes(o) for o, _ in fconv)), float(sum(m for _, m in fconv))
+    achieved = fconv_bytes / (fconv_ms * 1e-3) / 1e9
     total_ms = float(acc.sum())
     # what an event pair adds around ANY op (record + kernel boundary + a near-empty kernel): 64 one-element adds
-    from sparsefusion_amd.unet import OP_ELTWISE
     scratch = torch.zeros(64, device=hp.dev)
     tiny = (_lib.SfOp * 64)()
     for o in tiny:
@@ -190,31 +211,35 @@ def unet_roofline(hp):
     for _ in range(2):
         _lib.check(lib.sf_plan_profile(tiny, 64, _lib.stream_ptr(), tms))
     event_floor_us = float(np.median(np.array(list(tms)))) * 1e3
-    rocprof_us = None                                              # trace-timed conv (+ split-K reduce) time per conv op
-    stats_csv = os.path.join(ROOT, "profiles", "r01_unet_eval_b1_kernel_stats.csv")
+    rocprof_us, launches = None, None                              # trace-timed fused-conv time per launch
+    stats_csv = os.path.join(ROOT, "profiles", "r02_unet_eval_b1_kernel_stats.csv")
     if os.path.exists(stats_csv):
         import csv
         rows = list(csv.DictReader(open(stats_csv)))
         evals = max(int(r["Calls"]) for r in rows if r["Name"].startswith("k_pack_in"))
-        t = sum(float(r["TotalDurationNs"]) for r in rows if "k_conv_igemm" in r["Name"] or "k_splitk_reduce" in r["Name"])
-        rocprof_us = round(t / evals / n_conv / 1e3, 2)
-    traffic = None                                                 # HBM bytes per conv launch from the committed PMC passes
-    pmc = os.path.join(ROOT, "profiles", "r01_unet_eval_b1_pmc_hbm.json")
+        fr = [r for r in rows if "k_conv_fused" in r["Name"]]
+        rocprof_us = round(sum(float(r["TotalDurationNs"]) for r in fr) / max(sum(int(r["Calls"]) for r in fr), 1) / 1e3, 2)
+        launches = round(sum(int(r["Calls"]) for r in rows if "rocclr" not in r["Name"]) / evals, 1)
+    traffic = mfma_busy = None                                     # counters from the committed PMC passes
+    pmc = os.path.join(ROOT, "profiles", "r02_unet_eval_b1_pmc.json")
     if os.path.exists(pmc):
         j = json.load(open(pmc))
-        traffic = round(j["conv_fetch_bytes_corrected"] / j["conv_launches_per_eval"])
-    return {"bound": "hbm", "kernel": "k_conv_igemm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "traffic_note": "avg HBM fetch bytes per conv launch: rocprofv3 --pmc FETCH_SIZE pass (x2 gfx950 correction), "
-                            "profiles/r01_unet_eval_b1_pmc_hbm.json; algorithmic = %d B/launch" % (conv_bytes // n_conv),
-            "launches_per_eval": n_conv, "avg_launch_us": round(conv_ms / n_conv * 1e3, 2),
+        traffic = j.get("fconv_fetch_bytes_per_launch_corrected")
+        mfma_busy = j.get("fconv_mfma_busy_frac")
+    return {"bound": "hbm", "kernel": "k_conv_fused (GroupNorm / LayerNorm + conv in one launch)", "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "mfma_busy_frac": mfma_busy,
+            "traffic_note": "avg HBM fetch bytes per k_conv_fused launch: rocprofv3 --pmc FETCH_SIZE pass (x2 gfx950 correction), "
+                            "profiles/r02_unet_eval_b1_pmc.json; algorithmic = %d B/launch" % (fconv_bytes // max(len(fconv), 1)),
+            "launches_per_eval": len(fconv), "avg_launch_us": round(fconv_ms / max(len(fconv), 1) * 1e3, 2),
             "event_floor_us": round(event_floor_us, 2), "avg_launch_us_rocprof": rocprof_us,
-            "timing_note": "avg_launch_us = HIP events on the launch stream around each conv op (kernel + its split-K reduce "
-                           "+ one event/boundary, whose floor is event_floor_us for a one-element kernel); avg_launch_us_rocprof = "
-                           "same ops from the committed rocprofv3 kernel trace (profiles/r01_unet_eval_b1_kernel_stats.csv)",
-            "algorithmic_bytes_per_eval": conv_bytes,
-            "unet_eval_event_ms": round(total_ms, 3), "unet_ops_per_eval": len(plan.ops),
-            "unet_eval_weight_stream_GBs": round(801.4e6 / (total_ms * 1e-3) / 1e9, 1)}
+            "timing_note": "avg_launch_us = HIP events on the launch stream around each fused-conv op (one event / boundary each, whose "
+                           "floor is event_floor_us for a one-element kernel); avg_launch_us_rocprof = same kernels from the committed "
+                           "rocprofv3 kernel trace (profiles/r02_unet_eval_b1_kernel_stats.csv)",
+            "algorithmic_bytes_per_eval": fconv_bytes, "all_conv_ops": n_conv, "all_conv_bytes": conv_bytes,
+            "all_conv_avg_launch_us": round(conv_ms / n_conv * 1e3, 2),
+            "unet_eval_event_ms": round(total_ms, 3), "unet_ops_per_eval": n_ops, "unet_launches_per_eval_rocprof": launches,
+            "unet_eval_weight_stream_GBs": round(conv_bytes / (total_ms * 1e-3) / 1e9, 1)}
 
 
 def lds_conv_roofline(hp):
@@ -361,6 +386,7 @@ def main():
             "ngp_render_fwd": round(time_region(lambda: hp.render(hp.rays_novel[0]), 5), 3),
             "unet_eval_wall": round(time_region(lambda: hp.unet.forward_with_cond_scale(
                 torch.zeros(1, 4, 32, 32, device=dev), torch.zeros(1, device=dev), cond_images=hp.features[:1]), 10), 3),
+            "unet_eval_in_sampler": round(time_region(lambda: hp.unet.eval_prepared(hp.sampler_ctx(), hp.sampler_x, 1), 20), 3),
             "vae_encode": round(time_region(lambda: hp.vae.encode(torch.zeros(1, 3, 256, 256, device=dev)), 5), 3),
             "vae_decode": round(time_region(lambda: hp.vae.decode(torch.zeros(1, 4, 32, 32, device=dev)), 5), 3),
             "lpips_fwd_bwd": round(time_region(lambda: hp.percep(lp_a, lp_b).sum().backward(), 5), 3),

@@ -1,0 +1,61 @@
+"""Summarise the PMC passes of the UNet eval loop (tools/gpu_unet_pmc.sh) into profiles/r02_unet_eval_b1_pmc.json:
+HBM fetch / write bytes and MFMA-busy fraction of the fused conv kernels, per launch."""
+import csv, glob, json, sys
+from collections import defaultdict
+
+
+def collect(d):
+    res = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            res[name][r["Counter_Name"]][0] += float(r["Counter_Value"])
+            res[name][r["Counter_Name"]][1] += 1
+    return res
+
+
+out_path, dirs = sys.argv[1], sys.argv[2:]
+tot = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+for d in dirs:
+    for k, v in collect(d).items():
+        for c, (s, n) in v.items():
+            tot[k][c][0] += s
+            tot[k][c][1] += n
+
+
+def per_launch(pred, counter):
+    s = sum(v[counter][0] for k, v in tot.items() if pred(k) and counter in v)
+    n = sum(v[counter][1] for k, v in tot.items() if pred(k) and counter in v)
+    return (s / n) if n else None, n
+
+
+fused = lambda k: "k_conv_fused" in k
+allk = lambda k: "rocclr" not in k
+fetch, n_f = per_launch(fused, "FETCH_SIZE")
+write, _ = per_launch(fused, "WRITE_SIZE")
+busy, _ = per_launch(fused, "SQ_BUSY_CYCLES")
+mfma, _ = per_launch(fused, "SQ_VALU_MFMA_BUSY_CYCLES")
+wavec, _ = per_launch(fused, "SQ_WAVE_CYCLES")
+waitany, _ = per_launch(fused, "SQ_WAIT_ANY")
+valu, _ = per_launch(fused, "SQ_ACTIVE_INST_VALU")
+grbm, _ = per_launch(fused, "GRBM_GUI_ACTIVE")
+res = {
+    "source": "rocprofv3 --kernel-trace --pmc <one counter group per pass> -- python tools/unet_eval_loop.py 1 6 (sampler path); "
+              "means over all k_conv_fused launches",
+    "unit_note": "FETCH_SIZE / WRITE_SIZE are KiB; per MI355X_MICROARCH.md FETCH_SIZE reads 1/2 of wide coalesced streams on gfx950 "
+                 "-> doubled for the corrected figure; WRITE_SIZE uncalibrated.  SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over "
+                 "SIMDs, GRBM_GUI_ACTIVE the kernel's cycles: mfma_busy_frac = MFMA busy / (GUI active cycles x 1024 SIMDs)",
+    "fconv_launches_sampled": n_f,
+    "fconv_fetch_KiB_reported_per_launch": fetch,
+    "fconv_fetch_bytes_per_launch_corrected": (fetch * 1024 * 2) if fetch else None,
+    "fconv_write_KiB_reported_per_launch": write,
+    "fconv_mfma_busy_cycles_per_launch": mfma,
+    "fconv_gui_active_cycles_per_launch": grbm,
+    "fconv_mfma_busy_frac": (mfma / (grbm * 1024)) if (mfma and grbm) else None,
+    "fconv_wave_cycles_per_launch": wavec,
+    "fconv_wait_any_frac_of_wave_cycles": (waitany / wavec) if (waitany and wavec) else None,
+    "fconv_valu_issue_frac_of_wave_cycles": (valu / wavec) if (valu and wavec) else None,
+    "per_kernel": {k: {c: v[0] / v[1] for c, v in cs.items()} for k, cs in sorted(tot.items()) if allk(k)},
+}
+json.dump(res, open(out_path, "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if k != "per_kernel"}, indent=1))
