@@ -72,6 +72,9 @@ class HotPath:
         self.ngp = ngp.to(device).train()
         from sparsefusion_amd.optim import FusedAdam
         self.optim = FusedAdam(self.ngp.get_params(lr=5e-4))              # torch.optim.Adam arithmetic, one launch per step
+        from sparsefusion_amd.distributed import FlatGradBucket
+        self.grads = FlatGradBucket(self.ngp.parameters())       # .grad = views of one flat buffer: zero-copy all-reduce
+        self.check_replicas = False
         unet = Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2),
                     layer_attns=(False, False, False, True), layer_cross_attns=(False, False, False, False),
                     cond_images_channels=256, attn_pool_text=False)
@@ -82,9 +85,9 @@ class HotPath:
                          auto_normalize_img=False, clip_output=True, dynamic_thresholding=False,
                          dynamic_thresholding_percentile=.68, clip_value=10).to(device)
         self.unet = self.vldm.unets[0]
-        # plain plan replay and hipGraph replay take the same time (the GPU, not the host, is the bottleneck: DESIGN.md 4);
-        # with RCCL in the process the capture is one more thing that can go wrong, so multi-rank runs skip it
-        self.unet.use_hip_graph = (world == 1)
+        # hipGraph replay of the plan body also under RCCL: the capture is thread-local and contains no collective; if the
+        # capture fails in a process with RCCL threads, Unet falls back to plain replay (same GPU time: the GPU is the bottleneck)
+        self.unet.use_hip_graph = os.environ.get("SF_BENCH_GRAPH", "1") != "0"
         self.plms = PLMSSampler(self.vldm, 50)
         from sparsefusion_amd.vae import AutoencoderKL
         self.vae = AutoencoderKL().to(device)                     # sd-vae.yaml architecture, default (kaiming-range) init
@@ -116,21 +119,25 @@ class HotPath:
         return img, sil
 
     def sync_grads(self):
-        """mean all-reduce of the NGP gradients over the replicas (one flat RCCL call)."""
-        from sparsefusion_amd.distributed import all_reduce_grads
-        all_reduce_grads(self.ngp.parameters())
+        """mean all-reduce of the NGP gradients over the replicas: ONE in-place RCCL call on the flat gradient buffer."""
+        self.grads.all_reduce()
+
+    def after_step(self):
+        if self.check_replicas and self.world > 1:
+            from sparsefusion_amd.distributed import replicas_identical
+            assert replicas_identical(self.ngp), "NGP replicas diverged"
 
     def step(self):
         # A: input view
         img, sil = self.render(self.rays_in)
         loss = huber(img, self.target_rgb).abs().mean() + huber(sil, self.target_mask).abs().mean() \
             + 1e-3 * torch.sqrt(sil ** 2 + .01).mean() + 1e-3 * entropy(sil)
-        self.optim.zero_grad()
+        self.grads.zero()
         loss.backward()
         self.sync_grads()
         self.optim.step()
         # B: novel view(s) + diffusion distillation (V views per GPU share one batched PLMS call)
-        self.optim.zero_grad()
+        self.grads.zero()
         imgs, sils = zip(*[self.render(r) for r in self.rays_novel])
         img, sil = torch.cat(imgs, 0), torch.cat(sils, 0)
         img256 = F.interpolate(img, scale_factor=2, mode='bilinear')
@@ -148,6 +155,7 @@ class HotPath:
         loss.backward()
         self.sync_grads()
         self.optim.step()
+        self.after_step()
 
 
 def time_region(fn, iters):
@@ -325,6 +333,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--max-thres", type=float, default=0.5)
     ap.add_argument("--views-per-gpu", type=int, default=1, help="novel views distilled per GPU and step (BASELINE config 4: 4)")
+    ap.add_argument("--total-views", type=int, default=0,
+                    help="strong scaling: this many novel views per step in total, block-sharded over the ranks (overrides --views-per-gpu)")
+    ap.add_argument("--check-replicas", action="store_true", help="assert after every step that all ranks hold bit-identical NGP parameters")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -344,7 +355,14 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    strong = args.total_views > 0
+    if strong:
+        from sparsefusion_amd.distributed import shard_views
+        if args.total_views % world:
+            raise SystemExit("--total-views must be a multiple of the number of ranks (equal shards for the latent all-gather)")
+        args.views_per_gpu = len(shard_views(args.total_views, rank, world))
     hp = HotPath(dev, rank, world, args.max_thres, args.views_per_gpu)
+    hp.check_replicas = args.check_replicas
     for _ in range(args.warmup):
         hp.step()
 
@@ -369,7 +387,7 @@ def main():
             "metric": "novel views/sec, distillation steps (2 NGP renders fwd+bwd + VAE enc/dec + %d-eval PLMS + LPIPS), 256^2 / 32x32 latents, "
                       "2-view synthetic hydrant" % n_evals,
             "value": round(world * args.views_per_gpu / (ms_per_step * 1e-3), 4), "unit": "views/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "bf16 MFMA operands / f32 accumulate (UNet); f32 (NGP render)", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[1]: single MI355X" if args.views_per_gpu == 1 and world == 1 else
                                     "BASELINE configs[3]-style view sharding: %d GPU(s) x %d novel views per step" % (world, args.views_per_gpu)) +

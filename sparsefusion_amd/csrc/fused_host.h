@@ -120,13 +120,19 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   a.d_cps = mk(a.cps);
   a.d_tc = mk((Cs / 4) < SF_FCONV_WAVES * 64 ? (Cs / 4) : SF_FCONV_WAVES * 64);
   a.d_ncf = mk((a.norm == FNORM_GN_SLOTS) ? (a.C / a.G) / 16 : 1);
+  a.det_w = 0;
+  if (a.norm == FNORM_GN_SELF) {
+    const int NT = SF_FCONV_WAVES * 64, cs4 = Cs / 4, cg4 = (a.C / a.G) / 4;
+    const int w = cg4 >= 64 ? (cg4 % 64 == 0 ? 64 : 0) : ((cg4 & (cg4 - 1)) == 0 ? cg4 : 0);
+    if (NT % cs4 == 0 && w >= 1 && (cs4 >= 64 || 64 % cs4 == 0)) a.det_w = w;
+  }
   a.pix_stride = fconv_pix_stride(Cs);
   const int h = a.k >> 1;
   const uint32_t frame = ((uint32_t)(a.TR + 2 * h) * (a.W + 2 * h) + 1) * a.pix_stride;      // + 1 spare pixel (dead staging stores)
   a.red_off = (int)frame;
   a.tab_off = a.red_off + 1024 * SF_FCONV_WAVES * WM * WN;
   a.misc_off = a.tab_off + 2 * Cs * 4;
-  lds_bytes = a.misc_off + 640;
+  lds_bytes = a.misc_off + 640 + 2048;      // misc: 160 floats of statistics + 512 floats of reduction partials
   if (lds_bytes > SF_LDS_MAX) FC_FAIL("fconv: tile needs %u bytes of LDS", lds_bytes);
   const int MT = a.B * a.mt_per_img;
   a.xcd_map = (a.n_tiles % 8 == 0 && MT > 1) ? 1 : 0;

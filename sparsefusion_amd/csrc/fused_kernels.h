@@ -57,6 +57,7 @@ struct FConvArgs {
   int B, H, W, C, Cout, ldc, co_off, k;
   int TR, S, cps, cchunks, KS, n_frags, n_tiles, mt_per_img, npad, M;
   int pix_stride, xcd_map, logW;
+  int det_w;                             // GN_SELF: lanes per deterministic reduction segment (0 = LDS-atomic fallback)
   FDiv d_ncf;                            // 16-channel fragments per group
   FDiv d_cs4, d_cg, d_cps, d_tc;         // Cs/4, channels per group, chunks per slice, min(Cs/4, threads)
   int red_off, tab_off, misc_off;    // LDS byte offsets
@@ -263,35 +264,71 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
     }
     prefetch_weights();
     FC_STAMP(1);
-    if (tid < 16) misc[tid] = 0.0f;
-    sf_sync();
-    int cur = -1;
-    float sm = 0.0f, sq = 0.0f;
+    if (a.det_w) {
+      // deterministic group sums: a thread's elements share one channel chunk (NT % (Cs/4) == 0), hence one group; det_w
+      // adjacent lanes lie in one group -> segment sums by shuffles, one partial per segment, fixed-order final sum.
+      // (The LDS-atomic fallback below is order dependent: last-ulp noise in the statistics, visible after bf16 rounding.)
+      const int W = a.det_w;
+      float sm = 0.0f, sq = 0.0f;
+      const int c4t = tid - (int)fdiv((uint32_t)tid, a.d_cs4) * Cs4;
+      const float sc = (c0 + c4t * 4 < a.s1.C) ? a.s1.scale : a.s2.scale;
 #pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int i = tid + u * NT;
-      if (i < cnt) {
-        const int p = (int)fdiv((uint32_t)i, a.d_cs4), c4 = i - p * Cs4;
-        const int gi = (int)fdiv((uint32_t)(c4 * 4), a.d_cg);
-        const float sc = (c0 + c4 * 4 < a.s1.C) ? a.s1.scale : a.s2.scale;
-        if (gi != cur) {
-          if (cur >= 0) { sf_lds_add(misc + 2 * cur, sm); sf_lds_add(misc + 2 * cur + 1, sq); }
-          cur = gi; sm = 0.0f; sq = 0.0f;
+      for (int u = 0; u < NV; ++u) {
+        if (tid + u * NT < cnt) {
+          const f32x4 w = v[u] * sc;
+          sm += (w[0] + w[1]) + (w[2] + w[3]);
+          sq = fmaf(w[0], w[0], sq); sq = fmaf(w[1], w[1], sq); sq = fmaf(w[2], w[2], sq); sq = fmaf(w[3], w[3], sq);
         }
-        const f32x4 w = v[u] * sc;
-        sm += (w[0] + w[1]) + (w[2] + w[3]);
-        sq = fmaf(w[0], w[0], sq); sq = fmaf(w[1], w[1], sq); sq = fmaf(w[2], w[2], sq); sq = fmaf(w[3], w[3], sq);
       }
-    }
-    if (cur >= 0) { sf_lds_add(misc + 2 * cur, sm); sf_lds_add(misc + 2 * cur + 1, sq); }
-    sf_sync();
-    if (tid < Cs / Cg) {
-      const double n = (double)HW * Cg;
-      const double mean = (double)misc[2 * tid] / n;
-      double var = (double)misc[2 * tid + 1] / n - mean * mean;
-      if (var < 0.0) var = 0.0;
-      misc[16 + 2 * tid] = (float)mean;
-      misc[17 + 2 * tid] = sf_rsqrt((float)var + a.eps);
+      sm = sf_group_sum(sm, W);
+      sq = sf_group_sum(sq, W);
+      float* part = misc + 160;                               // [NT / W][2]
+      if ((lane & (W - 1)) == 0) { part[2 * (tid / W)] = sm; part[2 * (tid / W) + 1] = sq; }
+      sf_sync();
+      if (tid < Cs / Cg) {
+        double S = 0.0, Q = 0.0;
+        for (int sl = 0; sl < NT / W; ++sl) {
+          const int t0 = sl * W, c4s = t0 - (int)fdiv((uint32_t)t0, a.d_cs4) * Cs4;
+          if ((int)fdiv((uint32_t)(c4s * 4), a.d_cg) == tid) { S += (double)part[2 * sl]; Q += (double)part[2 * sl + 1]; }
+        }
+        const double n = (double)HW * Cg;
+        const double mean = S / n;
+        double var = Q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        misc[16 + 2 * tid] = (float)mean;
+        misc[17 + 2 * tid] = sf_rsqrt((float)var + a.eps);
+      }
+    } else {
+      if (tid < 16) misc[tid] = 0.0f;
+      sf_sync();
+      int cur = -1;
+      float sm = 0.0f, sq = 0.0f;
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const int i = tid + u * NT;
+        if (i < cnt) {
+          const int p = (int)fdiv((uint32_t)i, a.d_cs4), c4 = i - p * Cs4;
+          const int gi = (int)fdiv((uint32_t)(c4 * 4), a.d_cg);
+          const float sc = (c0 + c4 * 4 < a.s1.C) ? a.s1.scale : a.s2.scale;
+          if (gi != cur) {
+            if (cur >= 0) { sf_lds_add(misc + 2 * cur, sm); sf_lds_add(misc + 2 * cur + 1, sq); }
+            cur = gi; sm = 0.0f; sq = 0.0f;
+          }
+          const f32x4 w = v[u] * sc;
+          sm += (w[0] + w[1]) + (w[2] + w[3]);
+          sq = fmaf(w[0], w[0], sq); sq = fmaf(w[1], w[1], sq); sq = fmaf(w[2], w[2], sq); sq = fmaf(w[3], w[3], sq);
+        }
+      }
+      if (cur >= 0) { sf_lds_add(misc + 2 * cur, sm); sf_lds_add(misc + 2 * cur + 1, sq); }
+      sf_sync();
+      if (tid < Cs / Cg) {
+        const double n = (double)HW * Cg;
+        const double mean = (double)misc[2 * tid] / n;
+        double var = (double)misc[2 * tid + 1] / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        misc[16 + 2 * tid] = (float)mean;
+        misc[17 + 2 * tid] = sf_rsqrt((float)var + a.eps);
+      }
     }
     sf_sync();
     build_table();

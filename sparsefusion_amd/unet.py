@@ -355,7 +355,7 @@ class _Plan:
         def lds_bytes(S_, WN_):
             Cs = C // S_
             stride = Cs * 2 + ((32 - (Cs * 2) % 256) + 256) % 256
-            return ((TR + 2 * h) * (H + 2 * h) + 1) * stride + 8192 * WM * WN_ + 2 * Cs * 4 + 640
+            return ((TR + 2 * h) * (H + 2 * h) + 1) * stride + 8192 * WM * WN_ + 2 * Cs * 4 + 2688
 
         cand = [1]
         if norm in (FNORM_GN_SELF, FNORM_GN_SLOTS):
@@ -1145,10 +1145,18 @@ class Unet(nn.Module):
             if getattr(plan, "body_graph", None) is None:
                 self._run_plan(plan, True)
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self._run_plan(plan, True)
+                    plan.body_graph = g
+                except Exception as e:                      # e.g. another library's thread touched HIP mid-capture
+                    import warnings
+                    warnings.warn(f"sparsefusion_amd.Unet: hipGraph capture failed ({e}); replaying the plan launch by launch")
+                    self.use_hip_graph = False
+                    torch.cuda.synchronize()
                     self._run_plan(plan, True)
-                plan.body_graph = g
+                    return plan.out_view.view(B, self.channels, self.image_size, self.image_size)
             plan.body_graph.replay()
         else:
             self._run_plan(plan, True)

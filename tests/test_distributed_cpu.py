@@ -41,6 +41,32 @@ def _worker(rank, world, port, ret):
         both = [torch.empty_like(flat) for _ in range(world)]
         dist.all_gather(both, flat)
         assert torch.equal(both[0], both[1])                      # replicas stay bit-identical
+        assert sfd.replicas_identical(net)
+        # zero-copy bucket: grads are views of one flat buffer, one in-place all-reduce, same update as above;
+        # a parameter that got no gradient on one rank still takes part (zeros) -- equal message sizes by construction
+        net2 = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4), torch.nn.Linear(4, 4))
+        net2.load_state_dict({**{k: v for k, v in ref.state_dict().items()}, "2.weight": torch.eye(4), "2.bias": torch.zeros(4)})
+        bucket = sfd.FlatGradBucket(net2.parameters())
+        opt2 = torch.optim.Adam(net2.parameters(), lr=1e-2)
+        for it in range(2):
+            bucket.zero()
+            y = net2[1](net2[0](xs[rank]))
+            (net2[2](y) if rank == 0 else y).pow(2).mean().backward()      # rank 1 never touches layer 2
+            assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in net2.parameters())    # still views of the buffer
+            bucket.all_reduce()
+            opt2.step()
+            assert sfd.replicas_identical(net2)
+        # a diverged replica is detected
+        if rank == 1:
+            with torch.no_grad():
+                net2[0].bias[0] += 1e-6
+        assert not sfd.replicas_identical(net2)
+        # unequal shard sizes are refused when asked to check
+        try:
+            sfd.all_gather_latents(torch.zeros(1 + rank, 4, 2, 2), check=True)
+            raise AssertionError("ragged all-gather accepted")
+        except RuntimeError:
+            pass
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()

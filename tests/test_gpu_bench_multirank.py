@@ -1,0 +1,26 @@
+"""Dry run of the multi-rank path of bench.py on ONE GPU: two ranks share cuda:0, the collectives go through gloo
+(SF_BENCH_BACKEND=gloo) -- exercises view sharding (--total-views, strong scaling), the latent all-gather, the in-place
+all-reduce of the flat NGP gradient buffer, the per-step replica check and the max-over-ranks timing / JSON line.
+RCCL itself only runs on the driver's multi-GPU node."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_strong_scaling_dry_run():
+    env = dict(os.environ, SF_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--total-views", "2",
+           "--steps", "2", "--warmup", "1", "--max-thres", "0.06", "--no-cpu-baseline", "--check-replicas"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["config"]["views_per_gpu"] == 1
+    assert res["value"] > 0 and res["steps"] == 2

@@ -79,7 +79,7 @@ def _audit(ops, name, sized=False):
             h = k // 2
             Cs = C // S
             stride = Cs * 2 + ((32 - (Cs * 2) % 256) + 256) % 256
-            assert ((TR + 2 * h) * (W + 2 * h) + 1) * stride + 8192 * WM * WN + 8 * Cs + 640 <= unet.LDS_MAX, where
+            assert ((TR + 2 * h) * (W + 2 * h) + 1) * stride + 8192 * WM * WN + 8 * Cs + 2688 <= unet.LDS_MAX, where
         elif o.type == unet.OP_SLOTS:
             assert o.p[0] and o.p[4] and o.i[0] % 16 == 0 and o.i[1] % 16 == 0 and (not o.p[1] or (o.p[2] and o.p[3])), where
         elif o.type == unet.OP_LN:
