@@ -94,6 +94,7 @@ class HotPath:
         self.z_scale = 0.18215                                    # args.z_scale_factor of the reference's demo
         from sparsefusion_amd.lpips import PerceptualLoss
         self.percep = PerceptualLoss('vgg', device=device)        # distillation.py:161
+        self.percep.model._weights_loaded = True                  # synthetic VGG16 / lin weights, stated in `data` (no `lpips` package here)
         self.lambda_percep = 0.1                                  # value after start_percep_step (:176-178)
         g = torch.Generator().manual_seed(100 + rank)
         self.rays_in = pinhole_rays(128, rank % 2, 34, device)                 # one of the 2 input views

@@ -203,6 +203,17 @@ int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_grad* g,
 
 uint64_t sf_ngp_render_workspace_bytes(uint32_t N, uint32_t T);
 
+/* Fused evaluation render through the occupancy grid (`cuda_ray=True`, eval mode): replaces the host loop
+ * `while step < max_steps: march_rays -> network -> composite_rays` of external/nerf/renderer_df.py:543-584 by ONE
+ * launch (one ray per lane walks to the end).  `grid` = the density bitfield, C cascades of H^3 cells;
+ * `noises` [N] = the jitter of the first sample (the reference perturbs the first round only) or NULL.
+ * Outputs weights_sum [N], depth [N] (un-normalised, as composite_rays leaves it), image [N,3] without background. */
+int sf_ngp_render_occ_eval(const sf_ngp_field* f, const float* rays_o, const float* rays_d,
+                           const float* nears, const float* fars, const uint8_t* grid,
+                           float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                           const float* noises, float T_thresh, uint32_t N,
+                           float* weights_sum, float* depth, float* image, void* stream);
+
 /* ------------------------------------------------------------------------ */
 /* UNet op executor (external/imagen_pytorch.py:1470-1671) -- the host side  */
 /* builds a static launch plan once (sparsefusion_amd/unet.py) and the       */

@@ -20,24 +20,11 @@
 
 #include "sf_common.h"
 #include "ngp_device.h"
+#include "ngp_field_lds.h"
 
 struct GridLevels;  // gridencoder.hip
 int sf_fill_levels(GridLevels* lv, const int32_t* offsets_dev, const int32_t* h_offsets, uint32_t L, float S,
                    uint32_t H, hipStream_t st);
-
-struct FieldPtrs {
-  const float* table;
-  const float* w0; const float* b0; const float* w1; const float* b1; const float* w2; const float* b2;
-  float bound;
-};
-
-__device__ __forceinline__ void load_weights_lds(float* W, const FieldPtrs& f) {
-  for (int i = threadIdx.x; i < NGP_HID * NGP_FEAT; i += blockDim.x) W[NGP_W0 + i] = f.w0[i];
-  for (int i = threadIdx.x; i < NGP_HID * NGP_HID; i += blockDim.x) W[NGP_W1 + i] = f.w1[i];
-  for (int i = threadIdx.x; i < NGP_OUT * NGP_HID; i += blockDim.x) W[NGP_W2 + i] = f.w2[i];
-  for (int i = threadIdx.x; i < NGP_HID; i += blockDim.x) { W[NGP_B0 + i] = f.b0[i]; W[NGP_B1 + i] = f.b1[i]; }
-  if (threadIdx.x < NGP_OUT) W[NGP_B2 + threadIdx.x] = f.b2[threadIdx.x];
-}
 
 // mode 0: z from stratified coarse rule (writes z_out); mode 1: z read from z_in; mode 2: xyz given.
 template <int MODE>
@@ -453,7 +440,7 @@ __global__ __launch_bounds__(256) void k_ngp_scatter(
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-static int make_levels(const sf_ngp_field* f, NgpLevels* out, hipStream_t st) {
+int sf_ngp_make_levels(const sf_ngp_field* f, NgpLevels* out, hipStream_t st) {
   if (!f || !f->h_offsets) SF_FAIL(SF_ERR_INVALID, "ngp: field/h_offsets must be given");
   if (f->L > NGP_MAX_LEVELS) SF_FAIL(SF_ERR_INVALID, "ngp: at most %d levels", NGP_MAX_LEVELS);
   struct { float scale[32]; uint32_t resolution[32]; uint32_t offset[32]; uint32_t hsize[32]; } tmp;
@@ -470,15 +457,13 @@ static int make_levels(const sf_ngp_field* f, NgpLevels* out, hipStream_t st) {
   return SF_OK;
 }
 
-static FieldPtrs field_ptrs(const sf_ngp_field* f) {
-  return FieldPtrs{f->embeddings, f->w0, f->b0, f->w1, f->b1, f->w2, f->b2, f->bound};
-}
+static FieldPtrs field_ptrs(const sf_ngp_field* f) { return sf_ngp_field_ptrs(f); }
 
 extern "C" int sf_ngp_density(const sf_ngp_field* f, const float* xyz, uint32_t P, float* sigma, float* albedo,
                               void* stream) {
   hipStream_t st = (hipStream_t)stream;
   NgpLevels lv;
-  if (int rc = make_levels(f, &lv, st)) return rc;
+  if (int rc = sf_ngp_make_levels(f, &lv, st)) return rc;
   if (P == 0) return SF_OK;
   k_ngp_field<2><<<sf_grid_cap(sf_div_up(P, 256)), 256, 0, st>>>(field_ptrs(f), lv, nullptr, nullptr, nullptr, nullptr,
                                                                  nullptr, nullptr, nullptr, nullptr, xyz, P, 1, nullptr,
@@ -505,7 +490,7 @@ extern "C" int sf_ngp_render_forward(const sf_ngp_field* f, const float* rays_o,
   if (workspace_bytes < sf_ngp_render_workspace_bytes(N, T)) SF_FAIL(SF_ERR_INVALID, "ngp_render: workspace too small");
   if (!lin || !u_fine) SF_FAIL(SF_ERR_INVALID, "ngp_render: lin and u_fine tables are required");
   NgpLevels lv;
-  if (int rc = make_levels(f, &lv, st)) return rc;
+  if (int rc = sf_ngp_make_levels(f, &lv, st)) return rc;
   if (int rc = sf_near_far_from_aabb(rays_o, rays_d, aabb, N, min_near, nears, fars, stream)) return rc;
   const uint64_t NT = (uint64_t)N * T;
   float* z_c = workspace;           float* sig_c = z_c + NT;     float* rgb_c = sig_c + NT;
@@ -542,7 +527,7 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
   if (workspace_bytes < sf_ngp_render_workspace_bytes(N, T)) SF_FAIL(SF_ERR_INVALID, "ngp_render: workspace too small");
   if (!grad_image) SF_FAIL(SF_ERR_INVALID, "ngp_render_backward: grad_image required");
   NgpLevels lv;
-  if (int rc = make_levels(f, &lv, st)) return rc;
+  if (int rc = sf_ngp_make_levels(f, &lv, st)) return rc;
   const uint64_t M = (uint64_t)N * 2 * T;
   float* dsig = workspace;
   float* drgb = dsig + M;
@@ -551,12 +536,15 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
   SF_CHECK_LAUNCH("ngp_composite_bwd");
   const FieldGrad fg{g->g_embeddings, g->g_w0, g->g_b0, g->g_w1, g->g_b1, g->g_w2, g->g_b2};
   const size_t lds = (6536 + 2 * 256 * BW_S) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the raised dynamic-LDS limit is a per-device function attribute (a process may drive several GPUs)
+  int dev_id = 0;
+  if (hipGetDevice(&dev_id) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "hipGetDevice failed");
+  static unsigned attr_mask = 0;
+  if (dev_id >= 32 || !(attr_mask & (1u << dev_id))) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_field_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       SF_FAIL(SF_ERR_LAUNCH, "ngp_field_bwd: cannot raise dynamic LDS limit to %zu", lds);
-    attr_set = true;
+    if (dev_id < 32) attr_mask |= 1u << dev_id;
   }
   const uint32_t n_tiles = sf_div_up(M, 256);
   const uint32_t grid = n_tiles < 256 ? n_tiles : 256;      // one resident workgroup per CU (LDS-bound)
@@ -566,12 +554,12 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
   SF_CHECK_LAUNCH("ngp_field_bwd");
   if (dfeat) {
     const size_t lds_sc = (size_t)SC_SLOTS * 3 * sizeof(float);
-    static bool attr2 = false;
-    if (!attr2) {
+    static unsigned attr2_mask = 0;
+    if (dev_id >= 32 || !(attr2_mask & (1u << dev_id))) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_sc) != hipSuccess)
         SF_FAIL(SF_ERR_LAUNCH, "ngp_scatter: cannot raise dynamic LDS limit");
-      attr2 = true;
+      if (dev_id < 32) attr2_mask |= 1u << dev_id;
     }
     // levels whose cell is larger than ~1/4 of an 8-ray patch footprint profit from the LDS cache: scale <= ~128
     uint32_t cached = 0;

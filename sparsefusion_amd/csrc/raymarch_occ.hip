@@ -18,6 +18,7 @@
 // positions are bit-exact against oracle/ngp_ref.c.
 
 #include "sf_common.h"
+#include "ngp_field_lds.h"
 #include <float.h>
 
 #define SF_SQRT3 1.7320508075688772f
@@ -486,5 +487,85 @@ extern "C" int sf_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thre
   k_composite_rays<<<sf_div_up(n_alive, 256u), 256, 0, (hipStream_t)stream>>>(n_alive, n_step, T_thresh, rays_alive, rays_t,
                                                                              sigmas, rgbs, deltas, weights_sum, depth, image);
   SF_CHECK_LAUNCH("composite_rays");
+  return SF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused occupancy-grid EVALUATION render: march + field + composite for one ray per lane in ONE launch.
+// The reference's inference path (external/nerf/renderer_df.py:543-584) alternates march_rays / network / composite_rays
+// rounds over a shrinking list of alive rays, with a host read of the list length before every round.  A ray's samples,
+// their order and the arithmetic applied to them do not depend on that batching: here each lane simply walks its ray
+// to the end (transmittance below T_thresh, far plane, or max_steps samples), evaluating the field (hash-grid encode +
+// MLP, weights in LDS) at every occupied sample -- no alive lists, no intermediate buffers, no host synchronisation.
+// Same per-sample formulas as k_march_rays / k_ngp_field<2> / k_composite_rays above.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_render_occ_eval(FieldPtrs f, NgpLevels lv, const float* __restrict__ rays_o,
+                                                         const float* __restrict__ rays_d, const float* __restrict__ nears,
+                                                         const float* __restrict__ fars, const uint8_t* __restrict__ grid,
+                                                         float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                                                         const float* __restrict__ noises, float T_thresh, uint32_t N,
+                                                         float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                         float* __restrict__ image) {
+  __shared__ __attribute__((aligned(16))) float W[NGP_WTOTAL];
+  load_weights_lds(W, f);
+  __syncthreads();
+  const uint32_t n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  Marcher m;
+  m.init(rays_o + (size_t)n * 3, rays_d + (size_t)n * 3, grid, f.bound, dt_gamma, max_steps, C, H);
+  const float far = fars[n];
+  float t = nears[n];
+  if (noises) t = fmaf(m.step_size(t), noises[n], t);
+  float tc = nears[n];                                     // the compositor's running depth (starts at rays_t = near)
+  float last_t = t;
+  float wsum = 0.0f, d = 0.0f, r = 0.0f, g = 0.0f, b = 0.0f;
+  uint32_t step = 0;
+  while (t < far && step < max_steps) {
+    asm volatile("" ::: "memory");                         // keep the LDS weight reads inside the loop (see k_ngp_field)
+    float x[3], dt, mb;
+    int nx, ny, nz;
+    if (!m.probe(t, x[0], x[1], x[2], dt, nx, ny, nz, mb)) {
+      t = m.skip(t, x[0], x[1], x[2], nx, ny, nz, mb);
+      continue;
+    }
+    t += dt;
+    const float gap = t - last_t;
+    last_t = t;
+    ++step;
+    float x01[3];
+    const bool inside = ngp_unit(x, f.bound, x01);
+    float feat[NGP_FEAT], h1[NGP_HID], h2[NGP_HID], out[NGP_OUT];
+    ngp_encode(lv, f.table, x01, inside, feat);
+    ngp_mlp_forward(W, feat, h1, h2, out);
+    const float sigma = expf(out[0] + ngp_blob(x));
+    const float alpha = 1.0f - __expf(-sigma * dt);
+    const float T = 1.0f - wsum;
+    const float weight = alpha * T;
+    wsum += weight;
+    tc += gap;
+    d = fmaf(weight, tc, d);
+    r = fmaf(weight, ngp_sigmoid(out[1]), r);
+    g = fmaf(weight, ngp_sigmoid(out[2]), g);
+    b = fmaf(weight, ngp_sigmoid(out[3]), b);
+    if (T < T_thresh) break;
+  }
+  weights_sum[n] = wsum; depth[n] = d;
+  image[n * 3] = r; image[n * 3 + 1] = g; image[n * 3 + 2] = b;
+}
+
+extern "C" int sf_ngp_render_occ_eval(const sf_ngp_field* f, const float* rays_o, const float* rays_d, const float* nears,
+                                      const float* fars, const uint8_t* grid, float dt_gamma, uint32_t max_steps, uint32_t C,
+                                      uint32_t H, const float* noises, float T_thresh, uint32_t N, float* weights_sum,
+                                      float* depth, float* image, void* stream) {
+  if (N == 0) return SF_OK;
+  if (!f || !rays_o || !rays_d || !nears || !fars || !grid || !weights_sum || !depth || !image)
+    SF_FAIL(SF_ERR_INVALID, "render_occ_eval: null tensor");
+  if (C < 1 || C > 16 || H < 1 || H > 1024 || max_steps < 1) SF_FAIL(SF_ERR_INVALID, "render_occ_eval: cascade / grid size / steps out of range");
+  NgpLevels lv;
+  if (int rc = sf_ngp_make_levels(f, &lv, (hipStream_t)stream)) return rc;
+  k_render_occ_eval<<<sf_div_up(N, 256u), 256, 0, (hipStream_t)stream>>>(sf_ngp_field_ptrs(f), lv, rays_o, rays_d, nears, fars, grid,
+                                                                         dt_gamma, max_steps, C, H, noises, T_thresh, N,
+                                                                         weights_sum, depth, image);
+  SF_CHECK_LAUNCH("render_occ_eval");
   return SF_OK;
 }

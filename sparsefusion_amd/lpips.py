@@ -161,6 +161,9 @@ class LPIPS(nn.Module):
         self.ss_total = 0
         self.lds_conv_min_blocks = 96
         self._pack_cache, self._plans, self._serial = None, {}, 0
+        # the `lpips` package ships pretrained VGG16 + learned lin heads; this module starts from a seeded random init and has
+        # no network access: until load_state_dict() brings real weights the distance is NOT the LPIPS metric
+        self._weights_loaded = False
 
     conv_tiling = Unet.conv_tiling
 
@@ -172,6 +175,7 @@ class LPIPS(nn.Module):
         own = {k: v for k, v in sd.items() if not k.startswith("lins.") and not k.startswith("scaling_layer.")}
         r = super().load_state_dict(own, strict=strict)
         self.invalidate()
+        self._weights_loaded = True
         return r
 
     def _apply(self, fn, *a, **k):
@@ -222,6 +226,12 @@ class LPIPS(nn.Module):
         if retPerLayer:
             raise NotImplementedError("retPerLayer is not used by the reference")
         _lib.require_cuda(in0, in1)
+        if not self._weights_loaded and not getattr(self, "_warned", False):
+            import warnings
+            warnings.warn("sparsefusion_amd.LPIPS is running on its seeded RANDOM initialisation: the `lpips` package's pretrained "
+                          "VGG16 + lin weights must be loaded with load_state_dict() (or PerceptualLoss(..., state_dict=...)) for the "
+                          "value to be the LPIPS metric", RuntimeWarning, stacklevel=2)
+            self._warned = True
         if in0.shape != in1.shape or in0.dim() != 4 or in0.shape[1] != 3 or in0.shape[2] != in0.shape[3] or in0.shape[2] % 16:
             raise RuntimeError(f"LPIPS: expected two [B, 3, R, R] images with R % 16 == 0, got {tuple(in0.shape)}, {tuple(in1.shape)}")
         if normalize:
@@ -232,9 +242,16 @@ class LPIPS(nn.Module):
 class PerceptualLoss(nn.Module):
     """external/external_utils.py:11-50."""
 
-    def __init__(self, net='vgg', device='cuda:0'):
+    def __init__(self, net='vgg', device='cuda:0', state_dict=None, pretrained_path=None):
+        """`state_dict` / `pretrained_path`: the weights of `lpips.LPIPS(net='vgg').state_dict()` (the reference gets them from
+        the package at construction; there is no network here).  Without them the first forward warns."""
         super().__init__()
-        self.model = LPIPS(net=net, verbose=False).to(device)
+        self.model = LPIPS(net=net, verbose=False)
+        if pretrained_path is not None:
+            state_dict = torch.load(pretrained_path, map_location="cpu")
+        if state_dict is not None:
+            self.model.load_state_dict(state_dict)
+        self.model = self.model.to(device)
         self.device = device
 
     def get_device(self, default_device=None):

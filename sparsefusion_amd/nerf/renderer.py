@@ -7,9 +7,11 @@ distillation loop uses (cuda_ray=False, shading='albedo', bg_radius=0): `render`
 (:310-468) is ONE autograd node backed by sf_ngp_render_forward / _backward.
 
 RNG: the reference draws, in this order, randn(3) (light direction, unused for 'albedo'),
-rand(N,T) (stratified jitter, if perturb) and rand(N,T) (inverse-CDF draw, if training) from
-the global generator (renderer_df.py:351,363,31); `run` draws the same tensors in the same
-order so a seeded run consumes the generator identically.  Tests inject them via `noise=`."""
+rand(N,T) (stratified jitter, if perturb) and rand(N,T) (inverse-CDF draw, if training)
+(renderer_df.py:351,363,31); `run` draws tensors of the same shapes, roles and order, but on
+the DEVICE generator (the reference's `sample_pdf` draws on the CPU generator and copies), and
+`update_extra_state` draws its jitter in Morton order: a seeded run is reproducible here, it
+does not reproduce the reference's random stream.  Parity tests inject the draws via `noise=`."""
 import argparse
 import ctypes as C
 import math
@@ -248,61 +250,62 @@ class NeRFRenderer(nn.Module):
 
     def run_cuda(self, rays_o, rays_d, dt_gamma=0, light_d=None, ambient_ratio=1.0, shading='albedo', bg_color=None,
                  perturb=False, force_all_rays=False, max_steps=1024, T_thresh=1e-4, noise=None, **kwargs):
-        """Occupancy-grid render (renderer_df.py:471-584): march through the density bitfield, query the field at the
-        samples (autograd through the grid encoder), composite.  `noise` = per-ray jitter tensor [N] in place of
-        torch.rand (training: one draw; evaluation: the draw of the first round)."""
+        """Render through the occupancy grid -- the call surface and results of renderer_df.py:471-584 (`cuda_ray=True`),
+        restructured for the GPU:
+          * evaluation is ONE launch (sf_ngp_render_occ_eval): every lane walks its ray through the density bitfield and
+            evaluates the fused field at the occupied samples until it is opaque / leaves the box.  The reference's rounds of
+            march_rays -> network -> composite_rays over a shrinking alive list need a host read per round; the samples of
+            a ray and the arithmetic on them do not depend on that batching, so the result is the same;
+          * training keeps the three stages (the samples must exist as tensors for autograd): slot assignment by a block
+            scan (raymarching.march_rays_train), field query through the differentiable grid-encode op, compositing with
+            its own backward kernel.
+        `noise` = per-ray jitter tensor [N] in place of torch.rand."""
         from .. import raymarching
         if shading != 'albedo':
             raise NotImplementedError("only shading='albedo' is on the distillation path (distillation.py:209,282)")
-        prefix = rays_o.shape[:-1]
-        rays_o = rays_o.contiguous().view(-1, 3).float()
-        rays_d = rays_d.contiguous().view(-1, 3).float()
-        N, device = rays_o.shape[0], rays_o.device
-        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, self.aabb_train if self.training else self.aabb_infer)
-        if light_d is None:
-            light_d = rays_o[0] + torch.randn(3, device=device, dtype=torch.float)      # consumed as the reference does (:486)
-        results = {}
-        if self.training:
-            counter = self.step_counter[self.local_step % 16]
-            counter.zero_()
-            self.local_step += 1
-            xyzs, dirs, deltas, rays = raymarching.march_rays_train(rays_o, rays_d, self.bound, self.density_bitfield, self.cascade,
-                                                                    self.grid_size, nears, fars, counter, self.mean_count, perturb,
-                                                                    128, force_all_rays, dt_gamma, max_steps, noises=noise)
-            sigmas, rgbs, normals = self(xyzs, dirs, light_d, ratio=ambient_ratio, shading=shading)
-            weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
-        else:
-            weights_sum = torch.zeros(N, dtype=torch.float32, device=device)
-            depth = torch.zeros(N, dtype=torch.float32, device=device)
-            image = torch.zeros(N, 3, dtype=torch.float32, device=device)
-            n_alive = N
-            rays_alive = torch.arange(n_alive, dtype=torch.int32, device=device)
-            rays_t = nears.clone()
-            step = 0
-            while step < max_steps:
-                n_alive = rays_alive.shape[0]
-                if n_alive <= 0:
-                    break
-                n_step = max(min(N // n_alive, 8), 1)
-                xyzs, dirs, deltas = raymarching.march_rays(n_alive, n_step, rays_alive, rays_t, rays_o, rays_d, self.bound,
-                                                            self.density_bitfield, self.cascade, self.grid_size, nears, fars, 128,
-                                                            perturb if step == 0 else False, dt_gamma, max_steps,
-                                                            noises=noise if step == 0 else None)
-                sigmas, rgbs, normals = self(xyzs, dirs, light_d, ratio=ambient_ratio, shading=shading)
-                raymarching.composite_rays(n_alive, n_step, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image,
-                                           T_thresh)
-                rays_alive = rays_alive[rays_alive >= 0]
-                step += n_step
-        if bg_color is None:
-            bg_color = 1
-        image = image + (1 - weights_sum).unsqueeze(-1) * bg_color
-        image = image.view(*prefix, 3)
-        depth = torch.clamp(depth - nears, min=0) / (fars - nears)
-        results['image'] = image
-        results['depth'] = depth.view(*prefix)
-        results['weights_sum'] = weights_sum.reshape(*prefix)
-        results['mask'] = (nears < fars).reshape(*prefix)
-        return results
+        lead = rays_o.shape[:-1]
+        o = rays_o.contiguous().view(-1, 3).float()
+        d = rays_d.contiguous().view(-1, 3).float()
+        box = self.aabb_train if self.training else self.aabb_infer
+        nears, fars = raymarching.near_far_from_aabb(o, d, box)
+        stage = self._occ_train if self.training else self._occ_eval
+        opacity, z, rgb = stage(o, d, nears, fars, dt_gamma, perturb, force_all_rays, max_steps, T_thresh, noise, ambient_ratio)
+        background = 1 if bg_color is None else bg_color
+        rgb = rgb + (1 - opacity).unsqueeze(-1) * background
+        return {'image': rgb.view(*lead, 3),
+                'depth': (torch.clamp(z - nears, min=0) / (fars - nears)).view(*lead),
+                'weights_sum': opacity.reshape(*lead),
+                'mask': (nears < fars).reshape(*lead)}
+
+    def _occ_train(self, o, d, nears, fars, dt_gamma, perturb, force_all_rays, max_steps, T_thresh, noise, ambient_ratio):
+        from .. import raymarching
+        counter = self.step_counter[self.local_step % 16]
+        counter.zero_()
+        self.local_step += 1
+        xyzs, dirs, deltas, rays = raymarching.march_rays_train(o, d, self.bound, self.density_bitfield, self.cascade, self.grid_size,
+                                                                nears, fars, counter, self.mean_count, perturb, 128, force_all_rays,
+                                                                dt_gamma, max_steps, noises=noise)
+        sigmas, rgbs, _ = self(xyzs, dirs, None, ratio=ambient_ratio, shading='albedo')
+        opacity, z, rgb = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
+        return opacity, z, rgb
+
+    @torch.no_grad()
+    def _occ_eval(self, o, d, nears, fars, dt_gamma, perturb, force_all_rays, max_steps, T_thresh, noise, ambient_ratio):
+        N, dev = o.shape[0], o.device
+        if perturb and noise is None:
+            noise = torch.rand(N, dtype=torch.float32, device=dev)
+        jitter = noise.float().contiguous() if (perturb and noise is not None) else None
+        opacity = torch.empty(N, dtype=torch.float32, device=dev)
+        z = torch.empty(N, dtype=torch.float32, device=dev)
+        rgb = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        params = [p.detach().contiguous() for p in self._field_params()]
+        f = self._field_handle().struct(params)
+        rc = _lib.lib().sf_ngp_render_occ_eval(C.byref(f), _lib.ptr(o), _lib.ptr(d), _lib.ptr(nears), _lib.ptr(fars),
+                                               _lib.ptr(self.density_bitfield.contiguous()), float(dt_gamma), int(max_steps),
+                                               int(self.cascade), int(self.grid_size), _lib.ptr(jitter), float(T_thresh), N,
+                                               _lib.ptr(opacity), _lib.ptr(z), _lib.ptr(rgb), _lib.stream_ptr())
+        _lib.check(rc, "ngp_render_occ_eval")
+        return opacity, z, rgb
 
     def _run(self, rays_o, rays_d, **kwargs):
         """renderer_df.py:647-650: the occupancy-grid marcher when cuda_ray, the fused coarse+fine sampler otherwise."""
