@@ -21,6 +21,8 @@
 #include "sf_common.h"
 #include "ngp_device.h"
 #include "ngp_field_lds.h"
+#include "ngp_bwd_mfma.h"
+#include <stdlib.h>
 
 struct GridLevels;  // gridencoder.hip
 int sf_fill_levels(GridLevels* lv, const int32_t* offsets_dev, const int32_t* h_offsets, uint32_t L, float S,
@@ -546,12 +548,35 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
       SF_FAIL(SF_ERR_LAUNCH, "ngp_field_bwd: cannot raise dynamic LDS limit to %zu", lds);
     if (dev_id < 32) attr_mask |= 1u << dev_id;
   }
-  const uint32_t n_tiles = sf_div_up(M, 256);
-  const uint32_t grid = n_tiles < 256 ? n_tiles : 256;      // one resident workgroup per CU (LDS-bound)
   float* dfeat = g->g_embeddings ? drgb + 3 * M : nullptr;        // NULL table gradient = table frozen
-  k_ngp_field_bwd<<<grid, 256, lds, st>>>(field_ptrs(f), fg, lv, rays_o, rays_d, aabb, z_sorted, dsig, drgb, dfeat,
-                                          (uint32_t)M, 2 * T);
-  SF_CHECK_LAUNCH("ngp_field_bwd");
+  static const bool use_valu = getenv("SF_NGP_BWD_VALU") != nullptr;     // A/B switch: the first-round VALU kernel
+  if (use_valu) {
+    const uint32_t n_tiles = sf_div_up(M, 256);
+    const uint32_t grid = n_tiles < 256 ? n_tiles : 256;      // one resident workgroup per CU (LDS-bound)
+    k_ngp_field_bwd<<<grid, 256, lds, st>>>(field_ptrs(f), fg, lv, rays_o, rays_d, aabb, z_sorted, dsig, drgb, dfeat,
+                                            (uint32_t)M, 2 * T);
+    SF_CHECK_LAUNCH("ngp_field_bwd");
+  } else {
+    // matrix-core version: one wave per 32 points and trip, six fp32 GEMMs on v_mfma_f32_16x16x4_f32 (ngp_bwd_mfma.h)
+    const size_t lds2 = (size_t)FB_LDS_FLOATS * sizeof(float);
+    static unsigned attr3_mask = 0;
+    if (dev_id >= 32 || !(attr3_mask & (1u << dev_id))) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_field_bwd_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds2) != hipSuccess)
+        SF_FAIL(SF_ERR_LAUNCH, "ngp_field_bwd_mfma: cannot raise dynamic LDS limit to %zu", lds2);
+      if (dev_id < 32) attr3_mask |= 1u << dev_id;
+    }
+    FBArgs a;
+    a.table = f->embeddings; a.w0 = f->w0; a.b0 = f->b0; a.w1 = f->w1; a.b1 = f->b1; a.w2 = f->w2; a.b2 = f->b2; a.bound = f->bound;
+    a.g_w0 = g->g_w0; a.g_b0 = g->g_b0; a.g_w1 = g->g_w1; a.g_b1 = g->g_b1; a.g_w2 = g->g_w2; a.g_b2 = g->g_b2;
+    a.lv = lv;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.aabb = aabb; a.z_s = z_sorted; a.dsig = dsig; a.drgb = drgb; a.dfeat_out = dfeat;
+    a.P = (uint32_t)M; a.T2 = 2 * T;
+    const uint32_t trips = sf_div_up(M, FB_PTS);
+    const uint32_t grid = trips < 1024 ? sf_div_up(trips, 4) : 256;   // one resident workgroup per CU (LDS-bound), 4 waves each
+    k_ngp_field_bwd_mfma<<<grid, 256, lds2, st>>>(a);
+    SF_CHECK_LAUNCH("ngp_field_bwd_mfma");
+  }
   if (dfeat) {
     const size_t lds_sc = (size_t)SC_SLOTS * 3 * sizeof(float);
     static unsigned attr2_mask = 0;

@@ -33,6 +33,28 @@ static inline void sf_lds_add(float* p, float v) {
   } while (!__atomic_compare_exchange_n(u, &old, neu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
 }
 static inline float sf_rsqrt(float v) { return 1.0f / sqrtf(v); }
+static inline void sf_wave_sync() { hipemu::t_wave->bar.wait(); }
+static inline void sf_global_add(float* p, float v) { sf_lds_add(p, v); }
+// v_mfma_f32_16x16x4_f32: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15], D[i = 4 * (lane >> 4) + r][j = lane & 15]
+static inline f32x4 sf_mfma4(float a, float b, f32x4 c) {
+  hipemu::WaveState* w = hipemu::t_wave;
+  const int lane = hipemu::t_lane;
+  static float xa[64][64], xb[64][64];
+  const int ws = (int)(threadIdx.x >> 6);
+  xa[ws][lane] = a;
+  xb[ws][lane] = b;
+  w->bar.wait();
+  f32x4 d = c;
+  const int j = lane & 15;
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * (lane >> 4) + r;
+    float acc = d[r];
+    for (int k = 0; k < 4; ++k) acc = fmaf(xa[ws][k * 16 + i], xb[ws][k * 16 + j], acc);
+    d[r] = acc;
+  }
+  w->bar.wait();
+  return d;
+}
 static inline float sf_rcp(float v) { return 1.0f / v; }
 static inline long long sf_clock() { return 0; }
 // D = A (16 x 32, rows = lane & 15) * B (32 x 16, cols = lane & 15) + C; see tests/hostemu/hip_emu.h for the layout
@@ -71,6 +93,11 @@ SF_DEV T sf_shfl(T v, int src) { return __shfl(v, src, 64); }
 SF_DEV float sf_exp(float v) { return __expf(v); }
 SF_DEV void sf_lds_add(float* p, float v) { atomicAdd(p, v); }
 SF_DEV float sf_rsqrt(float v) { return rsqrtf(v); }
+// same-wave LDS hand-off: DS operations of one wave execute in order; this only keeps the compiler from reordering them
+SF_DEV void sf_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+typedef __attribute__((address_space(1))) float sf_dev_gfloat;
+SF_DEV void sf_global_add(float* p, float v) { (void)__builtin_amdgcn_global_atomic_fadd_f32((sf_dev_gfloat*)p, v); }
+SF_DEV f32x4 sf_mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 SF_DEV float sf_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 SF_DEV long long sf_clock() { return (long long)wall_clock64(); }      // 100 MHz constant clock
 SF_DEV f32x4 sf_mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
