@@ -321,3 +321,65 @@ def reference_eft(**kwargs):
     kw = dict(use_r=True, encoder='resnet18', return_features=True, remove_unused_layers=False)
     kw.update(kwargs)
     return EpipolarFeatureTransformer(**kw), RayBundle
+
+
+# ---------------------------------------------------------------------------------------------
+# EFT feature renderer (row E1, second half): the reference's CustomImplicitRenderer / LightFieldRaymarcher import on CPU
+# once pytorch3d's names exist; the ray sampler is pytorch3d's own class (absent, unpinned) and is restated below.
+# ---------------------------------------------------------------------------------------------
+def _unproject(cams, xy_depth):
+    """PerspectiveCameras.unproject_points (NDC): inverse of PinholeCameras.transform_points_ndc at the given depth."""
+    xy, depth = xy_depth[..., :2], xy_depth[..., 2:3]
+    cam = torch.cat([(xy - cams.principal[:, None]) / cams.focal[:, None] * depth, depth], -1)
+    return torch.bmm(cam - cams.T[:, None], cams.R.transpose(1, 2))
+
+
+class GridRaysamplerRef:
+    """Restatement of pytorch3d's GridRaysampler + _xy_to_ray_bundle (published algorithm): lattice of
+    NDC points y-major from (min_x, min_y) to (max_x, max_y) inclusive, ray = un-projection at depths 1 and 2,
+    directions = p2 - p1 (not normalised), origins = p1 - directions, lengths = linspace(min_depth, max_depth, n)."""
+
+    def __init__(self, min_x, max_x, min_y, max_y, image_width, image_height, n_pts_per_ray, min_depth, max_depth):
+        self.args = (min_x, max_x, min_y, max_y, image_width, image_height, n_pts_per_ray, min_depth, max_depth)
+
+    def __call__(self, cameras, **kwargs):
+        import collections
+        min_x, max_x, min_y, max_y, W, H, n, dmin, dmax = self.args
+        RayBundle = collections.namedtuple("RayBundle", ["origins", "directions", "lengths", "xys"])
+        N = len(cameras)
+        xy = torch.zeros(N, H, W, 2)
+        for r in range(H):
+            for c in range(W):
+                xy[:, r, c, 0] = min_x + (max_x - min_x) * c / (W - 1)
+                xy[:, r, c, 1] = min_y + (max_y - min_y) * r / (H - 1)
+        flat = xy.view(N, H * W, 2)
+        p1 = _unproject(cameras, torch.cat([flat, torch.ones(N, H * W, 1)], -1))
+        p2 = _unproject(cameras, torch.cat([flat, 2 * torch.ones(N, H * W, 1)], -1))
+        d = p2 - p1
+        lengths = torch.linspace(dmin, dmax, n)[None, None].expand(N, H * W, n)
+        return RayBundle((p1 - d).view(N, H, W, 3), d.view(N, H, W, 3), lengths.reshape(N, H, W, n), xy)
+
+
+def reference_eft_renderer(raysampler):
+    """The reference's `CustomImplicitRenderer(raysampler, LightFieldRaymarcher(), reg=True)` (utils/render_utils.py:170-183)."""
+    install()
+    for name in ("pytorch3d", "pytorch3d.ops", "pytorch3d.ops.utils", "pytorch3d.structures", "pytorch3d.transforms", "pytorch3d.renderer",
+                 "pytorch3d.renderer.cameras", "pytorch3d.renderer.implicit", "pytorch3d.renderer.implicit.raysampling",
+                 "pytorch3d.renderer.implicit.utils", "pytorch3d.renderer.implicit.raymarching"):
+        if name not in sys.modules:
+            _stub(name)
+    m = sys.modules
+    m["pytorch3d.ops.utils"].eyes = None
+    m["pytorch3d.structures"].Volumes = None
+    m["pytorch3d.transforms"].Transform3d = None
+    m["pytorch3d.renderer.cameras"].CamerasBase = object
+    m["pytorch3d.renderer.implicit.raysampling"].RayBundle = object
+    for n in ("_validate_ray_bundle_variables", "ray_bundle_variables_to_ray_points", "ray_bundle_to_ray_points"):
+        if not hasattr(m["pytorch3d.renderer.implicit.utils"], n):
+            setattr(m["pytorch3d.renderer.implicit.utils"], n, None)
+    m["pytorch3d.renderer"].EmissionAbsorptionRaymarcher = object
+    for n in ("_check_density_bounds", "_check_raymarcher_inputs", "_shifted_cumprod"):
+        setattr(m["pytorch3d.renderer.implicit.raymarching"], n, None)
+    from utils.eft_renderer import CustomImplicitRenderer
+    from utils.eft_raymarcher import LightFieldRaymarcher
+    return CustomImplicitRenderer(raysampler=raysampler, raymarcher=LightFieldRaymarcher(), reg=True)

@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsparsefusion_hip.so")
+# SF_HIP_LIB: an A/B build of the SAME library (sparsefusion_amd/build.py::build_variant), for tuning runs on the GPU box
+LIB_PATH = os.environ.get("SF_HIP_LIB") or os.path.join(_HERE, "libsparsefusion_hip.so")
 
 _lib = None
 

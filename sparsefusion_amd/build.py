@@ -63,6 +63,28 @@ def build(verbose=True, force=False):
     return LIB
 
 
+def build_variant(tag, defines, verbose=True, timing=False):
+    """A/B builds for GPU-side tuning: libsparsefusion_hip_<tag>.so = the product library with unet_fused.hip recompiled under
+    extra -D flags (select it with SF_HIP_LIB=<path>); with timing=True the instrumented libsf_fused_timing_<tag>.so."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    dflags = ["-D" + d for d in defines]
+    if timing:
+        out = os.path.join(HERE, f"libsf_fused_timing_{tag}.so")
+        srcs = [os.path.join(CSRC, f) for f in ("unet_fused.hip", "core.hip")]
+        cmd = [HIPCC] + FLAGS + dflags + ["-DSF_FCONV_TIMING", "-shared", "-o", out] + srcs
+    else:
+        build(verbose=False)
+        out = os.path.join(HERE, f"libsparsefusion_hip_{tag}.so")
+        obj = os.path.join(OBJ_DIR, f"unet_fused_{tag}.o")
+        subprocess.check_call([HIPCC] + FLAGS + dflags + ["-c", os.path.join(CSRC, "unet_fused.hip"), "-o", obj])
+        objs = [os.path.join(OBJ_DIR, s[:-4] + ".o") for s in _sources() if s != "unet_fused.hip"] + [obj]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_timing(verbose=True):
     """libsf_fused_timing.so: unet_fused.hip with in-kernel phase timestamps (-DSF_FCONV_TIMING), a measurement aid for
     tools/fconv_phases.py -- never loaded by the package."""

@@ -8,7 +8,8 @@
 //      17 GlobalContext to_k weight [Cout]  18 partial context logits [S * n_frags][M]   (both or neither)
 //   i: 0 B  1 H  2 W  3 C1  4 C2  5 Cout  6 ldc  7 co_off  8 k (1 | 3)  9 s1.mode  10 s1.groups  11 s1.npad
 //      12 norm (FNORM_*)  13 G  14 TR (image rows per tile)  15 WM  16 WN  17 S (input-channel slices)  18 ss_stride
-//   flags: 1 SiLU after the norm, 2 GELU before the LayerNorm, 4 accumulate into out, 8 GELU on the final output
+//   flags: 1 SiLU after the norm, 2 GELU before the LayerNorm, 4 accumulate into out, 8 GELU on the final output,
+//          16 pair: the NEXT op (an un-normalised fconv of the same tile shape) runs in the same launch (k_conv_fused_pair)
 //   f: 0 eps  1 s1.scale  2 s2.scale
 // SF_OP_SLOTS operands
 //   p: 0 x (or h)  1 gate [B, C] or null  2 res  3 out (gate mode)  4 slots ;  i: 0 M  1 C  2 HW
@@ -30,12 +31,23 @@
   X(1, 1, 12, FNORM_GN_SLOTS, 0) \
   X(1, 2, 8, FNORM_GN_SLOTS, 0) \
   X(2, 2, 8, FNORM_GN_SLOTS, 0) \
+  X(2, 1, 12, FNORM_GN_SLOTS, 0) \
+  X(2, 1, 12, FNORM_NONE, 0) \
   X(1, 1, 12, FNORM_NONE, 0) \
   X(1, 2, 8, FNORM_NONE, 0) \
   X(2, 2, 8, FNORM_NONE, 0) \
   X(1, 1, 12, FNORM_LN, 0) \
   X(1, 1, 12, FNORM_LN, 1) \
   X(1, 2, 8, FNORM_LN, 0)
+
+// Pairs (conv1 || res_conv in one launch, k_conv_fused_pair): (WM, WN, D, NORM of the first conv, LAZY of both)
+#define SF_FCONV_PAIR_VARIANTS(X) \
+  X(1, 1, 12, FNORM_GN_SELF, 0) \
+  X(1, 1, 12, FNORM_GN_SELF, 1) \
+  X(1, 1, 12, FNORM_GN_SELF, 2) \
+  X(1, 1, 12, FNORM_GN_SLOTS, 0) \
+  X(1, 2, 8, FNORM_GN_SLOTS, 0) \
+  X(2, 2, 8, FNORM_GN_SLOTS, 0)
 
 static inline int fconv_pix_stride(int Cs) {
   const int raw = Cs * 2;
@@ -66,7 +78,7 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   a.ss_stride = op.i[18];
   a.silu = (op.flags & 1) ? 1 : 0; a.pre_gelu = (op.flags & 2) ? 1 : 0; a.accum = (op.flags & 4) ? 1 : 0; a.out_gelu = (op.flags & 8) ? 1 : 0;
   a.eps = op.f[0]; a.s1.scale = op.f[1]; a.s2.scale = op.f[2];
-  if (!a.s1.p || !a.w || a.B < 1 || a.H < 1 || a.W < 1) FC_FAIL("fconv: missing operand");
+  if ((!a.s1.p && a.s1.mode == 0) || !a.w || a.B < 1 || a.H < 1 || a.W < 1) FC_FAIL("fconv: missing operand");
   if ((long)a.B * a.H * a.W * (a.s1.C > a.s2.C ? a.s1.C : a.s2.C) >= (1L << 29)) FC_FAIL("fconv: source too large for 32-bit element offsets");
   if (a.k != 1 && a.k != 3) FC_FAIL("fconv: k must be 1 or 3 (stride 1, same padding)");
   if (a.W & (a.W - 1)) FC_FAIL("fconv: W must be a power of two");
@@ -87,7 +99,8 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   if (a.s1.mode == 1 && (!a.s1.a || a.s1.groups < 1 || a.s1.npad % 4)) FC_FAIL("fconv: bad split-K source");
   if (a.s1.mode == 2 && (!a.s1.a || !a.s1.b || !a.s1.r)) FC_FAIL("fconv: gated source needs h, gate and res");
   if (a.s1.mode && a.s1.scale != 1.0f) FC_FAIL("fconv: lazy sources are unscaled");
-  if (a.s1.mode && (a.s1.p == a.s1.a || a.s1.p == a.s1.r)) FC_FAIL("fconv: a lazy source must materialise into its own buffer");
+  if (a.s1.mode && a.s1.p && (a.s1.p == a.s1.a || a.s1.p == a.s1.r)) FC_FAIL("fconv: a lazy source must materialise into its own buffer");
+  if (a.s1.mode && !a.s1.p && a.norm != FNORM_NONE) FC_FAIL("fconv: only the plain (res_conv) half of a pair may leave a lazy source unmaterialised");
   const int Cs = a.cps * 32;
   if (a.norm == FNORM_GN_SELF || a.norm == FNORM_GN_SLOTS) {
     if (!a.gamma || !a.beta || a.C % a.G) FC_FAIL("fconv: GroupNorm parameters missing");
@@ -139,6 +152,23 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   grid = (uint32_t)a.S * MT * a.n_tiles;
   return 0;
 #undef FC_FAIL
+}
+
+// Pair = op1 (flags & 16) + the op after it: same tile shape, op2 un-normalised, same lazy mode (op2 with s1.p == null when lazy).
+static inline int fconv_pair_setup(const sf_op& op1, const sf_op& op2, FConvPairArgs& p, int& WM, int& WN, uint32_t& grid, uint32_t& lds_bytes,
+                                   char* err, size_t errn) {
+  int WM2, WN2;
+  uint32_t g1, g2, l1, l2;
+  if (fconv_setup(op1, p.a, WM, WN, g1, l1, err, errn) || fconv_setup(op2, p.b, WM2, WN2, g2, l2, err, errn)) return 1;
+  if (op2.type != SF_OP_FCONV || WM2 != WM || WN2 != WN || p.b.norm != FNORM_NONE || p.b.s1.mode != p.a.s1.mode || (op2.flags & 16)) {
+    snprintf(err, errn, "fconv pair: the second op must be an un-normalised fconv of the same tile shape and lazy mode");
+    return 1;
+  }
+  if (p.a.dbg || p.b.dbg) { snprintf(err, errn, "fconv pair: no phase stamps"); return 1; }
+  p.grid_b = (int)g2;
+  grid = g1 + g2;
+  lds_bytes = l1 > l2 ? l1 : l2;
+  return 0;
 }
 
 // SF_OP_GCA operands (flags = stage)

@@ -25,7 +25,13 @@ struct FDiv { uint32_t d, magic; };
 SF_DEV uint32_t fdiv(uint32_t n, FDiv f) { return f.d == 1 ? n : (uint32_t)(((uint64_t)n * f.magic) >> 32); }
 
 #ifndef SF_STAGE_U
-#define SF_STAGE_U 8           // independent element loads in flight per thread while staging (plain sources)
+#define SF_STAGE_U 4           // float4 loads per staging batch and thread; two batches are live (one in flight, one in the VALU)
+#endif
+#ifndef SF_NT_W
+#define SF_NT_W 0              // 1: non-temporal (streaming) weight loads -- an A/B knob, see DESIGN.md section 4
+#endif
+#ifndef SF_RING_POS
+#define SF_RING_POS 1          // weight-ring issue point of the slot / plain prologue: 0 before the first staging batch, 1 after it, 2 after staging
 #endif
 enum { FNORM_NONE = 0, FNORM_GN_SELF = 1, FNORM_GN_SLOTS = 2, FNORM_LN = 3 };
 
@@ -100,12 +106,12 @@ struct FConst { static constexpr int value = N; };
 // and latency bound (SiLU per element, one workgroup per CU because of the LDS frame), so it wants 2 waves per SIMD;
 // the same 8 waves then split K eight ways and keep 8 x D KiB of weight fragments in flight per CU.
 template <int WM, int WN, int D, int NORM, int LAZY, int NW>
-SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
+SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
   constexpr int NT = NW * 64;
   SF_DYN_LDS(lds);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef SF_FCONV_TIMING      // tools/fconv_phases.py builds its own instrumented copy; a maybe-executed store would make every
-#define FC_STAMP(k) do { if (a.dbg && tid == 0) a.dbg[(long)blockIdx.x * 8 + (k)] = sf_clock(); } while (0)
+#define FC_STAMP(k) do { if (a.dbg && tid == 0) a.dbg[(long)bid * 8 + (k)] = sf_clock(); } while (0)
 #else                       // later s_waitcnt conservative, so the product has no trace of it
 #define FC_STAMP(k) do { } while (0)
 #endif
@@ -113,8 +119,8 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
   // ---- which tile
   const int MT = a.B * a.mt_per_img;
   const int tiles = MT * a.n_tiles;
-  const int s = blockIdx.x / tiles;
-  const int t = blockIdx.x - s * tiles;
+  const int s = bid / tiles;
+  const int t = bid - s * tiles;
   int mt, nt;
   if (a.xcd_map) {                       // workgroups b, b+8, ... run on one XCD: give them the m-tiles of ONE n-tile (weights hit in L2)
     const int x = t & 7, j = t >> 3;
@@ -146,7 +152,11 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
   }
   auto wload = [&](int j, int ni) -> bf16x8 {
     const int tap = (int)fdiv((uint32_t)j, a.d_cps), ccl = j - tap * a.cps;
+#if SF_NT_W
+    return __builtin_nontemporal_load(&wbase[ni][(long)(tap * a.cchunks + ccl) * 64]);
+#else
     return wbase[ni][(long)(tap * a.cchunks + ccl) * 64];
+#endif
   };
   bf16x8 fb[D][WN];
   // fill the ring: the HBM / L2 weight stream runs under the rest of the prologue.  The loads are UNCONDITIONAL (indices
@@ -398,36 +408,115 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
       }
     }
   } else {
-    // ---- (b2) statistics from the producer's slots (GroupNorm on large maps) or from the rows themselves (LayerNorm)
+    // ---- (b2) + (c): GroupNorm statistics from the producer's slots (or no normalisation), then the in-image frame rows
+    // fp32 -> normalise -> activate -> bf16 [frame pixel][channel].
+    // Thread layout: TC = min(Cs/4, NT) threads span the slice's float4 channel chunks (coalesced rows), NT / TC pixel
+    // lanes; a thread keeps ONE channel chunk, so its affine (A, B) lives in registers and the per-element index math
+    // is a shift and a mask.  The staging is software-pipelined: two register batches of U pixels, one in flight while
+    // the other is in the VALU, and the FIRST batch is issued before the statistics -- the cold round trip of the
+    // activations (written by the previous kernel on other XCDs) overlaps the one of the slots.  Loads are never
+    // under a branch (dead elements read a safe pixel and land in a spare LDS pixel behind the frame).
+    constexpr int U = (LAZY == 1) ? 2 : SF_STAGE_U;
+    const int TC = Cs4 < NT ? Cs4 : NT;
+    const int ppp = NT / TC;
+    const int tp = (int)fdiv((uint32_t)tid, a.d_tc), tcx = tid - tp * TC;
+    const int npx = FR << a.logW;
+    const int stp = ppp * U;
+    // frame pixel pi = fr * W + x of an in-image row is source pixel M0 + pi: addresses are LINEAR in pi
+    const int M0 = (int)mb + (row0 - h) * a.W;
+    const int pi_safe = h << a.logW;                                 // first own row: always inside the image
+    int cl = 0, c = 0, srcld = 0;
+    bool cact = false, first = true;
+    const float* srcp = nullptr;
+    auto chan = [&](int cb) {
+      const int c4 = cb + tcx;
+      cact = tp < ppp && c4 < Cs4;
+      cl = (c4 < Cs4 ? c4 : Cs4 - 1) * 4;
+      c = c0 + cl;
+      first = c < a.s1.C;
+      srcp = first ? a.s1.p + c : a.s2.p + (c - a.s1.C);             // plain sources: one unconditional load per element
+      srcld = first ? a.s1.C : a.s2.C;
+    };
+    auto issue = [&](int p0, f32x4 (&v)[U], int (&fpx)[U], int (&mx)[U]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int pi = p0 + u * ppp;
+        const int fr = pi >> a.logW;
+        const int r = row0 - h + fr;
+        const bool in = pi < npx && cact && r >= 0 && r < a.H;
+        mx[u] = M0 + (in ? pi : pi_safe);
+        // fpx < 0: nothing to store; bit 30: this workgroup owns the element (materialises a lazy source)
+        fpx[u] = in ? ((pi + 2 * h * fr + h) | ((nt == 0 && fr >= h && fr < h + a.TR) ? (1 << 30) : 0)) : -1;
+        if (LAZY == 0) v[u] = *reinterpret_cast<const f32x4*>(srcp + mx[u] * srcld);
+        else v[u] = fconv_value<LAZY>(a, mx[u], c);
+      }
+    };
+    // (A, Bv) with the source's scale folded in: y = v * A + Bv; SILU is a compile-time copy of a.silu
+    auto consume = [&](auto silu_c, f32x4 (&v)[U], int (&fpx)[U], int (&mx)[U], const f32x4& A, const f32x4& Bv) {
+      constexpr bool SILU = decltype(silu_c)::value != 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (LAZY && fpx[u] >= 0 && (fpx[u] >> 30) && first && a.s1.p) *reinterpret_cast<f32x4*>(a.s1.p + (long)mx[u] * a.s1.C + c) = v[u];
+        const int fp = fpx[u] < 0 ? FR * FW : (fpx[u] & 0x3fffffff);
+        f32x4 y = gn ? v[u] * A + Bv : v[u] * A;
+        if (SILU) {
+          const f32x4 t = y * -1.4426950408889634f;
+          f32x4 e;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) e[j] = sf_exp2(t[j]);
+          e = e + 1.0f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) e[j] = sf_rcp(e[j]);
+          y = y * e;
+        }
+        bf16x4 o;
+        o[0] = (__bf16)y[0]; o[1] = (__bf16)y[1]; o[2] = (__bf16)y[2]; o[3] = (__bf16)y[3];
+        *reinterpret_cast<bf16x4*>(lds + (long)fp * a.pix_stride + cl * 2) = o;
+      }
+    };
+    f32x4 va[U], vb[U];
+    int fpa[U], mxa[U], fpb[U], mxb[U];
+    f32x2 sl[4];
+    float slsc[4];
+    const int ngs = gn ? Cs / Cg : 0;
+    const int n_mf = HW >> 4, n_cf = (Cg >> 4) > 0 ? (Cg >> 4) : 1, scnt = n_mf * n_cf;
+    const int cf1 = a.s1.C >> 4, cf2 = a.s2.C >> 4;
+    auto slot_loads = [&](int gi, int i0) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int i = i0 + u * 64;
+        const bool live = i < scnt;
+        if (!live) i = scnt - 1;
+        const int mf = (int)fdiv((uint32_t)i, a.d_ncf), cfa = ((c0 + gi * Cg) >> 4) + (i - mf * n_cf);
+        const long mfg = (long)b * n_mf + mf;
+        const bool f1 = cfa < cf1;
+        const float* base = f1 ? a.s1.slots : a.s2.slots;
+        const long off = f1 ? (mfg * cf1 + cfa) : (mfg * cf2 + (cfa - cf1));
+        sl[u] = *reinterpret_cast<const f32x2*>(base + off * 2);
+        slsc[u] = live ? (f1 ? a.s1.scale : a.s2.scale) : 0.0f;
+      }
+    };
+    // issue order: slots of this wave's first group, first staging batch, weight ring (SF_RING_POS 0: ring first)
+    if (NORM == FNORM_GN_SLOTS && wave < ngs) slot_loads(wave, lane);
+#if SF_RING_POS == 0
+    prefetch_weights();
+#endif
+    chan(0);
+    issue(tp, va, fpa, mxa);
+#if SF_RING_POS == 1
+    prefetch_weights();
+#endif
+    FC_STAMP(1);
     if (NORM == FNORM_GN_SLOTS) {
       // one wave per group sums the (sum, sum of squares) slots of image b: 4 independent slot loads in flight per lane
-      const int ngs = Cs / Cg;
-      const int n_mf = HW >> 4, n_cf = (Cg >> 4) > 0 ? (Cg >> 4) : 1, cnt = n_mf * n_cf;
-      const int cf1 = a.s1.C >> 4, cf2 = a.s2.C >> 4;
-      bool ring = false;
       for (int gi = wave; gi < ngs; gi += NW) {
         float sm = 0.0f, sq = 0.0f;
-        for (int i0 = lane; i0 < cnt; i0 += 256) {
-          f32x2 sl[4];
-          float sc[4];
+        for (int i0 = lane; i0 < scnt; i0 += 256) {
+          if (gi != wave || i0 != lane) slot_loads(gi, i0);
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            int i = i0 + u * 64;
-            const bool live = i < cnt;
-            if (!live) i = cnt - 1;
-            const int mf = (int)fdiv((uint32_t)i, a.d_ncf), cfa = ((c0 + gi * Cg) >> 4) + (i - mf * n_cf);
-            const long mfg = (long)b * n_mf + mf;
-            const bool first = cfa < cf1;
-            const float* base = first ? a.s1.slots : a.s2.slots;
-            const long off = first ? (mfg * cf1 + cfa) : (mfg * cf2 + (cfa - cf1));
-            sl[u] = *reinterpret_cast<const f32x2*>(base + off * 2);
-            sc[u] = live ? (first ? a.s1.scale : a.s2.scale) : 0.0f;
-          }
-          if (!ring) { prefetch_weights(); ring = true; }            // behind the first slot loads, ahead of their use
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            sm = fmaf(sl[u][0], sc[u], sm);
-            sq = fmaf(sl[u][1], sc[u] * sc[u], sq);
+            sm = fmaf(sl[u][0], slsc[u], sm);
+            sq = fmaf(sl[u][1], slsc[u] * slsc[u], sq);
           }
         }
         sm = sf_wave_sum(sm);
@@ -441,73 +530,30 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
           misc[17 + 2 * gi] = sf_rsqrt((float)var + a.eps);
         }
       }
-      if (!ring) prefetch_weights();
-      FC_STAMP(1);
-      sf_sync();
-      build_table();      prefetch_weights();
-      FC_STAMP(1);
       sf_sync();
       build_table();
       sf_sync();
-    } else {
-      prefetch_weights();
-      FC_STAMP(1);
     }
     FC_STAMP(2);
-    // ---- (c) stage the in-image frame rows: fp32 -> normalise -> activate -> bf16 [frame pixel][channel].
-    // Thread layout: TC = min(Cs/4, NT) threads span the slice's float4 channel chunks (coalesced rows), NT / TC pixel
-    // lanes; a thread keeps ONE channel chunk, so its affine (A, B) lives in registers and the per-element index math
-    // is a shift and a mask.  Batches of U independent pixel loads are issued before the first one is used (a
-    // dependent load per trip costs a full L2 / HBM round trip; the per-element SiLU makes the rest VALU bound).
-    auto stage = [&](auto uc) {
-      constexpr int U = decltype(uc)::value;
-      const int TC = Cs4 < NT ? Cs4 : NT;
-      const int ppp = NT / TC;
-      const int tp = (int)fdiv((uint32_t)tid, a.d_tc), tcx = tid - tp * TC;
-      const int npx = FR << a.logW;
+    auto run = [&](auto silu_c) {
       for (int cb = 0; cb < Cs4; cb += TC) {
-        const int c4 = cb + tcx;
-        const bool cact = tp < ppp && c4 < Cs4;
-        const int cl = (c4 < Cs4 ? c4 : Cs4 - 1) * 4, c = c0 + cl;
-        const bool first = c < a.s1.C;
-        const float scale = first ? a.s1.scale : a.s2.scale;
-        const float* srcp = first ? a.s1.p + c : a.s2.p + (c - a.s1.C);      // plain sources: one unconditional load per element
-        const long srcld = first ? a.s1.C : a.s2.C;
+        if (cb) { chan(cb); issue(tp, va, fpa, mxa); }
         f32x4 A, Bv;
         affine_of(cl, A, Bv);
-        // frame pixel pi = fr * W + x of an in-image row is source pixel M0 + pi: addresses are LINEAR in pi (the first
-        // version spent ~40 of its ~75 instructions per element on index arithmetic and was issue bound)
-        const int M0 = (int)mb + (row0 - h) * a.W;
-        const int pi_safe = h << a.logW;                                 // first own row: always inside the image
-        for (int p0 = tp; p0 < npx; p0 += ppp * U) {
-          f32x4 v[U];
-          int fpx[U], mx[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int pi = p0 + u * ppp;
-            const int fr = pi >> a.logW;
-            const int r = row0 - h + fr;
-            const bool in = pi < npx && cact && r >= 0 && r < a.H;
-            mx[u] = M0 + (in ? pi : pi_safe);
-            // fpx < 0: nothing to store; bit 30: this workgroup owns the element (materialises a lazy source)
-            fpx[u] = in ? ((pi + 2 * h * fr + h) | ((nt == 0 && fr >= h && fr < h + a.TR) ? (1 << 30) : 0)) : -1;
-            if (LAZY == 0) v[u] = *reinterpret_cast<const f32x4*>(srcp + mx[u] * (int)srcld);
-            else v[u] = fconv_value<LAZY>(a, mx[u], c);
-          }
-          // no branch per element: dead elements (rows outside the image, the tail of the last batch) are normalised
-          // like the others and land in a spare pixel behind the frame, so that the U dependent SiLU chains of a batch
-          // sit in ONE basic block and interleave (the chain exp -> add -> rcp -> mul is latency, not issue, bound)
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            if (LAZY && fpx[u] >= 0 && (fpx[u] >> 30) && first) *reinterpret_cast<f32x4*>(a.s1.p + (long)mx[u] * a.s1.C + c) = v[u];
-            const int fp = fpx[u] < 0 ? FR * FW : (fpx[u] & 0x3fffffff);
-            finish(v[u] * scale, fp, cl, 0, A, Bv);
-          }
+        A = A * (first ? a.s1.scale : a.s2.scale);
+        for (int base = 0; base < npx; base += 2 * stp) {
+          issue(base + stp + tp, vb, fpb, mxb);
+          consume(silu_c, va, fpa, mxa, A, Bv);
+          issue(base + 2 * stp + tp, va, fpa, mxa);
+          consume(silu_c, vb, fpb, mxb, A, Bv);
         }
       }
     };
-    if (LAZY == 1) stage(FConst<4>());
-    else stage(FConst<SF_STAGE_U>());
+    if (a.silu) run(FConst<1>());
+    else run(FConst<0>());
+#if SF_RING_POS == 2
+    prefetch_weights();
+#endif
   }
   sf_sync();
   FC_STAMP(3);
@@ -636,6 +682,26 @@ SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
   }
   FC_STAMP(5);
 #undef FC_STAMP
+}
+
+template <int WM, int WN, int D, int NORM, int LAZY, int NW>
+SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
+  conv_fused_body<WM, WN, D, NORM, LAZY, NW>(a, (int)blockIdx.x);
+}
+
+// Two INDEPENDENT convs of one ResnetBlock in one launch: the block's first conv (GroupNorm + SiLU + 3x3, `a`) and its
+// res_conv (1x1 on the raw concat, `b`; imagen_pytorch.py:700-729 reads the same input for both).  Workgroups
+// [0, grid_b) run `b` -- the short ones first, so the CUs they free pick up the tail of `a` -- the rest run `a`.  `b`
+// evaluates a lazy first source like `a` does but never materialises it (b.s1.p == null): `a` owns that.
+struct FConvPairArgs {
+  FConvArgs a, b;
+  int grid_b;
+};
+
+template <int WM, int WN, int D, int NORM, int LAZY, int NW>
+SF_KERNEL(NW * 64) void k_conv_fused_pair(FConvPairArgs p) {
+  if ((int)blockIdx.x < p.grid_b) conv_fused_body<WM, WN, D, FNORM_NONE, LAZY, NW>(p.b, (int)blockIdx.x);
+  else conv_fused_body<WM, WN, D, NORM, LAZY, NW>(p.a, (int)blockIdx.x - p.grid_b);
 }
 
 // (sum, sum of squares) slots of an fp32 NHWC tensor [M, C], one wave per 16 pixels x 16 channels; with `gate` the

@@ -361,10 +361,15 @@ __global__ __launch_bounds__(256) void k_ngp_field_bwd(
 #define SC_RAYS 64
 #define SC_SLOTS 8192
 #define SC_EMPTY 0xffffffffu
-__global__ __launch_bounds__(256) void k_ngp_scatter(
+// NT threads share one 96 KB LDS cache (one workgroup per CU): NT = 1024 puts 4 waves on every SIMD -- the loop body is a
+// chain of dependent global loads, hash arithmetic and LDS atomics, and with the first version's 256 threads (ONE wave per
+// SIMD) every one of those latencies was exposed.  `last_level`: levels [0, last_level) are walked by this kernel.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_ngp_scatter(
     NgpLevels lv, float bound, float* __restrict__ gtable, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ aabb, const float* __restrict__ z_s,
-    const float* __restrict__ dfeat, uint32_t N, uint32_t T2, uint32_t rays_per_row, uint32_t cached_levels) {
+    const float* __restrict__ dfeat, uint32_t N, uint32_t T2, uint32_t rays_per_row, uint32_t cached_levels,
+    uint32_t last_level) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   uint32_t* tags = reinterpret_cast<uint32_t*>(smem);            // [SC_SLOTS]
   float* vals = smem + SC_SLOTS;                                 // [SC_SLOTS][2]
@@ -378,10 +383,10 @@ __global__ __launch_bounds__(256) void k_ngp_scatter(
   if (patch) { tiles_x = rays_per_row / 8; tile_y = blockIdx.x / tiles_x; tile_x = blockIdx.x % tiles_x; }
   const uint32_t pts = SC_RAYS * T2;
 
-  for (uint32_t l = 0; l < lv.L; ++l) {
+  for (uint32_t l = 0; l < last_level; ++l) {
     const bool cached = l < cached_levels;
     if (cached) {
-      for (uint32_t s = threadIdx.x; s < SC_SLOTS; s += 256) { tags[s] = SC_EMPTY; vals[2 * s] = 0.f; vals[2 * s + 1] = 0.f; }
+      for (uint32_t s = threadIdx.x; s < SC_SLOTS; s += NT) { tags[s] = SC_EMPTY; vals[2 * s] = 0.f; vals[2 * s + 1] = 0.f; }
       __syncthreads();
     }
     float* tab = gtable + (size_t)lv.offset[l] * 2;
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(256) void k_ngp_scatter(
     // lane quads share a sample: lane&1 = channel, lane&2 = x-corner.  The four adds of an x-corner pair (two
     // adjacent table rows x 2 channels = 16 contiguous bytes) sit in adjacent lanes of ONE atomic instruction: the
     // memory-side atomic unit merges lanes of one granule (measured 13.5 -> 7.6 ms with channel pairs alone).
-    for (uint32_t it = threadIdx.x; it < 4 * pts; it += 256) {
+    for (uint32_t it = threadIdx.x; it < 4 * pts; it += NT) {
       const uint32_t pl = it >> 2, ch = it & 1, xb = (it >> 1) & 1;
       const uint32_t r = pl / T2, k = pl - r * T2;
       uint32_t n = patch ? ((tile_y * 8 + (r >> 3)) * rays_per_row + tile_x * 8 + (r & 7)) : (blockIdx.x * SC_RAYS + r);
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(256) void k_ngp_scatter(
     }
     if (cached) {
       __syncthreads();
-      for (uint32_t s = threadIdx.x; s < SC_SLOTS; s += 256) {
+      for (uint32_t s = threadIdx.x; s < SC_SLOTS; s += NT) {
         const uint32_t row = tags[s];
         if (row != SC_EMPTY) {
           SF_ATOMIC_ADD(tab + (size_t)row * 2, vals[2 * s]);
@@ -435,6 +440,48 @@ __global__ __launch_bounds__(256) void k_ngp_scatter(
         }
       }
       __syncthreads();
+    }
+  }
+}
+
+// Fine levels (cell smaller than the patch footprint: nothing to merge in LDS): no LDS frame, so 8 waves per SIMD hide the
+// latency of the loads in front of every atomic.  Work item = (level, sample) in level-major order (the dfeat layout),
+// lane quads as above: 16 contiguous bytes per atomic instruction and quad.
+__global__ __launch_bounds__(256) void k_ngp_scatter_fine(
+    NgpLevels lv, float bound, float* __restrict__ gtable, const float* __restrict__ rays_o,
+    const float* __restrict__ rays_d, const float* __restrict__ aabb, const float* __restrict__ z_s,
+    const float* __restrict__ dfeat, uint32_t N, uint32_t T2, uint32_t first_level) {
+  const uint32_t P = N * T2;
+  float box[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) box[i] = aabb[i];
+  const uint64_t total = (uint64_t)4 * P * (lv.L - first_level);
+  for (uint64_t it = (uint64_t)blockIdx.x * 256 + threadIdx.x; it < total; it += (uint64_t)gridDim.x * 256) {
+    const uint32_t ch = (uint32_t)it & 1, xb = ((uint32_t)it >> 1) & 1;
+    const uint64_t q = it >> 2;
+    const uint32_t l = first_level + (uint32_t)(q / P), p = (uint32_t)(q % P);
+    const float dfc = dfeat[((size_t)l * P + p) * 2 + ch];
+    if (dfc == 0.0f) continue;
+    const uint32_t n = p / T2;
+    const float o[3] = {rays_o[n * 3], rays_o[n * 3 + 1], rays_o[n * 3 + 2]};
+    const float d[3] = {rays_d[n * 3], rays_d[n * 3 + 1], rays_d[n * 3 + 2]};
+    float x[3], x01[3];
+    ngp_point(o, d, z_s[p], box, x);
+    if (!ngp_unit(x, bound, x01)) continue;
+    NgpCell c;
+    ngp_cell(lv, l, x01, c);
+    float* tab = gtable + (size_t)lv.offset[l] * 2;
+    const uint32_t step = lv.resolution[l] + 1;
+    const bool z_dropped = lv.gridtype == 1 && (uint64_t)step * step > lv.hsize[l] && step <= lv.hsize[l];
+#pragma unroll
+    for (int yz = 0; yz < 4; ++yz) {
+      if (z_dropped && yz >= 2) continue;
+      const int i0 = yz << 1, i1 = i0 | 1;
+      const float w0 = z_dropped ? SF_ADD(c.w[i0 & 3], c.w[(i0 & 3) + 4]) : c.w[i0];
+      const float w1 = z_dropped ? SF_ADD(c.w[i1 & 3], c.w[(i1 & 3) + 4]) : c.w[i1];
+      const float w = xb ? w1 : w0;
+      const uint32_t row = xb ? c.row[i1] : c.row[i0];
+      SF_ATOMIC_ADD(tab + (size_t)row * 2 + ch, SF_MUL(w, dfc));
     }
   }
 }
@@ -579,19 +626,39 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
   }
   if (dfeat) {
     const size_t lds_sc = (size_t)SC_SLOTS * 3 * sizeof(float);
+    // tuning knobs (A/B on the GPU box): threads per cached-level workgroup, scale cutoff of the LDS cache, fine levels in
+    // their own high-occupancy launch
+    static const int sc_threads = getenv("SF_SC_THREADS") ? atoi(getenv("SF_SC_THREADS")) : 1024;
+    static const float sc_cutoff = getenv("SF_SC_CUTOFF") ? (float)atof(getenv("SF_SC_CUTOFF")) : 160.0f;
+    static const bool sc_split = getenv("SF_SC_SPLIT") ? atoi(getenv("SF_SC_SPLIT")) != 0 : true;
     static unsigned attr2_mask = 0;
     if (dev_id >= 32 || !(attr2_mask & (1u << dev_id))) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_scatter), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds_sc) != hipSuccess)
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_scatter<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_scatter<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_scatter<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess)
         SF_FAIL(SF_ERR_LAUNCH, "ngp_scatter: cannot raise dynamic LDS limit");
       if (dev_id < 32) attr2_mask |= 1u << dev_id;
     }
     // levels whose cell is larger than ~1/4 of an 8-ray patch footprint profit from the LDS cache: scale <= ~128
     uint32_t cached = 0;
-    while (cached < lv.L && lv.scale[cached] <= 160.0f) ++cached;
-    k_ngp_scatter<<<sf_div_up(N, SC_RAYS), 256, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat,
-                                                             N, 2 * T, rays_per_row, cached);
-    SF_CHECK_LAUNCH("ngp_scatter");
+    while (cached < lv.L && lv.scale[cached] <= sc_cutoff) ++cached;
+    const uint32_t last = sc_split ? cached : lv.L;
+    const uint32_t grid_sc = sf_div_up(N, SC_RAYS);
+    if (last > 0) {
+      if (sc_threads == 256)
+        k_ngp_scatter<256><<<grid_sc, 256, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, 2 * T, rays_per_row, cached, last);
+      else if (sc_threads == 512)
+        k_ngp_scatter<512><<<grid_sc, 512, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, 2 * T, rays_per_row, cached, last);
+      else
+        k_ngp_scatter<1024><<<grid_sc, 1024, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, 2 * T, rays_per_row, cached, last);
+      SF_CHECK_LAUNCH("ngp_scatter");
+    }
+    if (last < lv.L) {
+      const uint64_t items = (uint64_t)4 * M * (lv.L - last);
+      const uint32_t grid_f = (uint32_t)(items / 256 < 16384 ? (items + 255) / 256 : 16384);
+      k_ngp_scatter_fine<<<grid_f, 256, 0, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, 2 * T, last);
+      SF_CHECK_LAUNCH("ngp_scatter_fine");
+    }
   }
   return SF_OK;
 }

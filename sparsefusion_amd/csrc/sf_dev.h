@@ -22,6 +22,7 @@ static inline T sf_shfl_xor(T v, int m) { return hipemu::shfl_xor(v, m); }
 template <class T>
 static inline T sf_shfl(T v, int src) { return hipemu::shfl_xor(v, (src ^ hipemu::t_lane) & 63); }
 static inline float sf_exp(float v) { return expf(v); }
+static inline float sf_exp2(float v) { return exp2f(v); }
 static inline void sf_lds_add(float* p, float v) {
   uint32_t* u = reinterpret_cast<uint32_t*>(p);
   uint32_t old = __atomic_load_n(u, __ATOMIC_RELAXED), neu;
@@ -91,6 +92,7 @@ SF_DEV T sf_shfl_xor(T v, int m) { return __shfl_xor(v, m, 64); }
 template <class T>
 SF_DEV T sf_shfl(T v, int src) { return __shfl(v, src, 64); }
 SF_DEV float sf_exp(float v) { return __expf(v); }
+SF_DEV float sf_exp2(float v) { return __builtin_amdgcn_exp2f(v); }      // raw v_exp_f32 (no denormal fix-up: the result feeds 1 + e)
 SF_DEV void sf_lds_add(float* p, float v) { atomicAdd(p, v); }
 SF_DEV float sf_rsqrt(float v) { return rsqrtf(v); }
 // same-wave LDS hand-off: DS operations of one wave execute in order; this only keeps the compiler from reordering them

@@ -36,6 +36,27 @@ static int run_fconv(const sf_op& op, hipStream_t st) {
   SF_FAIL(SF_ERR_INVALID, "fconv: no kernel variant for tile %dx%d norm %d lazy %d", WM, WN, a.norm, a.s1.mode);
 }
 
+template <int WM, int WN, int D, int NORM, int LAZY>
+static int launch_fconv_pair(const FConvPairArgs& p, uint32_t grid, uint32_t lds, hipStream_t st) {
+  static unsigned mask = 0;
+  if (int rc = allow_big_lds(k_conv_fused_pair<WM, WN, D, NORM, LAZY, SF_FCONV_WAVES>, lds, mask)) return rc;
+  k_conv_fused_pair<WM, WN, D, NORM, LAZY, SF_FCONV_WAVES><<<grid, SF_FCONV_WAVES * 64, lds, st>>>(p);
+  SF_CHECK_LAUNCH("conv_fused_pair");
+  return SF_OK;
+}
+
+int sf_plan_fused_pair(const sf_op* op1, const sf_op* op2, void* stream) {
+  FConvPairArgs p;
+  int WM, WN;
+  uint32_t grid, lds;
+  if (fconv_pair_setup(*op1, *op2, p, WM, WN, grid, lds, sf_err_buf, sizeof(sf_err_buf))) return SF_ERR_INVALID;
+#define SF_TRY(wm, wn, d, nm_, lz_) \
+  if (WM == wm && WN == wn && p.a.norm == nm_ && p.a.s1.mode == lz_) return launch_fconv_pair<wm, wn, d, nm_, lz_>(p, grid, lds, (hipStream_t)stream);
+  SF_FCONV_PAIR_VARIANTS(SF_TRY)
+#undef SF_TRY
+  SF_FAIL(SF_ERR_INVALID, "fconv pair: no kernel variant for tile %dx%d norm %d lazy %d", WM, WN, p.a.norm, p.a.s1.mode);
+}
+
 static int run_slots(const sf_op& op, hipStream_t st) {
   const int M = op.i[0], C = op.i[1], HW = op.i[2];
   if (M % 16 || C % 16 || !op.p[0] || !op.p[4] || (op.p[1] && (!op.p[2] || !op.p[3])))

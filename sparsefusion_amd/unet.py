@@ -21,6 +21,8 @@ from . import _lib
 
 OP_CONV, OP_GN_ACT, OP_LN, OP_GEMV, OP_ATTN, OP_GCA_POOL, OP_ELTWISE, OP_MEMSET, OP_TIME_EMB, OP_SPLITK_REDUCE = range(1, 11)
 OP_FCONV, OP_SLOTS, OP_GCA = 14, 15, 16
+# (WM, WN, norm of conv1) for which k_conv_fused_pair is instantiated (csrc/fused_host.h SF_FCONV_PAIR_VARIANTS); FNORM_GN_SELF = 1, _SLOTS = 2
+PAIR_TILES = {(1, 1, 1), (1, 1, 2), (1, 2, 2), (2, 2, 2)}
 FNORM_NONE, FNORM_GN_SELF, FNORM_GN_SLOTS, FNORM_LN = range(4)      # csrc/fused_kernels.h
 LDS_MAX = 163840
 SKIP_SCALE = 2 ** -0.5            # scale_skip_connection (imagen_pytorch.py:1283)
@@ -393,7 +395,8 @@ class _Plan:
         return t
 
     def fconv(self, x, skip, H, wname, bname, out, Cout, k, norm, geom, gname=None, ss_ptr=0, silu=True, resid=None,
-              want_slots=False, pre_gelu=False, beta_name=None, ldc=None, co_off=0, logit=None, out_gelu=False):
+              want_slots=False, pre_gelu=False, beta_name=None, ldc=None, co_off=0, logit=None, out_gelu=False,
+              pair_first=False, pair_lazy=None):
         """One k_conv_fused launch: out = conv_k(act(norm(concat(x, skip * 2^-1/2)))).  With S > 1 input-channel slices the
         output stays a lazy split-K tensor (slabs + bias + resid) that the next fused conv / GroupNorm / gca pass reduces."""
         TR, WM, WN, S = geom
@@ -416,7 +419,12 @@ class _Plan:
         else:
             self.written.add((out.ptr, co_off))
         lp, li = (0, 0, 0), (0, 0, 0)
-        if x.lazy is not None:
+        x_ptr = x.ptr
+        if pair_lazy is not None:                               # second half of a pair: the first half's (lazy) view of x, read-only
+            lp, li = pair_lazy
+            if li[0]:
+                x_ptr = 0
+        elif x.lazy is not None:
             if x.lazy[0] == "gate" and (not x.lazy[3] or x.lazy[3] == x.ptr):
                 self.need(x)                                    # res lives in the target buffer: only a one-reader kernel may do that
             else:
@@ -430,8 +438,8 @@ class _Plan:
         gam = self.wptr(gname + ".weight") if norm in (FNORM_GN_SELF, FNORM_GN_SLOTS) else (self.wptr(gname) if gname else 0)
         bet = self.wptr(gname + ".bias") if norm in (FNORM_GN_SELF, FNORM_GN_SLOTS) else (self.wptr(beta_name) if beta_name else 0)
         assert not (out_gelu and S > 1)
-        self.op(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0) | (8 if out_gelu else 0),
-                p=(x.ptr, lp[0], lp[1], lp[2], x.slots or 0, skip.ptr if skip else 0, (skip.slots or 0) if skip else 0,
+        self.op(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0) | (8 if out_gelu else 0) | (16 if pair_first else 0),
+                p=(x_ptr, lp[0], lp[1], lp[2], x.slots or 0, skip.ptr if skip else 0, (skip.slots or 0) if skip else 0,
                    self.wptr(wname), 0 if S > 1 else bias, out.ptr, 0 if S > 1 else res, ws, slots_out, gam, bet, ss_ptr, 0,
                    logit[0] if logit else 0, logit[1] if logit else 0),
                 i=(B, H, H, C1, C2, Cout, ldc, co_off, k, li[0], li[1], li[2], norm, 8, TR, WM, WN, S, self.u.tb_stride),
@@ -440,6 +448,7 @@ class _Plan:
             out.lazy = ("splitk", ws, bias, res, S, n_frags * 16, wi)
             self.ws_owners[wi] = out
             out.slots = None
+        return lp, li
 
     def resnet_fused(self, name, x, skip, cout, H, gca=False, cross=False):
         """ResnetBlock (imagen_pytorch.py:665-729) with both GroupNorms inside their convs: 2 launches (+ res_conv, + gca)
@@ -455,12 +464,16 @@ class _Plan:
             return None
         slots = norm == FNORM_GN_SLOTS
         h = self.zf32(rows, cout, HW)
-        self.fconv(x, skip, H, f"{name}.block1.project.weight", f"{name}.block1.project.bias", h, cout, 3, norm, g1,
-                   gname=f"{name}.block1.groupnorm", want_slots=slots)
+        # conv1 and res_conv read the same input and are independent: one launch (k_conv_fused_pair) when their tiles match
+        pair = (cin != cout and getattr(self.u, "pair_res_conv", True) and g1[1:3] == gr[1:3] and gr[3] == 1
+                and (g1[1], g1[2], norm) in PAIR_TILES)
+        lz = self.fconv(x, skip, H, f"{name}.block1.project.weight", f"{name}.block1.project.bias", h, cout, 3, norm, g1,
+                        gname=f"{name}.block1.groupnorm", want_slots=slots, pair_first=pair)
         rc = None
-        if cin != cout:                                             # res_conv reads the raw concat (x is materialised now)
+        if cin != cout:                                             # res_conv reads the raw concat (x is materialised by conv1)
             rc = self.zf32(rows, cout, HW)
-            self.fconv(x, skip, H, f"{name}.res_conv.weight", f"{name}.res_conv.bias", rc, cout, 1, FNORM_NONE, gr, silu=False)
+            self.fconv(x, skip, H, f"{name}.res_conv.weight", f"{name}.res_conv.bias", rc, cout, 1, FNORM_NONE, gr, silu=False,
+                       pair_lazy=lz if pair else None)
         if cross:
             h = self.cross_attention(f"{name}.cross_attn.fn", h)
         ss_ptr = self.ss.ptr + self.u.ss_offset[name] * 4
@@ -905,6 +918,7 @@ class Unet(nn.Module):
         self.lazy_consumers = 3             # bit 0: split-K reductions, bit 1: gated residuals are materialised by their first consumer
         # GroupNorm inside the conv launches (k_conv_fused) wherever the layer fits; SF_UNET_FUSED=0 = the first-round plan (A/B runs)
         self.fused = os.environ.get("SF_UNET_FUSED", "1") != "0"
+        self.pair_res_conv = os.environ.get("SF_PAIR", "1") != "0"      # conv1 || res_conv of a ResnetBlock in one launch
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches
         self._pack_cache = None
         self._plans = {}

@@ -53,7 +53,7 @@ def run_ops(ops, backend):
 
 def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, silu=True, ss=True, accum=False, resid=False,
                   slots=True, pre_gelu=False, ln_bias=False, seed=0, G=8, scale2=2 ** -0.5, tol=4e-3, dbg=None, reps=1, logits=False,
-                  out_gelu=False):
+                  out_gelu=False, pair=False):
     dev = "cpu" if backend == "emu" else "cuda:0"
     d = lambda t: None if t is None else t.to(dev)
     g = torch.Generator().manual_seed(seed)
@@ -115,11 +115,27 @@ def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, 
                     p=(s1["p"], s1["a"], s1["b"], s1["r"], sl1, x2_d, sl2, wp, bias_d, out, res_d, wsl, slots_out, gamma_d, beta_d, ssv_d, dbg, wk_d, lpart),
                     i=(B, H, W, C1, C2, Cout, ldc, co_off, k, s1["mode"], s1["groups"], s1["npad"], norm, G, TR, WM, WN, S, 2 * C),
                     f=(1e-5, 1.0, scale2))
-    run_ops([op], backend)
+    ops = [op]
+    if pair:          # conv1 || res_conv in one launch (k_conv_fused_pair): a 1x1 conv of the RAW concat next to the normalised 3x3 one
+        w2 = rn(Cout, C, 1, 1) / C ** 0.5
+        bias2 = rn(Cout)
+        ref2 = to_rows(F.conv2d(bf(nhwc(xc, B, H, W)), bf(w2), None)) + bias2
+        out2 = d(torch.full((M, Cout), float("nan")))
+        wp2, bias2_d = d(fused.pack_conv_weights(w2)), d(bias2)
+        op.flags |= 16
+        ops.append(fused.mkop(OP_FCONV, 0,
+                              p=(s1["p"] if not lazy else None, s1["a"], s1["b"], s1["r"], None, x2_d, None, wp2, bias2_d, out2, None, None, None,
+                                 None, None, None, None, None, None),
+                              i=(B, H, W, C1, C2, Cout, Cout, 0, 1, s1["mode"], s1["groups"], s1["npad"], NONE, G, TR, WM, WN, 1, 0),
+                              f=(1e-5, 1.0, scale2)))
+    run_ops(ops, backend)
+    if pair:
+        e2 = rel(out2.cpu(), ref2)
+        assert e2 < tol, f"paired res_conv mismatch rel {e2}"
     if reps > 1:                                         # timing aid (tools/fconv_phases.py): the output is re-written, not checked again
         import time
         t0 = time.time()
-        run_ops([op] * reps, backend)
+        run_ops(ops * reps, backend)
         return (time.time() - t0) / reps
     out = out.cpu()
     if S > 1:
@@ -230,6 +246,10 @@ CONV_CASES = {
     # XCD-aware tile order (8 n-tiles)
     "gn_slots_xcd_map_16x16": dict(B=1, H=16, W=16, C1=128, C2=0, Cout=128, k=3, norm=GN_SLOTS, WM=1, WN=1, ss=False, seed=4, logits=True),
     "raw_1x1_concat_res_conv": dict(B=1, H=8, W=8, C1=64, C2=32, Cout=40, k=1, norm=NONE, WM=1, WN=1, silu=False, slots=False, seed=5),
+    # conv1 || res_conv pairs (one launch): slot statistics at 8x8, and the 4x4 level with a lazy split-K source read by both halves
+    "pair_gn_slots_concat_8x8": dict(B=1, H=8, W=8, C1=64, C2=64, Cout=32, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=21, pair=True),
+    "pair_gn_self_lazy_splitk_4x4": dict(B=2, H=4, W=4, C1=64, C2=64, Cout=48, k=3, norm=GN_SELF, WM=1, WN=1, S=2, lazy=1, seed=22, pair=True),
+    "pair_gn_slots_wm2_wn2": dict(B=1, H=2, W=32, C1=128, C2=0, Cout=64, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=23, pair=True),
     "layernorm_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=1, silu=False, seed=6, out_gelu=True),
     "layernorm_lazy_splitk_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=1, silu=False, lazy=1, seed=7),
     "gelu_layernorm_bias_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=2, silu=False, pre_gelu=True,
@@ -245,5 +265,8 @@ CONV_CASES_FULL = {
     "unet_32x32_res_conv": dict(B=1, H=32, W=32, C1=256, C2=256, Cout=256, k=1, norm=NONE, WM=2, WN=2, silu=False, seed=15),
     "unet_ln_ff2_2048": dict(B=1, H=4, W=4, C1=2048, C2=0, Cout=1024, k=1, norm=LN, WM=1, WN=1, silu=False, pre_gelu=True, resid=True, seed=17),
     "unet_ln_qkv_lazy": dict(B=1, H=4, W=4, C1=1024, C2=0, Cout=640, k=1, norm=LN, WM=1, WN=1, silu=False, lazy=1, seed=18),
+    "unet_pair_8x8_1536": dict(B=1, H=8, W=8, C1=1024, C2=512, Cout=1024, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=24, pair=True),
+    "unet_pair_4x4_2048_lazy": dict(B=1, H=4, W=4, C1=1024, C2=1024, Cout=1024, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=1, seed=25, pair=True),
+    "unet_pair_32x32_512": dict(B=1, H=32, W=32, C1=256, C2=256, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=26, pair=True),
     "unet_b4_4x4": dict(B=4, H=4, W=4, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SELF, WM=1, WN=1, S=1, seed=16),
 }

@@ -14,6 +14,24 @@ static void emu_fconv(const FConvArgs& a, uint32_t grid, uint32_t lds) {
   hipemu::launch(grid, SF_FCONV_WAVES * 64, lds, [&] { k_conv_fused<WM, WN, D, NORM, LAZY, SF_FCONV_WAVES>(a); });
 }
 
+template <int WM, int WN, int D, int NORM, int LAZY>
+static void emu_fconv_pair(const FConvPairArgs& p, uint32_t grid, uint32_t lds) {
+  hipemu::launch(grid, SF_FCONV_WAVES * 64, lds, [&] { k_conv_fused_pair<WM, WN, D, NORM, LAZY, SF_FCONV_WAVES>(p); });
+}
+
+static int emu_run_pair(const sf_op* op1, const sf_op* op2, char* err, int errn) {
+  FConvPairArgs p;
+  int WM, WN;
+  uint32_t grid, lds;
+  if (fconv_pair_setup(*op1, *op2, p, WM, WN, grid, lds, err, (size_t)errn)) return 1;
+#define SF_TRY(wm, wn, d, nm_, lz_) \
+  if (WM == wm && WN == wn && p.a.norm == nm_ && p.a.s1.mode == lz_) { emu_fconv_pair<wm, wn, d, nm_, lz_>(p, grid, lds); return 0; }
+  SF_FCONV_PAIR_VARIANTS(SF_TRY)
+#undef SF_TRY
+  snprintf(err, errn, "fconv pair: no kernel variant for tile %dx%d norm %d lazy %d", WM, WN, p.a.norm, p.a.s1.mode);
+  return 1;
+}
+
 extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
   err[0] = 0;
   if (op->type == SF_OP_FCONV) {
@@ -53,7 +71,14 @@ extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
 }
 
 extern "C" int emu_plan_run(const sf_op* ops, uint32_t n, char* err, int errn) {
-  for (uint32_t k = 0; k < n; ++k)
+  for (uint32_t k = 0; k < n; ++k) {
+    if (ops[k].type == SF_OP_FCONV && (ops[k].flags & 16)) {
+      if (k + 1 >= n) { snprintf(err, errn, "emu: a paired fconv needs a successor"); return 1; }
+      if (int rc = emu_run_pair(&ops[k], &ops[k + 1], err, errn)) return rc;
+      ++k;
+      continue;
+    }
     if (int rc = emu_run_op(&ops[k], err, errn)) return rc;
+  }
   return 0;
 }

@@ -144,3 +144,32 @@ def test_eft_rejects_unsupported():
     net = EpipolarFeatureTransformer(encoder='resnet18', return_features=True)
     with pytest.raises(RuntimeError):
         net.encode(None, torch.zeros(2, 3, 64, 64))                  # CPU tensor: no fallback
+
+
+def test_eft_feature_render_matches_reference_renderer():
+    """Row E1, renderer half: `renderer_feat(cameras=, volumetric_function=eft.batched_forward, n_batches=16, input_cameras=,
+    input_rgb=)` (sparsefusion/distillation.py:103-109) through the drop-ins of sparsefusion_amd/utils against the reference's
+    own CustomImplicitRenderer + LightFieldRaymarcher + EFT run on CPU (tests/golden/make_golden_eft_render.py)."""
+    from sparsefusion_amd.utils.cameras import PinholeCameras as Cams
+    from sparsefusion_amd.utils.render_utils import init_light_field_renderer
+    import math
+    G = torch.load(f"{GOLD}/eft_render.pt")
+    cfg = G["cfg"]
+    cams, images, _, _, _ = scene(cfg["NC"], cfg["R"], 4, 20, cfg["seed"])
+    net = _module()
+    _, _, renderer_feat = init_light_field_renderer(0, cfg["R"], cfg["R"], min=cfg["min_depth"], max=cfg["max_depth"],
+                                                    scale_factor=cfg["scale_factor"])
+    a = 0.25
+    c, s = math.cos(a), math.sin(a)
+    q = Cams(torch.tensor([[[c, 0, -s], [0, 1, 0], [s, 0, c]]]), torch.tensor([[0.02, 0.03, 4.1]]), torch.full((1, 2), 2.2)).to(DEV)
+    in_cams = Cams(cams.R, cams.T, cams.focal).to(DEV)
+    net.encode(in_cams, images.to(DEV))
+    feats, bundle, reg = renderer_feat(cameras=q, volumetric_function=net.batched_forward, n_batches=16, input_cameras=in_cams,
+                                       input_rgb=images.to(DEV))
+    assert reg == 0 and feats.shape == G["features"].shape == (1, 8, 8, 259)
+    assert torch.allclose(bundle.origins.cpu(), G["origins"], atol=1e-5) and torch.allclose(bundle.directions.cpu(), G["directions"], atol=1e-5)
+    rgb, f3 = feats.cpu().split([3, 256], dim=-1)
+    rgb_g, f3_g = G["features"].split([3, 256], dim=-1)
+    cos = F.cosine_similarity(f3.flatten().double(), f3_g.flatten().double(), dim=0).item()
+    print(f"feature render: f3 rel L2 {rel_err(f3, f3_g):.3e} cos {cos:.6f}; rgb max abs {float((rgb - rgb_g).abs().max()):.3e}")
+    assert rel_err(f3, f3_g) < 3e-2 and cos > 0.999 and float((rgb - rgb_g).abs().max()) < 1e-2

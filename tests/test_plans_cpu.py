@@ -30,8 +30,8 @@ def test_op_codes_match_header():
 def _audit(ops, name, sized=False):
     from sparsefusion_amd import unet
     n_conv = 0
-    for k, o in enumerate(ops):
-        where = f"{name} op {k} type {o.type}"
+    for kk, o in enumerate(ops):
+        where = f"{name} op {kk} type {o.type}"
         if o.type == unet.OP_CONV:
             n_conv += 1
             B, H, W, Cin, Ho, Wo, Cout, ldc, co_off, kh, kw, stride, pad, groups, tile = list(o.i)[:15]
@@ -60,7 +60,15 @@ def _audit(ops, name, sized=False):
             n_conv += 1
             B, H, W, C1, C2, Cout, ldc, co_off, k, lmode, lgroups, npad, norm, G, TR, WM, WN, S = list(o.i)[:18]
             C = C1 + C2
-            assert o.p[0] and o.p[7] and (o.p[9] or S > 1), where
+            second_of_pair = kk > 0 and ops[kk - 1].type == unet.OP_FCONV and (ops[kk - 1].flags & 16)
+            # the res_conv half of a pair reads a lazy source without materialising it (p[0] null): only there
+            assert (o.p[0] or (second_of_pair and lmode)) and o.p[7] and (o.p[9] or S > 1), where
+            if o.flags & 16:
+                nx = ops[kk + 1]
+                assert nx.type == unet.OP_FCONV and nx.i[12] == unet.FNORM_NONE and list(nx.i)[15:18] == [WM, WN, 1] and nx.i[9] == lmode, where + ": pair"
+                assert (WM, WN, norm) in unet.PAIR_TILES and not (nx.flags & 16), where + ": pair variant"
+            if second_of_pair:
+                assert norm == unet.FNORM_NONE and list(o.p)[1:4] == list(ops[kk - 1].p)[1:4], where + ": pair halves read the same source"
             assert C % 32 == 0 and C1 % 32 == 0 and k in (1, 3) and TR * W == 16 * WM and H % TR == 0, where
             assert (C // 32) % S == 0 and WM in (1, 2) and WN in (1, 2), where
             if S > 1:
@@ -73,7 +81,8 @@ def _audit(ops, name, sized=False):
                 else:
                     assert o.p[4] and (o.p[6] or not C2) and Cg % 16 == 0 and lmode != 1, where + ": slot statistics"
             if lmode:
-                assert (o.p[1] or not sized) and (lmode == 1 or (o.p[2] and o.p[3])) and o.p[3] != o.p[0] and o.p[1] != o.p[0], where
+                assert (o.p[1] or not sized) and (lmode == 1 or (o.p[2] and o.p[3])), where
+                assert not o.p[0] or (o.p[3] != o.p[0] and o.p[1] != o.p[0]), where
             if lmode == 1 and S > 1 and sized:
                 assert o.p[1] != o.p[11], where + ": a conv must not overwrite the slabs it reads"
             h = k // 2
@@ -117,7 +126,7 @@ def test_unet_plan_invariants():
         if o.type == 1:
             assert lo <= o.p[3] < hi and lo <= o.p[0] < hi
         if o.type == unet_mod.OP_FCONV:
-            assert lo <= o.p[0] < hi and (lo <= o.p[9] < hi) and (not o.p[11] or lo <= o.p[11] < hi)
+            assert (not o.p[0] or lo <= o.p[0] < hi) and (lo <= o.p[9] < hi) and (not o.p[11] or lo <= o.p[11] < hi)
     # the lazy plan drops launches but never changes the set of convs
     net.fused = False
     net.lazy_consumers = 3

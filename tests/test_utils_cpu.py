@@ -1,0 +1,95 @@
+"""CPU tests of the reference-`utils/` drop-ins (sparsefusion_amd/utils): ray samplers and cameras against the oracle's
+restatement of the pytorch3d conventions and the bundle the reference renderer consumed when the golden was made
+(tests/golden/make_golden_eft_render.py), renderer / raymarcher plumbing with a toy volumetric function."""
+import math
+import os
+
+import torch
+
+from oracle import ref_loader
+from sparsefusion_amd.utils.cameras import GridRaysampler, MonteCarloRaysampler, PinholeCameras, RayBundle, ray_bundle_to_ray_points
+from sparsefusion_amd.utils.eft_raymarcher import LightFieldRaymarcher
+from sparsefusion_amd.utils.eft_renderer import CustomImplicitRenderer
+from sparsefusion_amd.utils.render_utils import init_ray_sampler
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _cams(n=3):
+    Rs, Ts = [], []
+    for i in range(n):
+        a = 0.3 * i - 0.2
+        c, s = math.cos(a), math.sin(a)
+        Rs.append(torch.tensor([[c, 0, -s], [0, 1, 0], [s, 0, c]]))
+        Ts.append(torch.tensor([0.1 * i, -0.05 * i, 4.0 + 0.2 * i]))
+    return torch.stack(Rs), torch.stack(Ts), torch.tensor([[2.2, 2.1]]).expand(n, 2).contiguous(), torch.tensor([[0.02, -0.01]]).expand(n, 2).contiguous()
+
+
+def test_camera_projection_round_trip_and_oracle():
+    R, T, f, pp = _cams()
+    cams = PinholeCameras(R, T, f, pp)
+    ref = ref_loader.PinholeCameras(R, T, f, pp)
+    pts = torch.randn(3, 50, 3, generator=torch.Generator().manual_seed(0)) * 0.5
+    ndc = cams.transform_points_ndc(pts)
+    assert torch.allclose(ndc, ref.transform_points_ndc(pts), atol=1e-6)
+    assert torch.allclose(cams.get_camera_center(), ref.get_camera_center(), atol=1e-6)
+    back = cams.unproject_points(torch.cat([ndc[..., :2], 1.0 / ndc[..., 2:3]], -1))
+    assert torch.allclose(back, pts, atol=1e-4)
+    assert len(cams[1]) == 1 and torch.equal(cams[[0, 2]].T, T[[0, 2]])
+
+
+def test_grid_raysampler_matches_oracle_and_golden_bundle():
+    R, T, f, pp = _cams(2)
+    kw = dict(min_x=1 - 1 / 64, max_x=-1 + 1 / 64, min_y=1 - 1 / 64, max_y=-1 + 1 / 64, image_width=8, image_height=6, n_pts_per_ray=20,
+              min_depth=0.5, max_depth=4.0)
+    rb = GridRaysampler(**kw)(cameras=PinholeCameras(R, T, f, pp))
+    rr = ref_loader.GridRaysamplerRef(**kw)(ref_loader.PinholeCameras(R, T, f, pp))
+    for a, b in zip(rb, rr):
+        assert a.shape == b.shape and torch.allclose(a, b, atol=1e-5)
+    # origins are the camera centres, directions are not unit length, points re-project onto the lattice
+    cams = PinholeCameras(R, T, f, pp)
+    assert torch.allclose(rb.origins, cams.get_camera_center()[:, None, None].expand_as(rb.origins), atol=1e-5)
+    assert (rb.directions.norm(dim=-1) > 1.0).all()
+    pts = ray_bundle_to_ray_points(rb).reshape(2, -1, 3)
+    xy = cams.transform_points_ndc(pts)[..., :2].reshape(2, 6, 8, 20, 2)
+    assert torch.allclose(xy, rb.xys[:, :, :, None].expand_as(xy), atol=1e-4)
+    assert torch.allclose(rb.lengths[0, 0, 0], torch.linspace(0.5, 4.0, 20))
+    # the bundle the REFERENCE renderer consumed for tests/golden/eft_render.pt
+    G = torch.load(os.path.join(GOLD, "eft_render.pt"))
+    cfg = G["cfg"]
+    _, _, feat = init_ray_sampler(0, cfg["R"], cfg["R"], min=cfg["min_depth"], max=cfg["max_depth"], scale_factor=cfg["scale_factor"])
+    a = 0.25
+    q = PinholeCameras(torch.tensor([[[math.cos(a), 0, -math.sin(a)], [0, 1, 0], [math.sin(a), 0, math.cos(a)]]]),
+                       torch.tensor([[0.02, 0.03, 4.1]]), torch.full((1, 2), 2.2))
+    gb = feat(cameras=q)
+    assert torch.allclose(gb.origins, G["origins"], atol=1e-5) and torch.allclose(gb.directions, G["directions"], atol=1e-5)
+    assert torch.allclose(gb.lengths, G["lengths"], atol=1e-6)
+
+
+def test_sampler_factories_and_renderer_plumbing():
+    grid, mc = init_ray_sampler(0, 32, 32)
+    assert isinstance(grid, GridRaysampler) and isinstance(mc, MonteCarloRaysampler)
+    R, T, f, pp = _cams(2)
+    cams = PinholeCameras(R, T, f, pp)
+    b = mc(cameras=cams)
+    assert b.origins.shape == (2, 750, 3) and b.lengths.shape == (2, 750, 128) and float(b.xys.abs().max()) <= 1.0
+    _, mc2 = init_ray_sampler(0, 32, 32, bbox=torch.tensor([[-0.5, -0.25, 0.5, 0.75]]), n_rays=10, n_pts_per_ray=4)
+    x = mc2(cameras=cams).xys
+    assert float(x[..., 0].min()) >= -0.75 and float(x[..., 0].max()) <= 0.25 and float(x[..., 1].min()) >= -0.5
+
+    def field(ray_bundle, cameras, scale=1.0, **kw):
+        pts = ray_bundle_to_ray_points(ray_bundle)
+        return pts[..., :1].mean(-2) * scale, pts.mean(-2), 7
+
+    ren = CustomImplicitRenderer(raysampler=grid, raymarcher=LightFieldRaymarcher(), reg=True)
+    img, rb, reg = ren(cameras=cams, volumetric_function=field, scale=2.0)
+    assert reg == 7 and img.shape == (2, 32, 32, 4) and isinstance(rb, RayBundle)
+    pts = ray_bundle_to_ray_points(rb)
+    assert torch.allclose(img[..., 0], 2.0 * pts[..., 0].mean(-1), atol=1e-6) and torch.allclose(img[..., 1:], pts.mean(-2), atol=1e-6)
+    img2, _ = CustomImplicitRenderer(raysampler=grid, raymarcher=LightFieldRaymarcher())(cameras=cams, volumetric_function=field)
+    assert img2.shape == (2, 32, 32, 4)
+    try:
+        CustomImplicitRenderer(raysampler=None, raymarcher=LightFieldRaymarcher())
+        raise AssertionError("non-callable raysampler accepted")
+    except ValueError:
+        pass
