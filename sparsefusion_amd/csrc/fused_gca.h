@@ -25,6 +25,7 @@ struct GcaPoolArgs {
 // Every phase issues its loads as one independent batch: a dependent load per loop trip costs an L2 / fabric round trip
 // (~0.5 us), and the first version of this kernel spent 30 us summing 256 logit parts one after the other.
 SF_KERNEL(256) void k_gca_pool(GcaPoolArgs a) {
+  sf_touch_kernarg<(int)sizeof(GcaPoolArgs)>();
   SF_SHARED float e[128];
   SF_SHARED float red[16][132];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -32,6 +33,26 @@ SF_KERNEL(256) void k_gca_pool(GcaPoolArgs a) {
   const int cs = blockIdx.x % cslabs, bc = blockIdx.x / cslabs;      // bc = image * chunks + chunk
   const int b = bc / a.chunks, ch = bc - b * a.chunks;
   const long m0 = (long)b * a.HW + (long)ch * a.CH;
+  // the first trip of phase (3)'s operand loads goes out NOW: they do not depend on the logits, and issued after the softmax
+  // they were a second cold round trip (the data was written by the previous kernel on other XCDs)
+  const int c4 = tid & 15, pl = tid >> 4;
+  const int c = cs * 64 + c4 * 4;
+  const f32x4 bvec = (a.ws && a.bias) ? *reinterpret_cast<const f32x4*>(a.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 v[4];
+  auto load_trip = [&](int p0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * 16;
+      const long m = m0 + (p < a.CH ? p : a.CH - 1);
+      if (a.ws) {
+        v[u] = bvec;
+        for (int g = 0; g < a.groups; ++g) v[u] += *reinterpret_cast<const f32x4*>(a.ws + ((long)g * a.M + m) * a.npad + c);
+      } else {
+        v[u] = *reinterpret_cast<const f32x4*>(a.h2 + m * a.C + c);
+      }
+    }
+  };
+  load_trip(pl);
   // (1) logits of the chunk's pixels: CH (power of two, 16..128) pixels x PL = 256 / CH part lanes
   {
     const int p = tid & (a.CH - 1), pl = tid / a.CH, PL = 256 / a.CH;
@@ -69,23 +90,9 @@ SF_KERNEL(256) void k_gca_pool(GcaPoolArgs a) {
   if (tid == 0 && cs == 0) { a.part_ms[(long)bc * 2] = mx; a.part_ms[(long)bc * 2 + 1] = sm; }
   sf_sync();
   // (3) un-normalised pooled slab; h2 is evaluated (and written back) from the slabs when lazy
-  const int c4 = tid & 15, pl = tid >> 4;
-  const int c = cs * 64 + c4 * 4;
   f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-  const f32x4 bvec = (a.ws && a.bias) ? *reinterpret_cast<const f32x4*>(a.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
   for (int p0 = pl; p0 < a.CH; p0 += 64) {   // 4 pixels per thread and trip, all their loads in flight together
-    f32x4 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int p = p0 + u * 16;
-      const long m = m0 + (p < a.CH ? p : a.CH - 1);
-      if (a.ws) {
-        v[u] = bvec;
-        for (int g = 0; g < a.groups; ++g) v[u] += *reinterpret_cast<const f32x4*>(a.ws + ((long)g * a.M + m) * a.npad + c);
-      } else {
-        v[u] = *reinterpret_cast<const f32x4*>(a.h2 + m * a.C + c);
-      }
-    }
+    if (p0 != pl) load_trip(p0);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int p = p0 + u * 16;
@@ -118,6 +125,7 @@ struct GcaNetArgs {
 
 // grid = B * ceil(HID / 16); 4 waves x 4 rows each
 SF_KERNEL(256) void k_gca_net0(GcaNetArgs a) {
+  sf_touch_kernarg<(int)sizeof(GcaNetArgs)>();
   SF_SHARED float pooled[2048];
   SF_SHARED float wgt[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -134,6 +142,10 @@ SF_KERNEL(256) void k_gca_net0(GcaNetArgs a) {
       w[rr][it] = (r < a.HID && k < a.C) ? *reinterpret_cast<const bf16x8*>(a.W0 + (long)r * a.Kp + k) : sf_zero8();
     }
   }
+  // the pooled partials of this thread's first channel: independent of the merge weights, so in flight with them
+  float pj0[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) pj0[j] = a.part_pool[((long)b * a.chunks + (j < a.chunks ? j : a.chunks - 1)) * a.C + (tid < a.C ? tid : 0)];
   if (wave == 0) {                                        // online-softmax merge weights of the chunks (lanes = chunks)
     const bool on = lane < a.chunks;
     const float mj = on ? a.part_ms[((long)b * a.chunks + lane) * 2] : -INFINITY;
@@ -147,7 +159,7 @@ SF_KERNEL(256) void k_gca_net0(GcaNetArgs a) {
   for (int c = tid; c < a.C; c += 256) {
     float pj[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) pj[j] = a.part_pool[((long)b * a.chunks + (j < a.chunks ? j : a.chunks - 1)) * a.C + c];
+    for (int j = 0; j < 8; ++j) pj[j] = c == tid ? pj0[j] : a.part_pool[((long)b * a.chunks + (j < a.chunks ? j : a.chunks - 1)) * a.C + c];
     float s = 0.0f;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
@@ -185,6 +197,7 @@ struct GcaGateArgs {
 
 // one wave per (16 pixels, 16 channels); grid = ceil(M/16 * C/16 / 4)
 SF_KERNEL(256) void k_gca_gate(GcaGateArgs a) {
+  sf_touch_kernarg<(int)sizeof(GcaGateArgs)>();
   const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int CF = a.C >> 4;
   if (gw >= (a.M >> 4) * CF) return;

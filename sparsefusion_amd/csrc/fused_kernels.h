@@ -25,10 +25,13 @@ struct FDiv { uint32_t d, magic; };
 SF_DEV uint32_t fdiv(uint32_t n, FDiv f) { return f.d == 1 ? n : (uint32_t)(((uint64_t)n * f.magic) >> 32); }
 
 #ifndef SF_STAGE_U
-#define SF_STAGE_U 4           // float4 loads per staging batch and thread; two batches are live (one in flight, one in the VALU)
+#define SF_STAGE_U 2           // float4 loads per staging batch and thread; two batches are live (one in flight, one in the VALU).
+                               // Measured r02 (UNet eval, B = 1): U = 8 / 4 / 2 -> 1.79 / 1.65 / 1.62 ms: the prologue is instruction-issue
+                               // bound (a wave64 VALU op occupies its SIMD for 4 cycles), so the shorter unrolled body wins
 #endif
 #ifndef SF_NT_W
-#define SF_NT_W 0              // 1: non-temporal (streaming) weight loads -- an A/B knob, see DESIGN.md section 4
+#define SF_NT_W 1              // non-temporal (streaming) weight loads: every weight byte is used once per eval, keeping it out of the
+                               // L2's retained set leaves the activations / slots there (measured r02: 1.62 -> 1.54 ms per eval)
 #endif
 #ifndef SF_RING_POS
 #define SF_RING_POS 1          // weight-ring issue point of the slot / plain prologue: 0 before the first staging batch, 1 after it, 2 after staging
@@ -137,6 +140,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
   const int Cs = a.cps * 32, c0 = s * Cs, Cs4 = Cs >> 2;
   const int HW = a.H * a.W;
   const long mb = (long)b * HW;           // first pixel row of this image
+  const float sc1 = a.s1.scale, sc2 = a.s2.scale;     // as values: a select between two kernarg FIELDS becomes a scratch array
 
   // ---- weight stream: this wave's k-steps [k0, k1) of the slice-local list (tap-major, then 32-channel chunk)
   const int KSl = a.k * a.k * a.cps;
@@ -281,7 +285,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
       const int W = a.det_w;
       float sm = 0.0f, sq = 0.0f;
       const int c4t = tid - (int)fdiv((uint32_t)tid, a.d_cs4) * Cs4;
-      const float sc = (c0 + c4t * 4 < a.s1.C) ? a.s1.scale : a.s2.scale;
+      const float sc = (c0 + c4t * 4 < a.s1.C) ? sc1 : sc2;
 #pragma unroll
       for (int u = 0; u < NV; ++u) {
         if (tid + u * NT < cnt) {
@@ -319,7 +323,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
         if (i < cnt) {
           const int p = (int)fdiv((uint32_t)i, a.d_cs4), c4 = i - p * Cs4;
           const int gi = (int)fdiv((uint32_t)(c4 * 4), a.d_cg);
-          const float sc = (c0 + c4 * 4 < a.s1.C) ? a.s1.scale : a.s2.scale;
+          const float sc = (c0 + c4 * 4 < a.s1.C) ? sc1 : sc2;
           if (gi != cur) {
             if (cur >= 0) { sf_lds_add(misc + 2 * cur, sm); sf_lds_add(misc + 2 * cur + 1, sq); }
             cur = gi; sm = 0.0f; sq = 0.0f;
@@ -354,7 +358,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
         if (nt == 0 && LAZY && c < a.s1.C) *reinterpret_cast<f32x4*>(a.s1.p + (mb + p) * a.s1.C + c) = v[u];
         f32x4 A, Bv;
         affine_of(c4 * 4, A, Bv);
-        finish(v[u] * (c < a.s1.C ? a.s1.scale : a.s2.scale), (py + h) * FW + px + h, c4 * 4, 0, A, Bv);
+        finish(v[u] * (c < a.s1.C ? sc1 : sc2), (py + h) * FW + px + h, c4 * 4, 0, A, Bv);
       }
     }
   } else if (NORM == FNORM_LN) {
@@ -493,7 +497,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
         const float* base = f1 ? a.s1.slots : a.s2.slots;
         const long off = f1 ? (mfg * cf1 + cfa) : (mfg * cf2 + (cfa - cf1));
         sl[u] = *reinterpret_cast<const f32x2*>(base + off * 2);
-        slsc[u] = live ? (f1 ? a.s1.scale : a.s2.scale) : 0.0f;
+        slsc[u] = live ? (f1 ? sc1 : sc2) : 0.0f;
       }
     };
     // issue order: slots of this wave's first group, first staging batch, weight ring (SF_RING_POS 0: ring first)
@@ -540,7 +544,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
         if (cb) { chan(cb); issue(tp, va, fpa, mxa); }
         f32x4 A, Bv;
         affine_of(cl, A, Bv);
-        A = A * (first ? a.s1.scale : a.s2.scale);
+        A = A * (first ? sc1 : sc2);
         for (int base = 0; base < npx; base += 2 * stp) {
           issue(base + stp + tp, vb, fpb, mxb);
           consume(silu_c, va, fpa, mxa, A, Bv);
@@ -557,6 +561,29 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
   }
   sf_sync();
   FC_STAMP(3);
+
+  // ---- epilogue operands (bias, residual, previous contents, context-logit weight) are fetched NOW, ahead of the main loop:
+  // issued at the epilogue they were a cold round trip (~1 us) on the critical path of every final-mode launch
+  constexpr int F = WM * WN;
+  const long m0 = mb + (long)row0 * a.W;
+  const int my_mi = wave / WN, my_ni = wave - my_mi * WN;         // fragment of this wave (waves >= F only contribute partials)
+  const int my_nf = nt * WN + my_ni;
+  const bool fin = wave < F && my_nf < a.n_frags;
+  const int n = my_nf * 16 + (lane & 15);
+  const long mrow = m0 + my_mi * 16 + (lane >> 4) * 4;
+  float bv = 0.0f, rv[4] = {0.f, 0.f, 0.f, 0.f}, wkv = 0.0f;
+  if (fin && n < a.Cout) {
+    if (a.logit_part) wkv = a.wk[n];
+    if (a.S == 1) {
+      if (a.bias) bv = a.bias[n];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long o = (mrow + r) * a.ldc + a.co_off + n;
+        if (a.resid) rv[r] = a.resid[o];
+        if (a.accum) rv[r] += a.out[o];
+      }
+    }
+  }
 
   // ---- main loop: per k-step WM A fragments (16-byte LDS reads of shifted pixels, fetched one step ahead), WN weight
   // fragments from the ring, WM x WN MFMAs; the ring slot is refilled D steps ahead
@@ -609,24 +636,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
   FC_STAMP(4);
   // ---- epilogue: the NW K-slices of the workgroup meet in LDS; wave f finalises fragment f and fetches what it needs
   // for that (bias, residual, previous contents) BEFORE the reduction barrier
-  constexpr int F = WM * WN;
   float* red = reinterpret_cast<float*>(lds + a.red_off);         // [wave][frag][r][lane]
-  const long m0 = mb + (long)row0 * a.W;
-  const int my_mi = wave / WN, my_ni = wave - my_mi * WN;         // fragment of this wave (waves >= F only contribute partials)
-  const int my_nf = nt * WN + my_ni;
-  const bool fin = wave < F && my_nf < a.n_frags;
-  const int n = my_nf * 16 + (lane & 15);
-  const long mrow = m0 + my_mi * 16 + (lane >> 4) * 4;
-  float bv = 0.0f, rv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (fin && a.S == 1 && n < a.Cout) {
-    if (a.bias) bv = a.bias[n];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long o = (mrow + r) * a.ldc + a.co_off + n;
-      if (a.resid) rv[r] = a.resid[o];
-      if (a.accum) rv[r] += a.out[o];
-    }
-  }
 #pragma unroll
   for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
@@ -646,7 +656,6 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
       v[r] = sacc;
     }
     if (a.logit_part) {                      // bias terms are the same for every pixel: they cancel in the softmax
-      const float wkv = n < a.Cout ? a.wk[n] : 0.0f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float lp = v[r] * wkv;
@@ -686,6 +695,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
 
 template <int WM, int WN, int D, int NORM, int LAZY, int NW>
 SF_KERNEL(NW * 64) void k_conv_fused(FConvArgs a) {
+  sf_touch_kernarg<(int)sizeof(FConvArgs)>();
   conv_fused_body<WM, WN, D, NORM, LAZY, NW>(a, (int)blockIdx.x);
 }
 
@@ -700,6 +710,7 @@ struct FConvPairArgs {
 
 template <int WM, int WN, int D, int NORM, int LAZY, int NW>
 SF_KERNEL(NW * 64) void k_conv_fused_pair(FConvPairArgs p) {
+  sf_touch_kernarg<(int)sizeof(FConvPairArgs)>();
   if ((int)blockIdx.x < p.grid_b) conv_fused_body<WM, WN, D, FNORM_NONE, LAZY, NW>(p.b, (int)blockIdx.x);
   else conv_fused_body<WM, WN, D, NORM, LAZY, NW>(p.a, (int)blockIdx.x - p.grid_b);
 }

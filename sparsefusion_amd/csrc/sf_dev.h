@@ -5,6 +5,9 @@
 #include <math.h>
 #include <stdint.h>
 
+#ifndef SF_KA_TOUCH
+#define SF_KA_TOUCH 1          // 0: A/B switch of sf_touch_kernarg
+#endif
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -58,6 +61,8 @@ static inline f32x4 sf_mfma4(float a, float b, f32x4 c) {
 }
 static inline float sf_rcp(float v) { return 1.0f / v; }
 static inline long long sf_clock() { return 0; }
+template <int BYTES>
+static inline void sf_touch_kernarg() {}
 // D = A (16 x 32, rows = lane & 15) * B (32 x 16, cols = lane & 15) + C; see tests/hostemu/hip_emu.h for the layout
 static inline f32x4 sf_mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   hipemu::WaveState* w = hipemu::t_wave;
@@ -103,6 +108,21 @@ SF_DEV f32x4 sf_mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_
 SF_DEV float sf_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 SF_DEV long long sf_clock() { return (long long)wall_clock64(); }      // 100 MHz constant clock
 SF_DEV f32x4 sf_mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// Touch every 64-byte line of the kernel-argument segment with independent scalar loads and wait ONCE.  The compiler
+// fetches a large by-value argument struct piecemeal, each piece right before its first use and each behind its own
+// s_waitcnt: ~8 serialised cold misses of the scalar cache (~0.4 us each) in front of the first vector load of a 460-byte
+// FConvArgs.  After this call the lines sit in the scalar cache and those loads are hits.
+template <int BYTES>
+SF_DEV void sf_touch_kernarg() {
+#if SF_KA_TOUCH
+  typedef __attribute__((address_space(4))) const uint32_t* kptr;
+  kptr kp = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+  uint32_t acc = 0;
+#pragma unroll
+  for (int o = 0; o < BYTES; o += 64) acc |= kp[o / 4];
+  asm volatile("" ::"s"(acc));
+#endif
+}
 #endif
 
 SF_DEV float sf_silu(float v) { return v / (1.0f + sf_exp(-v)); }

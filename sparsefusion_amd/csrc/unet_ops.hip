@@ -27,6 +27,7 @@
 
 #include "sf_common.h"
 #include "plan_ops.h"
+#include "sf_dev.h"
 #include <math.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -79,6 +80,7 @@ struct ConvArgs {
 
 template <int WM, int WN, bool A_FP32>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
+  sf_touch_kernarg<(int)sizeof(ConvArgs)>();        // all kernel-argument lines in one scalar-cache round trip (sf_dev.h)
   __shared__ __attribute__((aligned(16))) float red[3][WM * WN * 4 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = blockIdx.x % (a.m_tiles * a.n_tiles);
@@ -788,6 +790,7 @@ __global__ void k_time_emb(const float* __restrict__ t, const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 template <int BNF, bool A_FP32>
 __global__ __launch_bounds__(256, 2) void k_conv_lds(ConvArgs a) {
+  sf_touch_kernarg<(int)sizeof(ConvArgs)>();
   constexpr int WNF = BNF / 2;                  // n-fragments per wave (waves are arranged 2 x 2)
   constexpr int BLD = BNF / 4;                  // B fragments each wave loads per k-step
   __shared__ bf16x8 sA[2][8][2][64];            // [stage buffer][m-frag][k-step][lane]  2 x 16 KiB
