@@ -9,6 +9,7 @@
 //   i: 0 B  1 H  2 W  3 C1  4 C2  5 Cout  6 ldc  7 co_off  8 k (1 | 3)  9 s1.mode  10 s1.groups  11 s1.npad
 //      12 norm (FNORM_*)  13 G  14 TR (image rows per tile)  15 WM  16 WN  17 S (input-channel slices)  18 ss_stride
 //   flags: 1 SiLU after the norm, 2 GELU before the LayerNorm, 4 accumulate into out, 8 GELU on the final output,
+//          32 pipelined kernel (k_conv_fused_pipe: slot GroupNorm, k = 3, plain source, C % 128 == 0),
 //          16 pair: the NEXT op (an un-normalised fconv of the same tile shape) runs in the same launch (k_conv_fused_pair)
 //   f: 0 eps  1 s1.scale  2 s2.scale
 // SF_OP_SLOTS operands
@@ -18,6 +19,7 @@
 #include <stdio.h>
 #include "../../include/sparsefusion_hip.h"
 #include "fused_kernels.h"
+#include "fused_pipe.h"
 #include "fused_gca.h"
 
 #define SF_LDS_MAX 163840
@@ -39,6 +41,14 @@
   X(1, 1, 12, FNORM_LN, 0) \
   X(1, 1, 12, FNORM_LN, 1) \
   X(1, 2, 8, FNORM_LN, 0)
+
+// Pipelined slot-GroupNorm 3x3 convs (k_conv_fused_pipe, op flag 32): (WM, WN, EPT = (TR + 2) * W / 8 staging elements per thread and chunk)
+#define SF_FCONV_PIPE_VARIANTS(X) \
+  X(1, 1, 4) \
+  X(1, 1, 6) \
+  X(1, 2, 6) \
+  X(2, 1, 12) \
+  X(2, 2, 12)
 
 // Pairs (conv1 || res_conv in one launch, k_conv_fused_pair): (WM, WN, D, NORM of the first conv, LAZY of both)
 #define SF_FCONV_PAIR_VARIANTS(X) \
@@ -150,9 +160,24 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   const int MT = a.B * a.mt_per_img;
   a.xcd_map = (a.n_tiles % 8 == 0 && MT > 1) ? 1 : 0;
   grid = (uint32_t)a.S * MT * a.n_tiles;
+  a.buf_bytes = 0;
+  if (op.flags & 32) {       // k_conv_fused_pipe: 128-channel chunks, two frame buffers, 4 matrix + 4 staging waves
+    if (a.norm != FNORM_GN_SLOTS || a.k != 3 || a.S != 1 || a.s1.mode != 0 || a.C % 128 || a.C > 4 * SF_FCONV_WAVES * 64 || a.G != 8 ||
+        ((a.TR + 2) * a.W) % 8)
+      FC_FAIL("fconv pipe: needs slot GroupNorm (8 groups), k = 3, one slice, a plain source, C %% 128 == 0");
+    a.pix_stride = fconv_pix_stride(128);
+    a.buf_bytes = (int)((((uint32_t)(a.TR + 2) * (a.W + 2) + 1) * a.pix_stride + 15) & ~15u);
+    a.red_off = 2 * a.buf_bytes;
+    a.tab_off = a.red_off + 1024 * (SF_FCONV_WAVES / 2) * WM * WN;
+    a.misc_off = a.tab_off + 2 * a.C * 4;
+    lds_bytes = a.misc_off + 640 + 2048;
+    if (lds_bytes > SF_LDS_MAX) FC_FAIL("fconv pipe: tile needs %u bytes of LDS", lds_bytes);
+  }
   return 0;
 #undef FC_FAIL
 }
+
+static inline int fconv_pipe_ept(const FConvArgs& a) { return (a.TR + 2) * a.W / 8; }
 
 // Pair = op1 (flags & 16) + the op after it: same tile shape, op2 un-normalised, same lazy mode (op2 with s1.p == null when lazy).
 static inline int fconv_pair_setup(const sf_op& op1, const sf_op& op2, FConvPairArgs& p, int& WM, int& WN, uint32_t& grid, uint32_t& lds_bytes,

@@ -70,6 +70,7 @@ struct FConvArgs {
   FDiv d_ncf;                            // 16-channel fragments per group
   FDiv d_cs4, d_cg, d_cps, d_tc;         // Cs/4, channels per group, chunks per slice, min(Cs/4, threads)
   int red_off, tab_off, misc_off;    // LDS byte offsets
+  int buf_bytes;                     // k_conv_fused_pipe: bytes of one of the two frame buffers (0 otherwise)
   const float* wk;                   // GlobalContext to_k weight [Cout] or null: the epilogue also emits partial context logits
   float* logit_part;                 //   logit_part[(s * n_frags + n_frag) * M + m] = sum over the fragment's 16 channels of value * wk
   long long* dbg;                    // optional [grid][8] phase timestamps (tools/fconv_phases.py), null in production

@@ -24,11 +24,27 @@ static int launch_fconv(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStre
   return SF_OK;
 }
 
+template <int WM, int WN, int EPT>
+static int launch_fconv_pipe(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStream_t st) {
+  static unsigned mask = 0;
+  if (int rc = allow_big_lds(k_conv_fused_pipe<WM, WN, EPT, SF_FCONV_WAVES>, lds, mask)) return rc;
+  k_conv_fused_pipe<WM, WN, EPT, SF_FCONV_WAVES><<<grid, SF_FCONV_WAVES * 64, lds, st>>>(a);
+  SF_CHECK_LAUNCH("conv_fused_pipe");
+  return SF_OK;
+}
+
 static int run_fconv(const sf_op& op, hipStream_t st) {
   FConvArgs a;
   int WM, WN;
   uint32_t grid, lds;
   if (fconv_setup(op, a, WM, WN, grid, lds, sf_err_buf, sizeof(sf_err_buf))) return SF_ERR_INVALID;
+  if (op.flags & 32) {
+    const int EPT = fconv_pipe_ept(a);
+#define SF_TRYP(wm, wn, ept) if (WM == wm && WN == wn && EPT == ept) return launch_fconv_pipe<wm, wn, ept>(a, grid, lds, st);
+    SF_FCONV_PIPE_VARIANTS(SF_TRYP)
+#undef SF_TRYP
+    SF_FAIL(SF_ERR_INVALID, "fconv pipe: no kernel variant for tile %dx%d, %d staging elements", WM, WN, EPT);
+  }
 #define SF_TRY(wm, wn, d, nm_, lz_) \
   if (WM == wm && WN == wn && a.norm == nm_ && a.s1.mode == lz_) return launch_fconv<wm, wn, d, nm_, lz_>(a, grid, lds, st);
   SF_FCONV_VARIANTS(SF_TRY)

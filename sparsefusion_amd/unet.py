@@ -23,6 +23,8 @@ OP_CONV, OP_GN_ACT, OP_LN, OP_GEMV, OP_ATTN, OP_GCA_POOL, OP_ELTWISE, OP_MEMSET,
 OP_FCONV, OP_SLOTS, OP_GCA = 14, 15, 16
 # (WM, WN, norm of conv1) for which k_conv_fused_pair is instantiated (csrc/fused_host.h SF_FCONV_PAIR_VARIANTS); FNORM_GN_SELF = 1, _SLOTS = 2
 PAIR_TILES = {(1, 1, 1), (1, 1, 2), (1, 2, 2), (2, 2, 2)}
+# (WM, WN, (TR + 2) * W / 8) for which k_conv_fused_pipe is instantiated (SF_FCONV_PIPE_VARIANTS)
+PIPE_TILES = {(1, 1, 4), (1, 1, 6), (1, 2, 6), (2, 1, 12), (2, 2, 12)}
 FNORM_NONE, FNORM_GN_SELF, FNORM_GN_SLOTS, FNORM_LN = range(4)      # csrc/fused_kernels.h
 LDS_MAX = 163840
 SKIP_SCALE = 2 ** -0.5            # scale_skip_connection (imagen_pytorch.py:1283)
@@ -438,7 +440,12 @@ class _Plan:
         gam = self.wptr(gname + ".weight") if norm in (FNORM_GN_SELF, FNORM_GN_SLOTS) else (self.wptr(gname) if gname else 0)
         bet = self.wptr(gname + ".bias") if norm in (FNORM_GN_SELF, FNORM_GN_SLOTS) else (self.wptr(beta_name) if beta_name else 0)
         assert not (out_gelu and S > 1)
-        self.op(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0) | (8 if out_gelu else 0) | (16 if pair_first else 0),
+        # staging and matrix work overlapped inside the workgroup (k_conv_fused_pipe) where the layer fits that kernel
+        pipe = (getattr(self.u, "fconv_pipe", False) and norm == FNORM_GN_SLOTS and k == 3 and S == 1 and li[0] == 0 and silu
+                and (C1 + C2) % 128 == 0 and C1 % 4 == 0 and ((TR + 2) * H) % 8 == 0 and (WM, WN, (TR + 2) * H // 8) in PIPE_TILES
+                and not pair_first and pair_lazy is None)
+        self.op(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0) | (8 if out_gelu else 0) | (16 if pair_first else 0)
+                | (32 if pipe else 0),
                 p=(x_ptr, lp[0], lp[1], lp[2], x.slots or 0, skip.ptr if skip else 0, (skip.slots or 0) if skip else 0,
                    self.wptr(wname), 0 if S > 1 else bias, out.ptr, 0 if S > 1 else res, ws, slots_out, gam, bet, ss_ptr, 0,
                    logit[0] if logit else 0, logit[1] if logit else 0),
@@ -466,7 +473,7 @@ class _Plan:
         h = self.zf32(rows, cout, HW)
         # conv1 and res_conv read the same input and are independent: one launch (k_conv_fused_pair) when their tiles match
         pair = (cin != cout and getattr(self.u, "pair_res_conv", True) and g1[1:3] == gr[1:3] and gr[3] == 1
-                and (g1[1], g1[2], norm) in PAIR_TILES)
+                and (g1[1], g1[2], norm) in PAIR_TILES and not (getattr(self.u, "fconv_pipe", False) and norm == FNORM_GN_SLOTS))
         lz = self.fconv(x, skip, H, f"{name}.block1.project.weight", f"{name}.block1.project.bias", h, cout, 3, norm, g1,
                         gname=f"{name}.block1.groupnorm", want_slots=slots, pair_first=pair)
         rc = None
@@ -919,6 +926,7 @@ class Unet(nn.Module):
         # GroupNorm inside the conv launches (k_conv_fused) wherever the layer fits; SF_UNET_FUSED=0 = the first-round plan (A/B runs)
         self.fused = os.environ.get("SF_UNET_FUSED", "1") != "0"
         self.pair_res_conv = os.environ.get("SF_PAIR", "1") != "0"      # conv1 || res_conv of a ResnetBlock in one launch
+        self.fconv_pipe = os.environ.get("SF_PIPE", "1") != "0"         # slot-GroupNorm 3x3 convs on k_conv_fused_pipe (staging || matrix work)
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches
         self._pack_cache = None
         self._plans = {}

@@ -39,6 +39,18 @@ extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
     int WM, WN;
     uint32_t grid, lds;
     if (fconv_setup(*op, a, WM, WN, grid, lds, err, (size_t)errn)) return 1;
+    if (op->flags & 32) {
+      const int EPT = fconv_pipe_ept(a);
+#define SF_TRYP(wm, wn, ept) \
+      if (WM == wm && WN == wn && EPT == ept) { \
+        hipemu::launch(grid, SF_FCONV_WAVES * 64, lds, [&] { k_conv_fused_pipe<wm, wn, ept, SF_FCONV_WAVES>(a); }); \
+        return 0; \
+      }
+      SF_FCONV_PIPE_VARIANTS(SF_TRYP)
+#undef SF_TRYP
+      snprintf(err, errn, "fconv pipe: no kernel variant for tile %dx%d, %d staging elements", WM, WN, EPT);
+      return 1;
+    }
 #define SF_TRY(wm, wn, d, nm_, lz_) \
     if (WM == wm && WN == wn && a.norm == nm_ && a.s1.mode == lz_) { emu_fconv<wm, wn, d, nm_, lz_>(a, grid, lds); return 0; }
     SF_FCONV_VARIANTS(SF_TRY)
