@@ -13,7 +13,8 @@
 //          16 pair: the NEXT op (an un-normalised fconv of the same tile shape) runs in the same launch (k_conv_fused_pair)
 //   f: 0 eps  1 s1.scale  2 s2.scale
 // SF_OP_SLOTS operands
-//   p: 0 x (or h)  1 gate [B, C] or null  2 res  3 out (gate mode)  4 slots ;  i: 0 M  1 C  2 HW
+//   p: 0 x (or h)  1 gate [B, C] or null  2 res  3 out (gate / split-K mode)  4 slots  5 split-K slabs or null  6 conv bias or null
+//   i: 0 M  1 C  2 HW  3 slab groups  4 slab row stride (npad)
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
@@ -161,6 +162,7 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   a.xcd_map = (a.n_tiles % 8 == 0 && MT > 1) ? 1 : 0;
   grid = (uint32_t)a.S * MT * a.n_tiles;
   a.buf_bytes = 0;
+  a.inv_n = (a.norm == FNORM_GN_SELF || a.norm == FNORM_GN_SLOTS) ? 1.0 / ((double)a.H * a.W * (a.C / a.G)) : 0.0;
   if (op.flags & 32) {       // k_conv_fused_pipe: 128-channel chunks, two frame buffers, 4 matrix + 4 staging waves
     if (a.norm != FNORM_GN_SLOTS || a.k != 3 || a.S != 1 || a.s1.mode != 0 || a.C % 128 || a.C > 4 * SF_FCONV_WAVES * 64 || a.G != 8 ||
         ((a.TR + 2) * a.W) % 8)

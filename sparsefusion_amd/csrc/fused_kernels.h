@@ -70,6 +70,7 @@ struct FConvArgs {
   FDiv d_ncf;                            // 16-channel fragments per group
   FDiv d_cs4, d_cg, d_cps, d_tc;         // Cs/4, channels per group, chunks per slice, min(Cs/4, threads)
   int red_off, tab_off, misc_off;    // LDS byte offsets
+  double inv_n;                      // GroupNorm: 1 / (pixels per image * channels per group)
   int buf_bytes;                     // k_conv_fused_pipe: bytes of one of the two frame buffers (0 otherwise)
   const float* wk;                   // GlobalContext to_k weight [Cout] or null: the epilogue also emits partial context logits
   float* logit_part;                 //   logit_part[(s * n_frags + n_frag) * M + m] = sum over the fragment's 16 channels of value * wk
@@ -181,6 +182,22 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
   float* tabB = tabA + Cs;
   float* misc = reinterpret_cast<float*>(lds + a.misc_off);      // [0..15] group sums, [16..] group / row (mean, rstd)
 
+  // ---- GN_SELF: the tile's elements go out FIRST (statistics wait on them; everything below runs under their round trip)
+  constexpr int NV = (NORM == FNORM_GN_SELF) ? 4096 / NT : 1;
+  const int cnt = HW * Cs4;
+  f32x4 v[NV];
+  if (NORM == FNORM_GN_SELF) {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int i = tid + u * NT;
+      if (i < cnt) {
+        const int p = (int)fdiv((uint32_t)i, a.d_cs4), c4 = i - p * Cs4;
+        v[u] = fconv_value<LAZY>(a, mb + p, c0 + c4 * 4);
+      }
+    }
+    prefetch_weights();          // right behind them: at the 4x4 level the launch is one HBM round trip of the whole weight slice
+  }
+
   // ---- (a) zero the frame pixels outside the image (conv zero padding); 8 threads per pixel
   if (h) {
     const int npix = FR * FW;
@@ -266,18 +283,6 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
     // ---- (b1) the 4x4 level: the tile holds all HW pixels of image b and the slice holds whole groups.  Every element is
     // loaded ONCE into registers (issued before the weight ring, so one round trip covers the whole prologue), group sums
     // meet in LDS, then the registers are normalised straight into the frame.
-    constexpr int NV = 4096 / NT;
-    const int cnt = HW * Cs4;
-    f32x4 v[NV];
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int i = tid + u * NT;
-      if (i < cnt) {
-        const int p = (int)fdiv((uint32_t)i, a.d_cs4), c4 = i - p * Cs4;
-        v[u] = fconv_value<LAZY>(a, mb + p, c0 + c4 * 4);
-      }
-    }
-    prefetch_weights();
     FC_STAMP(1);
     if (a.det_w) {
       // deterministic group sums: a thread's elements share one channel chunk (NT % (Cs/4) == 0), hence one group; det_w
@@ -300,15 +305,35 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
       float* part = misc + 160;                               // [NT / W][2]
       if ((lane & (W - 1)) == 0) { part[2 * (tid / W)] = sm; part[2 * (tid / W) + 1] = sq; }
       sf_sync();
-      if (tid < Cs / Cg) {
+      if (NT / W <= 64) {
+        // wave g sums the segments of group g: lanes = segments, a fixed shuffle tree (deterministic); the serial loop of the
+        // first version (one thread per group walking all segments) was ~1 us on the critical path of every 4x4 conv
+        if (wave < Cs / Cg) {
+          double S = 0.0, Q = 0.0;
+          if (lane < NT / W) {
+            const int t0 = lane * W, c4s = t0 - (int)fdiv((uint32_t)t0, a.d_cs4) * Cs4;
+            if ((int)fdiv((uint32_t)(c4s * 4), a.d_cg) == wave) { S = (double)part[2 * lane]; Q = (double)part[2 * lane + 1]; }
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) { S += sf_shfl_xor(S, o); Q += sf_shfl_xor(Q, o); }
+          if (lane == 0) {
+            const double rn = a.inv_n;                     // 1 / (HW * Cg) from the host: a double division is ~100 dependent instructions
+            const double mean = S * rn;
+            double var = Q * rn - mean * mean;
+            if (var < 0.0) var = 0.0;
+            misc[16 + 2 * wave] = (float)mean;
+            misc[17 + 2 * wave] = sf_rsqrt((float)var + a.eps);
+          }
+        }
+      } else if (tid < Cs / Cg) {
         double S = 0.0, Q = 0.0;
         for (int sl = 0; sl < NT / W; ++sl) {
           const int t0 = sl * W, c4s = t0 - (int)fdiv((uint32_t)t0, a.d_cs4) * Cs4;
           if ((int)fdiv((uint32_t)(c4s * 4), a.d_cg) == tid) { S += (double)part[2 * sl]; Q += (double)part[2 * sl + 1]; }
         }
-        const double n = (double)HW * Cg;
-        const double mean = S / n;
-        double var = Q / n - mean * mean;
+        const double rn = a.inv_n;                     // 1 / (HW * Cg) from the host: a double division is ~100 dependent instructions
+        const double mean = S * rn;
+        double var = Q * rn - mean * mean;
         if (var < 0.0) var = 0.0;
         misc[16 + 2 * tid] = (float)mean;
         misc[17 + 2 * tid] = sf_rsqrt((float)var + a.eps);
@@ -337,9 +362,9 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
       if (cur >= 0) { sf_lds_add(misc + 2 * cur, sm); sf_lds_add(misc + 2 * cur + 1, sq); }
       sf_sync();
       if (tid < Cs / Cg) {
-        const double n = (double)HW * Cg;
-        const double mean = (double)misc[2 * tid] / n;
-        double var = (double)misc[2 * tid + 1] / n - mean * mean;
+        const double rn = a.inv_n;                     // 1 / (HW * Cg) from the host: a double division is ~100 dependent instructions
+        const double mean = (double)misc[2 * tid] * rn;
+        double var = (double)misc[2 * tid + 1] * rn - mean * mean;
         if (var < 0.0) var = 0.0;
         misc[16 + 2 * tid] = (float)mean;
         misc[17 + 2 * tid] = sf_rsqrt((float)var + a.eps);
@@ -527,9 +552,9 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
         sm = sf_wave_sum(sm);
         sq = sf_wave_sum(sq);
         if (lane == 0) {
-          const double n = (double)HW * Cg;
-          const double mean = (double)sm / n;
-          double var = (double)sq / n - mean * mean;
+          const double rn = a.inv_n;                     // 1 / (HW * Cg) from the host: a double division is ~100 dependent instructions
+          const double mean = (double)sm * rn;
+          double var = (double)sq * rn - mean * mean;
           if (var < 0.0) var = 0.0;
           misc[16 + 2 * gi] = (float)mean;
           misc[17 + 2 * gi] = sf_rsqrt((float)var + a.eps);
@@ -719,15 +744,25 @@ SF_KERNEL(NW * 64) void k_conv_fused_pair(FConvPairArgs p) {
 // (sum, sum of squares) slots of an fp32 NHWC tensor [M, C], one wave per 16 pixels x 16 channels; with `gate` the
 // tensor is first formed as x = h * gate[batch] + res and written to `out` (GlobalContext gating + residual,
 // imagen_pytorch.py:727-729, :936-941) so that the next GroupNorm-fused conv finds both the values and their sums.
+// With `ws` the tensor is first reduced from split-K slabs: x = bias + sum_g ws[g][m][c (ld npad)], written to `out`
+// (a deferred k_conv_igemm reduction and the slot pass in ONE launch instead of k_splitk_reduce + k_slots).
 SF_KERNEL(256) void k_slots(const float* __restrict__ x, const float* __restrict__ gate, const float* __restrict__ res,
-                            float* __restrict__ out, float* __restrict__ slots, int M, int C, int HW) {
+                            float* __restrict__ out, float* __restrict__ slots, int M, int C, int HW,
+                            const float* __restrict__ ws, const float* __restrict__ bias, int groups, int npad) {
   const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int CF = C >> 4;
   if (gw >= (M >> 4) * CF) return;
   const int mf = gw / CF, cf = gw - mf * CF;
   const long m = (long)mf * 16 + (lane >> 2);
   const int c = cf * 16 + (lane & 3) * 4;
-  f32x4 v = *reinterpret_cast<const f32x4*>(x + m * C + c);
+  f32x4 v;
+  if (ws) {
+    v = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < groups; ++g) v += *reinterpret_cast<const f32x4*>(ws + ((long)g * M + m) * npad + c);
+    *reinterpret_cast<f32x4*>(out + m * C + c) = v;
+  } else {
+    v = *reinterpret_cast<const f32x4*>(x + m * C + c);
+  }
   if (gate) {
     const f32x4 g = *reinterpret_cast<const f32x4*>(gate + (m / HW) * C + c);
     const f32x4 r = *reinterpret_cast<const f32x4*>(res + m * C + c);

@@ -79,7 +79,8 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
   };
   // ONE register pool for both roles (the ring of the matrix waves, the two staging batches of the others): declared as
   // separate arrays the compiler keeps both alive across the role-independent code and allocates their SUM
-  constexpr int NP = (KPW * WN > 2 * EPT) ? KPW * WN : 2 * EPT;
+  constexpr int NB = EPT <= 4 ? 4 : (EPT <= 6 ? 3 : 2);       // staging batches (chunks) in registers: ~16-24 float4 loads in flight per thread
+  constexpr int NP = (KPW * WN > NB * EPT) ? KPW * WN : NB * EPT;
   f32x4 pool[NP];
 
   // ---- staging threads: a fixed float4 channel chunk (tcx) of every chunk, pixel lanes tp, tp + 8, ...
@@ -130,31 +131,8 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
     }
   };
 
-  // ---- first loads of every role go out before anything waits
-  if (mx_role) {
-#pragma unroll
-    for (int i = 0; i < KPW; ++i)
-#pragma unroll
-      for (int ni = 0; ni < WN; ++ni) pool[i * WN + ni] = __builtin_bit_cast(f32x4, wload(0, i, ni));
-  } else {
-    issue(0, 0);
-  }
-  // GroupNorm parameters of the whole input (C <= 4 * NT channels), statistics slots of this wave's group
-  constexpr int TABN = 4;
+  // ---- the statistics slots first (the critical path: slots -> statistics -> table -> first normalised chunk)
   const int Cg = a.C / a.G;
-  float tg[TABN], tb[TABN], tsc[TABN], tsh[TABN];
-  {
-    const float* ssrow = a.ss ? a.ss + (long)b * a.ss_stride : a.gamma;
-    const int shoff = a.ss ? a.C : 0;
-#pragma unroll
-    for (int k = 0; k < TABN; ++k) {
-      const int cl = tid + k * NT, cc = cl < a.C ? cl : a.C - 1;
-      tg[k] = a.gamma[cc];
-      tb[k] = a.beta[cc];
-      tsc[k] = ssrow[cc];
-      tsh[k] = ssrow[shoff + cc];
-    }
-  }
   const int ngs = a.G;                                   // all groups (S == 1)
   const int n_mf = HW >> 4, n_cf = Cg >> 4, scnt = n_mf * n_cf;
   const int cf1 = a.s1.C >> 4, cf2 = a.s2.C >> 4;
@@ -176,6 +154,31 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
     }
   };
   if (wave < ngs) slot_loads(wave, lane);
+  // ---- first loads of every role go out before anything waits
+  if (mx_role) {
+#pragma unroll
+    for (int i = 0; i < KPW; ++i)
+#pragma unroll
+      for (int ni = 0; ni < WN; ++ni) pool[i * WN + ni] = __builtin_bit_cast(f32x4, wload(0, i, ni));
+  } else {
+#pragma unroll
+    for (int j = 0; j < NB - 1; ++j) issue(j < NCH ? j : NCH - 1, j * EPT);
+  }
+  // GroupNorm parameters of the whole input (C <= 4 * NT channels), statistics slots of this wave's group
+  constexpr int TABN = 4;
+  float tg[TABN], tb[TABN], tsc[TABN], tsh[TABN];
+  {
+    const float* ssrow = a.ss ? a.ss + (long)b * a.ss_stride : a.gamma;
+    const int shoff = a.ss ? a.C : 0;
+#pragma unroll
+    for (int k = 0; k < TABN; ++k) {
+      const int cl = tid + k * NT, cc = cl < a.C ? cl : a.C - 1;
+      tg[k] = a.gamma[cc];
+      tb[k] = a.beta[cc];
+      tsc[k] = ssrow[cc];
+      tsh[k] = ssrow[shoff + cc];
+    }
+  }
   // epilogue operands of the finalising waves (matrix waves 0 .. F-1)
   constexpr int F = WM * WN;
   const long m0 = mb + (long)row0 * a.W;
@@ -226,9 +229,9 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
     sm = sf_wave_sum(sm);
     sq = sf_wave_sum(sq);
     if (lane == 0) {
-      const double nn = (double)HW * Cg;
-      const double mean = (double)sm / nn;
-      double var = (double)sq / nn - mean * mean;
+      const double rn = a.inv_n;
+      const double mean = (double)sm * rn;
+      double var = (double)sq * rn - mean * mean;
       if (var < 0.0) var = 0.0;
       misc[16 + 2 * gi] = (float)mean;
       misc[17 + 2 * gi] = sf_rsqrt((float)var + a.eps);
@@ -282,14 +285,17 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
       sf_sync();
     }
   } else {
-    for (int c = 0; c < NCH; c += 2) {
-      issue(c + 1 < NCH ? c + 1 : NCH - 1, EPT);
-      consume(c, 0);
-      sf_sync();
-      if (c + 1 < NCH) {
-        issue(c + 2 < NCH ? c + 2 : NCH - 1, 0);
-        consume(c + 1, EPT);
-        sf_sync();
+    // chunk c lives in register batch c % NB; the batch freed by chunk c - 1 is refilled with chunk c + NB - 1 before chunk c
+    // is normalised: NB - 1 chunks of loads are in flight behind the VALU work (one staging wave per SIMD has no partner
+    // to hide a cold L2 round trip behind)
+    for (int c = 0; c < NCH; c += NB) {
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        if (c + j < NCH) {
+          issue(c + j + NB - 1 < NCH ? c + j + NB - 1 : NCH - 1, ((j + NB - 1) % NB) * EPT);
+          consume(c + j, j * EPT);
+          sf_sync();
+        }
       }
     }
     sf_sync();                                           // phase NCH: the matrix waves finish the last chunk
@@ -356,4 +362,12 @@ template <int WM, int WN, int EPT, int NW>
 SF_KERNEL(NW * 64) void k_conv_fused_pipe(FConvArgs a) {
   sf_touch_kernarg<(int)sizeof(FConvArgs)>();
   conv_fused_pipe_body<WM, WN, EPT, NW>(a, (int)blockIdx.x);
+}
+
+// conv1 (pipelined) || res_conv (plain 1x1, k_conv_fused body) of one ResnetBlock in one launch: see k_conv_fused_pair.
+template <int WM, int WN, int EPT, int NW>
+SF_KERNEL(NW * 64) void k_conv_fused_pipe_pair(FConvPairArgs p) {
+  sf_touch_kernarg<(int)sizeof(FConvPairArgs)>();
+  if ((int)blockIdx.x < p.grid_b) conv_fused_body<WM, WN, (WM * WN == 1 ? 12 : 8), FNORM_NONE, 0, NW>(p.b, (int)blockIdx.x);
+  else conv_fused_pipe_body<WM, WN, EPT, NW>(p.a, (int)blockIdx.x - p.grid_b);
 }

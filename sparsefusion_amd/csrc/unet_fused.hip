@@ -61,11 +61,27 @@ static int launch_fconv_pair(const FConvPairArgs& p, uint32_t grid, uint32_t lds
   return SF_OK;
 }
 
+template <int WM, int WN, int EPT>
+static int launch_fconv_pipe_pair(const FConvPairArgs& p, uint32_t grid, uint32_t lds, hipStream_t st) {
+  static unsigned mask = 0;
+  if (int rc = allow_big_lds(k_conv_fused_pipe_pair<WM, WN, EPT, SF_FCONV_WAVES>, lds, mask)) return rc;
+  k_conv_fused_pipe_pair<WM, WN, EPT, SF_FCONV_WAVES><<<grid, SF_FCONV_WAVES * 64, lds, st>>>(p);
+  SF_CHECK_LAUNCH("conv_fused_pipe_pair");
+  return SF_OK;
+}
+
 int sf_plan_fused_pair(const sf_op* op1, const sf_op* op2, void* stream) {
   FConvPairArgs p;
   int WM, WN;
   uint32_t grid, lds;
   if (fconv_pair_setup(*op1, *op2, p, WM, WN, grid, lds, sf_err_buf, sizeof(sf_err_buf))) return SF_ERR_INVALID;
+  if (op1->flags & 32) {
+    const int EPT = fconv_pipe_ept(p.a);
+#define SF_TRYP(wm, wn, ept) if (WM == wm && WN == wn && EPT == ept) return launch_fconv_pipe_pair<wm, wn, ept>(p, grid, lds, (hipStream_t)stream);
+    SF_FCONV_PIPE_VARIANTS(SF_TRYP)
+#undef SF_TRYP
+    SF_FAIL(SF_ERR_INVALID, "fconv pipe pair: no kernel variant for tile %dx%d, %d staging elements", WM, WN, EPT);
+  }
 #define SF_TRY(wm, wn, d, nm_, lz_) \
   if (WM == wm && WN == wn && p.a.norm == nm_ && p.a.s1.mode == lz_) return launch_fconv_pair<wm, wn, d, nm_, lz_>(p, grid, lds, (hipStream_t)stream);
   SF_FCONV_PAIR_VARIANTS(SF_TRY)
@@ -75,11 +91,13 @@ int sf_plan_fused_pair(const sf_op* op1, const sf_op* op2, void* stream) {
 
 static int run_slots(const sf_op& op, hipStream_t st) {
   const int M = op.i[0], C = op.i[1], HW = op.i[2];
-  if (M % 16 || C % 16 || !op.p[0] || !op.p[4] || (op.p[1] && (!op.p[2] || !op.p[3])))
+  const int groups = op.i[3], npad = op.i[4];
+  if (M % 16 || C % 16 || (!op.p[0] && !op.p[5]) || !op.p[4] || (op.p[1] && (!op.p[2] || !op.p[3])))
     SF_FAIL(SF_ERR_INVALID, "slots: M, C must be multiples of 16; gate mode needs res and out");
+  if (op.p[5] && (op.p[1] || !op.p[3] || groups < 1 || npad % 4 || npad < C)) SF_FAIL(SF_ERR_INVALID, "slots: bad split-K source");
   const uint32_t waves = (uint32_t)(M / 16) * (C / 16);
   k_slots<<<sf_div_up(waves, 4), 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], (float*)op.p[3],
-                                                (float*)op.p[4], M, C, HW);
+                                                (float*)op.p[4], M, C, HW, (const float*)op.p[5], (const float*)op.p[6], groups, npad);
   SF_CHECK_LAUNCH("slots");
   return SF_OK;
 }

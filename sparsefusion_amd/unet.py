@@ -390,6 +390,11 @@ class _Plan:
             _, h, gate, res = t.lazy
             t.lazy = None
             self.op(OP_SLOTS, 0, p=(h, gate, res, t.ptr, slots), i=(t.rows, t.C, t.HW))
+        elif t.lazy is not None and t.lazy[0] == "splitk" and not t.lazy[3] and t.lazy[5] % 4 == 0:
+            _, ws, bias, _, groups, npad, wi = t.lazy          # deferred split-K conv: reduce + slots in one launch
+            t.lazy = None
+            self.ws_owners[wi] = None
+            self.op(OP_SLOTS, 0, p=(0, 0, 0, t.ptr, slots, ws, bias), i=(t.rows, t.C, t.HW or t.rows, groups, npad))
         else:
             self.need(t)
             self.op(OP_SLOTS, 0, p=(t.ptr, 0, 0, 0, slots), i=(t.rows, t.C, t.HW or t.rows))
@@ -443,7 +448,7 @@ class _Plan:
         # staging and matrix work overlapped inside the workgroup (k_conv_fused_pipe) where the layer fits that kernel
         pipe = (getattr(self.u, "fconv_pipe", False) and norm == FNORM_GN_SLOTS and k == 3 and S == 1 and li[0] == 0 and silu
                 and (C1 + C2) % 128 == 0 and C1 % 4 == 0 and ((TR + 2) * H) % 8 == 0 and (WM, WN, (TR + 2) * H // 8) in PIPE_TILES
-                and not pair_first and pair_lazy is None)
+                and pair_lazy is None)
         self.op(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0) | (8 if out_gelu else 0) | (16 if pair_first else 0)
                 | (32 if pipe else 0),
                 p=(x_ptr, lp[0], lp[1], lp[2], x.slots or 0, skip.ptr if skip else 0, (skip.slots or 0) if skip else 0,
@@ -473,7 +478,7 @@ class _Plan:
         h = self.zf32(rows, cout, HW)
         # conv1 and res_conv read the same input and are independent: one launch (k_conv_fused_pair) when their tiles match
         pair = (cin != cout and getattr(self.u, "pair_res_conv", True) and g1[1:3] == gr[1:3] and gr[3] == 1
-                and (g1[1], g1[2], norm) in PAIR_TILES and not (getattr(self.u, "fconv_pipe", False) and norm == FNORM_GN_SLOTS))
+                and (g1[1], g1[2], norm) in PAIR_TILES)
         lz = self.fconv(x, skip, H, f"{name}.block1.project.weight", f"{name}.block1.project.bias", h, cout, 3, norm, g1,
                         gname=f"{name}.block1.groupnorm", want_slots=slots, pair_first=pair)
         rc = None
@@ -795,7 +800,8 @@ class _Plan:
             hiddens.append(x)
             if lv < n_lv - 1:
                 y = self.zf32(B * (H // 2) ** 2, do, (H // 2) ** 2)
-                self.conv(x, True, H, H, f"downs.{lv}.4.weight", f"downs.{lv}.4.bias", y, do, 0, do, 4, 2, 1)
+                # split-K partials stay in the workspace: the consumer (slot pass / 4x4 GroupNorm prologue) reduces them
+                self.conv(x, True, H, H, f"downs.{lv}.4.weight", f"downs.{lv}.4.bias", y, do, 0, do, 4, 2, 1, defer=bool(u.fused))
                 H //= 2
             else:
                 y = self.zf32(B * H * H, do, H * H)

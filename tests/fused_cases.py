@@ -178,6 +178,15 @@ def run_slots_case(backend):
     run_ops([fused.mkop(OP_SLOTS, p=(hd, gd, rd, out, sl), i=(M, C, HW))], backend)
     x = h * gate.repeat_interleave(HW, 0) + res
     assert torch.allclose(out.cpu(), x, atol=1e-6) and torch.allclose(sl.cpu(), slots_of(x, M, C), rtol=1e-5, atol=1e-4)
+    # split-K source: x = bias + sum of slabs, materialised into `out3`
+    groups, npad = 3, C + 16
+    ws = torch.randn(groups, M, npad, generator=g)
+    bias = torch.randn(C, generator=g)
+    x3 = ws[:, :, :C].sum(0) + bias
+    out3, sl3 = torch.full((M, C), float("nan"), device=dev), torch.zeros_like(sl)
+    wsd, bd = ws.to(dev), bias.to(dev)
+    run_ops([fused.mkop(OP_SLOTS, p=(None, None, None, out3, sl3, wsd, bd), i=(M, C, HW, groups, npad))], backend)
+    assert torch.allclose(out3.cpu(), x3, atol=1e-5) and torch.allclose(sl3.cpu(), slots_of(x3, M, C), rtol=1e-5, atol=1e-4)
     sl2, xd = torch.zeros_like(sl), x.to(dev)
     run_ops([fused.mkop(OP_SLOTS, p=(xd, None, None, None, sl2), i=(M, C, HW))], backend)
     assert torch.allclose(sl2.cpu(), slots_of(x, M, C), rtol=1e-5, atol=1e-4)
@@ -255,6 +264,7 @@ CONV_CASES = {
     "pipe_gn_slots_concat_8x8": dict(B=1, H=8, W=8, C1=128, C2=128, Cout=32, k=3, norm=GN_SLOTS, WM=1, WN=1, resid=True, seed=31, pipe=True),
     "pipe_gn_slots_16x16_wn2": dict(B=1, H=16, W=16, C1=256, C2=128, Cout=64, k=3, norm=GN_SLOTS, WM=1, WN=2, seed=32, pipe=True, logits=True),
     "pipe_gn_slots_wm2_wn2_accum": dict(B=2, H=4, W=32, C1=128, C2=0, Cout=64, k=3, norm=GN_SLOTS, WM=2, WN=2, accum=True, seed=33, pipe=True),
+    "pipe_pair_gn_slots_concat_8x8": dict(B=1, H=8, W=8, C1=128, C2=128, Cout=32, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=38, pipe=True, pair=True),
     "layernorm_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=1, silu=False, seed=6, out_gelu=True),
     "layernorm_lazy_splitk_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=1, silu=False, lazy=1, seed=7),
     "gelu_layernorm_bias_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=2, silu=False, pre_gelu=True,
@@ -277,5 +287,6 @@ CONV_CASES_FULL = {
     "unet_pipe_16x16_768": dict(B=1, H=16, W=16, C1=512, C2=256, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=2, resid=True, seed=35, pipe=True),
     "unet_pipe_32x32_512": dict(B=1, H=32, W=32, C1=256, C2=256, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=36, pipe=True),
     "unet_pipe_32x32_256": dict(B=1, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=37, pipe=True, logits=True),
+    "unet_pipe_pair_16x16_768": dict(B=1, H=16, W=16, C1=512, C2=256, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=2, seed=39, pipe=True, pair=True),
     "unet_b4_4x4": dict(B=4, H=4, W=4, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SELF, WM=1, WN=1, S=1, seed=16),
 }

@@ -24,6 +24,18 @@ static int emu_run_pair(const sf_op* op1, const sf_op* op2, char* err, int errn)
   int WM, WN;
   uint32_t grid, lds;
   if (fconv_pair_setup(*op1, *op2, p, WM, WN, grid, lds, err, (size_t)errn)) return 1;
+  if (op1->flags & 32) {
+    const int EPT = fconv_pipe_ept(p.a);
+#define SF_TRYP(wm, wn, ept) \
+    if (WM == wm && WN == wn && EPT == ept) { \
+      hipemu::launch(grid, SF_FCONV_WAVES * 64, lds, [&] { k_conv_fused_pipe_pair<wm, wn, ept, SF_FCONV_WAVES>(p); }); \
+      return 0; \
+    }
+    SF_FCONV_PIPE_VARIANTS(SF_TRYP)
+#undef SF_TRYP
+    snprintf(err, errn, "fconv pipe pair: no kernel variant for tile %dx%d, %d staging elements", WM, WN, EPT);
+    return 1;
+  }
 #define SF_TRY(wm, wn, d, nm_, lz_) \
   if (WM == wm && WN == wn && p.a.norm == nm_ && p.a.s1.mode == lz_) { emu_fconv_pair<wm, wn, d, nm_, lz_>(p, grid, lds); return 0; }
   SF_FCONV_PAIR_VARIANTS(SF_TRY)
@@ -60,10 +72,11 @@ extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
   }
   if (op->type == SF_OP_SLOTS) {
     const int M = op->i[0], C = op->i[1], HW = op->i[2];
-    if (M % 16 || C % 16 || !op->p[0] || !op->p[4]) { snprintf(err, errn, "slots: bad operands"); return 1; }
+    if (M % 16 || C % 16 || (!op->p[0] && !op->p[5]) || !op->p[4]) { snprintf(err, errn, "slots: bad operands"); return 1; }
     const uint32_t waves = (uint32_t)(M / 16) * (C / 16);
     hipemu::launch((waves + 3) / 4, 256, 0, [&] {
-      k_slots((const float*)op->p[0], (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], (float*)op->p[4], M, C, HW);
+      k_slots((const float*)op->p[0], (const float*)op->p[1], (const float*)op->p[2], (float*)op->p[3], (float*)op->p[4], M, C, HW,
+              (const float*)op->p[5], (const float*)op->p[6], op->i[3], op->i[4]);
     });
     return 0;
   }

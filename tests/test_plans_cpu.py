@@ -89,14 +89,16 @@ def _audit(ops, name, sized=False):
             Cs = C // S
             stride = Cs * 2 + ((32 - (Cs * 2) % 256) + 256) % 256
             if o.flags & 32:                                                    # k_conv_fused_pipe contract
-                assert norm == unet.FNORM_GN_SLOTS and k == 3 and S == 1 and lmode == 0 and C % 128 == 0 and G == 8 and not (o.flags & 16), where
+                assert norm == unet.FNORM_GN_SLOTS and k == 3 and S == 1 and lmode == 0 and C % 128 == 0 and G == 8, where
                 assert (WM, WN, (TR + 2) * W // 8) in unet.PIPE_TILES and ((TR + 2) * W) % 8 == 0, where
                 buf = (((TR + 2) * (W + 2) + 1) * 288 + 15) // 16 * 16
                 assert 2 * buf + 4096 * WM * WN + 8 * C + 2688 <= unet.LDS_MAX, where
             else:
                 assert ((TR + 2 * h) * (W + 2 * h) + 1) * stride + 8192 * WM * WN + 8 * Cs + 2688 <= unet.LDS_MAX, where
         elif o.type == unet.OP_SLOTS:
-            assert o.p[0] and o.p[4] and o.i[0] % 16 == 0 and o.i[1] % 16 == 0 and (not o.p[1] or (o.p[2] and o.p[3])), where
+            assert (o.p[0] or o.p[5] or not sized) and o.p[4] and o.i[0] % 16 == 0 and o.i[1] % 16 == 0 and (not o.p[1] or (o.p[2] and o.p[3])), where
+            if o.i[3]:                                                        # split-K source: slabs + output buffer
+                assert (o.p[5] or not sized) and o.p[3] and not o.p[1] and o.i[4] % 4 == 0 and o.i[4] >= o.i[1], where
         elif o.type == unet.OP_LN:
             assert o.p[0] and o.p[1] and o.p[3] and o.i[1] % 64 == 0 and o.i[1] <= 2048, where
         elif o.type == unet.OP_GEMV:
