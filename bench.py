@@ -130,9 +130,9 @@ class HotPath:
 
     def step(self):
         # A: input view
+        from sparsefusion_amd.utils.losses import fusion_loss, render_loss, upsample2x
         img, sil = self.render(self.rays_in)
-        loss = huber(img, self.target_rgb).abs().mean() + huber(sil, self.target_mask).abs().mean() \
-            + 1e-3 * torch.sqrt(sil ** 2 + .01).mean() + 1e-3 * entropy(sil)
+        loss = render_loss(img, sil, self.target_rgb, self.target_mask, 1.0, 1.0, 1e-3, 1e-3)      # distillation.py:217-241, one launch each way
         self.grads.zero()
         loss.backward()
         self.sync_grads()
@@ -141,8 +141,7 @@ class HotPath:
         self.grads.zero()
         imgs, sils = zip(*[self.render(r) for r in self.rays_novel])
         img, sil = torch.cat(imgs, 0), torch.cat(sils, 0)
-        img256 = F.interpolate(img, scale_factor=2, mode='bilinear')
-        sil256 = F.interpolate(sil, scale_factor=2, mode='bilinear')
+        img256, sil256 = upsample2x(img), upsample2x(sil)                       # :287-288 (bilinear x2) on the HIP kernel + its adjoint
         with torch.no_grad():
             latents = self.vae.encode(img256 * 2 - 1).mode() * self.z_scale          # distillation.py:299
             from sparsefusion_amd.distributed import all_gather_latents
@@ -150,9 +149,8 @@ class HotPath:
             pred_x0, x_noisy, noise, acp = self.plms.sample(latents, cond_images=self.features, use_tqdm=False,
                                                             return_noise=True, max_thres=self.max_thres)
             pred_img = ((self.vae.decode(pred_x0 / self.z_scale) + 1) * 0.5).clip(0.0, 1.0)   # distillation.py:309
-        fusion = ((1 - acp).view(-1, 1, 1, 1) * (img256 - pred_img).abs()).mean()
-        fusion = fusion + self.percep(img256, pred_img, normalize=True).mean() * self.lambda_percep      # :312-314
-        loss = fusion + 1e-3 * torch.sqrt(sil256 ** 2 + .01).mean() + 1e-3 * entropy(sil256)
+        loss = fusion_loss(img256, sil256, pred_img, 1 - acp, 1e-3, 1e-3)       # (1 - a_bar) * L1 + opacity + entropy (:310-343)
+        loss = loss + self.percep(img256, pred_img, normalize=True).mean() * self.lambda_percep          # :312-314
         loss.backward()
         self.sync_grads()
         self.optim.step()

@@ -274,6 +274,27 @@ typedef struct {
 } sf_adam_args;
 int sf_adam_multi(const sf_adam_args* args, void* stream);
 
+/* ---- loss glue of the distillation step (csrc/loss_ops.hip).  Replaces the torch elementwise chains of
+ * sparsefusion/distillation.py:217-241 (stage A: |huber| colour + silhouette, opacity, entropy), :287-288
+ * (F.interpolate(scale_factor=2, mode='bilinear') of the render) and :310-343 (stage B: (1 - alpha_bar) * L1 to the decoded
+ * prediction, opacity, entropy).  Forward entry points leave per-workgroup partial sums, `sf_loss_partial_rows()` rows of
+ * 4 (stage A: |huber rgb|, |huber sil|, opacity, entropy) or 3 (stage B: weighted L1, opacity, entropy) floats; the caller
+ * sums the rows and applies lambda / element count.  Backward entry points take coefficient = lambda / element count per term and `grad_loss`, a DEVICE
+ * scalar holding the upstream gradient of the loss (null = 1).  Images are NCHW fp32; `target_mask` may be null (scene without masks). */
+uint32_t sf_loss_partial_rows(void);
+int sf_upsample2x_forward(const float* in, float* out, uint32_t planes, uint32_t h, uint32_t w, void* stream);
+int sf_upsample2x_backward(const float* grad_out, float* grad_in, uint32_t planes, uint32_t h, uint32_t w, void* stream);
+int sf_render_loss_forward(const float* img, const float* sil, const float* target_rgb, const float* target_mask, uint64_t n_img,
+                           uint64_t n_sil, float scaling, float* partial, void* stream);
+int sf_render_loss_backward(const float* img, const float* sil, const float* target_rgb, const float* target_mask, uint64_t n_img,
+                            uint64_t n_sil, float scaling, float c_rgb, float c_sil, float c_opacity, float c_entropy,
+                            const float* grad_loss, float* grad_img, float* grad_sil, void* stream);
+int sf_fusion_loss_forward(const float* img, const float* pred, const float* view_weight, const float* sil, uint32_t views,
+                           uint64_t per_view_img, uint64_t per_view_sil, float* partial, void* stream);
+int sf_fusion_loss_backward(const float* img, const float* pred, const float* view_weight, const float* sil, uint32_t views,
+                            uint64_t per_view_img, uint64_t per_view_sil, float c_l1, float c_opacity, float c_entropy,
+                            const float* grad_loss, float* grad_img, float* grad_sil, void* stream);
+
 int sf_plan_run(const sf_op* ops, uint32_t n_ops, void* stream);
 /* sf_plan_run with a HIP event before every op on the launch stream; h_ms[n_ops] (host) gets per-op
  * elapsed milliseconds.  Synchronises; measurement aid for bench.py (per-kernel roofline). */

@@ -77,6 +77,15 @@ SIGNATURES = {
     "sf_composite_rays": (C.c_int, [u32, u32, C.c_float, c_i32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                     c_f32p, C.c_void_p]),
     "sf_adam_multi": (C.c_int, [C.POINTER(SfAdamArgs), C.c_void_p]),
+    "sf_loss_partial_rows": (u32, []),
+    "sf_upsample2x_forward": (C.c_int, [c_f32p, c_f32p, u32, u32, u32, C.c_void_p]),
+    "sf_upsample2x_backward": (C.c_int, [c_f32p, c_f32p, u32, u32, u32, C.c_void_p]),
+    "sf_render_loss_forward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, u64, u64, C.c_float, c_f32p, C.c_void_p]),
+    "sf_render_loss_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, u64, u64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                          C.c_float, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "sf_fusion_loss_forward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, u32, u64, u64, c_f32p, C.c_void_p]),
+    "sf_fusion_loss_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, u32, u64, u64, C.c_float, C.c_float, C.c_float,
+                                          c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "sf_ngp_density": (C.c_int, [C.POINTER(SfNgpField), c_f32p, u32, c_f32p, c_f32p, C.c_void_p]),
     "sf_ngp_render_forward": (C.c_int, [C.POINTER(SfNgpField), c_f32p, c_f32p, c_f32p, u32, u32, C.c_float,
                                         c_f32p, c_f32p, c_f32p, u32, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p,

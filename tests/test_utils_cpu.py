@@ -93,3 +93,18 @@ def test_sampler_factories_and_renderer_plumbing():
         raise AssertionError("non-callable raysampler accepted")
     except ValueError:
         pass
+
+
+def test_metric_oracle_first_principles():
+    """oracle/metrics_ref.py (parity unpinned: scikit-image absent): identities and a closed-form case."""
+    import numpy as np
+    from oracle import metrics_ref
+    from sparsefusion_amd.utils.common_utils import get_metrics
+    rng = np.random.default_rng(0)
+    a = rng.random((32, 32, 3))
+    assert abs(metrics_ref.ssim(a, a) - 1.0) < 1e-12
+    b = a + 0.1
+    assert abs(metrics_ref.psnr(b, a) - 20.0) < 1e-9                      # mse = 0.01 -> 10 log10(1 / 0.01)
+    c = np.clip(a + 0.05 * rng.standard_normal(a.shape), 0, 1)
+    s, p = get_metrics(c, a, device="cpu")                               # the product's metric code is device-agnostic torch
+    assert abs(s - metrics_ref.ssim(c, a)) < 1e-9 and abs(p - metrics_ref.psnr(c, a)) < 1e-9 and 0 < s < 1
