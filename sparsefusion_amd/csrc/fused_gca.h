@@ -44,9 +44,16 @@ SF_KERNEL(256) void k_gca_pool(GcaPoolArgs a) {
     for (int u = 0; u < 4; ++u) {
       const int p = p0 + u * 16;
       const long m = m0 + (p < a.CH ? p : a.CH - 1);
-      if (a.ws) {
+      if (a.ws) {                                 // all slab loads before the first add (see fsrc_load4<1>); order bias, slab 0, 1, ...
+        const float* ap = a.ws + m * a.npad + c;
+        const long gstride = (long)a.M * a.npad;
+        const int gl = a.groups - 1;
+        f32x4 t[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t[g] = *reinterpret_cast<const f32x4*>(ap + (g < gl ? g : gl) * gstride);
         v[u] = bvec;
-        for (int g = 0; g < a.groups; ++g) v[u] += *reinterpret_cast<const f32x4*>(a.ws + ((long)g * a.M + m) * a.npad + c);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) v[u] += t[g] * (g <= gl ? 1.0f : 0.0f);
       } else {
         v[u] = *reinterpret_cast<const f32x4*>(a.h2 + m * a.C + c);
       }

@@ -107,7 +107,7 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   a.n_tiles = (a.n_frags + WN - 1) / WN;
   a.npad = a.n_frags * 16;
   if (a.s1.mode < 0 || a.s1.mode > 2) FC_FAIL("fconv: unknown lazy mode %d", a.s1.mode);
-  if (a.s1.mode == 1 && (!a.s1.a || a.s1.groups < 1 || a.s1.npad % 4)) FC_FAIL("fconv: bad split-K source");
+  if (a.s1.mode == 1 && (!a.s1.a || a.s1.groups < 1 || a.s1.groups > 8 || a.s1.npad % 4)) FC_FAIL("fconv: bad split-K source (1..8 slabs)");
   if (a.s1.mode == 2 && (!a.s1.a || !a.s1.b || !a.s1.r)) FC_FAIL("fconv: gated source needs h, gate and res");
   if (a.s1.mode && a.s1.scale != 1.0f) FC_FAIL("fconv: lazy sources are unscaled");
   if (a.s1.mode && a.s1.p && (a.s1.p == a.s1.a || a.s1.p == a.s1.r)) FC_FAIL("fconv: a lazy source must materialise into its own buffer");
@@ -213,7 +213,7 @@ static inline int gca_setup(const sf_op& op, GcaPoolArgs& pa, GcaNetArgs& na, Gc
     if (!pa.h2 || !pa.logit_part || !pa.part_pool || !pa.part_ms) GC_FAIL("gca pool: missing operand");
     if (pa.C % 64 || pa.CH < 16 || pa.CH > 128 || (pa.CH & (pa.CH - 1)) || pa.CH * pa.chunks != pa.HW || pa.M % pa.HW || pa.nparts < 1)
       GC_FAIL("gca pool: C %% 64, CH a power of two in 16..128, CH * chunks == HW required");
-    if (pa.ws && (pa.groups < 1 || pa.npad % 4)) GC_FAIL("gca pool: bad split-K source");
+    if (pa.ws && (pa.groups < 1 || pa.groups > 8 || pa.npad % 4)) GC_FAIL("gca pool: bad split-K source (1..8 slabs)");
     grid = (uint32_t)(pa.M / pa.HW) * pa.chunks * (pa.C / 64);
     return 0;
   }

@@ -81,9 +81,30 @@ template <int MODE>
 SF_DEV f32x4 fsrc_load4(const FSrc& s, int M, int HW, long m, int c) {
   f32x4 v;
   if (MODE == 1) {
-    v = s.b ? *reinterpret_cast<const f32x4*>(s.b + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int g = 0; g < s.groups; ++g) v += *reinterpret_cast<const f32x4*>(s.a + ((long)g * M + m) * s.npad + c);
-    if (s.r) v += *reinterpret_cast<const f32x4*>(s.r + m * s.C + c);
+    // EVERY load is issued before the first add, unconditionally (clamped slab index / any valid address, weight 0 or 1):
+    // `v += load` in a loop or under `if (ptr)` makes the compiler wait for each load in turn (s_waitcnt vmcnt(0) after
+    // every one of them: six serialised L2 round trips per element, ~2 us in front of every 4x4 conv).
+    // Summation order = bias, slab 0, 1, ..., residual, as k_splitk_reduce.
+    const float* ap = s.a + m * s.npad + c;
+    const long gstride = (long)M * s.npad;
+    const int gl = s.groups - 1;
+    f32x4 t[8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) t[g] = *reinterpret_cast<const f32x4*>(ap + (g < gl ? g : gl) * gstride);
+    const f32x4 bq = *reinterpret_cast<const f32x4*>(s.b ? s.b + c : ap);
+    const f32x4 rq = *reinterpret_cast<const f32x4*>(s.r ? s.r + m * s.C + c : ap);
+    if (s.groups > 4) {                                  // uniform: 5..8 slices
+#pragma unroll
+      for (int g = 4; g < 8; ++g) t[g] = *reinterpret_cast<const f32x4*>(ap + (g < gl ? g : gl) * gstride);
+    }
+    v = bq * (s.b ? 1.0f : 0.0f);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) v += t[g] * (g <= gl ? 1.0f : 0.0f);
+    if (s.groups > 4) {
+#pragma unroll
+      for (int g = 4; g < 8; ++g) v += t[g] * (g <= gl ? 1.0f : 0.0f);
+    }
+    v += rq * (s.r ? 1.0f : 0.0f);
   } else if (MODE == 2) {
     const f32x4 hv = *reinterpret_cast<const f32x4*>(s.a + m * s.C + c);
     const f32x4 gv = *reinterpret_cast<const f32x4*>(s.b + (m / HW) * s.C + c);
@@ -99,12 +120,76 @@ SF_DEV f32x4 fsrc_load4(const FSrc& s, int M, int HW, long m, int c) {
 template <int LAZY>
 SF_DEV f32x4 fconv_value(const FConvArgs& a, long m, int c) {
   const int HW = a.H * a.W;
+  if (LAZY == 0) {       // plain sources: SELECT the address, one unconditional load (a load under `if (c < C1)` is fenced by vmcnt(0))
+    const bool first = c < a.s1.C;
+    const float* p1 = a.s1.p + m * a.s1.C + (first ? c : 0);
+    const float* p2 = a.s2.C ? a.s2.p + m * a.s2.C + (first ? 0 : c - a.s1.C) : p1;
+    return *reinterpret_cast<const f32x4*>(first ? p1 : p2);
+  }
   if (c < a.s1.C) return fsrc_load4<LAZY>(a.s1, a.M, HW, m, c);
   return *reinterpret_cast<const f32x4*>(a.s2.p + m * a.s2.C + (c - a.s1.C));
 }
 
 template <int N>
 struct FConst { static constexpr int value = N; };
+
+// Branch-free two-phase evaluation of one float4 of the (virtual) concat for the register-resident 4x4 prologue: `issue`
+// puts every load the element needs into t[0..K) without any control flow (addresses and weights are SELECTED per lane: a
+// lane in the second source reads it K times with weight (1, 0, ..)), `combine` forms the value.  Keeping the loads of all
+// elements of a thread in one straight-line block lets them travel together (one round trip); inside `if (i < cnt)` /
+// `if (c < C1)` blocks each element's loads were fenced by s_waitcnt vmcnt(0).  K = loads per element of mode LAZY.
+template <int LAZY>
+struct FGather {
+  static constexpr int K = LAZY == 1 ? 6 : (LAZY == 2 ? 3 : 1);       // mode 1: slabs 0..3, bias, residual (groups <= 4)
+  f32x4 t[K];
+  float w[K];
+  SF_DEV void issue(const FConvArgs& a, long m, int c) {
+    const bool first = c < a.s1.C;
+    const float* p2 = a.s2.C ? a.s2.p + m * a.s2.C + (first ? 0 : c - a.s1.C) : nullptr;
+    if (LAZY == 0) {
+      const float* p1 = a.s1.p + m * a.s1.C + (first ? c : 0);
+      t[0] = *reinterpret_cast<const f32x4*>(first ? p1 : p2);
+      w[0] = 1.0f;
+    } else if (LAZY == 1) {
+      const int c1 = first ? c : 0;
+      const float* ap = a.s1.a + m * a.s1.npad + c1;
+      const long gstride = (long)a.M * a.s1.npad;
+      const int gl = a.s1.groups - 1;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float* q = ap + (g < gl ? g : gl) * gstride;
+        t[g] = *reinterpret_cast<const f32x4*>(first ? q : p2);
+        w[g] = first ? (g <= gl ? 1.0f : 0.0f) : (g == 0 ? 1.0f : 0.0f);
+      }
+      const float* bp = a.s1.b ? a.s1.b + c1 : ap;
+      const float* rp = a.s1.r ? a.s1.r + m * a.s1.C + c1 : ap;
+      t[4] = *reinterpret_cast<const f32x4*>(first ? bp : p2);
+      t[5] = *reinterpret_cast<const f32x4*>(first ? rp : p2);
+      w[4] = (first && a.s1.b) ? 1.0f : 0.0f;
+      w[5] = (first && a.s1.r) ? 1.0f : 0.0f;
+    } else {
+      const int c1 = first ? c : 0;
+      const float* hp = a.s1.a + m * a.s1.C + c1;
+      const float* gp = a.s1.b + (m / (a.H * a.W)) * a.s1.C + c1;
+      const float* rp = a.s1.r + m * a.s1.C + c1;
+      t[0] = *reinterpret_cast<const f32x4*>(first ? hp : p2);
+      t[1] = *reinterpret_cast<const f32x4*>(first ? gp : p2);
+      t[2] = *reinterpret_cast<const f32x4*>(first ? rp : p2);
+      w[0] = first ? 1.0f : 0.0f;
+    }
+  }
+  SF_DEV f32x4 combine() const {
+    if (LAZY == 0) return t[0];
+    if (LAZY == 1) {                       // order of k_splitk_reduce: bias, slab 0, 1, .., residual (second source: t[0] alone)
+      f32x4 v = t[4] * w[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) v += t[g] * w[g];
+      v += t[5] * w[5];
+      return v;
+    }
+    return w[0] != 0.0f ? t[0] * t[1] + t[2] : t[0];
+  }
+};
 
 // NORM / LAZY (normalisation kind, lazy mode of source 1) are compile-time: one straight-line prologue per variant
 // (the all-in-one version was 49 k instructions and spilled 190 SGPRs).  NW = waves per workgroup: the prologue is VALU
@@ -187,16 +272,37 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
   const int cnt = HW * Cs4;
   f32x4 v[NV];
   if (NORM == FNORM_GN_SELF) {
+    const int nlive = (cnt + NT - 1) / NT;                           // elements per thread (uniform), 1..NV
+    if (LAZY == 1 && a.s1.groups > 4) {                              // 5..8 slabs: the generic (per-element) path
 #pragma unroll
-    for (int u = 0; u < NV; ++u) {
-      const int i = tid + u * NT;
-      if (i < cnt) {
-        const int p = (int)fdiv((uint32_t)i, a.d_cs4), c4 = i - p * Cs4;
-        v[u] = fconv_value<LAZY>(a, mb + p, c0 + c4 * 4);
+      for (int u = 0; u < NV; ++u) {
+        const int i = tid + u * NT;
+        if (i < cnt) {
+          const int p = (int)fdiv((uint32_t)i, a.d_cs4), c4 = i - p * Cs4;
+          v[u] = fconv_value<LAZY>(a, mb + p, c0 + c4 * 4);
+        }
+      }
+    } else {
+      // batches of 4 elements: all their loads in one straight-line block, then the sums (dead elements read element cnt - 1)
+#pragma unroll
+      for (int u0 = 0; u0 < NV; u0 += 4) {
+        if (u0 < nlive) {
+          FGather<LAZY> gq[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            int i = tid + (u0 + u) * NT;
+            if (i > cnt - 1) i = cnt - 1;
+            const int p = (int)fdiv((uint32_t)i, a.d_cs4), c4 = i - p * Cs4;
+            gq[u].issue(a, mb + p, c0 + c4 * 4);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u0 + u] = gq[u].combine();
+        }
       }
     }
     prefetch_weights();          // right behind them: at the 4x4 level the launch is one HBM round trip of the whole weight slice
   }
+  FC_STAMP(6);
 
   // ---- (a) zero the frame pixels outside the image (conv zero padding); 8 threads per pixel
   if (h) {
@@ -211,6 +317,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
     }
   }
 
+  FC_STAMP(7);
   constexpr bool gn = NORM == FNORM_GN_SELF || NORM == FNORM_GN_SLOTS;
   const int Cg = gn ? a.C / a.G : 1;
   // per-channel affine of this (image, slice) from the group statistics in misc[16 + 2g], misc[17 + 2g]:
@@ -757,8 +864,15 @@ SF_KERNEL(256) void k_slots(const float* __restrict__ x, const float* __restrict
   const int c = cf * 16 + (lane & 3) * 4;
   f32x4 v;
   if (ws) {
-    v = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int g = 0; g < groups; ++g) v += *reinterpret_cast<const f32x4*>(ws + ((long)g * M + m) * npad + c);
+    const float* ap = ws + m * npad + c;                 // all slab loads before the first add (see fsrc_load4<1>), 1..8 slabs
+    const long gstride = (long)M * npad;
+    const int gl = groups - 1;
+    f32x4 t[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t[g] = *reinterpret_cast<const f32x4*>(ap + (g < gl ? g : gl) * gstride);
+    v = *reinterpret_cast<const f32x4*>(bias ? bias + c : ap) * (bias ? 1.0f : 0.0f);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) v += t[g] * (g <= gl ? 1.0f : 0.0f);
     *reinterpret_cast<f32x4*>(out + m * C + c) = v;
   } else {
     v = *reinterpret_cast<const f32x4*>(x + m * C + c);

@@ -164,6 +164,7 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
 #pragma unroll
     for (int j = 0; j < NB - 1; ++j) issue(j < NCH ? j : NCH - 1, j * EPT);
   }
+  FP_STAMP(6);
   // GroupNorm parameters of the whole input (C <= 4 * NT channels), statistics slots of this wave's group
   constexpr int TABN = 4;
   float tg[TABN], tb[TABN], tsc[TABN], tsh[TABN];
@@ -198,7 +199,7 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
       if (a.accum) rv[r] += a.out[o];
     }
   }
-  FP_STAMP(1);
+  FP_STAMP(7);
 
   // ---- zero the frame pixels outside the image in BOTH buffers (conv zero padding); 8 threads per pixel
   {
@@ -215,6 +216,7 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
       }
     }
   }
+  FP_STAMP(1);
   // ---- statistics: one wave per group sums the producer's (sum, sum of squares) slots of image b
   for (int gi = wave; gi < ngs; gi += NW) {
     float sm = 0.0f, sq = 0.0f;

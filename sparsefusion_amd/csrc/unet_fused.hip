@@ -94,7 +94,7 @@ static int run_slots(const sf_op& op, hipStream_t st) {
   const int groups = op.i[3], npad = op.i[4];
   if (M % 16 || C % 16 || (!op.p[0] && !op.p[5]) || !op.p[4] || (op.p[1] && (!op.p[2] || !op.p[3])))
     SF_FAIL(SF_ERR_INVALID, "slots: M, C must be multiples of 16; gate mode needs res and out");
-  if (op.p[5] && (op.p[1] || !op.p[3] || groups < 1 || npad % 4 || npad < C)) SF_FAIL(SF_ERR_INVALID, "slots: bad split-K source");
+  if (op.p[5] && (op.p[1] || !op.p[3] || groups < 1 || groups > 8 || npad % 4 || npad < C)) SF_FAIL(SF_ERR_INVALID, "slots: bad split-K source (1..8 slabs)");
   const uint32_t waves = (uint32_t)(M / 16) * (C / 16);
   k_slots<<<sf_div_up(waves, 4), 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], (float*)op.p[3],
                                                 (float*)op.p[4], M, C, HW, (const float*)op.p[5], (const float*)op.p[6], groups, npad);

@@ -294,7 +294,7 @@ class _Plan:
                 bnf, blocks = 4, ((m_frags + 7) // 8) * ((n_frags + 3) // 4)
             if blocks >= lds_min:
                 tile, groups, ws = 256 + bnf, 1, 0
-        defer = bool(defer and not relu and not gelu and groups > 1 and not accum and not pixshuf and co_off == 0 and ldc == Cout == out.C and M == out.rows
+        defer = bool(defer and not relu and not gelu and 1 < groups <= 8 and not accum and not pixshuf and co_off == 0 and ldc == Cout == out.C and M == out.rows
                      and (self.u.lazy_consumers & 1))
         bias, res = self.wptr(bname) if bname else 0, resid.ptr if resid else 0
         self.op(OP_CONV, (1 if x_f32 else 0) | (2 if pixshuf else 0) | (4 if accum else 0) | (8 if defer else 0) |

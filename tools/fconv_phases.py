@@ -31,3 +31,7 @@ for name in names:
           f"WG start spread {float(start.max()):5.2f}")
     for k, lab in enumerate(["prefetch-issue", "statistics", "staging", "main loop", "epilogue"]):
         print(f"      {lab:15s} mean {float(ph[:, k].mean()):6.2f}  max {float(ph[:, k].max()):6.2f}")
+    if float(d[:, 6].max()) > 0:                               # finer stamps inside "prefetch-issue": entry -> s6 -> s7 -> stamp 1
+        a6, a7 = (d[:, 6] - d[:, 0]) / 100.0, (d[:, 7] - d[:, 6]) / 100.0
+        a1 = (d[:, 1] - d[:, 7]) / 100.0
+        print(f"      [entry->first loads issued {float(a6.mean()):5.2f} | ->second block {float(a7.mean()):5.2f} | ->stamp1 {float(a1.mean()):5.2f}]")
