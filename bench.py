@@ -233,7 +233,7 @@ def unet_roofline(hp):
         j = json.load(open(pmc))
         traffic = j.get("fconv_fetch_bytes_per_launch_corrected")
         mfma_busy = j.get("fconv_mfma_busy_frac")
-    return {"bound": "hbm", "kernel": "k_conv_fused (GroupNorm / LayerNorm + conv in one launch)", "achieved": round(achieved, 1),
+    return {"bound": "hbm", "kernel": "k_conv_fused / k_conv_fused_pipe / _pair (GroupNorm | LayerNorm + conv in one launch; 80 conv ops in 71 launches)", "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "mfma_busy_frac": mfma_busy,
             "traffic_note": "avg HBM fetch bytes per k_conv_fused launch: rocprofv3 --pmc FETCH_SIZE pass (x2 gfx950 correction), "
