@@ -360,6 +360,7 @@ __global__ __launch_bounds__(256) void k_ngp_field_bwd(
 // ---------------------------------------------------------------------------
 #define SC_RAYS 64
 #define SC_SLOTS 8192
+#define SC_RUN 8                 /* consecutive samples of a ray per thread-item (run-length merged in registers) */
 #define SC_EMPTY 0xffffffffu
 // NT threads share one 96 KB LDS cache (one workgroup per CU): NT = 1024 puts 4 waves on every SIMD -- the loop body is a
 // chain of dependent global loads, hash arithmetic and LDS atomics, and with the first version's 256 threads (ONE wave per
@@ -381,7 +382,6 @@ __global__ __launch_bounds__(NT) void k_ngp_scatter(
   uint32_t tile_x = 0, tile_y = 0, tiles_x = 0;
   const bool patch = rays_per_row >= 8 && (rays_per_row % 8) == 0 && (N % rays_per_row) == 0 && ((N / rays_per_row) % 8) == 0;
   if (patch) { tiles_x = rays_per_row / 8; tile_y = blockIdx.x / tiles_x; tile_x = blockIdx.x % tiles_x; }
-  const uint32_t pts = SC_RAYS * T2;
 
   for (uint32_t l = 0; l < last_level; ++l) {
     const bool cached = l < cached_levels;
@@ -395,40 +395,62 @@ __global__ __launch_bounds__(NT) void k_ngp_scatter(
     // lane quads share a sample: lane&1 = channel, lane&2 = x-corner.  The four adds of an x-corner pair (two
     // adjacent table rows x 2 channels = 16 contiguous bytes) sit in adjacent lanes of ONE atomic instruction: the
     // memory-side atomic unit merges lanes of one granule (measured 13.5 -> 7.6 ms with channel pairs alone).
-    for (uint32_t it = threadIdx.x; it < 4 * pts; it += NT) {
-      const uint32_t pl = it >> 2, ch = it & 1, xb = (it >> 1) & 1;
-      const uint32_t r = pl / T2, k = pl - r * T2;
+    // A thread-item = (ray, run of SC_RUN consecutive sorted samples, lane of the quad).  Consecutive samples of a ray share
+    // their cell on the coarse levels, so equal rows are first summed in REGISTERS (run-length merge per corner pair) and
+    // only the run totals go to the LDS cache: on levels 0-5 nearly every lane of every atomic instruction used to hit
+    // the same handful of LDS addresses, and same-address LDS atomics serialise (0.18 ms per level for ~1 us of work).
+    const uint32_t runs = (T2 + SC_RUN - 1) / SC_RUN;
+    auto flush = [&](uint32_t row, float v, uint32_t ch) {
+      if (cached) {
+        const uint32_t slot = (row * 2654435761u) >> 19;         // 13 bits -> SC_SLOTS
+        const uint32_t prev = atomicCAS(&tags[slot], SC_EMPTY, row);
+        if (prev == SC_EMPTY || prev == row) {
+          atomicAdd(&vals[2 * slot + ch], v);
+          return;
+        }
+      }
+      SF_ATOMIC_ADD(tab + (size_t)row * 2 + ch, v);
+    };
+    for (uint32_t it = threadIdx.x; it < 4 * SC_RAYS * runs; it += NT) {
+      const uint32_t q = it >> 2, ch = it & 1, xb = (it >> 1) & 1;
+      const uint32_t r = q / runs, k0 = (q - r * runs) * SC_RUN;
       uint32_t n = patch ? ((tile_y * 8 + (r >> 3)) * rays_per_row + tile_x * 8 + (r & 7)) : (blockIdx.x * SC_RAYS + r);
       if (n >= N) continue;
-      const uint32_t p = n * T2 + k;
-      const float dfc = dfeat[((size_t)l * P + p) * 2 + ch];
-      if (dfc == 0.0f) continue;                                 // outside points / dead samples contribute nothing
       const float o[3] = {rays_o[n * 3], rays_o[n * 3 + 1], rays_o[n * 3 + 2]};
       const float d[3] = {rays_d[n * 3], rays_d[n * 3 + 1], rays_d[n * 3 + 2]};
-      float x[3], x01[3];
-      ngp_point(o, d, z_s[p], box, x);
-      if (!ngp_unit(x, bound, x01)) continue;
-      NgpCell c;
-      ngp_cell(lv, l, x01, c);
+      uint32_t prow[4] = {SC_EMPTY, SC_EMPTY, SC_EMPTY, SC_EMPTY};
+      float pacc[4] = {0.f, 0.f, 0.f, 0.f};
+      const uint32_t k1 = k0 + SC_RUN < T2 ? k0 + SC_RUN : T2;
+      for (uint32_t k = k0; k < k1; ++k) {
+        const uint32_t p = n * T2 + k;
+        const float dfc = dfeat[((size_t)l * P + p) * 2 + ch];
+        if (dfc == 0.0f) continue;                               // outside points / dead samples contribute nothing
+        float x[3], x01[3];
+        ngp_point(o, d, z_s[p], box, x);
+        if (!ngp_unit(x, bound, x01)) continue;
+        NgpCell c;
+        ngp_cell(lv, l, x01, c);
 #pragma unroll
-      for (int yz = 0; yz < 4; ++yz) {
-        if (z_dropped && yz >= 2) continue;
-        const int i0 = yz << 1, i1 = i0 | 1;          // the two x-corners of this (y, z) corner pair
-        const float w0 = z_dropped ? SF_ADD(c.w[i0 & 3], c.w[(i0 & 3) + 4]) : c.w[i0];
-        const float w1 = z_dropped ? SF_ADD(c.w[i1 & 3], c.w[(i1 & 3) + 4]) : c.w[i1];
-        const float w = xb ? w1 : w0;
-        const uint32_t row = xb ? c.row[i1] : c.row[i0];
-        const float v = SF_MUL(w, dfc);
-        if (cached) {
-          const uint32_t slot = (row * 2654435761u) >> 19;       // 13 bits -> SC_SLOTS
-          const uint32_t prev = atomicCAS(&tags[slot], SC_EMPTY, row);
-          if (prev == SC_EMPTY || prev == row) {
-            atomicAdd(&vals[2 * slot + ch], v);
-            continue;
+        for (int yz = 0; yz < 4; ++yz) {
+          if (z_dropped && yz >= 2) continue;
+          const int i0 = yz << 1, i1 = i0 | 1;        // the two x-corners of this (y, z) corner pair
+          const float w0 = z_dropped ? SF_ADD(c.w[i0 & 3], c.w[(i0 & 3) + 4]) : c.w[i0];
+          const float w1 = z_dropped ? SF_ADD(c.w[i1 & 3], c.w[(i1 & 3) + 4]) : c.w[i1];
+          const float w = xb ? w1 : w0;
+          const uint32_t row = xb ? c.row[i1] : c.row[i0];
+          const float v = SF_MUL(w, dfc);
+          if (row == prow[yz]) {
+            pacc[yz] += v;
+          } else {
+            if (prow[yz] != SC_EMPTY) flush(prow[yz], pacc[yz], ch);
+            prow[yz] = row;
+            pacc[yz] = v;
           }
         }
-        SF_ATOMIC_ADD(tab + (size_t)row * 2 + ch, v);
       }
+#pragma unroll
+      for (int yz = 0; yz < 4; ++yz)
+        if (prow[yz] != SC_EMPTY) flush(prow[yz], pacc[yz], ch);
     }
     if (cached) {
       __syncthreads();

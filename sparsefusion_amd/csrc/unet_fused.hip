@@ -103,6 +103,14 @@ static int run_slots(const sf_op& op, hipStream_t st) {
 }
 
 static int run_gca(const sf_op& op, hipStream_t st) {
+  if (op.flags == 4) {
+    GcaPoolNetArgs pn;
+    uint32_t g;
+    if (gca_poolnet_setup(op, pn, g, sf_err_buf, sizeof(sf_err_buf))) return SF_ERR_INVALID;
+    k_gca_poolnet<<<g, 256, 0, st>>>(pn);
+    SF_CHECK_LAUNCH("gca_poolnet");
+    return SF_OK;
+  }
   GcaPoolArgs pa;
   GcaNetArgs na;
   GcaGateArgs ga;

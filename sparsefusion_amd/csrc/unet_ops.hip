@@ -1302,6 +1302,38 @@ __global__ __launch_bounds__(256) void k_plms_combine(const float* __restrict__ 
   }
 }
 
+// combine + update in ONE launch (the steady state of the sampler: every step after the first)
+__global__ __launch_bounds__(256) void k_plms_step(const float* __restrict__ e0, const float* __restrict__ e1,
+                                                   const float* __restrict__ e2, const float* __restrict__ e3, float c0, float c1,
+                                                   float c2, float c3, float* __restrict__ keep, const float* __restrict__ x,
+                                                   const float* __restrict__ noise, Coef6 k, long n, float* __restrict__ x_prev) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    if (keep) keep[i] = e0[i];
+    float v = c0 * e0[i];                        // same expression order as k_plms_combine
+    if (e1) v += c1 * e1[i];
+    if (e2) v += c2 * e2[i];
+    if (e3) v += c3 * e3[i];
+    const float xv = x[i];
+    float s = __fdiv_rn(__fsub_rn(xv, __fmul_rn(k.sigma, v)), fmaxf(k.alpha, 1e-8f));
+    s = fminf(fmaxf(s, -k.clip), k.clip);
+    const float mean = __fmul_rn(k.alpha_next, __fadd_rn(__fdiv_rn(__fmul_rn(xv, __fsub_rn(1.0f, k.c)), k.alpha), __fmul_rn(k.c, s)));
+    float out = mean;
+    if (noise) out = __fadd_rn(mean, __fmul_rn(k.noise_scale, noise[i]));
+    x_prev[i] = out;
+  }
+}
+
+extern "C" int sf_plms_step(const float* e0, const float* e1, const float* e2, const float* e3, const float* h_c4, float* keep_e0,
+                            const float* x, const float* noise, const float* h_coef6, uint64_t n, float* x_prev, void* stream) {
+  if (!e0 || !h_c4 || !x || !h_coef6 || !x_prev) SF_FAIL(SF_ERR_INVALID, "plms_step: null argument");
+  if (n == 0) return SF_OK;
+  Coef6 k{h_coef6[0], h_coef6[1], h_coef6[2], h_coef6[3], h_coef6[4], h_coef6[5]};
+  k_plms_step<<<sf_grid_cap(sf_div_up(n, 256)), 256, 0, (hipStream_t)stream>>>(e0, e1, e2, e3, h_c4[0], h_c4[1], h_c4[2], h_c4[3], keep_e0, x,
+                                                                               noise, k, (long)n, x_prev);
+  SF_CHECK_LAUNCH("plms_step");
+  return SF_OK;
+}
+
 extern "C" int sf_plms_update(const float* x, const float* eps, const float* noise, const float* h_coef6, uint64_t n,
                               float* x_prev, float* x0, void* stream) {
   if (!x || !eps || !h_coef6 || !x_prev) SF_FAIL(SF_ERR_INVALID, "plms_update: null argument");

@@ -119,6 +119,18 @@ class PLMSSampler():
             _lib.check(lib.sf_plms_combine(*ptrs, c4.ctypes.data, n, _lib.ptr(out), _lib.ptr(keep), _lib.stream_ptr()), "plms_combine")
             return out
 
+        def step(es, cs, keep, x, t, t_next, out):
+            """combine + update in ONE launch: x_prev = update(x, sum_k cs[k] * es[k]); `keep` receives es[0]."""
+            c4 = np.zeros(4, dtype=np.float32)
+            c4[:len(cs)] = cs
+            ptrs = [_lib.ptr(e) for e in es] + [None] * (4 - len(es))
+            coef = step_coefficients(t, t_next, clip)
+            nz = draw()
+            x_prev = torch.empty_like(x) if out is None else out
+            _lib.check(lib.sf_plms_step(*ptrs, c4.ctypes.data, _lib.ptr(keep), _lib.ptr(x), _lib.ptr(nz), coef.ctypes.data, n,
+                                        _lib.ptr(x_prev), _lib.stream_ptr()), "plms_step")
+            return x_prev
+
         ring = [torch.empty(shape, device=dev) for _ in range(4)]   # eps history (the eval's output buffer is reused)
         old = []
         for k, (t, t_next) in enumerate(zip(tl[:-1], tl[1:])):
@@ -131,13 +143,15 @@ class PLMSSampler():
                 e_next = eps_model(x_prev, t_next)
                 draw()
                 e_prime = combine([e_t, e_next], [0.5, 0.5])
+            if len(old) == 0:
+                img = update(img, e_prime, t, t_next, out=x_slot if fast else None)
             elif len(old) == 1:
-                e_prime = combine([e_view, old[-1]], [3 / 2, -1 / 2], keep=e_t)
+                img = step([e_view, old[-1]], [3 / 2, -1 / 2], e_t, img, t, t_next, x_slot if fast else None)
             elif len(old) == 2:
-                e_prime = combine([e_view, old[-1], old[-2]], [23 / 12, -16 / 12, 5 / 12], keep=e_t)
+                img = step([e_view, old[-1], old[-2]], [23 / 12, -16 / 12, 5 / 12], e_t, img, t, t_next, x_slot if fast else None)
             else:
-                e_prime = combine([e_view, old[-1], old[-2], old[-3]], [55 / 24, -59 / 24, 37 / 24, -9 / 24], keep=e_t)
-            img = update(img, e_prime, t, t_next, out=x_slot if fast else None)
+                img = step([e_view, old[-1], old[-2], old[-3]], [55 / 24, -59 / 24, 37 / 24, -9 / 24], e_t, img, t, t_next,
+                           x_slot if fast else None)
             old.append(e_t)
             if len(old) >= 4:
                 old.pop(0)

@@ -192,7 +192,7 @@ def run_slots_case(backend):
     assert torch.allclose(sl2.cpu(), slots_of(x, M, C), rtol=1e-5, atol=1e-4)
 
 
-def run_gca_case(backend, B, H, C, lazy=False, seed=0):
+def run_gca_case(backend, B, H, C, lazy=False, seed=0, poolnet=False):
     """k_gca_pool -> k_gca_net0 -> k_gca_gate against GlobalContext + gated residual (imagen_pytorch.py:916-941, :727-729)."""
     dev = "cpu" if backend == "emu" else "cuda:0"
     g = torch.Generator().manual_seed(seed)
@@ -227,8 +227,10 @@ def run_gca_case(backend, B, H, C, lazy=False, seed=0):
     b0_d, b2_d = dv(b0), dv(b2)
     hid_d, out = torch.zeros(B, HID, device=dev), torch.zeros(M, C, device=dev)
     slots = torch.zeros(M // 16, C // 16, 2, device=dev)
-    ops = [fused.mkop(OP_GCA, 1, p=(h2_d, ws_d, bias_d, lp_d, part_pool, part_ms), i=(M, C, HW, CH, chunks, nparts, groups, npad)),
-           fused.mkop(OP_GCA, 2, p=(part_pool, part_ms, W0p, b0_d, hid_d), i=(B, C, Kp, HID, chunks)),
+    head = [fused.mkop(OP_GCA, 4, p=(h2_d, ws_d, bias_d, lp_d, W0p, b0_d, hid_d), i=(M, C, HW, nparts, groups, npad, Kp, HID))] if poolnet else \
+        [fused.mkop(OP_GCA, 1, p=(h2_d, ws_d, bias_d, lp_d, part_pool, part_ms), i=(M, C, HW, CH, chunks, nparts, groups, npad)),
+         fused.mkop(OP_GCA, 2, p=(part_pool, part_ms, W0p, b0_d, hid_d), i=(B, C, Kp, HID, chunks))]
+    ops = head + [
            fused.mkop(OP_GCA, 3, p=(h2_d, res_d, hid_d, W2p, b2_d, out, slots), i=(M, C, HW, HID, Kp2))]
     run_ops(ops, backend)
     assert torch.allclose(hid_d.cpu(), hid, rtol=2e-4, atol=2e-5), "hidden vector wrong"
@@ -238,8 +240,10 @@ def run_gca_case(backend, B, H, C, lazy=False, seed=0):
         assert torch.allclose(h2_d.cpu(), h2, atol=1e-5)
 
 
-GCA_CASES = {"4x4_lazy": dict(B=2, H=4, C=128, lazy=True), "8x8": dict(B=1, H=8, C=64, seed=1), "16x16": dict(B=1, H=16, C=64, seed=2)}
-GCA_CASES_FULL = {"unet_4x4": dict(B=1, H=4, C=1024, lazy=True, seed=3), "unet_8x8": dict(B=1, H=8, C=1024, seed=4),
+GCA_CASES = {"4x4_lazy": dict(B=2, H=4, C=128, lazy=True), "8x8": dict(B=1, H=8, C=64, seed=1), "16x16": dict(B=1, H=16, C=64, seed=2),
+             "poolnet_4x4_lazy": dict(B=2, H=4, C=128, lazy=True, seed=7, poolnet=True), "poolnet_8x8": dict(B=2, H=8, C=192, seed=8, poolnet=True)}
+GCA_CASES_FULL = {"unet_poolnet_4x4": dict(B=1, H=4, C=1024, lazy=True, seed=9, poolnet=True), "unet_poolnet_8x8": dict(B=1, H=8, C=1024, seed=10, poolnet=True),
+                  "unet_4x4": dict(B=1, H=4, C=1024, lazy=True, seed=3), "unet_8x8": dict(B=1, H=8, C=1024, seed=4),
                   "unet_32x32": dict(B=1, H=32, C=256, seed=5), "unet_b4_16x16": dict(B=4, H=16, C=512, seed=6)}
 
 
