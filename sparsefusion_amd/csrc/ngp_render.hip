@@ -360,7 +360,6 @@ __global__ __launch_bounds__(256) void k_ngp_field_bwd(
 // ---------------------------------------------------------------------------
 #define SC_RAYS 64
 #define SC_SLOTS 8192
-#define SC_RUN 8                 /* consecutive samples of a ray per thread-item (run-length merged in registers) */
 #define SC_EMPTY 0xffffffffu
 // NT threads share one 96 KB LDS cache (one workgroup per CU): NT = 1024 puts 4 waves on every SIMD -- the loop body is a
 // chain of dependent global loads, hash arithmetic and LDS atomics, and with the first version's 256 threads (ONE wave per
@@ -370,7 +369,7 @@ __global__ __launch_bounds__(NT) void k_ngp_scatter(
     NgpLevels lv, float bound, float* __restrict__ gtable, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ aabb, const float* __restrict__ z_s,
     const float* __restrict__ dfeat, uint32_t N, uint32_t T2, uint32_t rays_per_row, uint32_t cached_levels,
-    uint32_t last_level) {
+    uint32_t last_level, uint32_t sc_run) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   uint32_t* tags = reinterpret_cast<uint32_t*>(smem);            // [SC_SLOTS]
   float* vals = smem + SC_SLOTS;                                 // [SC_SLOTS][2]
@@ -395,11 +394,11 @@ __global__ __launch_bounds__(NT) void k_ngp_scatter(
     // lane quads share a sample: lane&1 = channel, lane&2 = x-corner.  The four adds of an x-corner pair (two
     // adjacent table rows x 2 channels = 16 contiguous bytes) sit in adjacent lanes of ONE atomic instruction: the
     // memory-side atomic unit merges lanes of one granule (measured 13.5 -> 7.6 ms with channel pairs alone).
-    // A thread-item = (ray, run of SC_RUN consecutive sorted samples, lane of the quad).  Consecutive samples of a ray share
+    // A thread-item = (ray, run of `sc_run` consecutive sorted samples, lane of the quad).  Consecutive samples of a ray share
     // their cell on the coarse levels, so equal rows are first summed in REGISTERS (run-length merge per corner pair) and
     // only the run totals go to the LDS cache: on levels 0-5 nearly every lane of every atomic instruction used to hit
     // the same handful of LDS addresses, and same-address LDS atomics serialise (0.18 ms per level for ~1 us of work).
-    const uint32_t runs = (T2 + SC_RUN - 1) / SC_RUN;
+    const uint32_t runs = (T2 + sc_run - 1) / sc_run;
     auto flush = [&](uint32_t row, float v, uint32_t ch) {
       if (cached) {
         const uint32_t slot = (row * 2654435761u) >> 19;         // 13 bits -> SC_SLOTS
@@ -413,14 +412,14 @@ __global__ __launch_bounds__(NT) void k_ngp_scatter(
     };
     for (uint32_t it = threadIdx.x; it < 4 * SC_RAYS * runs; it += NT) {
       const uint32_t q = it >> 2, ch = it & 1, xb = (it >> 1) & 1;
-      const uint32_t r = q / runs, k0 = (q - r * runs) * SC_RUN;
+      const uint32_t r = q / runs, k0 = (q - r * runs) * sc_run;
       uint32_t n = patch ? ((tile_y * 8 + (r >> 3)) * rays_per_row + tile_x * 8 + (r & 7)) : (blockIdx.x * SC_RAYS + r);
       if (n >= N) continue;
       const float o[3] = {rays_o[n * 3], rays_o[n * 3 + 1], rays_o[n * 3 + 2]};
       const float d[3] = {rays_d[n * 3], rays_d[n * 3 + 1], rays_d[n * 3 + 2]};
       uint32_t prow[4] = {SC_EMPTY, SC_EMPTY, SC_EMPTY, SC_EMPTY};
       float pacc[4] = {0.f, 0.f, 0.f, 0.f};
-      const uint32_t k1 = k0 + SC_RUN < T2 ? k0 + SC_RUN : T2;
+      const uint32_t k1 = k0 + sc_run < T2 ? k0 + sc_run : T2;
       for (uint32_t k = k0; k < k1; ++k) {
         const uint32_t p = n * T2 + k;
         const float dfc = dfeat[((size_t)l * P + p) * 2 + ch];
@@ -653,6 +652,7 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
     static const int sc_threads = getenv("SF_SC_THREADS") ? atoi(getenv("SF_SC_THREADS")) : 1024;
     static const float sc_cutoff = getenv("SF_SC_CUTOFF") ? (float)atof(getenv("SF_SC_CUTOFF")) : 640.0f;
     static const bool sc_split = getenv("SF_SC_SPLIT") ? atoi(getenv("SF_SC_SPLIT")) != 0 : true;
+    static const uint32_t sc_run = getenv("SF_SC_RUN") && atoi(getenv("SF_SC_RUN")) > 0 ? (uint32_t)atoi(getenv("SF_SC_RUN")) : 8u;
     static unsigned attr2_mask = 0;
     if (dev_id >= 32 || !(attr2_mask & (1u << dev_id))) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_scatter<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess ||
@@ -668,11 +668,11 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
     const uint32_t grid_sc = sf_div_up(N, SC_RAYS);
     if (last > 0) {
       if (sc_threads == 256)
-        k_ngp_scatter<256><<<grid_sc, 256, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, 2 * T, rays_per_row, cached, last);
+        k_ngp_scatter<256><<<grid_sc, 256, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, 2 * T, rays_per_row, cached, last, sc_run);
       else if (sc_threads == 512)
-        k_ngp_scatter<512><<<grid_sc, 512, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, 2 * T, rays_per_row, cached, last);
+        k_ngp_scatter<512><<<grid_sc, 512, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, 2 * T, rays_per_row, cached, last, sc_run);
       else
-        k_ngp_scatter<1024><<<grid_sc, 1024, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, 2 * T, rays_per_row, cached, last);
+        k_ngp_scatter<1024><<<grid_sc, 1024, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, 2 * T, rays_per_row, cached, last, sc_run);
       SF_CHECK_LAUNCH("ngp_scatter");
     }
     if (last < lv.L) {

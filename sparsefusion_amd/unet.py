@@ -524,7 +524,7 @@ class _Plan:
             h2.lazy = None
             self.ws_owners[wi] = None
         self.need(res)
-        if HW in (16, 64) and cout <= 2048 and cout % 8 == 0 and groups <= 8 and getattr(self.u, "gca_poolnet", True):
+        if HW in (16, 64) and cout <= 2048 and cout % 8 == 0 and groups <= 8 and getattr(self.u, "gca_poolnet", False):
             # small maps: pooling + first 1x1 conv in one launch (every workgroup re-derives the pooled context: k_gca_poolnet)
             self.op(OP_GCA, 4, p=(h2.ptr, ws, bias, lpart.ptr, self.wptr(f"{name}.gca.net.0.weight"), self.wptr(f"{name}.gca.net.0.bias"),
                                   hid.ptr), i=(rows, cout, HW, nparts, groups, npad, (cout + 7) // 8 * 8, hidc))
@@ -937,7 +937,7 @@ class Unet(nn.Module):
         # GroupNorm inside the conv launches (k_conv_fused) wherever the layer fits; SF_UNET_FUSED=0 = the first-round plan (A/B runs)
         self.fused = os.environ.get("SF_UNET_FUSED", "1") != "0"
         self.pair_res_conv = os.environ.get("SF_PAIR", "1") != "0"      # conv1 || res_conv of a ResnetBlock in one launch
-        self.gca_poolnet = os.environ.get("SF_POOLNET", "1") != "0"     # GlobalContext pooling + net.0 in one launch on the 4x4 / 8x8 maps
+        self.gca_poolnet = os.environ.get("SF_POOLNET", "0") != "0"     # GlobalContext pooling + net.0 in one launch on the 4x4 / 8x8 maps: measured SLOWER (1.428 vs 1.367 ms per eval: every workgroup re-reads the whole map), kept as an A/B switch
         self.fconv_pipe = os.environ.get("SF_PIPE", "1") != "0"         # slot-GroupNorm 3x3 convs on k_conv_fused_pipe (staging || matrix work)
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches
         self._pack_cache = None
