@@ -46,13 +46,11 @@
 
 // Pipelined slot-GroupNorm 3x3 convs (k_conv_fused_pipe, op flag 32): (WM, WN, EPT = ceil((TR + 2) * (TW + 2) / 8) staging elements per thread and chunk)
 #define SF_FCONV_PIPE_VARIANTS(X) \
-  X(1, 1, 4) \
   X(1, 1, 5) \
   X(1, 2, 5) \
   X(1, 4, 5)
 // conv1 (pipelined, tile WM x WN, EPT) || res_conv (k_conv_fused body NONE with ITS OWN tile WM2 x WN2: whole image rows)
 #define SF_FCONV_PIPE_PAIR_VARIANTS(X) \
-  X(1, 1, 4, 1, 1) \
   X(1, 1, 5, 1, 1) \
   X(1, 2, 5, 1, 2) \
   X(1, 4, 5, 2, 2) \
@@ -167,7 +165,7 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   a.tab_off = a.red_off + 1024 * SF_FCONV_WAVES * WM * WN;
   a.misc_off = a.tab_off + 2 * Cs * 4;
   lds_bytes = a.misc_off + 640 + 2048;      // misc: 160 floats of statistics + 512 floats of reduction partials
-  if (lds_bytes > SF_LDS_MAX && !(op.flags & 32)) FC_FAIL("fconv: tile needs %u bytes of LDS", lds_bytes);
+  if (lds_bytes > SF_LDS_MAX) FC_FAIL("fconv: tile needs %u bytes of LDS", lds_bytes);
   const int MT = a.B * a.mt_per_img;
   a.xcd_map = (a.n_tiles % 8 == 0 && MT > 1) ? 1 : 0;
   grid = (uint32_t)a.S * MT * a.n_tiles;
@@ -182,7 +180,7 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
       FC_FAIL("fconv pipe: needs slot GroupNorm (8 groups), k = 3, one slice, a plain source, C %% 128 == 0, TW a power of two >= 4");
     a.logTW = 0;
     while ((1 << a.logTW) < a.TW) ++a.logTW;
-    a.d_fw = mk((uint32_t)(a.TW == a.W ? a.TW : a.TW + 2));                  // staged pixels per frame row
+    a.d_fw = mk((uint32_t)a.TW + 2);
     a.pix_stride = fconv_pix_stride(128);
     a.buf_bytes = (int)((((uint32_t)(a.TR + 2) * (a.TW + 2) + 1) * a.pix_stride + 15) & ~15u);
     a.red_off = 2 * a.buf_bytes;
@@ -195,7 +193,7 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
 #undef FC_FAIL
 }
 
-static inline int fconv_pipe_ept(const FConvArgs& a) { return ((a.TR + 2) * (a.TW == a.W ? a.TW : a.TW + 2) + 7) / 8; }
+static inline int fconv_pipe_ept(const FConvArgs& a) { return ((a.TR + 2) * (a.TW + 2) + 7) / 8; }
 
 // Pair = op1 (flags & 16) + the op after it: same tile shape, op2 un-normalised, same lazy mode (op2 with s1.p == null when lazy).
 static inline int fconv_pair_setup(const sf_op& op1, const sf_op& op2, FConvPairArgs& p, int& WM, int& WN, uint32_t& grid, uint32_t& lds_bytes,

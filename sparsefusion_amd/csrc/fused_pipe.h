@@ -85,31 +85,25 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
   // separate arrays the compiler keeps both alive across the role-independent code and allocates their SUM
   constexpr int NB = EPT <= 4 ? 4 : (EPT <= 6 ? 3 : 2);       // staging batches (chunks) in registers: ~16-24 float4 loads in flight per thread
   constexpr int NE = KPW * WN;                          // weight fragments per matrix wave and chunk
-  constexpr int RD = 18;                                // ring depth: 18 KB of weights in flight per matrix wave (NE = 9: two chunks
-                                                        // ahead -- one 128-channel chunk passes in less than an HBM round trip)
-  constexpr int RC = RD / NE > 0 ? RD / NE : 1;         // chunks the ring spans when NE <= RD (the chunk loop is unrolled by RC)
-  static_assert(NE == 9 || NE == 18 || NE == 36, "ring indexing below assumes NE in {9, 18, 36}");
+  constexpr int RD = NE > 18 ? 18 : NE;                 // ring depth (fragments in flight per matrix wave): 18 KB at most
   constexpr int NP = (RD > NB * EPT) ? RD : NB * EPT;
   f32x4 pool[NP];
 
   // ---- staging threads: a fixed float4 channel chunk (tcx) of every chunk, pixel lanes tp, tp + 8, ...
   const int ts = tid - NWM * 64;
   const int tcx = ts & 31, tp = ts >> 5;
-  // staged pixels per frame row: all FW columns of a partial-width tile (its halo columns are real pixels of the neighbouring
-  // tiles), only the TW in-image columns of a full-width one (its halo columns lie outside the image: zero-filled below)
-  const int sw = a.TW == a.W ? a.TW : FW, xoff = a.TW == a.W ? 1 : 0;
-  const int npx = FR * sw;                               // <= EPT * 8 (host-checked)
+  const int npx = FR * FW;                               // <= EPT * 8 (host-checked)
   const int m_safe = (int)mb + row0 * a.W + x0;          // the tile's first pixel: always inside the image
   int fpx[EPT];                                          // LDS pixel of element e (the spare pixel for dead elements)
   int mxo[EPT];                                          // source pixel of element e
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     const int pi = tp + e * 8;
-    const int fr = (int)fdiv((uint32_t)pi, a.d_fw), fx = pi - fr * sw + xoff;       // d_fw divides by sw
+    const int fr = (int)fdiv((uint32_t)pi, a.d_fw), fx = pi - fr * FW;
     const int r = row0 - 1 + fr, x = x0 - 1 + fx;
     const bool in = pi < npx && r >= 0 && r < a.H && x >= 0 && x < a.W;
     mxo[e] = in ? (int)mb + r * a.W + x : m_safe;
-    fpx[e] = in ? fr * FW + fx : FR * FW;
+    fpx[e] = in ? pi : FR * FW;
   }
   auto issue = [&](int c, const int vo) {
     const int cg = c * CC + tcx * 4;
@@ -168,10 +162,7 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
   // ---- first loads of every role go out before anything waits
   if (mx_role) {
 #pragma unroll
-    for (int g = 0; g < RD; ++g) {                       // global element g = chunk * NE + e (chunks clamped to the last one)
-      const int cg0 = (g / NE) < NCH ? (g / NE) : NCH - 1, e = g % NE;
-      pool[g] = __builtin_bit_cast(f32x4, wload(cg0, e / WN, e % WN));
-    }
+    for (int e = 0; e < RD; ++e) pool[e] = __builtin_bit_cast(f32x4, wload(0, e / WN, e % WN));
   } else {
 #pragma unroll
     for (int j = 0; j < NB - 1; ++j) issue(j < NCH ? j : NCH - 1, j * EPT);
@@ -282,33 +273,25 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
       abase[mi] = (ty * FW + tx) * pstr + (lane >> 4) * 16;
     }
     sf_sync();                                           // phase 0: chunk 0 is being staged
-    for (int c0 = 0; c0 < NCH; c0 += RC) {
+    for (int c = 0; c < NCH; ++c) {
+      const char* buf = lds + (c & 1) * a.buf_bytes;
+      const int cn = c + 1 < NCH ? c + 1 : NCH - 1;      // the last revolution reloads the last chunk: loads stay unconditional
 #pragma unroll
-      for (int cj = 0; cj < RC; ++cj) {
-        const int c = c0 + cj;
-        if (c < NCH) {                                     // uniform
-          const char* buf = lds + (c & 1) * a.buf_bytes;
+      for (int i = 0; i < KPW; ++i) {
+        bf16x8 fa[WM];
 #pragma unroll
-          for (int i = 0; i < KPW; ++i) {
-            bf16x8 fa[WM];
+        for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8*>(buf + abase[mi] + toff[i]);
 #pragma unroll
-            for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8*>(buf + abase[mi] + toff[i]);
+        for (int ni = 0; ni < WN; ++ni) {
+          const int e = i * WN + ni;                       // element of this chunk; ring slot e % RD
 #pragma unroll
-            for (int ni = 0; ni < WN; ++ni) {
-              const int e = i * WN + ni;                   // element of this chunk
-              const int slot = (cj * NE + e) % RD;         // static: c0 is a multiple of RC
-#pragma unroll
-              for (int mi = 0; mi < WM; ++mi) acc[mi][ni] = sf_mfma16(fa[mi], __builtin_bit_cast(bf16x8, pool[slot]), acc[mi][ni]);
-              // refill the slot with the fragment RD elements ahead (same chunk, or 1..RC chunks on; clamped: loads stay unconditional)
-              const int gn = e + RD;
-              int cnx = c + gn / NE;
-              if (cnx > NCH - 1) cnx = NCH - 1;
-              pool[slot] = __builtin_bit_cast(f32x4, wload(cnx, (gn % NE) / WN, (gn % NE) % WN));
-            }
-          }
-          sf_sync();
+          for (int mi = 0; mi < WM; ++mi) acc[mi][ni] = sf_mfma16(fa[mi], __builtin_bit_cast(bf16x8, pool[e % RD]), acc[mi][ni]);
+          // refill the slot with the fragment RD elements ahead: later in this chunk, or in the next one
+          const int en = e + RD;
+          pool[e % RD] = __builtin_bit_cast(f32x4, en < NE ? wload(c, en / WN, en % WN) : wload(cn, (en - NE) / WN, (en - NE) % WN));
         }
       }
+      sf_sync();
     }
   } else {
     // chunk c lives in register batch c % NB; the batch freed by chunk c - 1 is refilled with chunk c + NB - 1 before chunk c

@@ -24,9 +24,9 @@ OP_FCONV, OP_SLOTS, OP_GCA = 14, 15, 16
 # (WM, WN, norm of conv1) for which k_conv_fused_pair is instantiated (csrc/fused_host.h SF_FCONV_PAIR_VARIANTS); FNORM_GN_SELF = 1, _SLOTS = 2
 PAIR_TILES = {(1, 1, 1), (1, 1, 2), (1, 2, 2), (2, 2, 2)}
 # (WM, WN, (TR + 2) * W / 8) for which k_conv_fused_pipe is instantiated (SF_FCONV_PIPE_VARIANTS)
-PIPE_TILES = {(1, 1, 4), (1, 1, 5), (1, 2, 5), (1, 4, 5)}
+PIPE_TILES = {(1, 1, 5), (1, 2, 5), (1, 4, 5)}
 # (WM, WN, EPT of the pipelined conv1, WM2, WN2 of its res_conv) for which k_conv_fused_pipe_pair is instantiated
-PIPE_PAIR_TILES = {(1, 1, 4, 1, 1), (1, 1, 5, 1, 1), (1, 2, 5, 1, 2), (1, 4, 5, 2, 2), (1, 2, 5, 2, 2), (1, 1, 5, 1, 2)}
+PIPE_PAIR_TILES = {(1, 1, 5, 1, 1), (1, 2, 5, 1, 2), (1, 4, 5, 2, 2), (1, 2, 5, 2, 2), (1, 1, 5, 1, 2)}
 FNORM_NONE, FNORM_GN_SELF, FNORM_GN_SLOTS, FNORM_LN = range(4)      # csrc/fused_kernels.h
 LDS_MAX = 163840
 SKIP_SCALE = 2 ** -0.5            # scale_skip_connection (imagen_pytorch.py:1283)
@@ -392,7 +392,7 @@ class _Plan:
         MT = self.B * (H // TR) * (H // TW)
         n_frags = Cout // 16
         WN = next((w for w in (4, 2) if n_frags % w == 0 and MT * (n_frags // w) >= 256), 1)
-        ept = ((TR + 2) * (TW if TW == H else TW + 2) + 7) // 8        # full-width tiles stage their in-image columns only
+        ept = ((TR + 2) * (TW + 2) + 7) // 8
         return (TR, TW, WM, WN, ept) if (WM, WN, ept) in PIPE_TILES else None
 
     def ensure_slots(self, t):

@@ -68,7 +68,7 @@ def _audit(ops, name, sized=False):
                 nx = ops[kk + 1]
                 assert nx.type == unet.OP_FCONV and nx.i[12] == unet.FNORM_NONE and nx.i[17] == 1 and nx.i[9] == lmode and not (nx.flags & (16 | 32)), where + ": pair"
                 if o.flags & 32:
-                    assert (WM, WN, ((TR + 2) * (TW if TW == W else TW + 2) + 7) // 8, nx.i[15], nx.i[16]) in unet.PIPE_PAIR_TILES, where + ": pipelined pair variant"
+                    assert (WM, WN, ((TR + 2) * (TW + 2) + 7) // 8, nx.i[15], nx.i[16]) in unet.PIPE_PAIR_TILES, where + ": pipelined pair variant"
                 else:
                     assert list(nx.i)[15:17] == [WM, WN] and (WM, WN, norm) in unet.PAIR_TILES, where + ": pair variant"
             if second_of_pair:
@@ -94,7 +94,7 @@ def _audit(ops, name, sized=False):
             stride = Cs * 2 + ((32 - (Cs * 2) % 256) + 256) % 256
             if o.flags & 32:                                                    # k_conv_fused_pipe contract
                 assert norm == unet.FNORM_GN_SLOTS and k == 3 and S == 1 and lmode == 0 and C % 128 == 0 and G == 8, where
-                assert (WM, WN, ((TR + 2) * (TW if TW == W else TW + 2) + 7) // 8) in unet.PIPE_TILES and TW % 4 == 0 and TW & (TW - 1) == 0, where
+                assert (WM, WN, ((TR + 2) * (TW + 2) + 7) // 8) in unet.PIPE_TILES and TW % 4 == 0 and TW & (TW - 1) == 0, where
                 buf = (((TR + 2) * (TW + 2) + 1) * 288 + 15) // 16 * 16
                 assert 2 * buf + 4096 * WM * WN + 8 * C + 2688 <= unet.LDS_MAX, where
             else:
