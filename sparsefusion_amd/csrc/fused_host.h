@@ -6,7 +6,6 @@
 //      11 split-K slabs (S > 1)  12 slots_out  13 gamma / LN gain  14 beta / LN bias  15 scale_shift
 //      16 debug: [grid][8] int64 phase timestamps (100 MHz), normally null
 //      17 GlobalContext to_k weight [Cout]  18 partial context logits [S * n_frags][M]   (both or neither)
-//   i: 19 TW (pipelined kernel: tile width, 0 = W)
 //   i: 0 B  1 H  2 W  3 C1  4 C2  5 Cout  6 ldc  7 co_off  8 k (1 | 3)  9 s1.mode  10 s1.groups  11 s1.npad
 //      12 norm (FNORM_*)  13 G  14 TR (image rows per tile)  15 WM  16 WN  17 S (input-channel slices)  18 ss_stride
 //   flags: 1 SiLU after the norm, 2 GELU before the LayerNorm, 4 accumulate into out, 8 GELU on the final output,
@@ -44,18 +43,13 @@
   X(1, 1, 12, FNORM_LN, 1) \
   X(1, 2, 8, FNORM_LN, 0)
 
-// Pipelined slot-GroupNorm 3x3 convs (k_conv_fused_pipe, op flag 32): (WM, WN, EPT = ceil((TR + 2) * (TW + 2) / 8) staging elements per thread and chunk)
+// Pipelined slot-GroupNorm 3x3 convs (k_conv_fused_pipe, op flag 32): (WM, WN, EPT = (TR + 2) * W / 8 staging elements per thread and chunk)
 #define SF_FCONV_PIPE_VARIANTS(X) \
-  X(1, 1, 5) \
-  X(1, 2, 5) \
-  X(1, 4, 5)
-// conv1 (pipelined, tile WM x WN, EPT) || res_conv (k_conv_fused body NONE with ITS OWN tile WM2 x WN2: whole image rows)
-#define SF_FCONV_PIPE_PAIR_VARIANTS(X) \
-  X(1, 1, 5, 1, 1) \
-  X(1, 2, 5, 1, 2) \
-  X(1, 4, 5, 2, 2) \
-  X(1, 2, 5, 2, 2) \
-  X(1, 1, 5, 1, 2)
+  X(1, 1, 4) \
+  X(1, 1, 6) \
+  X(1, 2, 6) \
+  X(2, 1, 12) \
+  X(2, 2, 12)
 
 // Pairs (conv1 || res_conv in one launch, k_conv_fused_pair): (WM, WN, D, NORM of the first conv, LAZY of both)
 #define SF_FCONV_PAIR_VARIANTS(X) \
@@ -101,16 +95,14 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   if (a.W & (a.W - 1)) FC_FAIL("fconv: W must be a power of two");
   if (a.C % 32 || a.s1.C % 32 || a.s1.C <= 0 || a.s2.C < 0) FC_FAIL("fconv: channel counts must be multiples of 32");
   if (a.s2.C && !a.s2.p) FC_FAIL("fconv: second source missing");
-  a.TW = (op.flags & 32) && op.i[19] > 0 ? op.i[19] : a.W;           // 2-D pixel tiles: the pipelined kernel only
-  if (a.TR < 1 || a.H % a.TR || a.W % a.TW || a.TR * a.TW != 16 * WM) FC_FAIL("fconv: tile of %d rows x %d != 16*WM (WM=%d)", a.TR, a.TW, WM);
-  if (!((WM == 1 || WM == 2) && (WN == 1 || WN == 2 || ((op.flags & 32) && WN == 4)))) FC_FAIL("fconv: unsupported wave tile %dx%d", WM, WN);
+  if (a.TR < 1 || a.H % a.TR || a.TR * a.W != 16 * WM) FC_FAIL("fconv: tile of %d rows x %d != 16*WM (WM=%d)", a.TR, a.W, WM);
+  if (!((WM == 1 || WM == 2) && (WN == 1 || WN == 2))) FC_FAIL("fconv: unsupported wave tile %dx%d", WM, WN);
   a.cchunks = a.C / 32;
   if (a.cchunks % a.S) FC_FAIL("fconv: %d chunks do not split into %d slices", a.cchunks, a.S);
   a.cps = a.cchunks / a.S;
   a.KS = a.k * a.k * a.cchunks;
   a.M = a.B * a.H * a.W;
-  a.xt_per_row = a.W / a.TW;
-  a.mt_per_img = (a.H / a.TR) * a.xt_per_row;
+  a.mt_per_img = a.H / a.TR;
   a.n_frags = (a.Cout + 15) / 16;
   a.n_tiles = (a.n_frags + WN - 1) / WN;
   a.npad = a.n_frags * 16;
@@ -170,19 +162,13 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   a.xcd_map = (a.n_tiles % 8 == 0 && MT > 1) ? 1 : 0;
   grid = (uint32_t)a.S * MT * a.n_tiles;
   a.buf_bytes = 0;
-  a.logTW = 0;
-  while ((1 << a.logTW) < a.TW) ++a.logTW;
-  a.d_fw = mk((uint32_t)a.TW + 2);
   a.inv_n = (a.norm == FNORM_GN_SELF || a.norm == FNORM_GN_SLOTS) ? 1.0 / ((double)a.H * a.W * (a.C / a.G)) : 0.0;
   if (op.flags & 32) {       // k_conv_fused_pipe: 128-channel chunks, two frame buffers, 4 matrix + 4 staging waves
     if (a.norm != FNORM_GN_SLOTS || a.k != 3 || a.S != 1 || a.s1.mode != 0 || a.C % 128 || a.C > 4 * SF_FCONV_WAVES * 64 || a.G != 8 ||
-        a.TW % 4 || (a.TW & (a.TW - 1)))
-      FC_FAIL("fconv pipe: needs slot GroupNorm (8 groups), k = 3, one slice, a plain source, C %% 128 == 0, TW a power of two >= 4");
-    a.logTW = 0;
-    while ((1 << a.logTW) < a.TW) ++a.logTW;
-    a.d_fw = mk((uint32_t)a.TW + 2);
+        ((a.TR + 2) * a.W) % 8)
+      FC_FAIL("fconv pipe: needs slot GroupNorm (8 groups), k = 3, one slice, a plain source, C %% 128 == 0");
     a.pix_stride = fconv_pix_stride(128);
-    a.buf_bytes = (int)((((uint32_t)(a.TR + 2) * (a.TW + 2) + 1) * a.pix_stride + 15) & ~15u);
+    a.buf_bytes = (int)((((uint32_t)(a.TR + 2) * (a.W + 2) + 1) * a.pix_stride + 15) & ~15u);
     a.red_off = 2 * a.buf_bytes;
     a.tab_off = a.red_off + 1024 * (SF_FCONV_WAVES / 2) * WM * WN;
     a.misc_off = a.tab_off + 2 * a.C * 4;
@@ -193,17 +179,15 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
 #undef FC_FAIL
 }
 
-static inline int fconv_pipe_ept(const FConvArgs& a) { return ((a.TR + 2) * (a.TW + 2) + 7) / 8; }
+static inline int fconv_pipe_ept(const FConvArgs& a) { return (a.TR + 2) * a.W / 8; }
 
 // Pair = op1 (flags & 16) + the op after it: same tile shape, op2 un-normalised, same lazy mode (op2 with s1.p == null when lazy).
 static inline int fconv_pair_setup(const sf_op& op1, const sf_op& op2, FConvPairArgs& p, int& WM, int& WN, uint32_t& grid, uint32_t& lds_bytes,
-                                   char* err, size_t errn, int& WM2o, int& WN2o) {
+                                   char* err, size_t errn) {
   int WM2, WN2;
   uint32_t g1, g2, l1, l2;
   if (fconv_setup(op1, p.a, WM, WN, g1, l1, err, errn) || fconv_setup(op2, p.b, WM2, WN2, g2, l2, err, errn)) return 1;
-  const bool pipe = (op1.flags & 32) != 0;           // the pipelined first half has its own (2-D) tile: the halves need not match
-  WM2o = WM2; WN2o = WN2;
-  if (op2.type != SF_OP_FCONV || (!pipe && (WM2 != WM || WN2 != WN)) || p.b.norm != FNORM_NONE || p.b.s1.mode != p.a.s1.mode || (op2.flags & (16 | 32))) {
+  if (op2.type != SF_OP_FCONV || WM2 != WM || WN2 != WN || p.b.norm != FNORM_NONE || p.b.s1.mode != p.a.s1.mode || (op2.flags & 16)) {
     snprintf(err, errn, "fconv pair: the second op must be an un-normalised fconv of the same tile shape and lazy mode");
     return 1;
   }

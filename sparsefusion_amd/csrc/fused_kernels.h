@@ -72,8 +72,6 @@ struct FConvArgs {
   int red_off, tab_off, misc_off;    // LDS byte offsets
   double inv_n;                      // GroupNorm: 1 / (pixels per image * channels per group)
   int buf_bytes;                     // k_conv_fused_pipe: bytes of one of the two frame buffers (0 otherwise)
-  int TW, logTW, xt_per_row;         // k_conv_fused_pipe: tile width (TR x TW = 16 * WM pixels), tiles per image row
-  FDiv d_fw;                         //   frame width TW + 2
   const float* wk;                   // GlobalContext to_k weight [Cout] or null: the epilogue also emits partial context logits
   float* logit_part;                 //   logit_part[(s * n_frags + n_frag) * M + m] = sum over the fragment's 16 channels of value * wk
   long long* dbg;                    // optional [grid][8] phase timestamps (tools/fconv_phases.py), null in production

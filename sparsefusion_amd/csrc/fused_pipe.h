@@ -39,13 +39,9 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
     nt = bid % a.n_tiles;
     mt = bid / a.n_tiles;
   }
-  // 2-D pixel tiles: TR rows x TW columns = 16 * WM pixels.  The frame a workgroup normalises is (TR + 2) x (TW + 2) pixels,
-  // so a compact tile (2 x 8, frame 40 px) re-stages far fewer halo pixels than a full image row (1 x 32: frame 102 px).
   const int b = mt / a.mt_per_img;
-  const int t_img = mt - b * a.mt_per_img;               // tile of this image: also its 16-pixel slot block(s)
-  const int trow = t_img / a.xt_per_row;
-  const int row0 = trow * a.TR, x0 = (t_img - trow * a.xt_per_row) * a.TW;
-  const int FW = a.TW + 2, FR = a.TR + 2;
+  const int row0 = (mt - b * a.mt_per_img) * a.TR;
+  const int FW = a.W + 2, FR = a.TR + 2;
   const int HW = a.H * a.W;
   const long mb = (long)b * HW;
   const float sc1 = a.s1.scale, sc2 = a.s2.scale;
@@ -84,26 +80,25 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
   // ONE register pool for both roles (the ring of the matrix waves, the two staging batches of the others): declared as
   // separate arrays the compiler keeps both alive across the role-independent code and allocates their SUM
   constexpr int NB = EPT <= 4 ? 4 : (EPT <= 6 ? 3 : 2);       // staging batches (chunks) in registers: ~16-24 float4 loads in flight per thread
-  constexpr int NE = KPW * WN;                          // weight fragments per matrix wave and chunk
-  constexpr int RD = NE > 18 ? 18 : NE;                 // ring depth (fragments in flight per matrix wave): 18 KB at most
-  constexpr int NP = (RD > NB * EPT) ? RD : NB * EPT;
+  constexpr int NP = (KPW * WN > NB * EPT) ? KPW * WN : NB * EPT;
   f32x4 pool[NP];
 
   // ---- staging threads: a fixed float4 channel chunk (tcx) of every chunk, pixel lanes tp, tp + 8, ...
   const int ts = tid - NWM * 64;
   const int tcx = ts & 31, tp = ts >> 5;
-  const int npx = FR * FW;                               // <= EPT * 8 (host-checked)
-  const int m_safe = (int)mb + row0 * a.W + x0;          // the tile's first pixel: always inside the image
+  const int npx = FR << a.logW;                          // == EPT * 8 (host-checked)
+  const int M0 = (int)mb + (row0 - 1) * a.W;
+  const int pi_safe = 1 << a.logW;                       // first own row: always inside the image
   int fpx[EPT];                                          // LDS pixel of element e (the spare pixel for dead elements)
   int mxo[EPT];                                          // source pixel of element e
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     const int pi = tp + e * 8;
-    const int fr = (int)fdiv((uint32_t)pi, a.d_fw), fx = pi - fr * FW;
-    const int r = row0 - 1 + fr, x = x0 - 1 + fx;
-    const bool in = pi < npx && r >= 0 && r < a.H && x >= 0 && x < a.W;
-    mxo[e] = in ? (int)mb + r * a.W + x : m_safe;
-    fpx[e] = in ? pi : FR * FW;
+    const int fr = pi >> a.logW;
+    const int r = row0 - 1 + fr;
+    const bool in = pi < npx && r >= 0 && r < a.H;
+    mxo[e] = M0 + (in ? pi : pi_safe);
+    fpx[e] = in ? (pi + 2 * fr + 1) : FR * FW;
   }
   auto issue = [&](int c, const int vo) {
     const int cg = c * CC + tcx * 4;
@@ -162,7 +157,9 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
   // ---- first loads of every role go out before anything waits
   if (mx_role) {
 #pragma unroll
-    for (int e = 0; e < RD; ++e) pool[e] = __builtin_bit_cast(f32x4, wload(0, e / WN, e % WN));
+    for (int i = 0; i < KPW; ++i)
+#pragma unroll
+      for (int ni = 0; ni < WN; ++ni) pool[i * WN + ni] = __builtin_bit_cast(f32x4, wload(0, i, ni));
   } else {
 #pragma unroll
     for (int j = 0; j < NB - 1; ++j) issue(j < NCH ? j : NCH - 1, j * EPT);
@@ -185,13 +182,12 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
   }
   // epilogue operands of the finalising waves (matrix waves 0 .. F-1)
   constexpr int F = WM * WN;
+  const long m0 = mb + (long)row0 * a.W;
   const int my_mi = wave / WN, my_ni = wave - my_mi * WN;
   const int my_nf = nt * WN + my_ni;
   const bool fin = wave < F && my_nf < a.n_frags;
   const int n = my_nf * 16 + (lane & 15);
-  const int p0 = my_mi * 16 + (lane >> 4) * 4;           // this lane's 4 tile pixels p0..p0+3: one tile row (TW % 4 == 0)
-  const long mrow = mb + (long)(row0 + (p0 >> a.logTW)) * a.W + x0 + (p0 & (a.TW - 1));
-  const long slot_mf = (long)b * (HW >> 4) + (long)t_img * WM + my_mi;     // any bijection tile -> 16-pixel slot block of the image
+  const long mrow = m0 + my_mi * 16 + (lane >> 4) * 4;
   float bv = 0.0f, rv[4] = {0.f, 0.f, 0.f, 0.f}, wkv = 0.0f;
   if (fin && n < a.Cout) {
     if (a.logit_part) wkv = a.wk[n];
@@ -210,7 +206,7 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
     const int npix = FR * FW;
     for (int q = tid >> 3; q < npix; q += NT / 8) {
       const int fr = q / FW, fx = q - fr * FW;
-      const int r = row0 - 1 + fr, x = x0 - 1 + fx;
+      const int r = row0 - 1 + fr, x = fx - 1;
       if (r < 0 || r >= a.H || x < 0 || x >= a.W) {
         char* dst = lds + (long)q * pstr;
         for (int c8 = (tid & 7); c8 < CC / 8; c8 += 8) {
@@ -269,7 +265,7 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
 #pragma unroll
     for (int mi = 0; mi < WM; ++mi) {
       const int p = mi * 16 + (lane & 15);
-      const int ty = p >> a.logTW, tx = p & (a.TW - 1);
+      const int ty = p >> a.logW, tx = p - (ty << a.logW);
       abase[mi] = (ty * FW + tx) * pstr + (lane >> 4) * 16;
     }
     sf_sync();                                           // phase 0: chunk 0 is being staged
@@ -282,14 +278,11 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8*>(buf + abase[mi] + toff[i]);
 #pragma unroll
-        for (int ni = 0; ni < WN; ++ni) {
-          const int e = i * WN + ni;                       // element of this chunk; ring slot e % RD
+        for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
-          for (int mi = 0; mi < WM; ++mi) acc[mi][ni] = sf_mfma16(fa[mi], __builtin_bit_cast(bf16x8, pool[e % RD]), acc[mi][ni]);
-          // refill the slot with the fragment RD elements ahead: later in this chunk, or in the next one
-          const int en = e + RD;
-          pool[e % RD] = __builtin_bit_cast(f32x4, en < NE ? wload(c, en / WN, en % WN) : wload(cn, (en - NE) / WN, (en - NE) % WN));
-        }
+          for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = sf_mfma16(fa[mi], __builtin_bit_cast(bf16x8, pool[i * WN + ni]), acc[mi][ni]);
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) pool[i * WN + ni] = __builtin_bit_cast(f32x4, wload(cn, i, ni));
       }
       sf_sync();
     }
@@ -357,9 +350,7 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
       sm = sf_wave_sum(sm);
       sq = sf_wave_sum(sq);
       if (lane == 0) {
-        // the slot table is only ever summed per (image, group): which 16-pixel block of the image a tile's sums are filed
-        // under is immaterial, as long as every block is written exactly once
-        float* slo = a.slots_out + (slot_mf * (long)(a.ldc >> 4) + (a.co_off >> 4) + my_nf) * 2;
+        float* slo = a.slots_out + (((m0 >> 4) + my_mi) * (long)(a.ldc >> 4) + (a.co_off >> 4) + my_nf) * 2;
         slo[0] = sm;
         slo[1] = sq;
       }
@@ -375,11 +366,10 @@ SF_KERNEL(NW * 64) void k_conv_fused_pipe(FConvArgs a) {
   conv_fused_pipe_body<WM, WN, EPT, NW>(a, (int)blockIdx.x);
 }
 
-// conv1 (pipelined, 2-D tile WM x WN) || res_conv (plain 1x1, k_conv_fused body with its own whole-row tile WM2 x WN2) of one
-// ResnetBlock in one launch: see k_conv_fused_pair.
-template <int WM, int WN, int EPT, int WM2, int WN2, int NW>
+// conv1 (pipelined) || res_conv (plain 1x1, k_conv_fused body) of one ResnetBlock in one launch: see k_conv_fused_pair.
+template <int WM, int WN, int EPT, int NW>
 SF_KERNEL(NW * 64) void k_conv_fused_pipe_pair(FConvPairArgs p) {
   sf_touch_kernarg<(int)sizeof(FConvPairArgs)>();
-  if ((int)blockIdx.x < p.grid_b) conv_fused_body<WM2, WN2, (WM2 * WN2 == 1 ? 12 : 8), FNORM_NONE, 0, NW>(p.b, (int)blockIdx.x);
+  if ((int)blockIdx.x < p.grid_b) conv_fused_body<WM, WN, (WM * WN == 1 ? 12 : 8), FNORM_NONE, 0, NW>(p.b, (int)blockIdx.x);
   else conv_fused_pipe_body<WM, WN, EPT, NW>(p.a, (int)blockIdx.x - p.grid_b);
 }

@@ -61,11 +61,11 @@ static int launch_fconv_pair(const FConvPairArgs& p, uint32_t grid, uint32_t lds
   return SF_OK;
 }
 
-template <int WM, int WN, int EPT, int WM2, int WN2>
+template <int WM, int WN, int EPT>
 static int launch_fconv_pipe_pair(const FConvPairArgs& p, uint32_t grid, uint32_t lds, hipStream_t st) {
   static unsigned mask = 0;
-  if (int rc = allow_big_lds(k_conv_fused_pipe_pair<WM, WN, EPT, WM2, WN2, SF_FCONV_WAVES>, lds, mask)) return rc;
-  k_conv_fused_pipe_pair<WM, WN, EPT, WM2, WN2, SF_FCONV_WAVES><<<grid, SF_FCONV_WAVES * 64, lds, st>>>(p);
+  if (int rc = allow_big_lds(k_conv_fused_pipe_pair<WM, WN, EPT, SF_FCONV_WAVES>, lds, mask)) return rc;
+  k_conv_fused_pipe_pair<WM, WN, EPT, SF_FCONV_WAVES><<<grid, SF_FCONV_WAVES * 64, lds, st>>>(p);
   SF_CHECK_LAUNCH("conv_fused_pipe_pair");
   return SF_OK;
 }
@@ -74,15 +74,13 @@ int sf_plan_fused_pair(const sf_op* op1, const sf_op* op2, void* stream) {
   FConvPairArgs p;
   int WM, WN;
   uint32_t grid, lds;
-  int WM2, WN2;
-  if (fconv_pair_setup(*op1, *op2, p, WM, WN, grid, lds, sf_err_buf, sizeof(sf_err_buf), WM2, WN2)) return SF_ERR_INVALID;
+  if (fconv_pair_setup(*op1, *op2, p, WM, WN, grid, lds, sf_err_buf, sizeof(sf_err_buf))) return SF_ERR_INVALID;
   if (op1->flags & 32) {
     const int EPT = fconv_pipe_ept(p.a);
-#define SF_TRYP(wm, wn, ept, wm2, wn2) \
-    if (WM == wm && WN == wn && EPT == ept && WM2 == wm2 && WN2 == wn2) return launch_fconv_pipe_pair<wm, wn, ept, wm2, wn2>(p, grid, lds, (hipStream_t)stream);
-    SF_FCONV_PIPE_PAIR_VARIANTS(SF_TRYP)
+#define SF_TRYP(wm, wn, ept) if (WM == wm && WN == wn && EPT == ept) return launch_fconv_pipe_pair<wm, wn, ept>(p, grid, lds, (hipStream_t)stream);
+    SF_FCONV_PIPE_VARIANTS(SF_TRYP)
 #undef SF_TRYP
-    SF_FAIL(SF_ERR_INVALID, "fconv pipe pair: no kernel variant for tiles %dx%d (%d staging elements) + %dx%d", WM, WN, EPT, WM2, WN2);
+    SF_FAIL(SF_ERR_INVALID, "fconv pipe pair: no kernel variant for tile %dx%d, %d staging elements", WM, WN, EPT);
   }
 #define SF_TRY(wm, wn, d, nm_, lz_) \
   if (WM == wm && WN == wn && p.a.norm == nm_ && p.a.s1.mode == lz_) return launch_fconv_pair<wm, wn, d, nm_, lz_>(p, grid, lds, (hipStream_t)stream);

@@ -24,9 +24,7 @@ OP_FCONV, OP_SLOTS, OP_GCA = 14, 15, 16
 # (WM, WN, norm of conv1) for which k_conv_fused_pair is instantiated (csrc/fused_host.h SF_FCONV_PAIR_VARIANTS); FNORM_GN_SELF = 1, _SLOTS = 2
 PAIR_TILES = {(1, 1, 1), (1, 1, 2), (1, 2, 2), (2, 2, 2)}
 # (WM, WN, (TR + 2) * W / 8) for which k_conv_fused_pipe is instantiated (SF_FCONV_PIPE_VARIANTS)
-PIPE_TILES = {(1, 1, 5), (1, 2, 5), (1, 4, 5)}
-# (WM, WN, EPT of the pipelined conv1, WM2, WN2 of its res_conv) for which k_conv_fused_pipe_pair is instantiated
-PIPE_PAIR_TILES = {(1, 1, 5, 1, 1), (1, 2, 5, 1, 2), (1, 4, 5, 2, 2), (1, 2, 5, 2, 2), (1, 1, 5, 1, 2)}
+PIPE_TILES = {(1, 1, 4), (1, 1, 6), (1, 2, 6), (2, 1, 12), (2, 2, 12)}
 FNORM_NONE, FNORM_GN_SELF, FNORM_GN_SLOTS, FNORM_LN = range(4)      # csrc/fused_kernels.h
 LDS_MAX = 163840
 SKIP_SCALE = 2 ** -0.5            # scale_skip_connection (imagen_pytorch.py:1283)
@@ -382,19 +380,6 @@ class _Plan:
         WN = 2 if (n_frags % 2 == 0 and MT * (n_frags // 2) * S >= 256 and lds_bytes(S, 2) <= LDS_MAX and norm != FNORM_GN_SELF) else 1
         return TR, WM, WN, S
 
-    def pipe_tile(self, H, C, Cout, norm, k):
-        """(TR, TW, WM, WN, EPT) of a k_conv_fused_pipe launch -- 2 x 8 pixel tiles (frame 4 x 10: the least halo re-staging of
-        the 16-pixel shapes), as many output fragments per workgroup as still leave >= 256 workgroups -- or None."""
-        if not (getattr(self.u, "fconv_pipe", False) and norm == FNORM_GN_SLOTS and k == 3 and H >= 8 and H % 8 == 0 and C % 128 == 0
-                and Cout % 16 == 0 and C <= 2048):
-            return None
-        TR, TW, WM = 2, 8, 1
-        MT = self.B * (H // TR) * (H // TW)
-        n_frags = Cout // 16
-        WN = next((w for w in (4, 2) if n_frags % w == 0 and MT * (n_frags // w) >= 256), 1)
-        ept = ((TR + 2) * (TW + 2) + 7) // 8
-        return (TR, TW, WM, WN, ept) if (WM, WN, ept) in PIPE_TILES else None
-
     def ensure_slots(self, t):
         """Make `t` a materialised tensor with a (sum, sum of squares) slot table (one launch when it has none)."""
         if t.slots is not None and t.lazy is None:
@@ -418,14 +403,12 @@ class _Plan:
 
     def fconv(self, x, skip, H, wname, bname, out, Cout, k, norm, geom, gname=None, ss_ptr=0, silu=True, resid=None,
               want_slots=False, pre_gelu=False, beta_name=None, ldc=None, co_off=0, logit=None, out_gelu=False,
-              pair_first=False, pair_lazy=None, use_pipe=True):
+              pair_first=False, pair_lazy=None):
         """One k_conv_fused launch: out = conv_k(act(norm(concat(x, skip * 2^-1/2)))).  With S > 1 input-channel slices the
         output stays a lazy split-K tensor (slabs + bias + resid) that the next fused conv / GroupNorm / gca pass reduces."""
         TR, WM, WN, S = geom
         B = self.B
         C1, C2 = x.C, (skip.C if skip else 0)
-        TW = 0
-        pt = self.pipe_tile(H, C1 + C2, Cout, norm, k) if (use_pipe and S == 1 and silu and pair_lazy is None and C1 % 4 == 0) else None
         self.need(skip)
         self.need(resid)
         if norm == FNORM_GN_SLOTS:
@@ -463,15 +446,15 @@ class _Plan:
         bet = self.wptr(gname + ".bias") if norm in (FNORM_GN_SELF, FNORM_GN_SLOTS) else (self.wptr(beta_name) if beta_name else 0)
         assert not (out_gelu and S > 1)
         # staging and matrix work overlapped inside the workgroup (k_conv_fused_pipe) where the layer fits that kernel
-        pipe = pt is not None and li[0] == 0
-        if pipe:
-            TR, TW, WM, WN = pt[:4]
+        pipe = (getattr(self.u, "fconv_pipe", False) and norm == FNORM_GN_SLOTS and k == 3 and S == 1 and li[0] == 0 and silu
+                and (C1 + C2) % 128 == 0 and C1 % 4 == 0 and ((TR + 2) * H) % 8 == 0 and (WM, WN, (TR + 2) * H // 8) in PIPE_TILES
+                and pair_lazy is None)
         self.op(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0) | (8 if out_gelu else 0) | (16 if pair_first else 0)
                 | (32 if pipe else 0),
                 p=(x_ptr, lp[0], lp[1], lp[2], x.slots or 0, skip.ptr if skip else 0, (skip.slots or 0) if skip else 0,
                    self.wptr(wname), 0 if S > 1 else bias, out.ptr, 0 if S > 1 else res, ws, slots_out, gam, bet, ss_ptr, 0,
                    logit[0] if logit else 0, logit[1] if logit else 0),
-                i=(B, H, H, C1, C2, Cout, ldc, co_off, k, li[0], li[1], li[2], norm, 8, TR, WM, WN, S, self.u.tb_stride, TW),
+                i=(B, H, H, C1, C2, Cout, ldc, co_off, k, li[0], li[1], li[2], norm, 8, TR, WM, WN, S, self.u.tb_stride),
                 f=(1e-5, 1.0, SKIP_SCALE))
         if S > 1:
             out.lazy = ("splitk", ws, bias, res, S, n_frags * 16, wi)
@@ -494,15 +477,10 @@ class _Plan:
         slots = norm == FNORM_GN_SLOTS
         h = self.zf32(rows, cout, HW)
         # conv1 and res_conv read the same input and are independent: one launch (k_conv_fused_pair) when their tiles match
-        pt1 = self.pipe_tile(H, cin, cout, norm, 3) if (x.lazy is None and x.C % 4 == 0) else None
-        if pt1 is not None:                                         # pipelined conv1: its res_conv keeps a whole-row tile of its own
-            pair = (cin != cout and getattr(self.u, "pair_res_conv", True) and gr[3] == 1
-                    and (pt1[2], pt1[3], pt1[4], gr[1], gr[2]) in PIPE_PAIR_TILES)
-        else:
-            pair = (cin != cout and getattr(self.u, "pair_res_conv", True) and g1[1:3] == gr[1:3] and gr[3] == 1
-                    and (g1[1], g1[2], norm) in PAIR_TILES)
+        pair = (cin != cout and getattr(self.u, "pair_res_conv", True) and g1[1:3] == gr[1:3] and gr[3] == 1
+                and (g1[1], g1[2], norm) in PAIR_TILES)
         lz = self.fconv(x, skip, H, f"{name}.block1.project.weight", f"{name}.block1.project.bias", h, cout, 3, norm, g1,
-                        gname=f"{name}.block1.groupnorm", want_slots=slots, pair_first=pair, use_pipe=pt1 is not None or x.lazy is None)
+                        gname=f"{name}.block1.groupnorm", want_slots=slots, pair_first=pair)
         rc = None
         if cin != cout:                                             # res_conv reads the raw concat (x is materialised by conv1)
             rc = self.zf32(rows, cout, HW)

@@ -23,18 +23,17 @@ static int emu_run_pair(const sf_op* op1, const sf_op* op2, char* err, int errn)
   FConvPairArgs p;
   int WM, WN;
   uint32_t grid, lds;
-  int WM2, WN2;
-  if (fconv_pair_setup(*op1, *op2, p, WM, WN, grid, lds, err, (size_t)errn, WM2, WN2)) return 1;
+  if (fconv_pair_setup(*op1, *op2, p, WM, WN, grid, lds, err, (size_t)errn)) return 1;
   if (op1->flags & 32) {
     const int EPT = fconv_pipe_ept(p.a);
-#define SF_TRYP(wm, wn, ept, wm2, wn2) \
-    if (WM == wm && WN == wn && EPT == ept && WM2 == wm2 && WN2 == wn2) { \
-      hipemu::launch(grid, SF_FCONV_WAVES * 64, lds, [&] { k_conv_fused_pipe_pair<wm, wn, ept, wm2, wn2, SF_FCONV_WAVES>(p); }); \
+#define SF_TRYP(wm, wn, ept) \
+    if (WM == wm && WN == wn && EPT == ept) { \
+      hipemu::launch(grid, SF_FCONV_WAVES * 64, lds, [&] { k_conv_fused_pipe_pair<wm, wn, ept, SF_FCONV_WAVES>(p); }); \
       return 0; \
     }
-    SF_FCONV_PIPE_PAIR_VARIANTS(SF_TRYP)
+    SF_FCONV_PIPE_VARIANTS(SF_TRYP)
 #undef SF_TRYP
-    snprintf(err, errn, "fconv pipe pair: no kernel variant for tiles %dx%d (%d staging elements) + %dx%d", WM, WN, EPT, WM2, WN2);
+    snprintf(err, errn, "fconv pipe pair: no kernel variant for tile %dx%d, %d staging elements", WM, WN, EPT);
     return 1;
   }
 #define SF_TRY(wm, wn, d, nm_, lz_) \

@@ -60,21 +60,17 @@ def _audit(ops, name, sized=False):
             n_conv += 1
             B, H, W, C1, C2, Cout, ldc, co_off, k, lmode, lgroups, npad, norm, G, TR, WM, WN, S = list(o.i)[:18]
             C = C1 + C2
-            TW = o.i[19] if (o.flags & 32) and o.i[19] else W
             second_of_pair = kk > 0 and ops[kk - 1].type == unet.OP_FCONV and (ops[kk - 1].flags & 16)
             # the res_conv half of a pair reads a lazy source without materialising it (p[0] null): only there
             assert (o.p[0] or (second_of_pair and lmode)) and o.p[7] and (o.p[9] or S > 1), where
             if o.flags & 16:
                 nx = ops[kk + 1]
-                assert nx.type == unet.OP_FCONV and nx.i[12] == unet.FNORM_NONE and nx.i[17] == 1 and nx.i[9] == lmode and not (nx.flags & (16 | 32)), where + ": pair"
-                if o.flags & 32:
-                    assert (WM, WN, ((TR + 2) * (TW + 2) + 7) // 8, nx.i[15], nx.i[16]) in unet.PIPE_PAIR_TILES, where + ": pipelined pair variant"
-                else:
-                    assert list(nx.i)[15:17] == [WM, WN] and (WM, WN, norm) in unet.PAIR_TILES, where + ": pair variant"
+                assert nx.type == unet.OP_FCONV and nx.i[12] == unet.FNORM_NONE and list(nx.i)[15:18] == [WM, WN, 1] and nx.i[9] == lmode, where + ": pair"
+                assert (WM, WN, norm) in unet.PAIR_TILES and not (nx.flags & 16), where + ": pair variant"
             if second_of_pair:
                 assert norm == unet.FNORM_NONE and list(o.p)[1:4] == list(ops[kk - 1].p)[1:4], where + ": pair halves read the same source"
-            assert C % 32 == 0 and C1 % 32 == 0 and k in (1, 3) and TR * TW == 16 * WM and H % TR == 0 and W % TW == 0, where
-            assert (C // 32) % S == 0 and WM in (1, 2) and WN in (1, 2, 4) and (WN < 4 or (o.flags & 32)), where
+            assert C % 32 == 0 and C1 % 32 == 0 and k in (1, 3) and TR * W == 16 * WM and H % TR == 0, where
+            assert (C // 32) % S == 0 and WM in (1, 2) and WN in (1, 2), where
             if S > 1:
                 assert (o.p[11] or not sized) and not (o.flags & 4) and not o.p[12], where + ": sliced convs write slabs only"
             if norm in (unet.FNORM_GN_SELF, unet.FNORM_GN_SLOTS):
@@ -94,8 +90,8 @@ def _audit(ops, name, sized=False):
             stride = Cs * 2 + ((32 - (Cs * 2) % 256) + 256) % 256
             if o.flags & 32:                                                    # k_conv_fused_pipe contract
                 assert norm == unet.FNORM_GN_SLOTS and k == 3 and S == 1 and lmode == 0 and C % 128 == 0 and G == 8, where
-                assert (WM, WN, ((TR + 2) * (TW + 2) + 7) // 8) in unet.PIPE_TILES and TW % 4 == 0 and TW & (TW - 1) == 0, where
-                buf = (((TR + 2) * (TW + 2) + 1) * 288 + 15) // 16 * 16
+                assert (WM, WN, (TR + 2) * W // 8) in unet.PIPE_TILES and ((TR + 2) * W) % 8 == 0, where
+                buf = (((TR + 2) * (W + 2) + 1) * 288 + 15) // 16 * 16
                 assert 2 * buf + 4096 * WM * WN + 8 * C + 2688 <= unet.LDS_MAX, where
             else:
                 assert ((TR + 2 * h) * (W + 2 * h) + 1) * stride + 8192 * WM * WN + 8 * Cs + 2688 <= unet.LDS_MAX, where
