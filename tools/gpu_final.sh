@@ -16,6 +16,7 @@ cp $(find /tmp/rp1 -name "*kernel_stats.csv" | head -1) $O/r02_unet_eval_b1_kern
 cp $(find /tmp/rp2 -name "*kernel_stats.csv" | head -1) $O/r02_bench_kernel_stats.csv
 cp $(find /tmp/rpn -name "*kernel_stats.csv" | head -1) $O/r02_ngp_microbench_kernel_stats.csv
 bash tools/gpu_unet_pmc.sh ${1:-final} > $O/pmc.log 2>&1
+bash tools/gpu_pmc2.sh ${1:-final} > $O/pmc2.log 2>&1
 SF_TIMING_LIB=sparsefusion_amd/libsf_fused_timing.so python tools/fconv_phases.py 2>&1 | grep -v amdgpu.ids > $O/r02_fconv_phases.log
 python tools/occ_eval_time.py > $O/occ_eval.log 2>&1
 python tools/unet_time.py 1 > $O/unet_time1.log 2>&1
@@ -23,5 +24,5 @@ python tools/unet_time.py 4 > $O/unet_time4.log 2>&1
 python tools/vae_time.py 1 > $O/vae_time.log 2>&1
 for f in bench_n1 bench_n1_views4 bench_n1_total32; do tail -n 1 $O/$f.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$f', {k:d[k] for k in ('value','ms_per_step','scaling')}, d.get('breakdown_ms'))"; done
 grep "^# launches" $O/r02_unet_eval_b1_timeline.txt; tail -n 2 $O/unet_time1.log $O/unet_time4.log $O/occ_eval.log $O/vae_time.log
-tail -4 $O/pmc.log
+tail -4 $O/pmc.log; tail -22 $O/pmc2.log
 head -8 $O/r02_bench_kernel_stats.csv | cut -c1-120
