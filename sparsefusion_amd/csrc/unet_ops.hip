@@ -1182,6 +1182,7 @@ static int plan_run_impl(const sf_op* ops, uint32_t n_ops, hipStream_t st, hipEv
       case SF_OP_POOL:
       case SF_OP_LPIPS: rc = sf_plan_extra_op(&op, st); break;
       case SF_OP_EFT: rc = sf_plan_eft_op(&op, st); break;
+      case SF_OP_INITX: rc = sf_plan_initx_op(&op, st); break;
       case SF_OP_FCONV:
         if (op.flags & 16) {                           // conv1 || res_conv of a ResnetBlock: one launch for this op and the next
           if (k + 1 >= n_ops) SF_FAIL(SF_ERR_INVALID, "plan: a paired fconv needs a successor");

@@ -20,7 +20,7 @@ import torch.nn as nn
 from . import _lib
 
 OP_CONV, OP_GN_ACT, OP_LN, OP_GEMV, OP_ATTN, OP_GCA_POOL, OP_ELTWISE, OP_MEMSET, OP_TIME_EMB, OP_SPLITK_REDUCE = range(1, 11)
-OP_FCONV, OP_SLOTS, OP_GCA = 14, 15, 16
+OP_FCONV, OP_SLOTS, OP_GCA, OP_INITX = 14, 15, 16, 17
 # (WM, WN, norm of conv1) for which k_conv_fused_pair is instantiated (csrc/fused_host.h SF_FCONV_PAIR_VARIANTS); FNORM_GN_SELF = 1, _SLOTS = 2
 PAIR_TILES = {(1, 1, 1), (1, 1, 2), (1, 2, 2), (2, 2, 2)}
 # (WM, WN, (TR + 2) * W / 8) for which k_conv_fused_pipe is instantiated (SF_FCONV_PIPE_VARIANTS)
@@ -784,13 +784,24 @@ class _Plan:
         # keeps the result (bias included) in `base`; an eval then only convolves the 4 latent channels and adds `base`.
         self.x0, self.base = x, self.f32(B * HW, u.dim, HW)
         full_ops, full_written, self.ops, self.written = self.ops, self.written, [], set()
-        xin_x = self.f32(B * HW, 32, HW)
-        self.op(OP_ELTWISE, 2, p=(self.x_in.ptr, self.x_in.ptr, 0, xin_x.ptr), i=(B, HW, 0, u.channels, 32))
-        co = 0
-        for i, k in enumerate((3, 7, 15)):
-            cw = u.spec_shapes[f"init_conv.convs.{i}.weight"][0]
-            self.conv(xin_x, True, R, R, f"__init_x__.{i}", None, x, u.dim, co, cw, k, 1, k // 2, resid=self.base)
-            co += cw
+        cws = [u.spec_shapes[f"init_conv.convs.{i}.weight"][0] for i in range(3)]
+        if (getattr(u, "initx_direct", True) and u.fused and R % 8 == 0 and u.channels <= 8 and cws[0] % 32 == 0 and cws[1] % 8 == 0
+                and cws[2] % 2 == 0 and u.dim % 2 == 0):
+            # ONE direct-convolution launch on the vector units (csrc/initx.hip) instead of pack + 3 implicit GEMMs + reduce
+            offs, woffs, acc_o, acc_w = [], [], 0, 0
+            for cw, k in zip(cws, (3, 7, 15)):
+                offs.append(acc_o); woffs.append(acc_w)
+                acc_o += cw; acc_w += u.channels * k * k * cw
+            self.op(OP_INITX, 0, p=(self.x_in.ptr, self.base.ptr, self.wptr("__init_xw__"), x.ptr),
+                    i=(B, R, R, u.channels, u.dim, cws[0], cws[1], cws[2], offs[0], offs[1], offs[2], woffs[0], woffs[1], woffs[2]))
+        else:
+            xin_x = self.f32(B * HW, 32, HW)
+            self.op(OP_ELTWISE, 2, p=(self.x_in.ptr, self.x_in.ptr, 0, xin_x.ptr), i=(B, HW, 0, u.channels, 32))
+            co = 0
+            for i, k in enumerate((3, 7, 15)):
+                cw = cws[i]
+                self.conv(xin_x, True, R, R, f"__init_x__.{i}", None, x, u.dim, co, cw, k, 1, k // 2, resid=self.base)
+                co += cw
         self.init_x_ops, self.ops, self.written = self.ops, full_ops, full_written
         hiddens = []
         H = R
@@ -938,6 +949,7 @@ class Unet(nn.Module):
         self.fused = os.environ.get("SF_UNET_FUSED", "1") != "0"
         self.pair_res_conv = os.environ.get("SF_PAIR", "1") != "0"      # conv1 || res_conv of a ResnetBlock in one launch
         self.gca_poolnet = os.environ.get("SF_POOLNET", "0") != "0"     # GlobalContext pooling + net.0 in one launch on the 4x4 / 8x8 maps: measured SLOWER (1.428 vs 1.367 ms per eval: every workgroup re-reads the whole map), kept as an A/B switch
+        self.initx_direct = os.environ.get("SF_INITX", "1") != "0"      # latent half of the init conv as one direct-convolution launch
         self.fconv_pipe = os.environ.get("SF_PIPE", "1") != "0"         # slot-GroupNorm 3x3 convs on k_conv_fused_pipe (staging || matrix work)
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches
         self._pack_cache = None
@@ -1064,6 +1076,9 @@ class Unet(nn.Module):
             buf = torch.empty(lib.sf_conv_packed_elems(co, 32, kh, kw), dtype=torch.int16)
             _lib.check(lib.sf_conv_pack_weights(w4.data_ptr(), co, ci, 32, kh, kw, buf.data_ptr()), "pack init x")
             packed[f"__init_x__.{i}"] = buf.to(device)
+        # the same slices as fp32 [tap = (ci, ky, kx)][channel] tables for the direct init-x conv (csrc/initx.hip)
+        packed["__init_xw__"] = torch.cat([sd[f"init_conv.convs.{i}.weight"].float().cpu()[:, self.cond_images_channels:]
+                                           .permute(1, 2, 3, 0).reshape(-1) for i in range(3)]).contiguous().to(device)
         packed["__time_mlps__.weight"] = self._gemv_pack(torch.cat(tm_w, 0), device)
         packed["__time_mlps__.bias"] = torch.cat(tm_b, 0).to(device)
         self._pack_cache = (str(device), packed)

@@ -324,3 +324,25 @@ def test_plms_update_kernels():
         mean, _, logvar = unet_ref.q_posterior(xs, x, tb, tnb)
         ref = mean + (0.0 if tn == 0 else 1.0) * (0.5 * logvar).exp() * nz
         assert torch.allclose(x0.cpu(), xs, rtol=1e-6, atol=1e-6) and torch.allclose(xp.cpu(), ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,R,Cx", [(1, 32, 4), (2, 16, 3)])
+def test_init_x_direct_conv(B, R, Cx):
+    """SF_OP_INITX (csrc/initx.hip): x0 = base + CrossEmbed(x) for the latent channels, three convs k = 3 / 7 / 15 into channel
+    slices (external/imagen_pytorch.py:1017-1042), fp32 direct convolution vs torch conv2d."""
+    g = torch.Generator().manual_seed(11)
+    cws, ks = (128, 64, 64), (3, 7, 15)
+    dim = sum(cws)
+    x = torch.randn(B, Cx, R, R, generator=g)
+    ws = [torch.randn(cw, Cx, k, k, generator=g) / (Cx * k * k) ** 0.5 for cw, k in zip(cws, ks)]
+    base = torch.randn(B * R * R, dim, generator=g)
+    want = torch.cat([F.conv2d(x, w, padding=k // 2) for w, k in zip(ws, ks)], 1).permute(0, 2, 3, 1).reshape(B * R * R, dim) + base
+    wt = torch.cat([w.permute(1, 2, 3, 0).reshape(-1) for w in ws]).contiguous().to(DEV)      # [tap = (ci, ky, kx)][channel]
+    offs, woffs, ao, aw = [], [], 0, 0
+    for cw, k in zip(cws, ks):
+        offs.append(ao); woffs.append(aw)
+        ao += cw; aw += Cx * k * k * cw
+    xd, bd = x.to(DEV), base.to(DEV)
+    out = torch.full((B * R * R, dim), float("nan"), device=DEV)
+    _run([_op(17, 0, p=(xd, bd, wt, out), i=(B, R, R, Cx, dim) + cws + tuple(offs) + tuple(woffs))])
+    assert torch.allclose(out.cpu(), want, rtol=1e-4, atol=1e-4), float((out.cpu() - want).abs().max())
