@@ -6,7 +6,7 @@
 // 7/8 of every MFMA k-step multiplying zeros, a split-K reduction -- five dependent launches, ~45 us, for 0.3 GFLOP.  It is a
 // direct convolution on the vector units instead: one workgroup = four waves on one 8 x 8 pixel tile, whose haloed 4-channel
 // patch (22 x 22 x 4 floats) sits in LDS; a wave = one (conv, QC output channels) unit: lane <-> pixel, QC accumulators per
-// lane, the weights of the unit are WAVE-UNIFORM (scalar loads, [tap][channel] layout) -- per tap one LDS read and QC
+// lane, the weights of the unit are WAVE-UNIFORM (scalar loads, one contiguous [tap][QC] block per unit) -- per tap one LDS read and QC
 // v_fmac with a scalar operand.  Units are sized to equal work (k = 15: 2 channels, k = 7: 8, k = 3: 32).  fp32 throughout
 // (closer to the fp32 reference than the bf16 MFMA path it replaces; same tolerance in the tests).
 #include "sf_common.h"
@@ -18,7 +18,7 @@
 struct InitXArgs {
   const float* x;        // [B][Cx][H][W]
   const float* base;     // [B*H*W][ld]
-  const float* w;        // conv i at w + woff[i]: [Cx * k_i * k_i taps][cw_i] fp32
+  const float* w;        // conv i at w + woff[i]: [cw_i / QC_i units][Cx * k_i * k_i taps][QC_i] fp32, QC = 32 / 8 / 2 for k = 3 / 7 / 15
   float* out;            // [B*H*W][ld]
   int B, H, W, Cx, ld;
   int cw[3], co[3], woff[3];
@@ -29,8 +29,9 @@ struct InitXArgs {
 template <int K, int QC>
 __device__ __forceinline__ void initx_unit(const InitXArgs& a, const float* __restrict__ patch, int conv, int q0, int lane, long m0) {
   const int py = lane >> 3, px = lane & 7;
-  const int cw = a.cw[conv];
-  const float* __restrict__ w = a.w + a.woff[conv] + q0;
+  // the unit's weights are ONE contiguous block [tap][QC] (a [tap][all channels] table made every scalar load of a 2-channel
+  // unit touch its own cache line: 3600 lines per unit through a 16 KB scalar cache)
+  const float* __restrict__ w = a.w + a.woff[conv] + (long)(q0 / QC) * (a.Cx * K * K * QC);
   float acc[QC];
 #pragma unroll
   for (int q = 0; q < QC; ++q) acc[q] = 0.0f;
@@ -41,7 +42,7 @@ __device__ __forceinline__ void initx_unit(const InitXArgs& a, const float* __re
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
         const float xv = pc[ky * IX_PW + kx];
-        const float* __restrict__ wt = w + (long)((ci * K + ky) * K + kx) * cw;      // wave-uniform: scalar loads
+        const float* __restrict__ wt = w + ((ci * K + ky) * K + kx) * QC;             // wave-uniform: scalar loads
 #pragma unroll
         for (int q = 0; q < QC; ++q) acc[q] = fmaf(xv, wt[q], acc[q]);
       }

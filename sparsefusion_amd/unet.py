@@ -30,6 +30,17 @@ LDS_MAX = 163840
 SKIP_SCALE = 2 ** -0.5            # scale_skip_connection (imagen_pytorch.py:1283)
 
 
+def init_x_weight_table(ws):
+    """fp32 weight table of SF_OP_INITX (csrc/initx.hip): conv i (k = 3 / 7 / 15) as [cw / QC units][tap = (ci, ky, kx)][QC] with
+    QC = 32 / 8 / 2 channels per wave-unit -- every unit's weights are one contiguous block of scalar loads."""
+    parts = []
+    for w, qc in zip(ws, (32, 8, 2)):
+        cw, ci, kh, kw = w.shape
+        assert cw % qc == 0
+        parts.append(w.reshape(cw // qc, qc, ci, kh, kw).permute(0, 2, 3, 4, 1).reshape(-1))
+    return torch.cat(parts).contiguous()
+
+
 def _cast_tuple(v, n):
     return tuple(v) if isinstance(v, (tuple, list)) else (v,) * n
 
@@ -1077,8 +1088,8 @@ class Unet(nn.Module):
             _lib.check(lib.sf_conv_pack_weights(w4.data_ptr(), co, ci, 32, kh, kw, buf.data_ptr()), "pack init x")
             packed[f"__init_x__.{i}"] = buf.to(device)
         # the same slices as fp32 [tap = (ci, ky, kx)][channel] tables for the direct init-x conv (csrc/initx.hip)
-        packed["__init_xw__"] = torch.cat([sd[f"init_conv.convs.{i}.weight"].float().cpu()[:, self.cond_images_channels:]
-                                           .permute(1, 2, 3, 0).reshape(-1) for i in range(3)]).contiguous().to(device)
+        packed["__init_xw__"] = init_x_weight_table([sd[f"init_conv.convs.{i}.weight"].float().cpu()[:, self.cond_images_channels:]
+                                                     for i in range(3)]).to(device)
         packed["__time_mlps__.weight"] = self._gemv_pack(torch.cat(tm_w, 0), device)
         packed["__time_mlps__.bias"] = torch.cat(tm_b, 0).to(device)
         self._pack_cache = (str(device), packed)

@@ -337,7 +337,8 @@ def test_init_x_direct_conv(B, R, Cx):
     ws = [torch.randn(cw, Cx, k, k, generator=g) / (Cx * k * k) ** 0.5 for cw, k in zip(cws, ks)]
     base = torch.randn(B * R * R, dim, generator=g)
     want = torch.cat([F.conv2d(x, w, padding=k // 2) for w, k in zip(ws, ks)], 1).permute(0, 2, 3, 1).reshape(B * R * R, dim) + base
-    wt = torch.cat([w.permute(1, 2, 3, 0).reshape(-1) for w in ws]).contiguous().to(DEV)      # [tap = (ci, ky, kx)][channel]
+    from sparsefusion_amd.unet import init_x_weight_table
+    wt = init_x_weight_table(ws).to(DEV)                                 # [unit][tap = (ci, ky, kx)][QC]
     offs, woffs, ao, aw = [], [], 0, 0
     for cw, k in zip(cws, ks):
         offs.append(ao); woffs.append(aw)
