@@ -1,105 +1,169 @@
-// The latent half of the UNet's init conv inside a sampler trajectory: x0 = base + CrossEmbed(x) where x is the 4-channel
+// The latent half of the UNet's init conv inside a sampler trajectory: x0 = base + CrossEmbed(x) where x is the (<= 4-channel)
 // latent and `base` holds the conditioning half + bias, evaluated once per trajectory (external/imagen_pytorch.py:1017-1042:
 // CrossEmbedLayer = three convs k = 3 / 7 / 15 into channel slices; the conv is linear in its input channels).
 //
 // The first plan ran this through the implicit-GEMM kernel: pack (NCHW -> NHWC padded to 32 channels), three launches with
-// 7/8 of every MFMA k-step multiplying zeros, a split-K reduction -- five dependent launches, ~45 us, for 0.3 GFLOP.  It is a
-// direct convolution on the vector units instead: one workgroup = four waves on one 8 x 8 pixel tile, whose haloed 4-channel
-// patch (22 x 22 x 4 floats) sits in LDS; a wave = one (conv, QC output channels) unit: lane <-> pixel, QC accumulators per
-// lane, the weights of the unit are WAVE-UNIFORM (scalar loads, one contiguous [tap][QC] block per unit) -- per tap one LDS read and QC
-// v_fmac with a scalar operand.  Units are sized to equal work (k = 15: 2 channels, k = 7: 8, k = 3: 32).  fp32 throughout
-// (closer to the fp32 reference than the bf16 MFMA path it replaces; same tolerance in the tests).
+// 7/8 of every MFMA k-step multiplying zeros, a split-K reduction -- five dependent launches, ~45 us, for 0.3 GFLOP.  A direct
+// convolution on the vector units with scalar-loaded weights came out no faster (35 us: one LDS read and one scalar load per two
+// FMAs).  This version keeps the matrix cores but needs no im2col and no channel padding: the haloed patch of an 8 x 8 pixel
+// tile sits in LDS as bf16 [row][column][4 channels], so the 8 K-elements a lane feeds to v_mfma_f32_16x16x32_bf16 -- two
+// horizontally adjacent taps x 4 channels -- are ONE contiguous 16-byte LDS read, and a k-step covers 8 taps of one kernel row:
+//     k = 15: 15 rows x 2 half-rows (kx padded to 16)  = 30 k-steps;  k = 7: 7 k-steps (kx padded to 8);
+//     k = 3 : 2 k-steps (two kernel rows each, kx padded to 4).
+// One workgroup = one (tile, conv); wave w owns output-channel fragments {w, w + 4, ..} for the tile's 64 pixels.
 #include "sf_common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 ix_bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 ix_bf16x4;
+typedef __attribute__((ext_vector_type(4))) float ix_f32x4;
 
 #define IX_TILE 8
 #define IX_HALO 7
-#define IX_PW (IX_TILE + 2 * IX_HALO)     /* 22 */
+#define IX_PH (IX_TILE + 2 * IX_HALO)     /* 22 rows */
+#define IX_PW 24                          /* 22 columns + 2 zero columns read by the padded kx = 15 tap */
 
 struct InitXArgs {
-  const float* x;        // [B][Cx][H][W]
-  const float* base;     // [B*H*W][ld]
-  const float* w;        // conv i at w + woff[i]: [cw_i / QC_i units][Cx * k_i * k_i taps][QC_i] fp32, QC = 32 / 8 / 2 for k = 3 / 7 / 15
-  float* out;            // [B*H*W][ld]
+  const float* x;            // [B][Cx][H][W]
+  const float* base;         // [B*H*W][ld]
+  const ix_bf16x8* w;        // conv i at w + woff[i] (in fragments of 64 lanes x 8): [k-step][n-frag][lane]
+  float* out;                // [B*H*W][ld]
   int B, H, W, Cx, ld;
   int cw[3], co[3], woff[3];
-  int units[3];          // wave-units per tile of each conv = cw / QC
-  int wgs_per_tile;
 };
 
-template <int K, int QC>
-__device__ __forceinline__ void initx_unit(const InitXArgs& a, const float* __restrict__ patch, int conv, int q0, int lane, long m0) {
-  const int py = lane >> 3, px = lane & 7;
-  // the unit's weights are ONE contiguous block [tap][QC] (a [tap][all channels] table made every scalar load of a 2-channel
-  // unit touch its own cache line: 3600 lines per unit through a 16 KB scalar cache)
-  const float* __restrict__ w = a.w + a.woff[conv] + (long)(q0 / QC) * (a.Cx * K * K * QC);
-  float acc[QC];
+// haloed patch as bf16 [row][column][4 channels], zero outside the image / beyond the latent's channels / in the pad columns
+__device__ __forceinline__ void initx_stage(const InitXArgs& a, char* __restrict__ patch, int tid, int b, int y0, int x0) {
+  constexpr int IT = (IX_PH * IX_PW + 255) / 256;
+  // every load is issued before the first use, from a clamped (always valid) address; the mask is applied to the value
+  // (a load under a branch is fenced by a full vmcnt(0) wait: 12 serial round trips instead of one)
+  float v[IT][4];
+  bool in[IT];
 #pragma unroll
-  for (int q = 0; q < QC; ++q) acc[q] = 0.0f;
+  for (int it = 0; it < IT; ++it) {
+    const int i = tid + it * 256;
+    const int fy = i / IX_PW, fx = i - fy * IX_PW;
+    const int yy = y0 - IX_HALO + fy, xx = x0 - IX_HALO + fx;
+    in[it] = i < IX_PH * IX_PW && fx < IX_PH && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+    const int yc = min(max(yy, 0), a.H - 1), xc = min(max(xx, 0), a.W - 1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[it][c] = a.x[(((long)b * a.Cx + min(c, a.Cx - 1)) * a.H + yc) * a.W + xc];
+  }
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int i = tid + it * 256;
+    ix_bf16x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = (__bf16)((in[it] && c < a.Cx) ? v[it][c] : 0.0f);
+    if (i < IX_PH * IX_PW) *reinterpret_cast<ix_bf16x4*>(patch + i * 8) = o;
+  }
+}
+
+// One (tile, conv) workgroup.  Wave w owns the n-fragments {w, w + 4, ..} (NFW of them) for all 64 pixels (4 m-fragments):
+// its STEPS x NFW weight fragments fit in registers and are fetched FIRST, before the patch is staged, so the one global-memory
+// latency of the kernel overlaps the staging; the main loop is LDS reads and MFMAs only.
+template <int K, int NFW>
+__device__ __forceinline__ void initx_conv(const InitXArgs& a, char* __restrict__ patch, int conv, int tid, int b, int y0, int x0) {
   constexpr int OFF = IX_HALO - K / 2;
-  for (int ci = 0; ci < a.Cx; ++ci) {
-    const float* pc = patch + ci * IX_PW * IX_PW + (py + OFF) * IX_PW + px + OFF;
-    for (int ky = 0; ky < K; ++ky) {
+  constexpr int STEPS = K == 15 ? 30 : (K == 7 ? 7 : 2);
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NF = a.cw[conv] >> 4;
+  const bool active = wave < NF;                              // a 32-channel slice keeps two waves for staging only
+  const int m = lane & 15, g = lane >> 4, n = lane & 15;
+  const ix_bf16x8* __restrict__ w = a.w + (long)a.woff[conv] * 64 + lane;
+  ix_bf16x8 wf[STEPS][NFW];
+  if (active) {
 #pragma unroll
-      for (int kx = 0; kx < K; ++kx) {
-        const float xv = pc[ky * IX_PW + kx];
-        const float* __restrict__ wt = w + ((ci * K + ky) * K + kx) * QC;             // wave-uniform: scalar loads
+    for (int s = 0; s < STEPS; ++s)
 #pragma unroll
-        for (int q = 0; q < QC; ++q) acc[q] = fmaf(xv, wt[q], acc[q]);
+      for (int j = 0; j < NFW; ++j) wf[s][j] = w[(long)(s * NF + wave + 4 * j) * 64];
+  }
+  const long m0 = (long)b * a.H * a.W + (long)y0 * a.W + x0;
+  // the epilogue's `base` operand too: D[i = 4 * (lane >> 4) + r][n = lane & 15] = pixel i of m-fragment mf, channel (wave + 4 j) * 16 + n
+  float bv[4][4][NFW];
+  if (active) {
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        const long mm = m0 + (long)(2 * mf + (i >> 3)) * a.W + (i & 7);
+#pragma unroll
+        for (int j = 0; j < NFW; ++j) bv[mf][r][j] = a.base[mm * a.ld + a.co[conv] + (wave + 4 * j) * 16 + n];
+      }
+  }
+  initx_stage(a, patch, tid, b, y0, x0);
+  __syncthreads();
+  if (!active) return;
+  ix_f32x4 acc[4][NFW];
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+    for (int j = 0; j < NFW; ++j) acc[mf][j] = ix_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int y = m >> 3, x = m & 7;                            // this lane's A row = pixel (2 mf + y, x) of the tile
+  // The A fragment of (m-fragment mf, k-step s) depends only on the patch row 2 mf + row(s) and the column half of s, so the
+  // loop runs over those (R x NH distinct fragments instead of 4 x STEPS) and feeds each to every (mf, s) that uses it.  The
+  // 16 bytes of a lane start at an 8-byte-aligned column: two ds_read_b64, not one (misaligned) ds_read_b128.
+  constexpr int NH = K == 15 ? 2 : 1;
+  constexpr int RSTEP = K == 3 ? 2 : 1;                       // k = 3 packs two kernel rows per k-step (row inside the lane: g >> 1)
+  constexpr int ROWS = K == 3 ? 3 : K;                        // row(s) in [0, ROWS) step RSTEP
+  const int lrow = K == 3 ? (g >> 1) : 0;
+  const int lcol = K == 3 ? (g & 1) * 2 : 2 * g;
+  const char* pa0 = patch + ((y + lrow + OFF) * IX_PW + x + lcol + OFF) * 8;
+#pragma unroll
+  for (int r = 0; r < 6 + ROWS; r += RSTEP) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const char* pa = pa0 + (r * IX_PW + h * 8) * 8;
+      const ix_bf16x4 lo = *reinterpret_cast<const ix_bf16x4*>(pa), hi = *reinterpret_cast<const ix_bf16x4*>(pa + 8);
+      const ix_bf16x8 fa = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf) {
+        const int row = r - 2 * mf;                           // kernel row (pair) of the k-step that meets this fragment at mf
+        if (row < 0 || row >= ROWS) continue;
+        const int st = K == 15 ? 2 * row + h : (K == 7 ? row : row / 2);
+#pragma unroll
+        for (int j = 0; j < NFW; ++j) acc[mf][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, wf[st][j], acc[mf][j], 0, 0, 0);
       }
     }
   }
-  const long m = m0 + (long)py * a.W + px;
-  const float* __restrict__ bp = a.base + m * a.ld + a.co[conv] + q0;
-  float* __restrict__ op = a.out + m * a.ld + a.co[conv] + q0;
-  float2 b2[QC / 2];                 // all loads before the first store: `out` may alias `base` as far as the compiler knows
 #pragma unroll
-  for (int q = 0; q < QC; q += 2) b2[q / 2] = *reinterpret_cast<const float2*>(bp + q);
+  for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
-  for (int q = 0; q < QC; q += 2) *reinterpret_cast<float2*>(op + q) = make_float2(b2[q / 2].x + acc[q], b2[q / 2].y + acc[q + 1]);
+    for (int r = 0; r < 4; ++r) {
+      const int i = 4 * g + r;
+      const long mm = m0 + (long)(2 * mf + (i >> 3)) * a.W + (i & 7);
+#pragma unroll
+      for (int j = 0; j < NFW; ++j) a.out[mm * a.ld + a.co[conv] + (wave + 4 * j) * 16 + n] = bv[mf][r][j] + acc[mf][j][r];
+    }
 }
 
 __global__ __launch_bounds__(256) void k_init_x(InitXArgs a) {
-  __shared__ float patch[8 * IX_PW * IX_PW];            // up to 8 latent channels
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // in an SGPR: the unit's weight addresses are then scalar loads
+  __shared__ __attribute__((aligned(16))) char patch[IX_PH * IX_PW * 8];
+  const int tid = threadIdx.x;
   const int tiles_x = a.W / IX_TILE, tiles = tiles_x * (a.H / IX_TILE);
-  const int g = blockIdx.x % a.wgs_per_tile;
-  const int bt = blockIdx.x / a.wgs_per_tile;
+  const int conv = blockIdx.x % 3;
+  const int bt = blockIdx.x / 3;
   const int b = bt / tiles, t = bt - b * tiles;
   const int ty = t / tiles_x, tx = t - ty * tiles_x;
   const int y0 = ty * IX_TILE, x0 = tx * IX_TILE;
-  // haloed patch, zero outside the image
-  for (int i = tid; i < a.Cx * IX_PW * IX_PW; i += 256) {
-    const int ci = i / (IX_PW * IX_PW), r = i - ci * IX_PW * IX_PW;
-    const int fy = r / IX_PW, fx = r - fy * IX_PW;
-    const int y = y0 - IX_HALO + fy, x = x0 - IX_HALO + fx;
-    patch[i] = (y >= 0 && y < a.H && x >= 0 && x < a.W) ? a.x[(((long)b * a.Cx + ci) * a.H + y) * a.W + x] : 0.0f;
-  }
-  __syncthreads();
-  // this wave's unit: units are listed conv 2 (k = 15) first, then conv 1, then conv 0
-  int u = g * 4 + wave;
-  const long m0 = (long)b * a.H * a.W + (long)y0 * a.W + x0;
-  if (u < a.units[2]) { initx_unit<15, 2>(a, patch, 2, u * 2, lane, m0); return; }
-  u -= a.units[2];
-  if (u < a.units[1]) { initx_unit<7, 8>(a, patch, 1, u * 8, lane, m0); return; }
-  u -= a.units[1];
-  if (u < a.units[0]) initx_unit<3, 32>(a, patch, 0, u * 32, lane, m0);
+  if (conv == 2) initx_conv<15, 1>(a, patch, 2, tid, b, y0, x0);
+  else if (conv == 1) initx_conv<7, 1>(a, patch, 1, tid, b, y0, x0);
+  else if (a.cw[0] == 128) initx_conv<3, 2>(a, patch, 0, tid, b, y0, x0);
+  else initx_conv<3, 1>(a, patch, 0, tid, b, y0, x0);
 }
 
-// op: p 0 x  1 base  2 weights  3 out ; i 0 B  1 H  2 W  3 Cx  4 ld  5..7 cw  8..10 channel offsets  11..13 weight offsets (floats)
+// op: p 0 x  1 base  2 weight fragments  3 out ; i 0 B  1 H  2 W  3 Cx  4 ld  5..7 cw  8..10 channel offsets  11..13 weight
+// offsets (fragments).  Channel slices: cw[0] in {64, 128}, cw[1], cw[2] in {32, 64} (the CrossEmbed split of dim 128 / 256).
 int sf_plan_initx_op(const sf_op* op, void* stream) {
   InitXArgs a;
-  a.x = (const float*)op->p[0]; a.base = (const float*)op->p[1]; a.w = (const float*)op->p[2]; a.out = (float*)op->p[3];
+  a.x = (const float*)op->p[0]; a.base = (const float*)op->p[1]; a.w = (const ix_bf16x8*)op->p[2]; a.out = (float*)op->p[3];
   a.B = op->i[0]; a.H = op->i[1]; a.W = op->i[2]; a.Cx = op->i[3]; a.ld = op->i[4];
   for (int k = 0; k < 3; ++k) { a.cw[k] = op->i[5 + k]; a.co[k] = op->i[8 + k]; a.woff[k] = op->i[11 + k]; }
   if (!a.x || !a.base || !a.w || !a.out || a.B < 1) SF_FAIL(SF_ERR_INVALID, "init_x: missing operand");
-  if (a.H % IX_TILE || a.W % IX_TILE || a.Cx < 1 || a.Cx > 8) SF_FAIL(SF_ERR_INVALID, "init_x: H, W multiples of 8 and 1..8 latent channels");
-  if (a.cw[0] % 32 || a.cw[1] % 8 || a.cw[2] % 2 || a.ld % 2 || (a.co[0] | a.co[1] | a.co[2]) % 2)
-    SF_FAIL(SF_ERR_INVALID, "init_x: channel slices must be multiples of 32 / 8 / 2 (k = 3 / 7 / 15)");
-  a.units[0] = a.cw[0] / 32; a.units[1] = a.cw[1] / 8; a.units[2] = a.cw[2] / 2;
-  const int units = a.units[0] + a.units[1] + a.units[2];
-  a.wgs_per_tile = (units + 3) / 4;
-  const uint32_t grid = (uint32_t)a.B * (a.H / IX_TILE) * (a.W / IX_TILE) * a.wgs_per_tile;
+  if (a.H % IX_TILE || a.W % IX_TILE || a.Cx < 1 || a.Cx > 4) SF_FAIL(SF_ERR_INVALID, "init_x: H, W multiples of 8 and 1..4 latent channels");
+  if ((a.cw[0] != 64 && a.cw[0] != 128) || (a.cw[1] != 32 && a.cw[1] != 64) || (a.cw[2] != 32 && a.cw[2] != 64))
+    SF_FAIL(SF_ERR_INVALID, "init_x: channel slices (%d, %d, %d) not instantiated", a.cw[0], a.cw[1], a.cw[2]);
+  const uint32_t grid = (uint32_t)a.B * (a.H / IX_TILE) * (a.W / IX_TILE) * 3;
   k_init_x<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   SF_CHECK_LAUNCH("init_x");
   return SF_OK;

@@ -31,14 +31,32 @@ SKIP_SCALE = 2 ** -0.5            # scale_skip_connection (imagen_pytorch.py:128
 
 
 def init_x_weight_table(ws):
-    """fp32 weight table of SF_OP_INITX (csrc/initx.hip): conv i (k = 3 / 7 / 15) as [cw / QC units][tap = (ci, ky, kx)][QC] with
-    QC = 32 / 8 / 2 channels per wave-unit -- every unit's weights are one contiguous block of scalar loads."""
-    parts = []
-    for w, qc in zip(ws, (32, 8, 2)):
-        cw, ci, kh, kw = w.shape
-        assert cw % qc == 0
-        parts.append(w.reshape(cw // qc, qc, ci, kh, kw).permute(0, 2, 3, 4, 1).reshape(-1))
-    return torch.cat(parts).contiguous()
+    """bf16 MFMA B-fragments of SF_OP_INITX (csrc/initx.hip) for the three CrossEmbed convs (k = 3 / 7 / 15), latent channels only:
+    [k-step][n-frag][lane 64][8] with lane = (n = lane & 15, g = lane >> 4) and element j = (tap kx0 + j // 4, channel j % 4):
+    k = 15: step s = (ky = s // 2, kx0 = 8 * (s % 2) + 2 g); k = 7: (ky = s, kx0 = 2 g); k = 3: (ky = 2 s + g // 2, kx0 = 2 * (g % 2)).
+    Returns (int16 tensor of bf16 bits, fragment offsets of the three convs)."""
+    parts, offs, acc = [], [], 0
+    for w in ws:
+        cw, ci, k, _ = w.shape
+        steps = {15: 30, 7: 7, 3: 2}[k]
+        nfr = cw // 16
+        wp = torch.zeros(cw, 4, k + 2, 16 + 2)                              # zero-padded taps / channels
+        wp[:, :ci, :k, :k] = w
+        t = torch.zeros(steps, nfr, 64, 8)
+        for s in range(steps):
+            for g in range(4):
+                if k == 15:
+                    ky, kx0 = s // 2, 8 * (s % 2) + 2 * g
+                elif k == 7:
+                    ky, kx0 = s, 2 * g
+                else:
+                    ky, kx0 = 2 * s + g // 2, 2 * (g % 2)
+                blk = wp[:, :, ky, kx0:kx0 + 2]                             # [cw, 4 ch, 2 taps]
+                t[s, :, g * 16:(g + 1) * 16, :] = blk.permute(0, 2, 1).reshape(nfr, 16, 8)
+        parts.append(t.reshape(-1))
+        offs.append(acc)
+        acc += steps * nfr
+    return torch.cat(parts).to(torch.bfloat16).view(torch.int16).contiguous(), offs
 
 
 def _cast_tuple(v, n):
@@ -796,13 +814,11 @@ class _Plan:
         self.x0, self.base = x, self.f32(B * HW, u.dim, HW)
         full_ops, full_written, self.ops, self.written = self.ops, self.written, [], set()
         cws = [u.spec_shapes[f"init_conv.convs.{i}.weight"][0] for i in range(3)]
-        if (getattr(u, "initx_direct", True) and u.fused and R % 8 == 0 and u.channels <= 8 and cws[0] % 32 == 0 and cws[1] % 8 == 0
-                and cws[2] % 2 == 0 and u.dim % 2 == 0):
-            # ONE direct-convolution launch on the vector units (csrc/initx.hip) instead of pack + 3 implicit GEMMs + reduce
-            offs, woffs, acc_o, acc_w = [], [], 0, 0
-            for cw, k in zip(cws, (3, 7, 15)):
-                offs.append(acc_o); woffs.append(acc_w)
-                acc_o += cw; acc_w += u.channels * k * k * cw
+        if (getattr(u, "initx_direct", True) and u.fused and R % 8 == 0 and u.channels <= 4 and cws[0] in (64, 128)
+                and cws[1] in (32, 64) and cws[2] in (32, 64) and "__init_xw__" in self.w):
+            # ONE launch (csrc/initx.hip: MFMA straight out of a [row][column][4 channels] LDS patch) instead of pack + 3 implicit
+            # GEMMs + reduce
+            offs, woffs = [0, cws[0], cws[0] + cws[1]], u.initx_woffs
             self.op(OP_INITX, 0, p=(self.x_in.ptr, self.base.ptr, self.wptr("__init_xw__"), x.ptr),
                     i=(B, R, R, u.channels, u.dim, cws[0], cws[1], cws[2], offs[0], offs[1], offs[2], woffs[0], woffs[1], woffs[2]))
         else:
@@ -1088,8 +1104,10 @@ class Unet(nn.Module):
             _lib.check(lib.sf_conv_pack_weights(w4.data_ptr(), co, ci, 32, kh, kw, buf.data_ptr()), "pack init x")
             packed[f"__init_x__.{i}"] = buf.to(device)
         # the same slices as fp32 [tap = (ci, ky, kx)][channel] tables for the direct init-x conv (csrc/initx.hip)
-        packed["__init_xw__"] = init_x_weight_table([sd[f"init_conv.convs.{i}.weight"].float().cpu()[:, self.cond_images_channels:]
-                                                     for i in range(3)]).to(device)
+        if self.channels <= 4:
+            tab, self.initx_woffs = init_x_weight_table([sd[f"init_conv.convs.{i}.weight"].float().cpu()[:, self.cond_images_channels:]
+                                                         for i in range(3)])
+            packed["__init_xw__"] = tab.to(device)
         packed["__time_mlps__.weight"] = self._gemv_pack(torch.cat(tm_w, 0), device)
         packed["__time_mlps__.bias"] = torch.cat(tm_b, 0).to(device)
         self._pack_cache = (str(device), packed)

@@ -326,24 +326,21 @@ def test_plms_update_kernels():
         assert torch.allclose(x0.cpu(), xs, rtol=1e-6, atol=1e-6) and torch.allclose(xp.cpu(), ref, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("B,R,Cx", [(1, 32, 4), (2, 16, 3)])
-def test_init_x_direct_conv(B, R, Cx):
+@pytest.mark.parametrize("B,R,Cx,cws", [(1, 32, 4, (128, 64, 64)), (2, 16, 3, (64, 32, 32))])
+def test_init_x_direct_conv(B, R, Cx, cws):
     """SF_OP_INITX (csrc/initx.hip): x0 = base + CrossEmbed(x) for the latent channels, three convs k = 3 / 7 / 15 into channel
-    slices (external/imagen_pytorch.py:1017-1042), fp32 direct convolution vs torch conv2d."""
+    slices (external/imagen_pytorch.py:1017-1042): MFMA on bf16 operands vs torch conv2d on the same bf16-rounded operands."""
+    from sparsefusion_amd.unet import init_x_weight_table
     g = torch.Generator().manual_seed(11)
-    cws, ks = (128, 64, 64), (3, 7, 15)
+    ks = (3, 7, 15)
     dim = sum(cws)
     x = torch.randn(B, Cx, R, R, generator=g)
     ws = [torch.randn(cw, Cx, k, k, generator=g) / (Cx * k * k) ** 0.5 for cw, k in zip(cws, ks)]
     base = torch.randn(B * R * R, dim, generator=g)
-    want = torch.cat([F.conv2d(x, w, padding=k // 2) for w, k in zip(ws, ks)], 1).permute(0, 2, 3, 1).reshape(B * R * R, dim) + base
-    from sparsefusion_amd.unet import init_x_weight_table
-    wt = init_x_weight_table(ws).to(DEV)                                 # [unit][tap = (ci, ky, kx)][QC]
-    offs, woffs, ao, aw = [], [], 0, 0
-    for cw, k in zip(cws, ks):
-        offs.append(ao); woffs.append(aw)
-        ao += cw; aw += Cx * k * k * cw
-    xd, bd = x.to(DEV), base.to(DEV)
+    want = torch.cat([F.conv2d(bf(x), bf(w), padding=k // 2) for w, k in zip(ws, ks)], 1).permute(0, 2, 3, 1).reshape(B * R * R, dim) + base
+    wt, woffs = init_x_weight_table(ws)
+    offs = [0, cws[0], cws[0] + cws[1]]
+    xd, bd, wd = x.to(DEV), base.to(DEV), wt.to(DEV)
     out = torch.full((B * R * R, dim), float("nan"), device=DEV)
-    _run([_op(17, 0, p=(xd, bd, wt, out), i=(B, R, R, Cx, dim) + cws + tuple(offs) + tuple(woffs))])
-    assert torch.allclose(out.cpu(), want, rtol=1e-4, atol=1e-4), float((out.cpu() - want).abs().max())
+    _run([_op(17, 0, p=(xd, bd, wd, out), i=(B, R, R, Cx, dim) + tuple(cws) + tuple(offs) + tuple(woffs))])
+    assert torch.allclose(out.cpu(), want, rtol=1e-4, atol=2e-4), float((out.cpu() - want).abs().max())
