@@ -26,3 +26,5 @@ for f in bench_n1 bench_n1_views4 bench_n1_total32; do tail -n 1 $O/$f.json | py
 grep "^# launches" $O/r02_unet_eval_b1_timeline.txt; tail -n 2 $O/unet_time1.log $O/unet_time4.log $O/occ_eval.log $O/vae_time.log
 tail -4 $O/pmc.log; tail -22 $O/pmc2.log
 head -8 $O/r02_bench_kernel_stats.csv | cut -c1-120
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -n 3 $O/smoke.log
+timeout 240 python -m pytest tests -q -m gpu -x > $O/tests_all.log 2>&1; tail -n 2 $O/tests_all.log

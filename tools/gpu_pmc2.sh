@@ -19,14 +19,14 @@ kern = {"ngp": ["k_ngp_field<0>", "k_ngp_field<1>", "k_ngp_field_bwd_mfma", "k_n
         "unet": ["k_conv_fused_pipe<2, 2, 12", "k_conv_fused_pipe<1, 1, 4", "k_conv_fused_pipe<1, 2, 6", "k_conv_fused<1, 1, 12, 1, 1", "k_gca_pool", "k_gca_net0", "k_gca_gate"]}
 out = {"source": "tools/gpu_pmc2.sh: rocprofv3 --kernel-trace --pmc, three passes per target (FETCH_SIZE | WRITE_SIZE | SQ_* + GRBM_GUI_ACTIVE); "
                  "means per dispatch.  FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE reads 1/2 of wide coalesced streams on gfx950 (MI355X_MICROARCH.md). "
-                 "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs)"}
+                 "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): GRBM_GUI_ACTIVE is summed over the XCDs (GRBM / 8 / trace duration = 2.35 GHz on k_ngp_field_bwd_mfma, k_ngp_scatter)"}
 for tag, names in kern.items():
     for n in names:
         j = json.loads(subprocess.check_output([sys.executable, "tools/pmc_collect.py", f"/tmp/q_{tag}_f", n, f"/tmp/q_{tag}_w", f"/tmp/q_{tag}_s"]))
         d = {k: v["mean_per_dispatch"] for k, v in j.items()}
         d["dispatches"] = max([v["dispatches"] for v in j.values()] or [0])
         if d.get("GRBM_GUI_ACTIVE") and "SQ_VALU_MFMA_BUSY_CYCLES" in d:
-            d["mfma_busy_frac"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] * 1024)
+            d["mfma_busy_frac"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8 * 1024)
         if d.get("SQ_WAVE_CYCLES"):
             d["wait_any_frac"] = d.get("SQ_WAIT_ANY", 0) / d["SQ_WAVE_CYCLES"]
             d["valu_issue_frac"] = d.get("SQ_ACTIVE_INST_VALU", 0) / d["SQ_WAVE_CYCLES"]

@@ -44,14 +44,15 @@ res = {
               "means over all k_conv_fused launches",
     "unit_note": "FETCH_SIZE / WRITE_SIZE are KiB; per MI355X_MICROARCH.md FETCH_SIZE reads 1/2 of wide coalesced streams on gfx950 "
                  "-> doubled for the corrected figure; WRITE_SIZE uncalibrated.  SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over "
-                 "SIMDs, GRBM_GUI_ACTIVE the kernel's cycles: mfma_busy_frac = MFMA busy / (GUI active cycles x 1024 SIMDs)",
+                 "the chip's 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs (GRBM / 8 / trace duration = 2.35 GHz on the "
+                 "long NGP kernels of r02_ngp_vae_pmc.json): mfma_busy_frac = MFMA busy / (GUI active / 8 x 1024 SIMDs)",
     "fconv_launches_sampled": n_f,
     "fconv_fetch_KiB_reported_per_launch": fetch,
     "fconv_fetch_bytes_per_launch_corrected": (fetch * 1024 * 2) if fetch else None,
     "fconv_write_KiB_reported_per_launch": write,
     "fconv_mfma_busy_cycles_per_launch": mfma,
     "fconv_gui_active_cycles_per_launch": grbm,
-    "fconv_mfma_busy_frac": (mfma / (grbm * 1024)) if (mfma and grbm) else None,
+    "fconv_mfma_busy_frac": (mfma / (grbm / 8 * 1024)) if (mfma and grbm) else None,
     "fconv_wave_cycles_per_launch": wavec,
     "fconv_wait_any_frac_of_wave_cycles": (waitany / wavec) if (waitany and wavec) else None,
     "fconv_valu_issue_frac_of_wave_cycles": (valu / wavec) if (valu and wavec) else None,
