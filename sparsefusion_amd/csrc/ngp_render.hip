@@ -22,6 +22,7 @@
 #include "ngp_device.h"
 #include "ngp_field_lds.h"
 #include "ngp_bwd_mfma.h"
+#include "ngp_composite_wave.h"
 #include <stdlib.h>
 
 struct GridLevels;  // gridencoder.hip
@@ -578,9 +579,15 @@ extern "C" int sf_ngp_render_forward(const sf_ngp_field* f, const float* rays_o,
   k_ngp_field<1><<<gridp, 256, 0, st>>>(fp, lv, rays_o, rays_d, aabb, nears, fars, nullptr, nullptr, z_f, nullptr, P, T,
                                         nullptr, sig_f, rgb_f);
   SF_CHECK_LAUNCH("ngp_field_fine");
-  k_ngp_composite<<<gridr, 64, 2 * T * 64 * sizeof(float), st>>>(z_c, sig_c, rgb_c, z_f, sig_f, rgb_f, nears, fars, N, T,
-                                                                bg_color, z_sorted, sigma_s, rgb_s, image, depth,
-                                                                weights_sum);
+  static const bool composite_wave = !(getenv("SF_COMPOSITE_WAVE") && atoi(getenv("SF_COMPOSITE_WAVE")) == 0);   // A/B switch
+  if (composite_wave)
+    k_ngp_composite_wave<<<sf_div_up(N, 4), 256, 4 * 5 * 2 * T * sizeof(float), st>>>(
+        CompositeArgs{z_c, sig_c, rgb_c, z_f, sig_f, rgb_f, nears, fars, N, T, bg_color, z_sorted, sigma_s, rgb_s, image, depth,
+                      weights_sum});
+  else
+    k_ngp_composite<<<gridr, 64, 2 * T * 64 * sizeof(float), st>>>(z_c, sig_c, rgb_c, z_f, sig_f, rgb_f, nears, fars, N, T,
+                                                                  bg_color, z_sorted, sigma_s, rgb_s, image, depth,
+                                                                  weights_sum);
   SF_CHECK_LAUNCH("ngp_composite");
   return SF_OK;
 }

@@ -28,6 +28,7 @@
 #include "sf_common.h"
 #include "plan_ops.h"
 #include "sf_dev.h"
+#include "gemm_rows.h"
 #include <math.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -1063,7 +1064,15 @@ static int run_ln(const sf_op& op, hipStream_t st) {
 
 static int run_gemv(const sf_op& op, hipStream_t st) {
   const int M = op.i[0], N = op.i[1];
-  if (M > 8) SF_FAIL(SF_ERR_INVALID, "gemv: at most 8 rows");
+  if (M > 64) SF_FAIL(SF_ERR_INVALID, "gemv: at most 64 rows");
+  if (M > 8) {                                                  // many rows (a sampler's time table): rows on the MFMA M side, weights read once
+    GemmRowsArgs a{(const float*)op.p[0], (const __bf16*)op.p[1], (const float*)op.p[2], (float*)op.p[3], M, N, op.i[2], op.i[3], op.i[4],
+                   op.i[5], (int)(op.flags & 1), (int)((op.flags >> 1) & 3)};
+    if (a.Kp < 8 || a.Kp % 8) SF_FAIL(SF_ERR_INVALID, "gemv: padded K must be a multiple of 8");
+    k_gemm_rows<<<sf_div_up(N, 64), 256, 0, st>>>(a);
+    SF_CHECK_LAUNCH("gemm_rows");
+    return SF_OK;
+  }
   if (N <= 2048)
     k_gemv<1><<<sf_div_up(N, 4), 256, 0, st>>>((const float*)op.p[0], (const __bf16*)op.p[1], (const float*)op.p[2], (float*)op.p[3], M,
                                               N, op.i[2], op.i[3], op.i[4], op.i[5], op.flags & 1, (op.flags >> 1) & 3);

@@ -355,8 +355,10 @@ class _Plan:
 
     def gemv(self, x_ptr, M, ldx, wname, bname, y_ptr, ldy, N, K, in_silu=False, out_act=0):
         Kp = (K + 7) // 8 * 8
-        for m0 in range(0, M, 8):
-            mm = min(8, M - m0)
+        # > 8 rows (a sampler's time table): k_gemm_rows, up to 64 rows per launch (SF_GEMM_ROWS=0: the 8-row kernel, A/B switch)
+        step = 8 if (M <= 8 or os.environ.get("SF_GEMM_ROWS", "1") == "0") else 64
+        for m0 in range(0, M, step):
+            mm = min(step, M - m0)
             self.op(OP_GEMV, (1 if in_silu else 0) | (out_act << 1),
                     p=(x_ptr + m0 * ldx * 4, self.wptr(wname), self.wptr(bname) if bname else 0, y_ptr + m0 * ldy * 4),
                     i=(mm, N, K, Kp, ldx, ldy))

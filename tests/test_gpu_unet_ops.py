@@ -243,6 +243,29 @@ def test_gemv(M, N, K, in_silu, act):
         assert torch.equal(y1.cpu()[0, :N], y.cpu()[m, :N]), m
 
 
+@pytest.mark.parametrize("M,N,K,in_silu,act", [(51, 1024, 17, False, 1), (51, 4160, 1024, True, 0), (20, 136, 300, False, 2)])
+def test_gemv_many_rows_on_mfma(M, N, K, in_silu, act):
+    """OP_GEMV with 9..64 rows (a sampler's time table, Unet.time_table) runs on k_gemm_rows (csrc/gemm_rows.h): rows on the MFMA
+    M side, x split into bf16 hi + lo.  Same arithmetic as k_gemv (fp32 x times bf16 w) to ~1e-5, row by row."""
+    g = torch.Generator().manual_seed(N + K)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    x = torch.randn(M, K + 3, generator=g)
+    Kp = (K + 7) // 8 * 8
+    wp = F.pad(w, (0, Kp - K)).to(torch.bfloat16).contiguous().to(DEV)
+    y = torch.full((M, N + 2), float("nan"), device=DEV)
+    flags = (1 if in_silu else 0) | (act << 1)
+    _run([_op(4, flags, p=(x.to(DEV), wp, b.to(DEV), y), i=(M, N, K, Kp, K + 3, N + 2))])
+    xin = x[:, :K]
+    ref = F.linear(F.silu(xin) if in_silu else xin, bf(w), b)
+    ref = F.silu(ref) if act == 1 else torch.sigmoid(ref) if act == 2 else ref
+    assert torch.allclose(y.cpu()[:, :N], ref, rtol=1e-4, atol=1e-4), float((y.cpu()[:, :N] - ref).abs().max())
+    assert bool(torch.isnan(y[:, N:]).all())
+    y8 = torch.zeros(8, N + 2, device=DEV)                    # the 8-row kernel on the first rows: the two kernels agree
+    _run([_op(4, flags, p=(x[:8].contiguous().to(DEV), wp, b.to(DEV), y8), i=(8, N, K, Kp, K + 3, N + 2))])
+    assert torch.allclose(y8.cpu()[:, :N], y.cpu()[:8, :N], rtol=3e-5, atol=3e-5)
+
+
 def test_attention_core_self_and_cross():
     g = torch.Generator().manual_seed(9)
     B, heads, dh = 2, 8, 64
