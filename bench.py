@@ -223,7 +223,7 @@ def unet_roofline(hp):
     if os.path.exists(stats_csv):
         import csv
         rows = list(csv.DictReader(open(stats_csv)))
-        evals = max(int(r["Calls"]) for r in rows if r["Name"].startswith("k_pack_in"))
+        evals = max(int(r["Calls"]) for r in rows if r["Name"].startswith("k_unpack_out"))       # one per eval
         fr = [r for r in rows if "k_conv_fused" in r["Name"]]
         rocprof_us = round(sum(float(r["TotalDurationNs"]) for r in fr) / max(sum(int(r["Calls"]) for r in fr), 1) / 1e3, 2)
         launches = round(sum(int(r["Calls"]) for r in rows if "rocclr" not in r["Name"]) / evals, 1)
