@@ -25,6 +25,7 @@ static inline T sf_shfl_xor(T v, int m) { return hipemu::shfl_xor(v, m); }
 template <class T>
 static inline T sf_shfl(T v, int src) { return hipemu::shfl_xor(v, (src ^ hipemu::t_lane) & 63); }
 static inline uint32_t sf_readlane(uint32_t v, uint32_t src) { return sf_shfl(v, (int)src); }      // src is wave-uniform
+static inline int sf_uniform(int v) { return v; }
 static inline float sf_exp(float v) { return expf(v); }
 static inline float sf_exp2(float v) { return exp2f(v); }
 static inline void sf_lds_add(float* p, float v) {
@@ -97,6 +98,7 @@ template <class T>
 SF_DEV T sf_shfl_xor(T v, int m) { return __shfl_xor(v, m, 64); }
 template <class T>
 SF_DEV T sf_shfl(T v, int src) { return __shfl(v, src, 64); }
+SF_DEV int sf_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }      // tell the compiler v is wave-uniform (scalar registers)
 SF_DEV uint32_t sf_readlane(uint32_t v, uint32_t src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }   // src wave-uniform
 SF_DEV float sf_exp(float v) { return __expf(v); }
 SF_DEV float sf_exp2(float v) { return __builtin_amdgcn_exp2f(v); }      // raw v_exp_f32 (no denormal fix-up: the result feeds 1 + e)

@@ -1,0 +1,19 @@
+// CPU harness for k_init_x (sparsefusion_amd/csrc/initx.h): the kernel source runs on CPU threads (hip_emu.h).
+#ifndef SF_HOST_EMU
+#define SF_HOST_EMU
+#endif
+#define HIPEMU_IMPLEMENTATION
+#include "hip_emu.h"
+#include <algorithm>
+using std::min;
+using std::max;
+#include "../../sparsefusion_amd/csrc/initx.h"
+
+extern "C" void emu_init_x(const float* x, const float* base, const uint16_t* w, float* out, int B, int H, int W, int Cx, int ld,
+                           const int* cw, const int* co, const int* woff) {
+  InitXArgs a;
+  a.x = x; a.base = base; a.w = reinterpret_cast<const ix_bf16x8*>(w); a.out = out;
+  a.B = B; a.H = H; a.W = W; a.Cx = Cx; a.ld = ld;
+  for (int k = 0; k < 3; ++k) { a.cw[k] = cw[k]; a.co[k] = co[k]; a.woff[k] = woff[k]; }
+  hipemu::launch((unsigned)(B * (H / IX_TILE) * (W / IX_TILE) * 3), 256, 0, [&] { k_init_x(a); });
+}
