@@ -143,6 +143,24 @@ def test_unet_plan_invariants():
     assert lazy_ops < len(_Plan(net, 1, CPU).build().ops)
 
 
+def test_time_table_plan_uses_one_launch_per_linear(monkeypatch):
+    """A sampler's time table (Unet.time_table, 51 log-snr rows): every Linear of the time path is ONE OP_GEMV with all rows
+    (k_gemm_rows: <= 64 rows on the MFMA M side), not one per 8 rows; SF_GEMM_ROWS=0 restores the 8-row launches."""
+    from sparsefusion_amd import unet as unet_mod
+    from sparsefusion_amd.unet import Unet, _TimePlan
+    net = Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2), layer_attns=(False, False, False, True),
+               layer_cross_attns=(False,) * 4, cond_images_channels=256, attn_pool_text=False)
+    plan = _TimePlan(net, 51, CPU).build()
+    gemvs = [o for o in plan.ops if o.type == unet_mod.OP_GEMV]
+    assert gemvs and all(o.i[0] == 51 and o.i[3] % 8 == 0 and o.p[1] for o in gemvs)
+    assert max(o.i[1] for o in gemvs) == net.ss_total                 # the 27 time_mlp Linears batched into one matrix
+    big = _TimePlan(net, 100, CPU).build()                            # more rows than one launch takes: chunks of 64
+    assert sorted({o.i[0] for o in big.ops if o.type == unet_mod.OP_GEMV}) == [36, 64]
+    monkeypatch.setenv("SF_GEMM_ROWS", "0")
+    old = [o for o in _TimePlan(net, 51, CPU).build().ops if o.type == unet_mod.OP_GEMV]
+    assert len(old) == 7 * len(gemvs) and max(o.i[0] for o in old) == 8
+
+
 def test_vae_lpips_eft_plan_invariants():
     from sparsefusion_amd.vae import AutoencoderKL, _VaePlan
     from sparsefusion_amd.lpips import LPIPS, _LpipsPlan
