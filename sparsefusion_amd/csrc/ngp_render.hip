@@ -23,6 +23,7 @@
 #include "ngp_field_lds.h"
 #include "ngp_bwd_mfma.h"
 #include "ngp_composite_wave.h"
+#include "ngp_fwd_mfma.h"
 #include <stdlib.h>
 
 struct GridLevels;  // gridencoder.hip
@@ -569,15 +570,46 @@ extern "C" int sf_ngp_render_forward(const sf_ngp_field* f, const float* rays_o,
   const FieldPtrs fp = field_ptrs(f);
   const uint32_t P = (uint32_t)NT;
   const uint32_t gridp = sf_grid_cap(sf_div_up(P, 256));
-  k_ngp_field<0><<<gridp, 256, 0, st>>>(fp, lv, rays_o, rays_d, aabb, nears, fars, lin, u_coarse, nullptr, nullptr, P, T,
-                                        z_c, sig_c, rgb_c);
+  // EXPERIMENTAL (SF_NGP_FWD_MFMA=1): hidden layers of the field on the matrix cores (ngp_fwd_mfma.h); parity-checked on CPU
+  // threads, not yet measured -- the default stays the VALU kernel.
+  static const bool fwd_mfma = getenv("SF_NGP_FWD_MFMA") && atoi(getenv("SF_NGP_FWD_MFMA")) != 0;
+  FFArgs fa;
+  uint32_t grid_ff = 0;
+  const size_t lds_ff = (size_t)FF_LDS_FLOATS * sizeof(float);
+  if (fwd_mfma) {
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    static unsigned attr_ff_mask = 0;
+    if (dev_id >= 32 || !(attr_ff_mask & (1u << dev_id))) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_field_fwd_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_ff) != hipSuccess)
+        SF_FAIL(SF_ERR_LAUNCH, "ngp_field_fwd_mfma: cannot raise dynamic LDS limit to %zu", lds_ff);
+      if (dev_id < 32) attr_ff_mask |= 1u << dev_id;
+    }
+    fa.table = f->embeddings; fa.w0 = f->w0; fa.b0 = f->b0; fa.w1 = f->w1; fa.b1 = f->b1; fa.w2 = f->w2; fa.b2 = f->b2;
+    fa.bound = f->bound; fa.lv = lv;
+    fa.rays_o = rays_o; fa.rays_d = rays_d; fa.aabb = aabb; fa.nears = nears; fa.fars = fars;
+    fa.P = P; fa.T = T;
+    const uint32_t trips = sf_div_up(P, FB_PTS);
+    grid_ff = trips < 1024 ? sf_div_up(trips, 4) : 256;       // one resident workgroup per CU (LDS-bound), 4 waves each
+    fa.lin = lin; fa.u = u_coarse; fa.z_in = nullptr; fa.mode = 0; fa.z_out = z_c; fa.sigma = sig_c; fa.rgb = rgb_c;
+    k_ngp_field_fwd_mfma<<<grid_ff, 256, lds_ff, st>>>(fa);
+  } else {
+    k_ngp_field<0><<<gridp, 256, 0, st>>>(fp, lv, rays_o, rays_d, aabb, nears, fars, lin, u_coarse, nullptr, nullptr, P, T,
+                                          z_c, sig_c, rgb_c);
+  }
   SF_CHECK_LAUNCH("ngp_field_coarse");
   const uint32_t gridr = sf_div_up(N, 64);
   k_ngp_sample_fine<<<gridr, 64, 2 * T * 64 * sizeof(float), st>>>(z_c, sig_c, u_fine, u_fine_row_stride, nears, fars,
                                                                   N, T, z_f);
   SF_CHECK_LAUNCH("ngp_sample_fine");
-  k_ngp_field<1><<<gridp, 256, 0, st>>>(fp, lv, rays_o, rays_d, aabb, nears, fars, nullptr, nullptr, z_f, nullptr, P, T,
-                                        nullptr, sig_f, rgb_f);
+  if (fwd_mfma) {
+    fa.lin = nullptr; fa.u = nullptr; fa.z_in = z_f; fa.mode = 1; fa.z_out = nullptr; fa.sigma = sig_f; fa.rgb = rgb_f;
+    k_ngp_field_fwd_mfma<<<grid_ff, 256, lds_ff, st>>>(fa);
+  } else {
+    k_ngp_field<1><<<gridp, 256, 0, st>>>(fp, lv, rays_o, rays_d, aabb, nears, fars, nullptr, nullptr, z_f, nullptr, P, T,
+                                          nullptr, sig_f, rgb_f);
+  }
   SF_CHECK_LAUNCH("ngp_field_fine");
   static const bool composite_wave = !(getenv("SF_COMPOSITE_WAVE") && atoi(getenv("SF_COMPOSITE_WAVE")) == 0);   // A/B switch
   if (composite_wave)
