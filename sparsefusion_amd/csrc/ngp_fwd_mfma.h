@@ -1,6 +1,9 @@
-// Field forward of the fused Instant-NGP render on the matrix cores (gfx950), fp32 in / fp32 out.  EXPERIMENTAL: built and
-// parity-checked on CPU threads (tests/test_hostemu_ngp_fwd.py), selected with SF_NGP_FWD_MFMA=1, not yet measured on the GPU --
-// the default forward stays k_ngp_field (one thread per point, fp32 VALU mat-vecs at 26 TFLOP/s, 0.51 ms per 1.05 M points).
+// Field forward of the fused Instant-NGP render on the matrix cores (gfx950), fp32 in / fp32 out.  EXPERIMENTAL, selected with
+// SF_NGP_FWD_MFMA=1: parity-green (CPU threads: tests/test_hostemu_ngp_fwd.py; GPU: the reference-golden render and density tests
+// of tests/test_gpu_ngp.py) but SLOWER than the default k_ngp_field in its first shape -- render forward 1.34 vs 1.12 ms at
+// 16 384 rays (r02, one run): 94 KB of LDS per workgroup leave one wave per SIMD, so the 64 table gathers per lane are exposed,
+// and the forward has no wgrad / dgrad GEMMs to amortise them over as the backward does.  Next: 16-point tiles (8 waves per
+// workgroup on one weight image), or the VALU kernel's occupancy with the hidden layers on MFMA through registers.
 //
 // What it computes per sample point (external/nerf/network_grid.py:77-104 through common_forward): hash-grid features ->
 // h1 = relu(W0 f + b0) -> h2 = relu(W1 h1 + b1) -> out = W2 h2 + b2; sigma = trunc_exp(out0 + blob), albedo = sigmoid(out1..3).
