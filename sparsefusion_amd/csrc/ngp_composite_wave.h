@@ -50,7 +50,6 @@ SF_KERNEL(256) void k_ngp_composite_wave(CompositeArgs a) {
   const uint64_t mine0 = ((uint64_t)key0 << 32) | lane;        // index in the concatenation: coarse l, fine T + l
   const uint64_t mine1 = ((uint64_t)key1 << 32) | (T + lane);
   uint32_t rank0 = 0, rank1 = 0;
-#pragma unroll 8
   for (uint32_t j = 0; j < T; ++j) {
     const uint64_t oc = ((uint64_t)sf_readlane(key0, j) << 32) | j;
     const uint64_t of = ((uint64_t)sf_readlane(key1, j) << 32) | (T + j);
