@@ -57,7 +57,6 @@ SF_KERNEL(256) void k_gemm_rows(GemmRowsArgs a) {
     sf_sync();
     const int left = a.K - kc;
     const int steps = left >= GR_KC ? GR_KC / 32 : (left + 31) / 32;
-
     for (int ks = 0; ks < steps; ++ks) {
       const int k0 = kc + ks * 32 + 8 * g;
       bf16x8 b = *reinterpret_cast<const bf16x8*>(wrow + min(k0, a.Kp - 8));

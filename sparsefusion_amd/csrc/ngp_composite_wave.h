@@ -117,3 +117,73 @@ SF_KERNEL(256) void k_ngp_composite_wave(CompositeArgs a) {
     a.weights_sum[n] = acc[0];
   }
 }
+
+// Backward of the composite, one wave per ray (the thread-per-ray k_ngp_composite_bwd takes 0.105 ms for 16 384 rays): the
+// arithmetic of ngp_composite_backward with lane l owning sorted positions 2l, 2l + 1 -- transmittance by the same exclusive
+// product scan as the forward, the tail sums sum_{j>m} a_j w_j by an exclusive SUFFIX scan in double.
+struct CompositeBwdArgs {
+  const float* z_s; const float* sig_s; const float* rgb_s;      // sorted ray [N][2T], [N][2T], [N][2T][3]
+  const float* nears; const float* fars;
+  uint32_t N, T;
+  float bg;
+  const float* g_image; const float* g_ws;                       // [N][3], [N] or null
+  float* dsig; float* drgb;                                      // [N][2T], [N][2T][3]
+};
+
+SF_KERNEL(256) void k_ngp_composite_bwd_wave(CompositeBwdArgs a) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t n = blockIdx.x * 4 + wave;
+  if (n >= a.N) return;
+  const uint32_t T = a.T, M = 2 * T;
+  const uint32_t m0 = 2 * lane;
+  const bool live = m0 < M;
+  const size_t q = (size_t)n * M + (live ? m0 : 0);
+  const float z0 = a.z_s[q], z1 = a.z_s[q + 1], s0 = a.sig_s[q], s1 = a.sig_s[q + 1];
+  float c0[3], c1[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { c0[c] = a.rgb_s[q * 3 + c]; c1[c] = a.rgb_s[q * 3 + 3 + c]; }
+  const float gI[3] = {a.g_image[n * 3], a.g_image[n * 3 + 1], a.g_image[n * 3 + 2]};
+  const float gW = a.g_ws ? a.g_ws[n] : 0.0f;
+  const float near = a.nears[n], far = a.fars[n];
+  const float sample_dist = SF_DIV(SF_SUB(far, near), (float)T);
+  const float z_next = sf_shfl(z0, (int)((lane + 1) & 63));
+  const float d0 = SF_SUB(z1, z0);
+  const float d1 = (m0 + 2 < M) ? SF_SUB(z_next, z1) : sample_dist;
+  const float e0 = expf(SF_MUL(-d0, s0)), e1 = expf(SF_MUL(-d1, s1));          // 1 - alpha
+  const float a0 = live ? SF_SUB(1.0f, e0) : 0.0f, a1 = live ? SF_SUB(1.0f, e1) : 0.0f;
+  const double f0 = live ? (double)SF_ADD(SF_SUB(1.0f, a0), 1e-15f) : 1.0;
+  const double f1 = live ? (double)SF_ADD(SF_SUB(1.0f, a1), 1e-15f) : 1.0;
+  double incl = f0 * f1;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double up = sf_shfl(incl, (int)((lane - d) & 63));
+    if ((int)lane >= d) incl *= up;
+  }
+  double excl = sf_shfl(incl, (int)((lane - 1) & 63));
+  if (lane == 0) excl = 1.0;
+  const float tr0 = (float)excl, tr1 = (float)(excl * f0);
+  const float w0 = SF_MUL(a0, tr0), w1 = SF_MUL(a1, tr1);
+  const float gsum = gI[0] + gI[1] + gI[2];
+  const float av0 = gI[0] * c0[0] + gI[1] * c0[1] + gI[2] * c0[2] - a.bg * gsum + gW;
+  const float av1 = gI[0] * c1[0] + gI[1] * c1[1] + gI[2] * c1[2] - a.bg * gsum + gW;
+  const double t0 = live ? (double)av0 * (double)w0 : 0.0, t1 = live ? (double)av1 * (double)w1 : 0.0;
+  double suf = t0 + t1;                                         // inclusive suffix sum over lanes
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double dn = sf_shfl(suf, (int)((lane + d) & 63));
+    if ((int)lane + d < 64) suf += dn;
+  }
+  double after = sf_shfl(suf, (int)((lane + 1) & 63));         // sum over the lanes behind this one
+  if (lane == 63) after = 0.0;
+  if (live) {
+    const float one0 = SF_ADD(SF_SUB(1.0f, SF_SUB(1.0f, e0)), 1e-15f), one1 = SF_ADD(SF_SUB(1.0f, SF_SUB(1.0f, e1)), 1e-15f);
+    const float da1 = av1 * tr1 - (float)(after / (double)one1);
+    const float da0 = av0 * tr0 - (float)((after + t1) / (double)one0);
+    float* ds = a.dsig + q;
+    float* dr = a.drgb + q * 3;
+    ds[0] = da0 * d0 * e0;
+    ds[1] = da1 * d1 * e1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { dr[c] = w0 * gI[c]; dr[3 + c] = w1 * gI[c]; }
+  }
+}

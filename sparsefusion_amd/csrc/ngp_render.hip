@@ -640,8 +640,13 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
   const uint64_t M = (uint64_t)N * 2 * T;
   float* dsig = workspace;
   float* drgb = dsig + M;
-  k_ngp_composite_bwd<<<sf_div_up(N, 64), 64, 4 * T * 64 * sizeof(float), st>>>(
-      z_sorted, sigma_s, rgb_s, nears, fars, N, T, bg_color, grad_image, grad_weights_sum, dsig, drgb);
+  static const bool composite_bwd_wave = getenv("SF_COMPOSITE_BWD_WAVE") && atoi(getenv("SF_COMPOSITE_BWD_WAVE")) != 0;   // A/B switch
+  if (composite_bwd_wave)
+    k_ngp_composite_bwd_wave<<<sf_div_up(N, 4), 256, 0, st>>>(
+        CompositeBwdArgs{z_sorted, sigma_s, rgb_s, nears, fars, N, T, bg_color, grad_image, grad_weights_sum, dsig, drgb});
+  else
+    k_ngp_composite_bwd<<<sf_div_up(N, 64), 64, 4 * T * 64 * sizeof(float), st>>>(
+        z_sorted, sigma_s, rgb_s, nears, fars, N, T, bg_color, grad_image, grad_weights_sum, dsig, drgb);
   SF_CHECK_LAUNCH("ngp_composite_bwd");
   const FieldGrad fg{g->g_embeddings, g->g_w0, g->g_b0, g->g_w1, g->g_b1, g->g_w2, g->g_b2};
   const size_t lds = (6536 + 2 * 256 * BW_S) * sizeof(float);

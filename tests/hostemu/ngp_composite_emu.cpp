@@ -29,3 +29,20 @@ extern "C" void emu_composite(const float* z_c, const float* sig_c, const float*
     ws[n] = r.weights_sum;
   }
 }
+
+extern "C" void emu_composite_bwd(const float* z_s, const float* sig_s, const float* rgb_s, const float* nears, const float* fars,
+                                  uint32_t N, uint32_t T, float bg, const float* g_image, const float* g_ws, int use_ref, float* dsig,
+                                  float* drgb) {
+  if (!use_ref) {
+    CompositeBwdArgs a{z_s, sig_s, rgb_s, nears, fars, N, T, bg, g_image, g_ws, dsig, drgb};
+    hipemu::launch((N + 3) / 4, 256, 0, [&] { k_ngp_composite_bwd_wave(a); });
+    return;
+  }
+  std::vector<float> tr(2 * T), wt(2 * T);
+  for (uint32_t n = 0; n < N; ++n) {
+    const float gI[3] = {g_image[n * 3], g_image[n * 3 + 1], g_image[n * 3 + 2]};
+    ngp_composite_backward(z_s + (size_t)n * 2 * T, sig_s + (size_t)n * 2 * T, rgb_s + (size_t)n * 6 * T, nears[n], fars[n], T, bg, gI,
+                           g_ws ? g_ws[n] : 0.0f, SfCol{tr.data(), 1}, SfCol{wt.data(), 1}, dsig + (size_t)n * 2 * T,
+                           drgb + (size_t)n * 6 * T);
+  }
+}

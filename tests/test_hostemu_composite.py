@@ -55,3 +55,31 @@ def test_wave_composite_matches_per_ray_loop(N, T):
     for name, a, b in zip(("image", "depth", "weights_sum"), got[3:], ref[3:]):
         assert torch.allclose(a, b, rtol=0, atol=5e-7, equal_nan=True), (name, float((a - b).abs().nan_to_num().max()))
     assert bool(torch.isnan(got[4][2])) and bool(torch.isnan(ref[4][2]))          # miss ray: NaN depth, as the reference
+
+
+@pytest.mark.parametrize("N,T,with_ws", [(6, 64, True), (5, 16, False), (3, 4, True)])
+def test_wave_composite_backward_matches_per_ray_loop(N, T, with_ws):
+    """k_ngp_composite_bwd_wave against ngp_composite_backward (the adjoint of the alpha compositing, renderer_df.py:318-345):
+    d(loss)/d(sigma), d(loss)/d(rgb) of sorted rays, with and without a weights_sum gradient."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(7 * N + T)
+    near = torch.rand(N, generator=g) + 0.5
+    far = near + 2.0 + torch.rand(N, generator=g)
+    z = (near[:, None] + (far - near)[:, None] * torch.rand(N, 2 * T, generator=g)).sort(1).values.contiguous()
+    z[0, 3] = z[0, 2]                                         # a zero-length interval
+    sig = (torch.rand(N, 2 * T, generator=g) * 8).contiguous()
+    rgb = torch.rand(N, 2 * T, 3, generator=g)
+    gi = torch.randn(N, 3, generator=g)
+    gw = torch.randn(N, generator=g) if with_ws else None
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+    def run(use_ref):
+        out = [torch.full((N, 2 * T), float("nan")), torch.full((N, 2 * T, 3), float("nan"))]
+        lib.emu_composite_bwd(ptr(z), ptr(sig), ptr(rgb), ptr(near), ptr(far), C.c_uint32(N), C.c_uint32(T), C.c_float(0.25), ptr(gi),
+                              ptr(gw), C.c_int(use_ref), *[ptr(t) for t in out])
+        return out
+
+    ref, got = run(1), run(0)
+    for name, a, b in zip(("dsigma", "drgb"), got, ref):
+        scale = float(b.abs().max())
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6 * scale), (name, float((a - b).abs().max()), scale)
