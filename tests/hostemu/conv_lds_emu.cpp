@@ -1,0 +1,37 @@
+// CPU harness for k_conv_lds (sparsefusion_amd/csrc/conv_lds.h): the kernel source runs on CPU threads (hip_emu.h).  Argument
+// set-up mirrors run_conv of csrc/unet_ops.hip for tile codes >= 256.
+#ifndef SF_HOST_EMU
+#define SF_HOST_EMU
+#endif
+#define HIPEMU_IMPLEMENTATION
+#include "hip_emu.h"
+#include <algorithm>
+using std::min;
+using std::max;
+#include "../../sparsefusion_amd/csrc/conv_lds.h"
+
+extern "C" int emu_conv_lds(const void* in, const uint16_t* w, const float* bias, float* out, const float* resid, int B, int H, int W,
+                            int Cin, int Ho, int Wo, int Cout, int ldc, int co_off, int k, int stride, int pad, int bnf, int a_f32,
+                            int accum, int ups, int relu) {
+  ConvArgs a;
+  a.in = in; a.w = reinterpret_cast<const bf16x8*>(w); a.bias = bias; a.out = out; a.resid = resid; a.ws = nullptr;
+  a.accum = accum; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.ldc = ldc; a.co_off = co_off;
+  a.kh = a.kw = k; a.stride = stride; a.pad = pad; a.groups = 1; a.pixshuf = 0; a.ups = ups; a.relu = relu;
+  a.cchunks = Cin / 32;
+  a.KS = k * k * a.cchunks;
+  a.m_frags = (B * Ho * Wo + 15) / 16;
+  a.n_frags = (Cout + 15) / 16;
+  a.npad = a.n_frags * 16;
+  a.m_tiles = (a.m_frags + 7) / 8;
+  a.n_tiles = (a.n_frags + bnf - 1) / bnf;
+  a.steps_per_wave = 0;
+  const unsigned nblk = (unsigned)(a.m_tiles * a.n_tiles);
+  if (bnf == 8) {
+    if (a_f32) hipemu::launch(nblk, 256, 0, [&] { k_conv_lds<8, true>(a); }); else hipemu::launch(nblk, 256, 0, [&] { k_conv_lds<8, false>(a); });
+  } else if (bnf == 4) {
+    if (a_f32) hipemu::launch(nblk, 256, 0, [&] { k_conv_lds<4, true>(a); }); else hipemu::launch(nblk, 256, 0, [&] { k_conv_lds<4, false>(a); });
+  } else {
+    return 1;
+  }
+  return 0;
+}

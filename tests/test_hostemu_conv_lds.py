@@ -1,0 +1,88 @@
+"""Kernel-logic test of k_conv_lds (sparsefusion_amd/csrc/conv_lds.h: the LDS-tiled large-M implicit GEMM of the SD-VAE, LPIPS and
+EFT plans) on CPU threads against torch conv2d on the same bf16-rounded operands: 3x3 / 1x1, stride 2 with explicit output size,
+nearest x2 upsampling folded into the addressing, fp32 and bf16 activations, both channel tiles, ragged M and Cout, residual /
+accumulate / ReLU epilogues, XCD-aware tile order (tile count a multiple of 8)."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hostemu import fused
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostemu")
+SO = os.path.join(HERE, "_build", "libconv_lds_emu.so")
+pytestmark = pytest.mark.skipif(not fused.available(), reason="host clang not found")
+
+
+def _lib():
+    srcs = [os.path.join(HERE, "conv_lds_emu.cpp"), os.path.join(HERE, "hip_emu.h")] + \
+           [os.path.join(HERE, "..", "..", "sparsefusion_amd", "csrc", f) for f in ("conv_lds.h", "sf_dev.h")]
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(s) for s in srcs):
+        os.makedirs(os.path.dirname(SO), exist_ok=True)
+        subprocess.check_call([fused.CLANG, "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + HERE, "-Wall", "-Wno-unused-function",
+                               "-ffp-contract=off", srcs[0], "-o", SO, "-lpthread"])
+    return C.CDLL(SO)
+
+
+def _pack(w):
+    from sparsefusion_amd import _lib as L
+    lib = L.lib()
+    co, ci, kh, kw = w.shape
+    cpad = (ci + 31) // 32 * 32
+    buf = torch.empty(lib.sf_conv_packed_elems(co, cpad, kh, kw), dtype=torch.int16)
+    L.check(lib.sf_conv_pack_weights(w.contiguous().data_ptr(), co, ci, cpad, kh, kw, buf.data_ptr()))
+    return buf, cpad
+
+
+bf = lambda t: t.to(torch.bfloat16).float()
+
+CASES = [
+    # B, H, Cin, Cout, k, stride, pad, bnf, a_f32, ups, resid, accum, relu
+    (1, 16, 64, 128, 3, 1, 1, 8, True, 0, False, False, 0),       # M = 256: two pixel tiles
+    (1, 12, 32, 72, 3, 1, 1, 4, False, 0, True, False, 1),        # ragged M = 144 and Cout = 72 (4.5 fragments, 2 channel tiles)
+    (2, 16, 64, 64, 1, 1, 0, 4, False, 0, False, True, 0),        # 1x1, accumulate into the output (nin_shortcut)
+    (1, 17, 32, 64, 3, 2, 0, 4, True, 0, False, False, 0),        # Downsample: stride 2, pad 0, explicit 8x8 output (asymmetric pad)
+    (1, 16, 32, 128, 3, 1, 1, 8, True, 1, False, False, 0),       # Upsample: nearest x2 folded into the addressing (input 8x8)
+    (1, 32, 32, 128, 3, 1, 1, 8, False, 0, False, False, 0),      # 8 tiles: the XCD-aware tile order is active
+]
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,stride,pad,bnf,a_f32,ups,resid,accum,relu", CASES)
+def test_conv_lds_matches_conv2d(B, H, Cin, Cout, k, stride, pad, bnf, a_f32, ups, resid, accum, relu):
+    lib = _lib()
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    Hin = H >> ups
+    x = torch.randn(B, Cin, Hin, Hin, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    Ho = 8 if stride == 2 else H
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+    if stride == 2:                                           # ldm Downsample: pad (0, 1, 0, 1) then a stride-2 conv without padding
+        want = F.conv2d(F.pad(bf(xin), (0, 1, 0, 1)), bf(w), b, stride=2)[:, :, :Ho, :Ho]
+    else:
+        want = F.conv2d(bf(xin), bf(w), b, padding=pad)
+    want = want.permute(0, 2, 3, 1).reshape(B * Ho * Ho, Cout)
+    ldc = Cout + 8
+    res = torch.randn(B * Ho * Ho, ldc, generator=g) if resid else None
+    out = torch.randn(B * Ho * Ho, ldc, generator=g) if accum else torch.full((B * Ho * Ho, ldc), float("nan"))
+    if resid:
+        want = want + res[:, :Cout]
+    if accum:
+        want = want + out[:, :Cout]
+    if relu:
+        want = want.relu()
+    wp, cpad = _pack(w)
+    assert cpad == Cin
+    xn = x.permute(0, 2, 3, 1).contiguous()                   # NHWC
+    xa = xn if a_f32 else xn.to(torch.bfloat16)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    rc = lib.emu_conv_lds(ptr(xa), ptr(wp), ptr(b), ptr(out), ptr(res), B, H, H, Cin, Ho, Ho, Cout, ldc, 0, k, stride, pad, bnf,
+                          int(a_f32), int(accum), ups, relu)
+    assert rc == 0
+    got = out[:, :Cout]
+    assert torch.allclose(got, want, rtol=1e-4, atol=2e-4), float((got - want).abs().max())
+    if not accum:
+        assert bool(torch.isnan(out[:, Cout:]).all())        # nothing written beyond Cout
