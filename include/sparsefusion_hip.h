@@ -237,7 +237,8 @@ enum {
   SF_OP_FCONV = 14,    /* [GroupNorm | LayerNorm] (+scale/shift, SiLU) fused into the conv's A-operand prologue (Block, :641-662) */
   SF_OP_SLOTS = 15,    /* (sum, sum of squares) slots of a tensor for the next fused GroupNorm; optional gate*h + residual first */
   SF_OP_GCA = 16,      /* fused GlobalContext stages (imagen_pytorch.py:916-941) */
-  SF_OP_INITX = 17     /* latent half of the init CrossEmbed conv inside a sampler trajectory: x0 = base + conv_{3,7,15}(x) (:1017-1042) */
+  SF_OP_INITX = 17,    /* latent half of the init CrossEmbed conv inside a sampler trajectory: x0 = base + conv_{3,7,15}(x) (:1017-1042) */
+  SF_OP_GN_FINALIZE = 18   /* GroupNorm statistics from the per-tile partial sums a conv epilogue left (experimental VAE path) */
 };
 
 /* One op = one or two kernel launches.  Interpretation of p[]/i[]/f[] per op type is

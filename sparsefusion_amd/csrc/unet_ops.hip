@@ -813,6 +813,21 @@ static int run_conv(const sf_op& op, hipStream_t st) {
     a.m_tiles = (a.m_frags + 7) / 8;
     a.n_tiles = (a.n_frags + bnf - 1) / bnf;
     const int nblk = a.m_tiles * a.n_tiles;
+    if (op.flags & 128) {                                // EXPERIMENTAL: epilogue leaves GroupNorm partial sums (conv_lds.h)
+      double* part = (double*)op.p[6];
+      const int cg = op.i[15];
+      if (!part || (cg != 4 && cg != 8 && cg != 16) || a.Cout % cg || a.co_off || a.ldc != a.Cout || (a.Ho * a.Wo) % 128)
+        SF_FAIL(SF_ERR_INVALID, "conv: GroupNorm-partials epilogue needs whole rows, 128 | Ho*Wo, group width 4 / 8 / 16");
+      if (bnf == 8) {
+        if (f32) k_conv_lds_gn<8, true><<<nblk, 256, 0, st>>>(a, part, cg); else k_conv_lds_gn<8, false><<<nblk, 256, 0, st>>>(a, part, cg);
+      } else if (bnf == 4) {
+        if (f32) k_conv_lds_gn<4, true><<<nblk, 256, 0, st>>>(a, part, cg); else k_conv_lds_gn<4, false><<<nblk, 256, 0, st>>>(a, part, cg);
+      } else {
+        SF_FAIL(SF_ERR_INVALID, "conv: unsupported LDS tile %d", bnf);
+      }
+      SF_CHECK_LAUNCH("conv_lds_gn");
+      return SF_OK;
+    }
     if (bnf == 8) {
       if (f32) k_conv_lds<8, true><<<nblk, 256, 0, st>>>(a); else k_conv_lds<8, false><<<nblk, 256, 0, st>>>(a);
     } else if (bnf == 4) {
@@ -866,7 +881,10 @@ static int run_gn(const sf_op& op, hipStream_t st) {
   LazySrc lz;
   if (int rc = lazy_from_op(op, 5, B * HW, lz)) return rc;
   const int c4 = C / 4;
-  if (!op.p[1] && !lz.mode && C / G <= 16 && c4 <= 256 && 256 % c4 == 0) {
+  if (op.flags & 2) {
+    // the statistics are already in p[7] (k_gn_finalize over the producing conv's partial sums): no pass over the tensor
+    if (op.p[1] || lz.mode) SF_FAIL(SF_ERR_INVALID, "gn_act: ready-made statistics need a plain single source");
+  } else if (!op.p[1] && !lz.mode && C / G <= 16 && c4 <= 256 && 256 % c4 == 0) {
     const int ppi = 256 / c4;
     int slabs = HW / (ppi * 16);                       // >= 16 pixels per thread row before splitting further
     slabs = slabs < 1 ? 1 : (slabs > 1024 ? 1024 : slabs);
@@ -1031,6 +1049,15 @@ static int plan_run_impl(const sf_op* ops, uint32_t n_ops, hipStream_t st, hipEv
       case SF_OP_LPIPS: rc = sf_plan_extra_op(&op, st); break;
       case SF_OP_EFT: rc = sf_plan_eft_op(&op, st); break;
       case SF_OP_INITX: rc = sf_plan_initx_op(&op, st); break;
+      case SF_OP_GN_FINALIZE: {                            // p 0 partials  1 stats ; i 0 B  1 tiles per image  2 groups
+        const int G = op.i[2];
+        if (!op.p[0] || !op.p[1] || op.i[0] < 1 || op.i[1] < 1 || G < 1 || G > 256 || 256 % G)
+          SF_FAIL(SF_ERR_INVALID, "gn_finalize: bad operands");
+        k_gn_finalize<<<op.i[0], 256, 0, st>>>((const double*)op.p[0], (double*)op.p[1], op.i[1], G);
+        SF_CHECK_LAUNCH("gn_finalize");
+        rc = SF_OK;
+        break;
+      }
       case SF_OP_FCONV:
         if (op.flags & 16) {                           // conv1 || res_conv of a ResnetBlock: one launch for this op and the next
           if (k + 1 >= n_ops) SF_FAIL(SF_ERR_INVALID, "plan: a paired fconv needs a successor");

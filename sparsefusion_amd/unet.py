@@ -20,7 +20,7 @@ import torch.nn as nn
 from . import _lib
 
 OP_CONV, OP_GN_ACT, OP_LN, OP_GEMV, OP_ATTN, OP_GCA_POOL, OP_ELTWISE, OP_MEMSET, OP_TIME_EMB, OP_SPLITK_REDUCE = range(1, 11)
-OP_FCONV, OP_SLOTS, OP_GCA, OP_INITX = 14, 15, 16, 17
+OP_FCONV, OP_SLOTS, OP_GCA, OP_INITX, OP_GN_FINALIZE = 14, 15, 16, 17, 18
 # (WM, WN, norm of conv1) for which k_conv_fused_pair is instantiated (csrc/fused_host.h SF_FCONV_PAIR_VARIANTS); FNORM_GN_SELF = 1, _SLOTS = 2
 PAIR_TILES = {(1, 1, 1), (1, 1, 2), (1, 2, 2), (2, 2, 2)}
 # (WM, WN, (TR + 2) * W / 8) for which k_conv_fused_pipe is instantiated (SF_FCONV_PIPE_VARIANTS)
@@ -187,7 +187,7 @@ class _Arena:
 
 class _T:
     """A planned activation: device pointer + logical shape [B, HW, C] (NHWC) or [rows, C]."""
-    __slots__ = ("ptr", "rows", "C", "HW", "lazy", "slots")
+    __slots__ = ("ptr", "rows", "C", "HW", "lazy", "slots", "writer")
 
     def __init__(self, ptr, rows, C, HW=None):
         self.ptr, self.rows, self.C, self.HW = ptr, rows, C, HW
@@ -197,6 +197,8 @@ class _T:
         # slots: device pointer of the [rows/16][C/16][2] (sum, sum of squares) table of the materialised values that a
         # GroupNorm-fused conv reads its statistics from (csrc/fused_kernels.h), or None
         self.slots = None
+        # writer: the OP_CONV op (k_conv_lds) that wrote the whole tensor last, or None (experimental GroupNorm-partials epilogue)
+        self.writer = None
 
 
 class _Plan:
@@ -334,6 +336,7 @@ class _Plan:
             out.lazy = ("splitk", ws, bias, res, groups, n_frags * 16, wi)
             self.ws_owners[wi] = out
         out.slots = None
+        out.writer = self.ops[-1] if (tile >= 256 and co_off == 0 and ldc == Cout == out.C and M == out.rows) else None
         return Ho, Wo
 
     def gn_act(self, x, skip, gname, ss_ptr, out, raw=None, silu=True, groups=8, eps=1e-5):
@@ -341,7 +344,20 @@ class _Plan:
         self.need(skip)
         lp, li = self.take_lazy(x, ("splitk", "gate"))
         stats = self.zero.alloc(self.B * groups * 2 * 8)     # f64 (sum, sum of squares) per (b, group), zeroed per eval
-        self.op(OP_GN_ACT, 0 if silu else 1,
+        ready = 0
+        wr = x.writer
+        cg = (C1 // groups) if not skip else 0
+        if (getattr(self.u, "gn_epilogue", False) and wr is not None and not (wr.flags & 128) and li[0] == 0 and cg in (4, 8, 16)
+                and x.HW and x.HW % 128 == 0 and x.rows == self.B * x.HW):
+            # EXPERIMENTAL (SF_VAE_GN_EPI=1): the producing k_conv_lds leaves per-tile partial sums, k_gn_finalize adds them up,
+            # and the statistics pass over the tensor (k_gn_stats_px) is skipped
+            part = self.misc.alloc(x.rows // 128 * groups * 2 * 8)
+            wr.flags |= 128
+            wr.p[6] = part or None
+            wr.i[15] = cg
+            self.op(OP_GN_FINALIZE, 0, p=(part, stats), i=(self.B, x.HW // 128, groups))
+            ready = 2
+        self.op(OP_GN_ACT, (0 if silu else 1) | ready,
                 p=(x.ptr, skip.ptr if skip else 0, self.wptr(gname + ".weight"), self.wptr(gname + ".bias"), ss_ptr, out.ptr,
                    raw.ptr if raw else 0, stats) + lp,
                 i=(self.B, x.HW, C1, C2, getattr(self.u, "tb_stride", 0)) + li + (groups,), f=(eps, SKIP_SCALE))

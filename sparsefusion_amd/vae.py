@@ -13,6 +13,8 @@ Forward only (the reference calls both under torch.no_grad()).  No CPU fallback:
 import math
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -272,6 +274,9 @@ class AutoencoderKL(nn.Module):
         self.lazy_consumers = 0                # VAE convs are large-M: no split-K partials worth deferring
         self.ss_total = 0
         self.lds_conv_min_blocks = 96
+        # EXPERIMENTAL, not yet measured: GroupNorm statistics from the producing conv's epilogue (csrc/conv_lds.h) instead of a pass
+        # over the tensor; parity-checked on CPU threads (tests/test_hostemu_conv_lds.py)
+        self.gn_epilogue = os.environ.get("SF_VAE_GN_EPI", "0") == "1"
         self._pack_cache, self._plans = None, {}
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)

@@ -10,9 +10,10 @@ using std::min;
 using std::max;
 #include "../../sparsefusion_amd/csrc/conv_lds.h"
 
+// gn_part != null: the GroupNorm-partials variant (k_conv_lds_gn) followed by k_gn_finalize into `stats` [B][G][2]
 extern "C" int emu_conv_lds(const void* in, const uint16_t* w, const float* bias, float* out, const float* resid, int B, int H, int W,
                             int Cin, int Ho, int Wo, int Cout, int ldc, int co_off, int k, int stride, int pad, int bnf, int a_f32,
-                            int accum, int ups, int relu) {
+                            int accum, int ups, int relu, double* gn_part, int gn_cg, double* stats) {
   ConvArgs a;
   a.in = in; a.w = reinterpret_cast<const bf16x8*>(w); a.bias = bias; a.out = out; a.resid = resid; a.ws = nullptr;
   a.accum = accum; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.ldc = ldc; a.co_off = co_off;
@@ -26,6 +27,21 @@ extern "C" int emu_conv_lds(const void* in, const uint16_t* w, const float* bias
   a.n_tiles = (a.n_frags + bnf - 1) / bnf;
   a.steps_per_wave = 0;
   const unsigned nblk = (unsigned)(a.m_tiles * a.n_tiles);
+  if (gn_part) {
+    if ((Ho * Wo) % 128 || co_off || ldc != Cout || (gn_cg != 4 && gn_cg != 8 && gn_cg != 16)) return 2;
+    if (bnf == 8) {
+      if (a_f32) hipemu::launch(nblk, 256, 0, [&] { k_conv_lds_gn<8, true>(a, gn_part, gn_cg); });
+      else hipemu::launch(nblk, 256, 0, [&] { k_conv_lds_gn<8, false>(a, gn_part, gn_cg); });
+    } else if (bnf == 4) {
+      if (a_f32) hipemu::launch(nblk, 256, 0, [&] { k_conv_lds_gn<4, true>(a, gn_part, gn_cg); });
+      else hipemu::launch(nblk, 256, 0, [&] { k_conv_lds_gn<4, false>(a, gn_part, gn_cg); });
+    } else {
+      return 1;
+    }
+    const int G = Cout / gn_cg, tiles_per_image = Ho * Wo / 128;
+    hipemu::launch((unsigned)B, 256, 0, [&] { k_gn_finalize(gn_part, stats, tiles_per_image, G); });
+    return 0;
+  }
   if (bnf == 8) {
     if (a_f32) hipemu::launch(nblk, 256, 0, [&] { k_conv_lds<8, true>(a); }); else hipemu::launch(nblk, 256, 0, [&] { k_conv_lds<8, false>(a); });
   } else if (bnf == 4) {

@@ -80,9 +80,48 @@ def test_conv_lds_matches_conv2d(B, H, Cin, Cout, k, stride, pad, bnf, a_f32, up
     xa = xn if a_f32 else xn.to(torch.bfloat16)
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
     rc = lib.emu_conv_lds(ptr(xa), ptr(wp), ptr(b), ptr(out), ptr(res), B, H, H, Cin, Ho, Ho, Cout, ldc, 0, k, stride, pad, bnf,
-                          int(a_f32), int(accum), ups, relu)
+                          int(a_f32), int(accum), ups, relu, None, 0, None)
     assert rc == 0
     got = out[:, :Cout]
     assert torch.allclose(got, want, rtol=1e-4, atol=2e-4), float((got - want).abs().max())
     if not accum:
         assert bool(torch.isnan(out[:, Cout:]).all())        # nothing written beyond Cout
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,bnf,a_f32,resid,accum", [
+    (1, 16, 64, 128, 8, True, True, False),       # GroupNorm(32) of 128 channels: 4 per group, residual epilogue (ResnetBlock output)
+    (2, 16, 32, 256, 8, False, False, True),      # 8 per group, two images, accumulate epilogue (nin_shortcut), two channel tiles
+    (1, 32, 32, 64, 4, False, False, False),      # 64-channel tile; a 32-group norm of 64 channels has 2 per group: 4-wide groups tested here
+])
+def test_conv_lds_gn_epilogue_statistics(B, H, Cin, Cout, bnf, a_f32, resid, accum):
+    """k_conv_lds_gn + k_gn_finalize (EXPERIMENTAL, SF_VAE_GN_EPI=1): same output as k_conv_lds, and stats[b][g] = (sum, sum of
+    squares) of the written tensor per image and GroupNorm group -- what k_gn_stats_px computes in a separate pass."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(3 * Cin + Cout + H)
+    cg = 4 if Cout <= 128 else 8
+    G = Cout // cg
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    M = B * H * H
+    want = F.conv2d(bf(x), bf(w), b, padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
+    res = torch.randn(M, Cout, generator=g) if resid else None
+    out = torch.randn(M, Cout, generator=g) if accum else torch.full((M, Cout), float("nan"))
+    if resid:
+        want = want + res
+    if accum:
+        want = want + out
+    wp, _ = _pack(w)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    xa = xn if a_f32 else xn.to(torch.bfloat16)
+    part = torch.full((M // 128, G, 2), float("nan"), dtype=torch.float64)
+    stats = torch.full((B, G, 2), float("nan"), dtype=torch.float64)
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    rc = lib.emu_conv_lds(ptr(xa), ptr(wp), ptr(b), ptr(out), ptr(res), B, H, H, Cin, H, H, Cout, Cout, 0, 3, 1, 1, bnf, int(a_f32),
+                          int(accum), 0, 0, ptr(part), cg, ptr(stats))
+    assert rc == 0
+    assert torch.allclose(out, want, rtol=1e-4, atol=2e-4)
+    o = out.double().view(B, H * H, G, cg)                     # statistics of what the kernel WROTE
+    ref = torch.stack([o.sum((1, 3)), (o * o).sum((1, 3))], -1)
+    assert torch.allclose(stats, ref, rtol=2e-6, atol=1e-4), float((stats - ref).abs().max())
+    assert not bool(torch.isnan(part).any())

@@ -182,6 +182,34 @@ def test_vae_lpips_eft_plan_invariants():
     assert _audit(f.ops, "eft fwd") == 3 * (1 + 4 * 4)                              # 3 x (pre + 4 layers x (qkv, out, ff1, ff2))
 
 
+def test_vae_gn_epilogue_plan(monkeypatch):
+    """EXPERIMENTAL SF_VAE_GN_EPI=1: every GroupNorm whose input was last written by a whole-tensor k_conv_lds launch takes its
+    statistics from that conv's epilogue (flag 128 + partials buffer + group width on the conv, OP_GN_FINALIZE, flag 2 on the
+    GroupNorm); the others keep the statistics pass.  Off by default: the default plans are unchanged."""
+    from sparsefusion_amd import unet as unet_mod
+    from sparsefusion_amd.vae import AutoencoderKL, _VaePlan
+    base = _VaePlan(AutoencoderKL(), "dec", 1, CPU).build()
+    assert not any(o.type == unet_mod.OP_GN_FINALIZE or (o.type == unet_mod.OP_CONV and o.flags & 128) for o in base.ops)
+    monkeypatch.setenv("SF_VAE_GN_EPI", "1")
+    vae = AutoencoderKL()
+    for kind, B in (("enc", 1), ("dec", 2)):
+        s = _VaePlan(vae, kind, B, CPU).build()
+        plan = _VaePlan(vae, kind, B, CPU, (s.zero.off, s.misc.off + 512, 0, 0)).build()
+        ops = plan.ops
+        gns = [k for k, o in enumerate(ops) if o.type == unet_mod.OP_GN_ACT]
+        ready = [k for k in gns if ops[k].flags & 2]
+        assert len(ready) >= len(gns) // 2, (kind, len(ready), len(gns))                # the large maps (the small ones run k_conv_igemm)
+        for k in ready:
+            fin = ops[k - 1]
+            assert fin.type == unet_mod.OP_GN_FINALIZE and fin.p[1] == ops[k].p[7]                       # same statistics buffer
+            B_, HW, C = ops[k].i[0], ops[k].i[1], ops[k].i[2]
+            assert fin.i[0] == B_ and fin.i[1] == HW // 128 and fin.i[2] == 32 and HW % 128 == 0
+            prod = [o for o in ops[:k] if o.type == unet_mod.OP_CONV and o.p[3] == ops[k].p[0]][-1]      # last writer of the input
+            assert prod.flags & 128 and prod.p[6] == fin.p[0] and prod.i[15] == C // 32 and prod.i[14] >= 256
+            assert prod.i[6] == prod.i[7] == C and prod.i[8] == 0
+        assert sum(1 for o in ops if o.type == unet_mod.OP_CONV and o.flags & 128) == len(ready)
+
+
 def test_lds_conv_selection_rule():
     """Large-M layers switch to the LDS-tiled kernel by tile count; small-M UNet layers at B = 1 never do."""
     from sparsefusion_amd.unet import OP_CONV, Unet, _Plan
