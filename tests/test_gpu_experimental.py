@@ -1,0 +1,78 @@
+"""Opt-in GPU checks of the EXPERIMENTAL kernels that are built and parity-checked on CPU threads but not (fully) run on the GPU
+yet: each variant is evaluated in a child process with its A/B switch set (the switches are read once
+per process) and compared with the default path evaluated the same way.  Skipped unless SF_TEST_EXPERIMENTAL=1, so the regular
+`pytest -m gpu` run is not affected:
+
+    SF_TEST_EXPERIMENTAL=1 python -m pytest tests/test_gpu_experimental.py -q -m gpu
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("SF_TEST_EXPERIMENTAL") != "1", reason="set SF_TEST_EXPERIMENTAL=1 to run")]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+VAE_SNIPPET = """
+import sys, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + '/tests')
+from vae_common import CONFIGS, ddconfig, inputs, state
+from sparsefusion_amd.vae import AutoencoderKL
+cfg = CONFIGS['canonical']
+net = AutoencoderKL(ddconfig=ddconfig(cfg), embed_dim=cfg['embed_dim'])
+net.load_state_dict(state('canonical'))
+net = net.cuda()
+img, z = inputs(cfg, 1, 5)
+torch.save({{'lat': net.encode(img.cuda()).mode().cpu(), 'dec': net.decode(z.cuda()).cpu()}}, {out!r})
+"""
+
+NGP_SNIPPET = """
+import sys, torch
+sys.path.insert(0, {root!r})
+from oracle import ngp_ref
+from sparsefusion_amd.nerf import NeRFNetwork, get_default_torch_ngp_opt
+p = ngp_ref.init_params(bound=4, seed=1, table_std=0.5, sigma_bias=-3.0)
+net = NeRFNetwork(get_default_torch_ngp_opt())
+net.load_state_dict({{k: p[k] for k in net.state_dict().keys()}})
+net = net.cuda().train()
+o, d = ngp_ref.circle_rays(48, view=7)
+torch.manual_seed(3)
+r = net.render(o[None].cuda(), d[None].cuda(), staged=False, perturb=True, bg_color=0, shading='albedo', **vars(net.opt))
+g = torch.Generator().manual_seed(9)
+gi, gw = torch.randn(1, 48 * 48, 3, generator=g).cuda(), torch.randn(48 * 48, generator=g).cuda()
+((r['image'] * gi).sum() + (r['weights_sum'] * gw).sum()).backward()
+torch.save({{'image': r['image'].detach().cpu(), 'ws': r['weights_sum'].detach().cpu(),
+            'g_table': net.encoder.embeddings.grad.cpu(), 'g_w1': net.sigma_net.net[1].weight.grad.cpu()}}, {out!r})
+"""
+
+
+def _run(snippet, env):
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "o.pt")
+        subprocess.check_call([sys.executable, "-c", snippet.format(root=ROOT, out=out)], env=dict(os.environ, **env), cwd=ROOT)
+        return torch.load(out)
+
+
+def _rel(a, b):
+    return float((a - b).norm() / b.norm())
+
+
+def test_vae_gn_statistics_from_the_conv_epilogue():
+    """SF_VAE_GN_EPI=1 (k_conv_lds_gn + k_gn_finalize) gives the same encode / decode as the statistics pass: the sums differ
+    only in fp32 association, far below the bf16 tolerance of the path."""
+    ref, got = _run(VAE_SNIPPET, {"SF_VAE_GN_EPI": "0"}), _run(VAE_SNIPPET, {"SF_VAE_GN_EPI": "1"})
+    for k in ("lat", "dec"):
+        assert torch.isfinite(got[k]).all() and _rel(got[k], ref[k]) < 3e-3, (k, _rel(got[k], ref[k]))
+
+
+@pytest.mark.parametrize("knob", ["SF_COMPOSITE_BWD_WAVE", "SF_NGP_FWD_MFMA"])
+def test_ngp_render_variants_match_default(knob):
+    ref, got = _run(NGP_SNIPPET, {knob: "0"}), _run(NGP_SNIPPET, {knob: "1"})
+    assert torch.allclose(got["image"], ref["image"], atol=2e-6) and torch.allclose(got["ws"], ref["ws"], atol=2e-6)
+    assert _rel(got["g_w1"], ref["g_w1"]) < 1e-4
+    lvl = lambda t: t.abs().sum()
+    assert abs(float(lvl(got["g_table"]) / lvl(ref["g_table"])) - 1.0) < 1e-3
