@@ -63,9 +63,11 @@ def build(verbose=True, force=False):
     return LIB
 
 
-def build_variant(tag, defines, verbose=True, timing=False):
-    """A/B builds for GPU-side tuning: libsparsefusion_hip_<tag>.so = the product library with unet_fused.hip recompiled under
-    extra -D flags (select it with SF_HIP_LIB=<path>); with timing=True the instrumented libsf_fused_timing_<tag>.so."""
+def build_variant(tag, defines, verbose=True, timing=False, sources=("unet_fused.hip",)):
+    """A/B builds for GPU-side tuning: libsparsefusion_hip_<tag>.so = the product library with `sources` (default: unet_fused.hip)
+    recompiled under extra -D flags (select it with SF_HIP_LIB=<path>); with timing=True the instrumented
+    libsf_fused_timing_<tag>.so.  The software-dependent-launch experiment of DESIGN.md section 8 is
+    build_variant("pdl", ["SF_PDL=1"], sources=("unet_fused.hip", "unet_ops.hip"))."""
     os.makedirs(OBJ_DIR, exist_ok=True)
     dflags = ["-D" + d for d in defines]
     if timing:
@@ -75,9 +77,12 @@ def build_variant(tag, defines, verbose=True, timing=False):
     else:
         build(verbose=False)
         out = os.path.join(HERE, f"libsparsefusion_hip_{tag}.so")
-        obj = os.path.join(OBJ_DIR, f"unet_fused_{tag}.o")
-        subprocess.check_call([HIPCC] + FLAGS + dflags + ["-c", os.path.join(CSRC, "unet_fused.hip"), "-o", obj])
-        objs = [os.path.join(OBJ_DIR, s[:-4] + ".o") for s in _sources() if s != "unet_fused.hip"] + [obj]
+        vobjs = []
+        for src in sources:
+            obj = os.path.join(OBJ_DIR, f"{src[:-4]}_{tag}.o")
+            subprocess.check_call([HIPCC] + FLAGS + dflags + ["-c", os.path.join(CSRC, src), "-o", obj])
+            vobjs.append(obj)
+        objs = [os.path.join(OBJ_DIR, s[:-4] + ".o") for s in _sources() if s not in sources] + vobjs
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs
     if verbose:
         print(" ".join(cmd), flush=True)

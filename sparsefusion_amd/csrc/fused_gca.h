@@ -19,6 +19,9 @@ struct GcaPoolArgs {
   float* part_pool;          // [B * chunks][C]
   float* part_ms;            // [B * chunks][2] (max, sum of exp)
   int M, C, HW, CH, chunks, nparts, groups, npad;
+#if SF_PDL
+  SfPdl pdl;                 // software dependent launch (variant build only)
+#endif
 };
 
 // grid = B * chunks * (C / 64); 256 threads = 16 channel float4 lanes x 16 pixel lanes.
@@ -26,6 +29,9 @@ struct GcaPoolArgs {
 // (~0.5 us), and the first version of this kernel spent 30 us summing 256 logit parts one after the other.
 SF_KERNEL(256) void k_gca_pool(GcaPoolArgs a) {
   sf_touch_kernarg<(int)sizeof(GcaPoolArgs)>();
+#if SF_PDL
+  sf_pdl_wait(a.pdl);
+#endif
   SF_SHARED float e[128];
   SF_SHARED float red[16][132];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -119,6 +125,9 @@ SF_KERNEL(256) void k_gca_pool(GcaPoolArgs a) {
     for (int k = 0; k < 16; ++k) s += red[k][tid];
     a.part_pool[(long)bc * a.C + cs * 64 + tid] = s;
   }
+#if SF_PDL
+  sf_pdl_arrive(a.pdl);
+#endif
 }
 
 struct GcaNetArgs {
@@ -128,6 +137,9 @@ struct GcaNetArgs {
   const float* b0;
   float* hid;                // [B][hid]
   int B, C, Kp, HID, chunks;
+#if SF_PDL
+  SfPdl pdl;
+#endif
 };
 
 // grid = B * ceil(HID / 16); 4 waves x 4 rows each
@@ -149,6 +161,9 @@ SF_KERNEL(256) void k_gca_net0(GcaNetArgs a) {
       w[rr][it] = (r < a.HID && k < a.C) ? *reinterpret_cast<const bf16x8*>(a.W0 + (long)r * a.Kp + k) : sf_zero8();
     }
   }
+#if SF_PDL
+  sf_pdl_wait(a.pdl);                                     // the weight rows above are all this launch fetches early
+#endif
   // the pooled partials of this thread's first channel: independent of the merge weights, so in flight with them
   float pj0[8];
 #pragma unroll
@@ -189,6 +204,9 @@ SF_KERNEL(256) void k_gca_net0(GcaNetArgs a) {
     acc = sf_wave_sum(acc);
     if (lane == 0 && r < a.HID) a.hid[(long)b * a.HID + r] = sf_silu(acc + a.b0[r]);
   }
+#if SF_PDL
+  sf_pdl_arrive(a.pdl);
+#endif
 }
 
 struct GcaPoolNetArgs {

@@ -75,6 +75,9 @@ struct FConvArgs {
   const float* wk;                   // GlobalContext to_k weight [Cout] or null: the epilogue also emits partial context logits
   float* logit_part;                 //   logit_part[(s * n_frags + n_frag) * M + m] = sum over the fragment's 16 channels of value * wk
   long long* dbg;                    // optional [grid][8] phase timestamps (tools/fconv_phases.py), null in production
+#if SF_PDL
+  SfPdl pdl;                         // software dependent launch (variant build only)
+#endif
 };
 
 template <int MODE>
@@ -263,6 +266,14 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
     }
   };
 
+#if SF_PDL
+  // software dependent launch: the weight ring is all this launch may fetch before its predecessor has finished
+  prefetch_weights();
+  sf_pdl_wait(a.pdl);
+#define FC_PREFETCH() do { } while (0)
+#else
+#define FC_PREFETCH() prefetch_weights()
+#endif
   float* tabA = reinterpret_cast<float*>(lds + a.tab_off);
   float* tabB = tabA + Cs;
   float* misc = reinterpret_cast<float*>(lds + a.misc_off);      // [0..15] group sums, [16..] group / row (mean, rstd)
@@ -300,7 +311,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
         }
       }
     }
-    prefetch_weights();          // right behind them: at the 4x4 level the launch is one HBM round trip of the whole weight slice
+    FC_PREFETCH();          // right behind them: at the 4x4 level the launch is one HBM round trip of the whole weight slice
   }
   FC_STAMP(6);
 
@@ -508,7 +519,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
       const int c4 = part + u * tpr;
       v[u] = fconv_value<LAZY>(a, m, (c4 < Cs4 ? c4 : Cs4 - 1) * 4);
     }
-    prefetch_weights();
+    FC_PREFETCH();
     FC_STAMP(1);
     float sm = 0.0f;
 #pragma unroll
@@ -636,12 +647,12 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
     // issue order: slots of this wave's first group, first staging batch, weight ring (SF_RING_POS 0: ring first)
     if (NORM == FNORM_GN_SLOTS && wave < ngs) slot_loads(wave, lane);
 #if SF_RING_POS == 0
-    prefetch_weights();
+    FC_PREFETCH();
 #endif
     chan(0);
     issue(tp, va, fpa, mxa);
 #if SF_RING_POS == 1
-    prefetch_weights();
+    FC_PREFETCH();
 #endif
     FC_STAMP(1);
     if (NORM == FNORM_GN_SLOTS) {
@@ -689,7 +700,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
     if (a.silu) run(FConst<1>());
     else run(FConst<0>());
 #if SF_RING_POS == 2
-    prefetch_weights();
+    FC_PREFETCH();
 #endif
   }
   sf_sync();
@@ -824,6 +835,10 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
   }
   FC_STAMP(5);
 #undef FC_STAMP
+#undef FC_PREFETCH
+#if SF_PDL
+  sf_pdl_arrive(a.pdl);
+#endif
 }
 
 template <int WM, int WN, int D, int NORM, int LAZY, int NW>

@@ -1016,10 +1016,87 @@ static int run_eltwise(const sf_op& op, hipStream_t st) {
   return SF_OK;
 }
 
-static int plan_run_impl(const sf_op* ops, uint32_t n_ops, hipStream_t st, hipEvent_t* ev) {
+#if SF_PDL
+// ---- software dependent launch (EXPERIMENTAL variant build).  Fused convs and the first two GlobalContext
+// kernels can wait for their predecessor on a device-side flag; two such launches in a row go to ALTERNATING streams, so the
+// second has a stream-order edge to the launch before its predecessor only and overlaps its weight prefetch with the predecessor.
+// Everything else keeps plain stream order (it continues on the stream of its predecessor).
+struct PdlRun {
+  bool on = false;
+  hipStream_t s[2];
+  int idx = 0;                 // stream of the previous launch
+  bool prev_sup = false;
+  unsigned prev_grid = 0;
+  uint32_t prev_k = 0;
+  bool aux_used = false;
+};
+static unsigned* g_pdl_flags = nullptr;                      // [SF_PDL_MAX_OPS][8][32] arrival counters
+static hipStream_t g_pdl_aux = nullptr;
+static hipEvent_t g_pdl_fork = nullptr, g_pdl_join = nullptr;
+#define SF_PDL_MAX_OPS 4096
+static bool pdl_supported(const sf_op& op) { return op.type == SF_OP_FCONV || (op.type == SF_OP_GCA && (op.flags == 1 || op.flags == 2)); }
+static int pdl_begin(PdlRun& pr, hipStream_t st, uint32_t n_ops) {
+  static const bool enabled = !(getenv("SF_PDL") && atoi(getenv("SF_PDL")) == 0);
+  if (!enabled || n_ops > SF_PDL_MAX_OPS) return SF_OK;
+  if (!g_pdl_flags) {
+    if (hipMalloc(&g_pdl_flags, (size_t)(SF_PDL_MAX_OPS + 1) * 1024) != hipSuccess ||
+        hipMemset(g_pdl_flags, 0, (size_t)(SF_PDL_MAX_OPS + 1) * 1024) != hipSuccess || hipStreamCreateWithFlags(&g_pdl_aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&g_pdl_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g_pdl_join, hipEventDisableTiming) != hipSuccess)
+      SF_FAIL(SF_ERR_LAUNCH, "pdl: cannot create the flag buffer / auxiliary stream");
+  }
+  if (hipMemsetAsync(g_pdl_flags, 0, (size_t)n_ops * 1024, st) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "pdl: memset failed");
+  if (hipEventRecord(g_pdl_fork, st) != hipSuccess || hipStreamWaitEvent(g_pdl_aux, g_pdl_fork, 0) != hipSuccess)
+    SF_FAIL(SF_ERR_LAUNCH, "pdl: fork failed");
+  pr.on = true; pr.s[0] = st; pr.s[1] = g_pdl_aux;
+  g_sf_pdl.timeouts = g_pdl_flags + (size_t)SF_PDL_MAX_OPS * 256;        // never reset: a run that timed out anywhere is suspect
+  return SF_OK;
+}
+// waits that gave up since the library was loaded (synchronises); 0 = every hand-off completed
+extern "C" int sf_pdl_timeouts(void) {
+  unsigned v = 0;
+  if (g_pdl_flags && hipMemcpy(&v, g_pdl_flags + (size_t)SF_PDL_MAX_OPS * 256, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int)v;
+}
+static hipStream_t pdl_pick(PdlRun& pr, const sf_op& op, uint32_t k) {
+  const bool sup = pdl_supported(op);
+  if (sup && pr.prev_sup) {
+    pr.idx ^= 1;
+    g_sf_pdl.wait = g_pdl_flags + (size_t)pr.prev_k * 256;
+    g_sf_pdl.wait_grid = pr.prev_grid;
+  } else {
+    g_sf_pdl.wait = nullptr;
+    g_sf_pdl.wait_grid = 0;
+  }
+  g_sf_pdl.arrive = sup ? g_pdl_flags + (size_t)k * 256 : nullptr;
+  g_sf_pdl.last_grid = 0;
+  if (pr.idx) pr.aux_used = true;
+  return pr.s[pr.idx];
+}
+static void pdl_after(PdlRun& pr, const sf_op& op, uint32_t k) {
+  pr.prev_sup = pdl_supported(op) && g_sf_pdl.last_grid > 0;
+  pr.prev_grid = g_sf_pdl.last_grid;
+  pr.prev_k = k;
+}
+static int pdl_end(PdlRun& pr) {
+  if (pr.on && (hipEventRecord(g_pdl_join, pr.s[1]) != hipSuccess || hipStreamWaitEvent(pr.s[0], g_pdl_join, 0) != hipSuccess))
+    SF_FAIL(SF_ERR_LAUNCH, "pdl: join failed");
+  return SF_OK;
+}
+#endif
+
+static int plan_run_impl(const sf_op* ops, uint32_t n_ops, hipStream_t st_main, hipEvent_t* ev) {
+#if SF_PDL
+  PdlRun pdl;
+  if (!ev) { if (int rc0 = pdl_begin(pdl, st_main, n_ops)) return rc0; }
+#endif
   for (uint32_t k = 0; k < n_ops; ++k) {
     const sf_op& op = ops[k];
     int rc = SF_OK;
+    hipStream_t st = st_main;
+#if SF_PDL
+    const uint32_t k_first = k;
+    if (pdl.on) st = pdl_pick(pdl, op, k);
+#endif
     if (ev && hipEventRecord(ev[k], st) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "plan: hipEventRecord failed");
     switch (op.type) {
       case SF_OP_CONV: rc = run_conv(op, st); break;
@@ -1080,8 +1157,14 @@ static int plan_run_impl(const sf_op* ops, uint32_t n_ops, hipStream_t st, hipEv
       snprintf(sf_err_buf, sizeof(sf_err_buf), "plan op %u (type %d): %s", k, op.type, tmp);
       return rc;
     }
+#if SF_PDL
+    if (pdl.on) pdl_after(pdl, ops[k_first], k_first);
+#endif
   }
-  if (ev && hipEventRecord(ev[n_ops], st) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "plan: hipEventRecord failed");
+#if SF_PDL
+  if (int rc1 = pdl_end(pdl)) return rc1;
+#endif
+  if (ev && hipEventRecord(ev[n_ops], st_main) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "plan: hipEventRecord failed");
   return SF_OK;
 }
 
