@@ -10,7 +10,10 @@ from sparsefusion_amd import _lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "..", "..", "sparsefusion_amd", "csrc")
-_SO = os.path.join(_HERE, "_build", "libfused_emu.so")
+# SF_EMU_DEFINES="SF_PDL=1": the kernels as the software-dependent-launch variant compiles them (flag waits are no-ops on CPU
+# threads; what is checked is the re-ordered prologue: weight ring first, every other load behind the wait)
+_DEFS = [d for d in os.environ.get("SF_EMU_DEFINES", "").split(",") if d]
+_SO = os.path.join(_HERE, "_build", "libfused_emu" + "".join("_" + d.replace("=", "") for d in _DEFS) + ".so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 _handle = None
 
@@ -23,8 +26,8 @@ def lib():
                [os.path.join(_HERE, "..", "..", "include", "sparsefusion_hip.h")]
         if not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
             os.makedirs(os.path.dirname(_SO), exist_ok=True)
-            subprocess.check_call([CLANG, "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + _HERE, "-Wall", "-Wno-unused-function",
-                                   os.path.join(_HERE, "fused_emu.cpp"), "-o", _SO, "-lpthread"])
+            subprocess.check_call([CLANG, "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + _HERE, "-Wall", "-Wno-unused-function"] +
+                                  ["-D" + d for d in _DEFS] + [os.path.join(_HERE, "fused_emu.cpp"), "-o", _SO, "-lpthread"])
         _handle = C.CDLL(_SO)
         _handle.emu_plan_run.restype = C.c_int
         _handle.emu_plan_run.argtypes = [C.POINTER(_lib.SfOp), C.c_uint32, C.c_char_p, C.c_int]
