@@ -341,14 +341,25 @@ struct GcaGateArgs {
   float* out;
   float* slots;              // [M/16][C/16][2] or null
   int M, C, HW, HID, Kp2;
+#if SF_PDL
+  SfPdl pdl;
+#endif
 };
 
 // one wave per (16 pixels, 16 channels); grid = ceil(M/16 * C/16 / 4)
 SF_KERNEL(256) void k_gca_gate(GcaGateArgs a) {
   sf_touch_kernarg<(int)sizeof(GcaGateArgs)>();
-  const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int CF = a.C >> 4;
+#if SF_PDL
+  // software dependent launch: every operand of this kernel comes from its predecessors -> wait first.  No early exit in front of
+  // the arrive barrier: surplus waves repeat the last tile (identical stores).
+  sf_pdl_wait(a.pdl);
+  const int gw_raw = blockIdx.x * 4 + (threadIdx.x >> 6), gw_last = (a.M >> 4) * CF - 1;
+  const int lane = threadIdx.x & 63, gw = gw_raw < gw_last ? gw_raw : gw_last;
+#else
+  const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (gw >= (a.M >> 4) * CF) return;
+#endif
   const int mf = gw / CF, cf = gw - mf * CF;
   const int b = (mf * 16) / a.HW;
   // the tile's own operands first (independent of the gate): lane -> pixel (lane >> 2), channels cf*16 + (lane & 3)*4 .. +3
@@ -403,4 +414,7 @@ SF_KERNEL(256) void k_gca_gate(GcaGateArgs a) {
     sq = sf_wave_sum(sq);
     if (lane == 0) { a.slots[(long)gw * 2] = sm; a.slots[(long)gw * 2 + 1] = sq; }
   }
+#if SF_PDL
+  sf_pdl_arrive(a.pdl);
+#endif
 }

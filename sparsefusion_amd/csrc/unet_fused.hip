@@ -130,6 +130,7 @@ static int run_gca(const sf_op& op, hipStream_t st) {
   if (gca_setup(op, pa, na, ga, grid, sf_err_buf, sizeof(sf_err_buf))) return SF_ERR_INVALID;
   SF_PDL_SET(pa, grid);
   SF_PDL_SET(na, grid);
+  SF_PDL_SET(ga, grid);
   if (op.flags == 1) k_gca_pool<<<grid, 256, 0, st>>>(pa);
   else if (op.flags == 2) k_gca_net0<<<grid, 256, 0, st>>>(na);
   else k_gca_gate<<<grid, 256, 0, st>>>(ga);

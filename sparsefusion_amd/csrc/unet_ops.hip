@@ -1017,7 +1017,7 @@ static int run_eltwise(const sf_op& op, hipStream_t st) {
 }
 
 #if SF_PDL
-// ---- software dependent launch (EXPERIMENTAL variant build).  Fused convs and the first two GlobalContext
+// ---- software dependent launch (EXPERIMENTAL variant build).  Fused convs and the three GlobalContext
 // kernels can wait for their predecessor on a device-side flag; two such launches in a row go to ALTERNATING streams, so the
 // second has a stream-order edge to the launch before its predecessor only and overlaps its weight prefetch with the predecessor.
 // Everything else keeps plain stream order (it continues on the stream of its predecessor).
@@ -1034,7 +1034,7 @@ static unsigned* g_pdl_flags = nullptr;                      // [SF_PDL_MAX_OPS]
 static hipStream_t g_pdl_aux = nullptr;
 static hipEvent_t g_pdl_fork = nullptr, g_pdl_join = nullptr;
 #define SF_PDL_MAX_OPS 4096
-static bool pdl_supported(const sf_op& op) { return op.type == SF_OP_FCONV || (op.type == SF_OP_GCA && (op.flags == 1 || op.flags == 2)); }
+static bool pdl_supported(const sf_op& op) { return op.type == SF_OP_FCONV || (op.type == SF_OP_GCA && op.flags >= 1 && op.flags <= 3); }
 static int pdl_begin(PdlRun& pr, hipStream_t st, uint32_t n_ops) {
   static const bool enabled = !(getenv("SF_PDL") && atoi(getenv("SF_PDL")) == 0);
   if (!enabled || n_ops > SF_PDL_MAX_OPS) return SF_OK;

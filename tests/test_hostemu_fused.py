@@ -61,7 +61,7 @@ def test_kernels_in_the_dependent_launch_order():
     re-ordered kernels still compute the same results (a child process: the harness library is chosen at import)."""
     import subprocess
     import sys
-    sel = "pipe_gn_slots_concat_8x8 or pair_gn_self_lazy_splitk_4x4 or pipe_pair_gn_slots_concat_8x8 or gn_self_concat_gate_lazy_4x4 or 4x4_lazy"
+    sel = "pipe_gn_slots_concat_8x8 or pair_gn_self_lazy_splitk_4x4 or pipe_pair_gn_slots_concat_8x8 or gn_self_concat_gate_lazy_4x4 or 4x4_lazy or 16x16"
     env = dict(os.environ, SF_EMU_DEFINES="SF_PDL=1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", sel, "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, timeout=900)
