@@ -1059,7 +1059,11 @@ extern "C" int sf_pdl_timeouts(void) {
 }
 static hipStream_t pdl_pick(PdlRun& pr, const sf_op& op, uint32_t k) {
   const bool sup = pdl_supported(op);
-  if (sup && pr.prev_sup) {
+  // The predecessor must be fully RESIDENT before this launch may take CU slots and spin: with more workgroups than the chip
+  // holds at once, its tail could be locked out by our pollers (two hardware queues, no ordering between them) -- a deadlock.
+  // One workgroup per CU is always resident for these kernels: 256 (SF_PDL_MAX_PREV overrides).
+  static const unsigned max_prev = getenv("SF_PDL_MAX_PREV") ? (unsigned)atoi(getenv("SF_PDL_MAX_PREV")) : 256u;
+  if (sup && pr.prev_sup && pr.prev_grid <= max_prev) {
     pr.idx ^= 1;
     g_sf_pdl.wait = g_pdl_flags + (size_t)pr.prev_k * 256;
     g_sf_pdl.wait_grid = pr.prev_grid;
