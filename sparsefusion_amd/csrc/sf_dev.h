@@ -116,25 +116,27 @@ template <class T>
 SF_DEV T sf_shfl_xor(T v, int m) { return __shfl_xor(v, m, 64); }
 template <class T>
 SF_DEV T sf_shfl(T v, int src) { return __shfl(v, src, 64); }
-// every thread of the workgroup calls these (workgroup barriers inside)
+// every thread of the workgroup calls these (workgroup barriers inside).  Counters of one launch: word 32 x of its 1 KB block
+// = arrivals of the workgroups with blockIdx & 7 == x (one 128-byte line per XCD: arrivals of one XCD do not queue behind the
+// others'), word 16 = shards that are complete.  The last arriver of a shard bumps word 16, so a waiting workgroup polls ONE word
+// with ONE thread (256 pollers on the fabric per hand-off, as the XCD-hierarchical barrier of MI355X_MICROARCH.md).
 SF_DEV void sf_pdl_wait(const SfPdl& p) {
   if (p.wait) {
-    if (threadIdx.x < 8) {
-      const unsigned want = (p.wait_grid + 7 - threadIdx.x) >> 3;      // workgroups of the predecessor with blockIdx & 7 == threadIdx.x
-      // bounded: a logic error must not hang the GPU (2^20 x 64 cycles ~ 30 ms); a wait that gave up is counted
+    if (threadIdx.x == 0) {
+      const unsigned want = p.wait_grid < 8u ? p.wait_grid : 8u;       // non-empty shards of the predecessor
 #if SF_PDL_BOUNDED
       // bounded by the 100 MHz wall clock (30 ms), a wait that gave up is counted.  NOTE: any loop-carried bound in this poll
-      // (spin counter, clock, out-of-line helper) crashes the register allocator of ROCm 7.2 on k_conv_fused_pair<1,1,12,1,1,8>,
+      // (spin counter, clock, out-of-line helper) crashed the register allocator of ROCm 7.2 on k_conv_fused_pair<1,1,12,1,1,8>,
       // so the bounded form is opt-in and the experiment script bounds the PROCESS instead (tools/pdl_try.py: timeout per child).
       const long long t0 = (long long)wall_clock64();
       bool ok = true;
-      while (__hip_atomic_load(&p.wait[threadIdx.x * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        __builtin_amdgcn_s_sleep(1);
+      while (__hip_atomic_load(&p.wait[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(2);
         if ((long long)wall_clock64() - t0 > 3000000LL) { ok = false; break; }
       }
       if (!ok) __hip_atomic_fetch_add(p.timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
-      while (__hip_atomic_load(&p.wait[threadIdx.x * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+      while (__hip_atomic_load(&p.wait[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2);
 #endif
     }
     __syncthreads();
@@ -146,7 +148,9 @@ SF_DEV void sf_pdl_arrive(const SfPdl& p) {
     __syncthreads();
     if (threadIdx.x == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __hip_atomic_fetch_add(&p.arrive[(blockIdx.x & 7) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned x = blockIdx.x & 7, in_shard = (gridDim.x + 7 - x) >> 3;      // workgroups of this launch in shard x
+      const unsigned n = __hip_atomic_fetch_add(&p.arrive[x * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (n + 1 == in_shard) __hip_atomic_fetch_add(&p.arrive[16], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

@@ -1,6 +1,6 @@
 // Micro-experiment for DESIGN.md section 8, item 1 ("software dependent launch"): a chain of weight-streaming "layers" where
 // layer L + 1 is launched with a graph edge to layer L - 1 only (two alternating capture streams), pulls its weight slice into
-// registers at once, and waits for layer L on a device-side flag (8 per-XCD arrival counters) before it touches L's output --
+// registers at once, and waits for layer L on a device-side flag (8 per-XCD arrival counters + one top word) before it touches L's output --
 // against the same chain as plainly dependent launches.  Each layer streams its own 18.9 MB of weights (74 KB per workgroup,
 // as a 1024 -> 1024 3x3 conv of the 4x4 level does), reads a 4 KB record written by workgroups of OTHER XCDs in the previous
 // layer, and writes its own.  Prints us per layer for both forms and checks that both produce the same final records.
@@ -17,10 +17,12 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 struct Flags { unsigned cnt[8][32]; };                        // one 128-byte line per XCD shard
 
+// the protocol of csrc/sf_dev.h (sf_pdl_wait / sf_pdl_arrive): per-XCD arrival shards, the last arriver of a shard bumps a top
+// word (kept in shard 0's line, word 16), a waiting workgroup polls that one word with one thread
 __device__ __forceinline__ void pdl_wait(const Flags* f, unsigned grid_prev) {
-  if (threadIdx.x < 8) {
-    const unsigned want = (grid_prev + 7 - threadIdx.x) >> 3;
-    while (__hip_atomic_load(&f->cnt[threadIdx.x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+  if (threadIdx.x == 0) {
+    const unsigned want = grid_prev < 8u ? grid_prev : 8u;
+    while (__hip_atomic_load(&f->cnt[0][16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2);
   }
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -30,7 +32,9 @@ __device__ __forceinline__ void pdl_arrive(Flags* f) {
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_fetch_add(&f->cnt[blockIdx.x & 7][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned x = blockIdx.x & 7, in_shard = (gridDim.x + 7 - x) >> 3;
+    const unsigned n = __hip_atomic_fetch_add(&f->cnt[x][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n + 1 == in_shard) __hip_atomic_fetch_add(&f->cnt[0][16], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
