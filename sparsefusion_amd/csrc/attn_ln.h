@@ -1,0 +1,98 @@
+// k_layernorm and k_attn16 (operand contracts: the comment blocks in unet_ops.hip).  Written against sf_dev.h so that
+// tests/hostemu runs the same source on CPU threads (tests/test_hostemu_attn_ln.py).
+#pragma once
+#include "sf_dev.h"
+
+SF_KERNEL(256) void k_layernorm(const float* __restrict__ in, const float* __restrict__ gain,
+                                                   const float* __restrict__ bias, void* __restrict__ out,
+                                                   const float* __restrict__ resid, int R, int C, float eps, int pre_gelu,
+                                                   int out_f32) {
+  SF_SHARED float red[8];
+  const int row = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const float* x = in + (long)row * C;
+  float v[8];                                   // C <= 2048 = 8 * 256
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x + i * 256;
+    v[i] = 0.0f;
+    if (c < C) { const float t = x[c]; v[i] = pre_gelu ? sf_gelu(t) : t; s += v[i]; }
+  }
+  s = sf_wave_sum(s);
+  if (lane == 0) red[wv] = s;
+  sf_sync();
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (threadIdx.x + i * 256 < C) { const float d = v[i] - mean; q = fmaf(d, d, q); }
+  q = sf_wave_sum(q);
+  if (lane == 0) red[4 + wv] = q;
+  sf_sync();
+  const float rstd = sf_rsqrt((red[4] + red[5] + red[6] + red[7]) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < C) {
+      float y = (v[i] - mean) * rstd * gain[c];
+      if (bias) y += bias[c];
+      if (out_f32) {
+        if (resid) y += resid[(long)row * C + c];
+        reinterpret_cast<float*>(out)[(long)row * C + c] = y;
+      } else {
+        reinterpret_cast<__bf16*>(out)[(long)row * C + c] = (__bf16)y;
+      }
+    }
+  }
+}
+
+struct AttnSeg { const float* k; const float* v; int rows, row_stride, batch_stride, head_stride; };
+SF_KERNEL(256) void k_attn16(const float* __restrict__ q, void* __restrict__ out, AttnSeg s0, AttnSeg s1,
+                                                AttnSeg s2, int heads, int ldq, float scale, int out_f32) {
+  // 4 waves per (b, head): the kernel is a chain of dependent phases (load, q.k, softmax, p.v), so the only lever is to make
+  // every phase short -- rows of q / k / v are fetched by different waves at once, the 16 x J scores and the 16 output rows
+  // are spread over all 256 lanes
+  SF_SHARED float sq[16][65];
+  SF_SHARED float sk[24][65];
+  SF_SHARED float sv[24][65];
+  SF_SHARED float sim[16][25];
+  const int b = blockIdx.x / heads, h = blockIdx.x % heads, t = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i = wv; i < 16; i += 4) sq[i][t] = q[((long)b * 16 + i) * ldq + h * 64 + t] * scale;
+  const AttnSeg segs[3] = {s0, s1, s2};
+  int J = 0;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    for (int r = wv; r < segs[s].rows; r += 4) {
+      const long off = (long)b * segs[s].batch_stride + (long)r * segs[s].row_stride + (long)h * segs[s].head_stride + t;
+      sk[J + r][t] = segs[s].k[off];
+      sv[J + r][t] = segs[s].v[off];
+    }
+    J += segs[s].rows;
+  }
+  sf_sync();
+  for (int e = threadIdx.x; e < 16 * J; e += 256) {
+    const int i = e / J, j = e - i * J;
+    float a = 0.0f;
+#pragma unroll 8
+    for (int d = 0; d < 64; ++d) a = fmaf(sq[i][d], sk[j][d], a);
+    sim[i][j] = a;
+  }
+  sf_sync();
+  if (threadIdx.x < 16) {
+    const int i = threadIdx.x;
+    float mx = -INFINITY;
+    for (int j = 0; j < J; ++j) mx = fmaxf(mx, sim[i][j]);
+    float den = 0.0f;
+    for (int j = 0; j < J; ++j) { const float e = expf(sim[i][j] - mx); sim[i][j] = e; den += e; }
+    const float inv = 1.0f / den;
+    for (int j = 0; j < J; ++j) sim[i][j] *= inv;
+  }
+  sf_sync();
+  for (int i = wv; i < 16; i += 4) {
+    float a = 0.0f;
+    for (int j = 0; j < J; ++j) a = fmaf(sim[i][j], sv[j][t], a);
+    const long o = ((long)b * 16 + i) * (heads * 64) + h * 64 + t;
+    if (out_f32) reinterpret_cast<float*>(out)[o] = a;          // consumed by a fused linear (fp32 A operand prologue)
+    else reinterpret_cast<__bf16*>(out)[o] = (__bf16)a;
+  }
+}

@@ -31,6 +31,7 @@
 #include "gemm_rows.h"
 #include "conv_lds.h"
 #include "conv_igemm.h"
+#include "attn_ln.h"
 #include <math.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -243,48 +244,6 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ s1, 
 //   p[0] in f32 [R,C], p[1] gain [C], p[2] bias [C] or NULL, p[3] out (bf16 or f32), p[4] residual f32 or NULL
 //   i = R, C ; f = eps ; flags: 1 = GELU(x) before normalising, 2 = f32 output (+ residual), else bf16 output
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ in, const float* __restrict__ gain,
-                                                   const float* __restrict__ bias, void* __restrict__ out,
-                                                   const float* __restrict__ resid, int R, int C, float eps, int pre_gelu,
-                                                   int out_f32) {
-  __shared__ float red[8];
-  const int row = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const float* x = in + (long)row * C;
-  float v[8];                                   // C <= 2048 = 8 * 256
-  float s = 0.0f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = threadIdx.x + i * 256;
-    v[i] = 0.0f;
-    if (c < C) { const float t = x[c]; v[i] = pre_gelu ? gelu_f(t) : t; s += v[i]; }
-  }
-  s = wave_sum(s);
-  if (lane == 0) red[wv] = s;
-  __syncthreads();
-  const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)C;
-  float q = 0.0f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-    if (threadIdx.x + i * 256 < C) { const float d = v[i] - mean; q = fmaf(d, d, q); }
-  q = wave_sum(q);
-  if (lane == 0) red[4 + wv] = q;
-  __syncthreads();
-  const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)C + eps);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = threadIdx.x + i * 256;
-    if (c < C) {
-      float y = (v[i] - mean) * rstd * gain[c];
-      if (bias) y += bias[c];
-      if (out_f32) {
-        if (resid) y += resid[(long)row * C + c];
-        reinterpret_cast<float*>(out)[(long)row * C + c] = y;
-      } else {
-        reinterpret_cast<__bf16*>(out)[(long)row * C + c] = (__bf16)y;
-      }
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // GEMV: y[m][n] = act_out(bias[n] + sum_k W[n][k] * act_in(x[m][k])), M <= 8 rows, one wave per n.
@@ -351,56 +310,6 @@ __global__ __launch_bounds__(256) void k_gemv(const float* __restrict__ x, const
 //   segment s (s = 0..2): p[2+2s] keys, p[3+2s] values (f32); i[4+4s..] = rows, row_stride, batch_stride, head_stride
 //   i[0] = B, i[1] = heads, i[2] = ldq ; f[0] = q scale ; flags: 1 = fp32 output.   One 256-thread workgroup per (b, head).
 // ---------------------------------------------------------------------------------------------
-struct AttnSeg { const float* k; const float* v; int rows, row_stride, batch_stride, head_stride; };
-__global__ __launch_bounds__(256) void k_attn16(const float* __restrict__ q, void* __restrict__ out, AttnSeg s0, AttnSeg s1,
-                                                AttnSeg s2, int heads, int ldq, float scale, int out_f32) {
-  // 4 waves per (b, head): the kernel is a chain of dependent phases (load, q.k, softmax, p.v), so the only lever is to make
-  // every phase short -- rows of q / k / v are fetched by different waves at once, the 16 x J scores and the 16 output rows
-  // are spread over all 256 lanes
-  __shared__ float sq[16][65];
-  __shared__ float sk[24][65];
-  __shared__ float sv[24][65];
-  __shared__ float sim[16][25];
-  const int b = blockIdx.x / heads, h = blockIdx.x % heads, t = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int i = wv; i < 16; i += 4) sq[i][t] = q[((long)b * 16 + i) * ldq + h * 64 + t] * scale;
-  const AttnSeg segs[3] = {s0, s1, s2};
-  int J = 0;
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    for (int r = wv; r < segs[s].rows; r += 4) {
-      const long off = (long)b * segs[s].batch_stride + (long)r * segs[s].row_stride + (long)h * segs[s].head_stride + t;
-      sk[J + r][t] = segs[s].k[off];
-      sv[J + r][t] = segs[s].v[off];
-    }
-    J += segs[s].rows;
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < 16 * J; e += 256) {
-    const int i = e / J, j = e - i * J;
-    float a = 0.0f;
-#pragma unroll 8
-    for (int d = 0; d < 64; ++d) a = fmaf(sq[i][d], sk[j][d], a);
-    sim[i][j] = a;
-  }
-  __syncthreads();
-  if (threadIdx.x < 16) {
-    const int i = threadIdx.x;
-    float mx = -INFINITY;
-    for (int j = 0; j < J; ++j) mx = fmaxf(mx, sim[i][j]);
-    float den = 0.0f;
-    for (int j = 0; j < J; ++j) { const float e = expf(sim[i][j] - mx); sim[i][j] = e; den += e; }
-    const float inv = 1.0f / den;
-    for (int j = 0; j < J; ++j) sim[i][j] *= inv;
-  }
-  __syncthreads();
-  for (int i = wv; i < 16; i += 4) {
-    float a = 0.0f;
-    for (int j = 0; j < J; ++j) a = fmaf(sim[i][j], sv[j][t], a);
-    const long o = ((long)b * 16 + i) * (heads * 64) + h * 64 + t;
-    if (out_f32) reinterpret_cast<float*>(out)[o] = a;          // consumed by a fused linear (fp32 A operand prologue)
-    else reinterpret_cast<__bf16*>(out)[o] = (__bf16)a;
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // GCA_POOL: pooled[b][c] = sum_p softmax_p(h[b,p,:] . wk + bk) * h[b,p,c]     (GlobalContext :930-941)
