@@ -3,6 +3,7 @@
 Functions take/return CPU torch tensors (fp32 / int32) and mirror the positional signatures
 of the reference's pybind modules so the reference's own Python (loaded by ref_loader.py) can
 run on top of them."""
+import contextlib
 import ctypes as C
 import os
 import subprocess
@@ -12,12 +13,14 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "liboracle_ngp.so")
+_SO_NOFMA = os.path.join(_HERE, "_build", "liboracle_ngp_nofma.so")
 _lib = None
+_libs = {}
 
 
 def build(force=False):
     src = os.path.join(_HERE, "ngp_ref.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    if force or not os.path.exists(_SO) or not os.path.exists(_SO_NOFMA) or min(os.path.getmtime(_SO), os.path.getmtime(_SO_NOFMA)) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B" if force else "-s"])
     return _SO
 
@@ -26,8 +29,22 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = C.CDLL(_SO)
+        _lib = _libs.setdefault(_SO, C.CDLL(_SO))
     return _lib
+
+
+@contextlib.contextmanager
+def unfused():
+    """Inside this context every function of this module runs on the -DORACLE_NO_FMA build (all fmaf() unfused): the form that
+    is compared bit for bit with the reference's sources compiled -ffp-contract=off (ref_native.unfused())."""
+    global _lib
+    build()
+    prev = _lib
+    _lib = _libs.setdefault(_SO_NOFMA, C.CDLL(_SO_NOFMA))
+    try:
+        yield
+    finally:
+        _lib = prev
 
 
 def _p(t):

@@ -12,9 +12,13 @@
  *   near/far            raymarching/src/raymarching.cu:91-145
  *   morton / packbits   raymarching/src/raymarching.cu:56-82, :214-289
  *
- * PARITY UNPINNED by the reference: it ships no test, golden vector or CPU path for these
- * kernels; tests/test_oracle_first_principles.py cross-checks
- * this file against an independent dense trilinear interpolation instead.
+ * PINNED (round 3): the reference ships no test, golden vector or CPU path for these kernels
+ * (SURVEY.md section 4 / 8(c)), so its own .cu sources are compiled for the host by
+ * oracle/build_ref.py (oracle/_ref/libref_native*.so) and this file is compared with them bit
+ * for bit: tests/test_oracle_native_pin.py (live, dev container) and the committed vectors
+ * tests/golden/ngp_native.pt (made by tests/golden/make_golden_native.py; checked everywhere).
+ * First-principles cross-checks (dense trilinear interpolation, adjoint identity, slab test):
+ * tests/test_oracle_ngp.py, tests/test_oracle_occ.py.
  *
  * a*b+c patterns that nvcc contracts into one FMA under its default -fmad=true are written
  * as fmaf() (compile with -ffp-contract=off so nothing else is contracted).  Level geometry
@@ -24,6 +28,10 @@
 #include <float.h>
 #include <stdint.h>
 #include <string.h>
+
+#ifdef ORACLE_NO_FMA          /* second build (liboracle_ngp_nofma.so): every fmaf() unfused, to be compared bit for bit */
+#define fmaf(a, b, c) ((a) * (b) + (c)) /* with the reference's own sources compiled -ffp-contract=off (oracle/build_ref.py) */
+#endif
 
 #define MAXD 5
 #define MAXC 8
