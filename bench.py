@@ -94,7 +94,7 @@ class HotPath:
         self.z_scale = 0.18215                                    # args.z_scale_factor of the reference's demo
         from sparsefusion_amd.lpips import PerceptualLoss
         self.percep = PerceptualLoss('vgg', device=device)        # distillation.py:161
-        self.percep.model._weights_loaded = True                  # synthetic VGG16 / lin weights, stated in `data` (no `lpips` package here)
+        self.percep.model.accept_synthetic_weights()              # synthetic VGG16 / lin weights, stated in `data` (no `lpips` package here)
         self.lambda_percep = 0.1                                  # value after start_percep_step (:176-178)
         g = torch.Generator().manual_seed(100 + rank)
         self.rays_in = pinhole_rays(128, rank % 2, 34, device)                 # one of the 2 input views
@@ -106,7 +106,7 @@ class HotPath:
 
     def sampler_ctx(self):
         """a prepared trajectory context (time table + conditioning part of the init conv) for timing single evals"""
-        if getattr(self, "_sctx", None) is None:
+        if getattr(self, "_sctx", None) is None or self._sctx["generation"] != self._sctx["plan"].generation:
             self._sctx = self.unet.begin_sampling(self.features[:1], torch.linspace(-3, 3, 4, device=self.dev))
             self.sampler_x = torch.zeros(1, 4, 32, 32, device=self.dev)
         return self._sctx

@@ -19,9 +19,6 @@ struct GcaPoolArgs {
   float* part_pool;          // [B * chunks][C]
   float* part_ms;            // [B * chunks][2] (max, sum of exp)
   int M, C, HW, CH, chunks, nparts, groups, npad;
-#if SF_PDL
-  SfPdl pdl;                 // software dependent launch (variant build only)
-#endif
 };
 
 // grid = B * chunks * (C / 64); 256 threads = 16 channel float4 lanes x 16 pixel lanes.
@@ -29,9 +26,6 @@ struct GcaPoolArgs {
 // (~0.5 us), and the first version of this kernel spent 30 us summing 256 logit parts one after the other.
 SF_KERNEL(256) void k_gca_pool(GcaPoolArgs a) {
   sf_touch_kernarg<(int)sizeof(GcaPoolArgs)>();
-#if SF_PDL
-  sf_pdl_wait(a.pdl);
-#endif
   SF_SHARED float e[128];
   SF_SHARED float red[16][132];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -125,9 +119,6 @@ SF_KERNEL(256) void k_gca_pool(GcaPoolArgs a) {
     for (int k = 0; k < 16; ++k) s += red[k][tid];
     a.part_pool[(long)bc * a.C + cs * 64 + tid] = s;
   }
-#if SF_PDL
-  sf_pdl_arrive(a.pdl);
-#endif
 }
 
 struct GcaNetArgs {
@@ -137,9 +128,6 @@ struct GcaNetArgs {
   const float* b0;
   float* hid;                // [B][hid]
   int B, C, Kp, HID, chunks;
-#if SF_PDL
-  SfPdl pdl;
-#endif
 };
 
 // grid = B * ceil(HID / 16); 4 waves x 4 rows each
@@ -161,9 +149,6 @@ SF_KERNEL(256) void k_gca_net0(GcaNetArgs a) {
       w[rr][it] = (r < a.HID && k < a.C) ? *reinterpret_cast<const bf16x8*>(a.W0 + (long)r * a.Kp + k) : sf_zero8();
     }
   }
-#if SF_PDL
-  sf_pdl_wait(a.pdl);                                     // the weight rows above are all this launch fetches early
-#endif
   // the pooled partials of this thread's first channel: independent of the merge weights, so in flight with them
   float pj0[8];
 #pragma unroll
@@ -204,132 +189,6 @@ SF_KERNEL(256) void k_gca_net0(GcaNetArgs a) {
     acc = sf_wave_sum(acc);
     if (lane == 0 && r < a.HID) a.hid[(long)b * a.HID + r] = sf_silu(acc + a.b0[r]);
   }
-#if SF_PDL
-  sf_pdl_arrive(a.pdl);
-#endif
-}
-
-struct GcaPoolNetArgs {
-  float* h2;                 // [M, C] final values (written by the first row block of every image when lazy)
-  const float* ws;           // lazy: split-K slabs [groups][M][npad], else null
-  const float* bias;         // lazy: conv bias [C] or null
-  const float* logit_part;   // [nparts][M]
-  const __bf16* W0;          // [hid][Kp]
-  const float* b0;
-  float* hid;                // [B][hid]
-  int M, C, HW, nparts, groups, npad, Kp, HID;
-};
-
-// Small maps (HW = 16 or 64 pixels): k_gca_pool and k_gca_net0 in ONE launch.  Every workgroup (16 rows of the hidden
-// vector) re-derives the softmax-pooled context itself -- logits from the conv's partial sums, softmax over the image's
-// pixels, pooled[c] = sum_p softmax_p * h2[p, c] for all C channels (HW * C * 4 bytes = 64..256 KB from L2 per workgroup,
-// ~2 us) -- instead of waiting behind a separate pooling launch (~5.6 us of dependent-launch latency).
-// grid = B * ceil(HID / 16), 256 threads; C % 4 == 0, C <= 2048, HW in {16, 64}.
-SF_KERNEL(256) void k_gca_poolnet(GcaPoolNetArgs a) {
-  sf_touch_kernarg<(int)sizeof(GcaPoolNetArgs)>();
-  SF_SHARED float e[64];
-  SF_SHARED float red[16][68];
-  SF_SHARED float pooled[2048];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int rb = (a.HID + 15) / 16;
-  const int b = blockIdx.x / rb, rblk = blockIdx.x - b * rb, r0 = rblk * 16;
-  const long m0 = (long)b * a.HW;
-  // this wave's 4 weight rows (as k_gca_net0): issued first, consumed last
-  bf16x8 w[4][4];
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int r = r0 + wave * 4 + rr;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int k = lane * 8 + it * 512;
-      w[rr][it] = (r < a.HID && k < a.C) ? *reinterpret_cast<const bf16x8*>(a.W0 + (long)r * a.Kp + k) : sf_zero8();
-    }
-  }
-  // (1) logits of the image's pixels: HW pixels x PL = 256 / HW part lanes, 8 independent loads per trip
-  {
-    const int p = tid & (a.HW - 1), pl = tid / a.HW, PL = 256 / a.HW;
-    float l = 0.0f;
-    for (int k0 = pl; k0 < a.nparts; k0 += 8 * PL) {
-      float t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int k = k0 + u * PL;
-        t[u] = a.logit_part[(long)(k < a.nparts ? k : a.nparts - 1) * a.M + m0 + p];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (k0 + u * PL < a.nparts) l += t[u];
-    }
-    red[pl][p] = l;
-  }
-  sf_sync();
-  if (tid < a.HW) {
-    const int PL = 256 / a.HW;
-    float l = 0.0f;
-    for (int k = 0; k < PL; ++k) l += red[k][tid];
-    e[tid] = l;
-  }
-  sf_sync();
-  // (2) softmax numerators and their sum (every wave computes the same values)
-  float mx = -INFINITY;
-  for (int p = lane; p < a.HW; p += 64) mx = fmaxf(mx, e[p]);
-  mx = sf_wave_max(mx);
-  float sm = 0.0f;
-  for (int p = lane; p < a.HW; p += 64) sm += sf_exp(e[p] - mx);
-  sm = sf_wave_sum(sm);
-  sf_sync();
-  if (tid < a.HW) e[tid] = sf_exp(e[tid] - mx);
-  sf_sync();
-  const float rz = 1.0f / sm;
-  // (3) pooled[c] for ALL channels: thread -> float4 channel chunk(s), pixels in trips of 8 loads
-  for (int c4 = tid; c4 < (a.C >> 2); c4 += 256) {
-    const int c = c4 * 4;
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 bvec = (a.ws && a.bias) ? *reinterpret_cast<const f32x4*>(a.bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int p0 = 0; p0 < a.HW; p0 += 8) {
-      f32x4 v[8];
-      if (a.ws) {
-        const long gstride = (long)a.M * a.npad;
-        const int gl = a.groups - 1;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {                       // 8 pixels x (<= 4 | <= 8) slabs: all loads of a pixel before its adds
-          const float* ap = a.ws + (m0 + p0 + u) * a.npad + c;
-          f32x4 t[8];
-#pragma unroll
-          for (int g = 0; g < 8; ++g) t[g] = *reinterpret_cast<const f32x4*>(ap + (g < gl ? g : gl) * gstride);
-          v[u] = bvec;
-#pragma unroll
-          for (int g = 0; g < 8; ++g) v[u] += t[g] * (g <= gl ? 1.0f : 0.0f);
-        }
-      } else {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(a.h2 + (m0 + p0 + u) * a.C + c);
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (a.ws && rblk == 0) *reinterpret_cast<f32x4*>(a.h2 + (m0 + p0 + u) * a.C + c) = v[u];
-        acc += v[u] * e[p0 + u];
-      }
-    }
-    *reinterpret_cast<f32x4*>(pooled + c) = acc * rz;
-  }
-  sf_sync();
-  // (4) hid = SiLU(W0 . pooled + b0)
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int r = r0 + wave * 4 + rr;
-    float acc = 0.0f;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int k = lane * 8 + it * 512;
-      if (k < a.C) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc = fmaf((float)w[rr][it][j], pooled[k + j], acc);
-      }
-    }
-    acc = sf_wave_sum(acc);
-    if (lane == 0 && r < a.HID) a.hid[(long)b * a.HID + r] = sf_silu(acc + a.b0[r]);
-  }
 }
 
 struct GcaGateArgs {
@@ -341,25 +200,14 @@ struct GcaGateArgs {
   float* out;
   float* slots;              // [M/16][C/16][2] or null
   int M, C, HW, HID, Kp2;
-#if SF_PDL
-  SfPdl pdl;
-#endif
 };
 
 // one wave per (16 pixels, 16 channels); grid = ceil(M/16 * C/16 / 4)
 SF_KERNEL(256) void k_gca_gate(GcaGateArgs a) {
   sf_touch_kernarg<(int)sizeof(GcaGateArgs)>();
   const int CF = a.C >> 4;
-#if SF_PDL
-  // software dependent launch: every operand of this kernel comes from its predecessors -> wait first.  No early exit in front of
-  // the arrive barrier: surplus waves repeat the last tile (identical stores).
-  sf_pdl_wait(a.pdl);
-  const int gw_raw = blockIdx.x * 4 + (threadIdx.x >> 6), gw_last = (a.M >> 4) * CF - 1;
-  const int lane = threadIdx.x & 63, gw = gw_raw < gw_last ? gw_raw : gw_last;
-#else
   const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (gw >= (a.M >> 4) * CF) return;
-#endif
   const int mf = gw / CF, cf = gw - mf * CF;
   const int b = (mf * 16) / a.HW;
   // the tile's own operands first (independent of the gate): lane -> pixel (lane >> 2), channels cf*16 + (lane & 3)*4 .. +3
@@ -414,7 +262,4 @@ SF_KERNEL(256) void k_gca_gate(GcaGateArgs a) {
     sq = sf_wave_sum(sq);
     if (lane == 0) { a.slots[(long)gw * 2] = sm; a.slots[(long)gw * 2 + 1] = sq; }
   }
-#if SF_PDL
-  sf_pdl_arrive(a.pdl);
-#endif
 }

@@ -136,6 +136,7 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
     if (a.slots_out && (a.Cout % 16 || a.ldc % 16 || a.co_off % 16)) FC_FAIL("fconv: slots need 16-aligned channels");
   }
   if (a.norm == FNORM_GN_SELF && (a.H * a.W * (Cs / 4) > 4096)) FC_FAIL("fconv: GN_SELF tile exceeds the register-resident prologue");
+  if (a.norm == FNORM_GN_SELF && Cs / (a.C / a.G) > 16) FC_FAIL("fconv: GN_SELF slice holds more than 16 groups");
   a.logW = 0;
   while ((1 << a.logW) < a.W) ++a.logW;
   auto mk = [](uint32_t d) { FDiv f; f.d = d ? d : 1; f.magic = (uint32_t)(0x100000000ull / f.d) + 1u; return f; };
@@ -203,23 +204,6 @@ static inline int fconv_pair_setup(const sf_op& op1, const sf_op& op2, FConvPair
 //           i: 0 M  1 C  2 HW  3 CH (pixels per chunk)  4 chunks per image  5 nparts  6 groups  7 npad
 //   2 NET0  p: 0 part_pool  1 part_ms  2 W0 bf16 [HID][Kp]  3 b0  4 hid ;  i: 0 B  1 C  2 Kp  3 HID  4 chunks
 //   3 GATE  p: 0 h2  1 res  2 hid  3 W2 bf16 [C][Kp2]  4 b2  5 out  6 slots or null ;  i: 0 M  1 C  2 HW  3 HID  4 Kp2
-//   4 POOLNET (small maps: stages 1 + 2 in one launch)
-//           p: 0 h2  1 split-K slabs or null  2 conv bias or null  3 logit_part  4 W0 bf16 [HID][Kp]  5 b0  6 hid
-//           i: 0 M  1 C  2 HW (16 | 64)  3 nparts  4 groups  5 npad  6 Kp  7 HID
-static inline int gca_poolnet_setup(const sf_op& op, GcaPoolNetArgs& a, uint32_t& grid, char* err, size_t errn) {
-  a.h2 = (float*)op.p[0]; a.ws = (const float*)op.p[1]; a.bias = (const float*)op.p[2]; a.logit_part = (const float*)op.p[3];
-  a.W0 = (const __bf16*)op.p[4]; a.b0 = (const float*)op.p[5]; a.hid = (float*)op.p[6];
-  a.M = op.i[0]; a.C = op.i[1]; a.HW = op.i[2]; a.nparts = op.i[3]; a.groups = op.i[4]; a.npad = op.i[5]; a.Kp = op.i[6]; a.HID = op.i[7];
-  if (!a.h2 || !a.logit_part || !a.W0 || !a.b0 || !a.hid) { snprintf(err, errn, "gca poolnet: missing operand"); return 1; }
-  if ((a.HW != 16 && a.HW != 64) || a.M % a.HW || a.C % 8 || a.C > 2048 || a.Kp < a.C || a.nparts < 1 || a.HID < 1) {
-    snprintf(err, errn, "gca poolnet: HW in {16, 64}, C %% 8 == 0, C <= 2048 required");
-    return 1;
-  }
-  if (a.ws && (a.groups < 1 || a.groups > 8 || a.npad % 4)) { snprintf(err, errn, "gca poolnet: bad split-K source (1..8 slabs)"); return 1; }
-  grid = (uint32_t)(a.M / a.HW) * ((a.HID + 15) / 16);
-  return 0;
-}
-
 static inline int gca_setup(const sf_op& op, GcaPoolArgs& pa, GcaNetArgs& na, GcaGateArgs& ga, uint32_t& grid, char* err, size_t errn) {
 #define GC_FAIL(...) do { snprintf(err, errn, __VA_ARGS__); return 1; } while (0)
   if (op.flags == 1) {

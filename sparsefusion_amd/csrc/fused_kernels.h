@@ -75,9 +75,6 @@ struct FConvArgs {
   const float* wk;                   // GlobalContext to_k weight [Cout] or null: the epilogue also emits partial context logits
   float* logit_part;                 //   logit_part[(s * n_frags + n_frag) * M + m] = sum over the fragment's 16 channels of value * wk
   long long* dbg;                    // optional [grid][8] phase timestamps (tools/fconv_phases.py), null in production
-#if SF_PDL
-  SfPdl pdl;                         // software dependent launch (variant build only)
-#endif
 };
 
 template <int MODE>
@@ -266,14 +263,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
     }
   };
 
-#if SF_PDL
-  // software dependent launch: the weight ring is all this launch may fetch before its predecessor has finished
-  prefetch_weights();
-  sf_pdl_wait(a.pdl);
-#define FC_PREFETCH() do { } while (0)
-#else
 #define FC_PREFETCH() prefetch_weights()
-#endif
   float* tabA = reinterpret_cast<float*>(lds + a.tab_off);
   float* tabB = tabA + Cs;
   float* misc = reinterpret_cast<float*>(lds + a.misc_off);      // [0..15] group sums, [16..] group / row (mean, rstd)
@@ -457,32 +447,34 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
         misc[17 + 2 * tid] = sf_rsqrt((float)var + a.eps);
       }
     } else {
-      if (tid < 16) misc[tid] = 0.0f;
-      sf_sync();
-      int cur = -1;
-      float sm = 0.0f, sq = 0.0f;
+      // slice shapes the segment scheme does not cover (NT % (Cs/4) != 0, odd group widths): still ORDER-INDEPENDENT --
+      // per group, every thread's partial goes through the fixed wave shuffle tree, the <= 8 per-wave partials meet in LDS and
+      // one thread adds them in wave order (r02 used LDS float atomics here: last-ulp run-to-run noise in the statistics).
+      const int ng = (int)fdiv((uint32_t)Cs, a.d_cg);          // groups in this slice, <= 16 (host check)
+      float* part = misc + 160;                               // [waves][16][2]
+      for (int g = 0; g < ng; ++g) {
+        float sm = 0.0f, sq = 0.0f;
 #pragma unroll
-      for (int u = 0; u < NV; ++u) {
-        const int i = tid + u * NT;
-        if (i < cnt) {
+        for (int u = 0; u < NV; ++u) {
+          const int i = tid + u * NT;
           const int p = (int)fdiv((uint32_t)i, a.d_cs4), c4 = i - p * Cs4;
-          const int gi = (int)fdiv((uint32_t)(c4 * 4), a.d_cg);
-          const float sc = (c0 + c4 * 4 < a.s1.C) ? sc1 : sc2;
-          if (gi != cur) {
-            if (cur >= 0) { sf_lds_add(misc + 2 * cur, sm); sf_lds_add(misc + 2 * cur + 1, sq); }
-            cur = gi; sm = 0.0f; sq = 0.0f;
+          if (i < cnt && (int)fdiv((uint32_t)(c4 * 4), a.d_cg) == g) {
+            const f32x4 w = v[u] * ((c0 + c4 * 4 < a.s1.C) ? sc1 : sc2);
+            sm += (w[0] + w[1]) + (w[2] + w[3]);
+            sq = fmaf(w[0], w[0], sq); sq = fmaf(w[1], w[1], sq); sq = fmaf(w[2], w[2], sq); sq = fmaf(w[3], w[3], sq);
           }
-          const f32x4 w = v[u] * sc;
-          sm += (w[0] + w[1]) + (w[2] + w[3]);
-          sq = fmaf(w[0], w[0], sq); sq = fmaf(w[1], w[1], sq); sq = fmaf(w[2], w[2], sq); sq = fmaf(w[3], w[3], sq);
         }
+        sm = sf_wave_sum(sm);
+        sq = sf_wave_sum(sq);
+        if (lane == 0) { part[(wave * 16 + g) * 2] = sm; part[(wave * 16 + g) * 2 + 1] = sq; }
       }
-      if (cur >= 0) { sf_lds_add(misc + 2 * cur, sm); sf_lds_add(misc + 2 * cur + 1, sq); }
       sf_sync();
-      if (tid < Cs / Cg) {
+      if (tid < ng) {
+        double S = 0.0, Q = 0.0;
+        for (int w = 0; w < NT / 64; ++w) { S += (double)part[(w * 16 + tid) * 2]; Q += (double)part[(w * 16 + tid) * 2 + 1]; }
         const double rn = a.inv_n;                     // 1 / (HW * Cg) from the host: a double division is ~100 dependent instructions
-        const double mean = (double)misc[2 * tid] * rn;
-        double var = (double)misc[2 * tid + 1] * rn - mean * mean;
+        const double mean = S * rn;
+        double var = Q * rn - mean * mean;
         if (var < 0.0) var = 0.0;
         misc[16 + 2 * tid] = (float)mean;
         misc[17 + 2 * tid] = sf_rsqrt((float)var + a.eps);
@@ -836,9 +828,6 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
   FC_STAMP(5);
 #undef FC_STAMP
 #undef FC_PREFETCH
-#if SF_PDL
-  sf_pdl_arrive(a.pdl);
-#endif
 }
 
 template <int WM, int WN, int D, int NORM, int LAZY, int NW>

@@ -153,21 +153,6 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
       slsc[u] = live ? (f1 ? sc1 : sc2) : 0.0f;
     }
   };
-#if SF_PDL
-  // software dependent launch: only the weight ring may go out before the predecessor has finished
-  if (mx_role) {
-#pragma unroll
-    for (int i = 0; i < KPW; ++i)
-#pragma unroll
-      for (int ni = 0; ni < WN; ++ni) pool[i * WN + ni] = __builtin_bit_cast(f32x4, wload(0, i, ni));
-  }
-  sf_pdl_wait(a.pdl);
-  if (wave < ngs) slot_loads(wave, lane);
-  if (!mx_role) {
-#pragma unroll
-    for (int j = 0; j < NB - 1; ++j) issue(j < NCH ? j : NCH - 1, j * EPT);
-  }
-#else
   if (wave < ngs) slot_loads(wave, lane);
   // ---- first loads of every role go out before anything waits
   if (mx_role) {
@@ -179,7 +164,6 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
 #pragma unroll
     for (int j = 0; j < NB - 1; ++j) issue(j < NCH ? j : NCH - 1, j * EPT);
   }
-#endif
   FP_STAMP(6);
   // GroupNorm parameters of the whole input (C <= 4 * NT channels), statistics slots of this wave's group
   constexpr int TABN = 4;
@@ -374,9 +358,6 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
   }
   FP_STAMP(5);
 #undef FP_STAMP
-#if SF_PDL
-  sf_pdl_arrive(a.pdl);
-#endif
 }
 
 template <int WM, int WN, int EPT, int NW>

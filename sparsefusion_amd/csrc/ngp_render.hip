@@ -92,264 +92,6 @@ __global__ __launch_bounds__(64) void k_ngp_sample_fine(
                   cdf, bins, z_f + (size_t)n * T);
 }
 
-__global__ __launch_bounds__(64) void k_ngp_composite(
-    const float* __restrict__ z_c, const float* __restrict__ sig_c, const float* __restrict__ rgb_c,
-    const float* __restrict__ z_f, const float* __restrict__ sig_f, const float* __restrict__ rgb_f,
-    const float* __restrict__ nears, const float* __restrict__ fars, uint32_t N, uint32_t T, float bg,
-    float* __restrict__ z_s, float* __restrict__ sig_s, float* __restrict__ rgb_s, float* __restrict__ image,
-    float* __restrict__ depth, float* __restrict__ weights_sum) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const uint32_t n = blockIdx.x * 64 + threadIdx.x;
-  if (n >= N) return;
-  SfCol key{smem + threadIdx.x, 64};
-  SfCol ord{smem + (size_t)T * 64 + threadIdx.x, 64};
-  NgpRayOut r;
-  ngp_merge_composite(z_c + (size_t)n * T, sig_c + (size_t)n * T, rgb_c + (size_t)n * T * 3, z_f + (size_t)n * T,
-                      sig_f + (size_t)n * T, rgb_f + (size_t)n * T * 3, nears[n], fars[n], T, bg, key, ord,
-                      z_s + (size_t)n * 2 * T, sig_s + (size_t)n * 2 * T, rgb_s + (size_t)n * 6 * T, r);
-  image[n * 3 + 0] = r.image[0]; image[n * 3 + 1] = r.image[1]; image[n * 3 + 2] = r.image[2];
-  depth[n] = r.depth;
-  weights_sum[n] = r.weights_sum;
-}
-
-__global__ __launch_bounds__(64) void k_ngp_composite_bwd(
-    const float* __restrict__ z_s, const float* __restrict__ sig_s, const float* __restrict__ rgb_s,
-    const float* __restrict__ nears, const float* __restrict__ fars, uint32_t N, uint32_t T, float bg,
-    const float* __restrict__ g_image, const float* __restrict__ g_ws, float* __restrict__ dsig,
-    float* __restrict__ drgb) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const uint32_t n = blockIdx.x * 64 + threadIdx.x;
-  if (n >= N) return;
-  SfCol tr{smem + threadIdx.x, 64};
-  SfCol wt{smem + (size_t)2 * T * 64 + threadIdx.x, 64};
-  const float gI[3] = {g_image[n * 3], g_image[n * 3 + 1], g_image[n * 3 + 2]};
-  const float gW = g_ws ? g_ws[n] : 0.0f;
-  ngp_composite_backward(z_s + (size_t)n * 2 * T, sig_s + (size_t)n * 2 * T, rgb_s + (size_t)n * 6 * T, nears[n],
-                         fars[n], T, bg, gI, gW, tr, wt, dsig + (size_t)n * 2 * T, drgb + (size_t)n * 6 * T);
-}
-
-// ---------------------------------------------------------------------------
-// Field backward.  256 threads = 256 points per tile; LDS: W + two [256][66] staging arrays.
-// Per-point vectors (h1, h2, dh2, dh1) live in the thread's own LDS row; matrix-vector products
-// run as 16-output chunks (rolled outer loop) so the kernel stays well under 256 VGPRs.
-// ---------------------------------------------------------------------------
-#define BW_S 66   // row stride (floats): 8-byte aligned rows, ds_read_b64 conflict-free, cols 64,65 spare
-struct FieldGrad { float* g_table; float* g_w0; float* g_b0; float* g_w1; float* g_b1; float* g_w2; float* g_b2; };
-
-// out_row[j] = act(bias[j] + sum_k Wm[j*K + k] * in[k]),  j < 64, in[] in registers
-template <int K, bool RELU>
-__device__ __forceinline__ void bw_matvec(const float* __restrict__ Wm, const float* __restrict__ bias,
-                                          const float (&in)[K], float* __restrict__ out_row) {
-#pragma unroll 1
-  for (int jc = 0; jc < NGP_HID; jc += 16) {
-    float a[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) a[i] = bias[jc + i];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) a[i] = fmaf(Wm[(jc + i) * K + k], in[k], a[i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) out_row[jc + i] = RELU ? fmaxf(a[i], 0.0f) : a[i];
-  }
-}
-
-// out[k] = sum_j Wm[j*K + k] * in_row[j]  (transposed product; in_row in LDS, K outputs in chunks of 16)
-template <int K>
-__device__ __forceinline__ void bw_matvec_t(const float* __restrict__ Wm, const float* __restrict__ in_row,
-                                            float (&out)[K]) {
-#pragma unroll
-  for (int k = 0; k < K; ++k) out[k] = 0.0f;
-#pragma unroll 1
-  for (int j = 0; j < NGP_HID; j += 4) {
-    const float d0 = in_row[j], d1 = in_row[j + 1], d2 = in_row[j + 2], d3 = in_row[j + 3];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      out[k] = fmaf(Wm[(j + 0) * K + k], d0, out[k]);
-      out[k] = fmaf(Wm[(j + 1) * K + k], d1, out[k]);
-      out[k] = fmaf(Wm[(j + 2) * K + k], d2, out[k]);
-      out[k] = fmaf(Wm[(j + 3) * K + k], d3, out[k]);
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void k_ngp_field_bwd(
-    FieldPtrs f, FieldGrad g, NgpLevels lv, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-    const float* __restrict__ aabb, const float* __restrict__ z_s, const float* __restrict__ dsig,
-    const float* __restrict__ drgb, float* __restrict__ dfeat_out, uint32_t P, uint32_t T2) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* W = smem;                                   // NGP_WTOTAL (rounded to 6536)
-  float* X = smem + 6536;                            // [256][BW_S]
-  float* Y = X + 256 * BW_S;                         // [256][BW_S]
-  load_weights_lds(W, f);
-  float box[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) box[i] = aabb[i];
-
-  const uint32_t t = threadIdx.x;
-  float* xr = X + t * BW_S;
-  float* yr = Y + t * BW_S;
-  // gradient strips owned by this thread
-  const uint32_t j1 = t >> 2, kb1 = (t & 3) * 16;    // dW1[j1][kb1..+15]
-  const uint32_t kb0 = (t & 3) * 8;                  // dW0[j1][kb0..+7]
-  const uint32_t o2 = t >> 6, k2 = t & 63;           // dW2[o2][k2]
-  float acc1[16], acc0[8], acc2 = 0.0f, accb1 = 0.0f, accb0 = 0.0f, accb2 = 0.0f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc1[i] = 0.0f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) acc0[i] = 0.0f;
-  __syncthreads();
-
-  const uint32_t n_tiles = (P + 255) / 256;
-#pragma unroll 1
-  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const uint32_t p = tile * 256 + t;
-    const bool live = p < P;
-    float x[3] = {0.f, 0.f, 0.f}, x01[3] = {0.f, 0.f, 0.f};
-    bool inside = false;
-    float feat[NGP_FEAT], dout[NGP_OUT];
-    if (live) {
-      const uint32_t n = p / T2;
-      const float o[3] = {rays_o[n * 3], rays_o[n * 3 + 1], rays_o[n * 3 + 2]};
-      const float d[3] = {rays_d[n * 3], rays_d[n * 3 + 1], rays_d[n * 3 + 2]};
-      ngp_point(o, d, z_s[p], box, x);
-      inside = ngp_unit(x, f.bound, x01) && live;
-    }
-    ngp_encode(lv, f.table, x01, inside, feat);
-    // ---- recompute the MLP forward: h1 -> own row of X, h2 -> own row of Y
-    bw_matvec<NGP_FEAT, true>(W + NGP_W0, W + NGP_B0, feat, xr);
-    {
-      float h1[NGP_HID];
-#pragma unroll
-      for (int k = 0; k < NGP_HID; ++k) h1[k] = xr[k];
-      bw_matvec<NGP_HID, true>(W + NGP_W1, W + NGP_B1, h1, yr);
-    }
-    {
-      float out[NGP_OUT];
-#pragma unroll
-      for (int j = 0; j < NGP_OUT; ++j) out[j] = W[NGP_B2 + j];
-#pragma unroll 4
-      for (int k = 0; k < NGP_HID; ++k) {
-        const float hk = yr[k];
-#pragma unroll
-        for (int j = 0; j < NGP_OUT; ++j) out[j] = fmaf(W[NGP_W2 + j * NGP_HID + k], hk, out[j]);
-      }
-      if (live) {
-        const float pre = out[0] + ngp_blob(x);
-        dout[0] = dsig[p] * expf(fminf(fmaxf(pre, -15.0f), 15.0f));     // trunc_exp backward
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float sg = ngp_sigmoid(out[1 + c]);
-          dout[1 + c] = drgb[p * 3 + c] * sg * (1.0f - sg);
-        }
-      } else {
-        dout[0] = dout[1] = dout[2] = dout[3] = 0.0f;
-      }
-    }
-    xr[64] = dout[0]; xr[65] = dout[1]; yr[64] = dout[2]; yr[65] = dout[3];
-    __syncthreads();                                                   // S1
-
-    // ---- dW2[o][k] += sum_p dout[p][o] * h2[p][k];  db2
-    {
-      const float* dcol = (o2 < 2 ? X : Y) + 64 + (o2 & 1);
-      float a = 0.0f, b = 0.0f;
-#pragma unroll 8
-      for (uint32_t q = 0; q < 256; ++q) {
-        const float dv = dcol[q * BW_S];
-        a = fmaf(dv, Y[q * BW_S + k2], a);
-        b += dv;
-      }
-      acc2 += a;
-      if (k2 == 0) accb2 += b;
-    }
-    {  // dh2 = W2^T dout, masked by own h2 (own row of Y)
-      float dh2[NGP_HID];
-#pragma unroll
-      for (int k = 0; k < NGP_HID; ++k) {
-        float a = 0.0f;
-#pragma unroll
-        for (int j = 0; j < NGP_OUT; ++j) a = fmaf(W[NGP_W2 + j * NGP_HID + k], dout[j], a);
-        dh2[k] = yr[k] > 0.0f ? a : 0.0f;
-      }
-      __syncthreads();                                                 // S2: Y (h2) fully consumed
-#pragma unroll
-      for (int k = 0; k < NGP_HID; ++k) yr[k] = dh2[k];
-    }
-    __syncthreads();                                                   // S3
-
-    // ---- dW1[j][k] += sum_p dh2[p][j] * h1[p][k];  db1
-    {
-      float b = 0.0f;
-#pragma unroll 2
-      for (uint32_t q = 0; q < 256; ++q) {
-        const float dv = Y[q * BW_S + j1];
-        const float2* hv = reinterpret_cast<const float2*>(X + q * BW_S + kb1);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float2 h = hv[i];
-          acc1[2 * i] = fmaf(dv, h.x, acc1[2 * i]);
-          acc1[2 * i + 1] = fmaf(dv, h.y, acc1[2 * i + 1]);
-        }
-        b += dv;
-      }
-      if ((t & 3) == 0) accb1 += b;
-    }
-    {  // dh1 = W1^T dh2 (own row of Y), masked by own h1 (own row of X)
-      float dh1[NGP_HID];
-      bw_matvec_t<NGP_HID>(W + NGP_W1, yr, dh1);
-#pragma unroll
-      for (int k = 0; k < NGP_HID; ++k) dh1[k] = xr[k] > 0.0f ? dh1[k] : 0.0f;
-      __syncthreads();                                                 // S4: X (h1), Y (dh2) consumed
-#pragma unroll
-      for (int k = 0; k < NGP_HID; ++k) xr[k] = dh1[k];
-#pragma unroll
-      for (int k = 0; k < NGP_FEAT; ++k) yr[k] = feat[k];
-    }
-    __syncthreads();                                                   // S5
-
-    // ---- dW0[j][k] += sum_p dh1[p][j] * feat[p][k];  db0
-    {
-      float b = 0.0f;
-#pragma unroll 4
-      for (uint32_t q = 0; q < 256; ++q) {
-        const float dv = X[q * BW_S + j1];
-        const float2* fv = reinterpret_cast<const float2*>(Y + q * BW_S + kb0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float2 h = fv[i];
-          acc0[2 * i] = fmaf(dv, h.x, acc0[2 * i]);
-          acc0[2 * i + 1] = fmaf(dv, h.y, acc0[2 * i + 1]);
-        }
-        b += dv;
-      }
-      if ((t & 3) == 0) accb0 += b;
-    }
-    // ---- d(features) = W0^T dh1 (own row of X) and table scatter
-    {
-      float dfeat[NGP_FEAT];
-      bw_matvec_t<NGP_FEAT>(W + NGP_W0, xr, dfeat);
-      if (dfeat_out && live) {                         // level-major [L][P][2]: coalesced for the scatter passes
-#pragma unroll
-        for (uint32_t l = 0; l < NGP_MAX_LEVELS; ++l)
-          if (l < lv.L)
-            *reinterpret_cast<float2*>(dfeat_out + ((size_t)l * P + p) * 2) =
-                inside ? make_float2(dfeat[2 * l], dfeat[2 * l + 1]) : make_float2(0.f, 0.f);
-      }
-    }
-    __syncthreads();                                                   // S6: before the next tile restages
-  }
-
-  // flush this workgroup's MLP gradient strips
-#pragma unroll
-  for (int i = 0; i < 16; ++i) SF_ATOMIC_ADD(g.g_w1 + j1 * NGP_HID + kb1 + i, acc1[i]);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) SF_ATOMIC_ADD(g.g_w0 + j1 * NGP_FEAT + kb0 + i, acc0[i]);
-  SF_ATOMIC_ADD(g.g_w2 + o2 * NGP_HID + k2, acc2);
-  if ((t & 3) == 0) { SF_ATOMIC_ADD(g.g_b1 + j1, accb1); SF_ATOMIC_ADD(g.g_b0 + j1, accb0); }
-  if (k2 == 0) SF_ATOMIC_ADD(g.g_b2 + o2, accb2);
-}
-
 // ---------------------------------------------------------------------------
 // Table-gradient scatter.  Device-memory fp32 atomics execute at the memory side on MI355X (the 8 XCD
 // L2s are not coherent): ~17 G scattered lane-ops/s, so the scatter is bound by the NUMBER of atomics.
@@ -611,15 +353,10 @@ extern "C" int sf_ngp_render_forward(const sf_ngp_field* f, const float* rays_o,
                                           nullptr, sig_f, rgb_f);
   }
   SF_CHECK_LAUNCH("ngp_field_fine");
-  static const bool composite_wave = !(getenv("SF_COMPOSITE_WAVE") && atoi(getenv("SF_COMPOSITE_WAVE")) == 0);   // A/B switch
-  if (composite_wave)
-    k_ngp_composite_wave<<<sf_div_up(N, 4), 256, 4 * 5 * 2 * T * sizeof(float), st>>>(
-        CompositeArgs{z_c, sig_c, rgb_c, z_f, sig_f, rgb_f, nears, fars, N, T, bg_color, z_sorted, sigma_s, rgb_s, image, depth,
-                      weights_sum});
-  else
-    k_ngp_composite<<<gridr, 64, 2 * T * 64 * sizeof(float), st>>>(z_c, sig_c, rgb_c, z_f, sig_f, rgb_f, nears, fars, N, T,
-                                                                  bg_color, z_sorted, sigma_s, rgb_s, image, depth,
-                                                                  weights_sum);
+  // one WAVE per ray: rank sort of cat([coarse, fine]) by readlane keys + scans (ngp_composite_wave.h)
+  k_ngp_composite_wave<<<sf_div_up(N, 4), 256, 4 * 5 * 2 * T * sizeof(float), st>>>(
+      CompositeArgs{z_c, sig_c, rgb_c, z_f, sig_f, rgb_f, nears, fars, N, T, bg_color, z_sorted, sigma_s, rgb_s, image, depth,
+                    weights_sum});
   SF_CHECK_LAUNCH("ngp_composite");
   return SF_OK;
 }
@@ -640,37 +377,14 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
   const uint64_t M = (uint64_t)N * 2 * T;
   float* dsig = workspace;
   float* drgb = dsig + M;
-  // wave-per-ray backward: parity-green (golden + isolated-backward GPU tests), render fwd+bwd 6.34 vs 6.46 ms; off until a
-  // full GPU suite has run with it
-  static const bool composite_bwd_wave = getenv("SF_COMPOSITE_BWD_WAVE") && atoi(getenv("SF_COMPOSITE_BWD_WAVE")) != 0;
-  if (composite_bwd_wave)
-    k_ngp_composite_bwd_wave<<<sf_div_up(N, 4), 256, 0, st>>>(
-        CompositeBwdArgs{z_sorted, sigma_s, rgb_s, nears, fars, N, T, bg_color, grad_image, grad_weights_sum, dsig, drgb});
-  else
-    k_ngp_composite_bwd<<<sf_div_up(N, 64), 64, 4 * T * 64 * sizeof(float), st>>>(
-        z_sorted, sigma_s, rgb_s, nears, fars, N, T, bg_color, grad_image, grad_weights_sum, dsig, drgb);
+  // wave-per-ray backward: the forward's scans run in reverse (suffix sums in double)
+  k_ngp_composite_bwd_wave<<<sf_div_up(N, 4), 256, 0, st>>>(
+      CompositeBwdArgs{z_sorted, sigma_s, rgb_s, nears, fars, N, T, bg_color, grad_image, grad_weights_sum, dsig, drgb});
   SF_CHECK_LAUNCH("ngp_composite_bwd");
-  const FieldGrad fg{g->g_embeddings, g->g_w0, g->g_b0, g->g_w1, g->g_b1, g->g_w2, g->g_b2};
-  const size_t lds = (6536 + 2 * 256 * BW_S) * sizeof(float);
-  // the raised dynamic-LDS limit is a per-device function attribute (a process may drive several GPUs)
-  int dev_id = 0;
+  int dev_id = 0;                                  // raised dynamic-LDS limits are per-device function attributes
   if (hipGetDevice(&dev_id) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "hipGetDevice failed");
-  static unsigned attr_mask = 0;
-  if (dev_id >= 32 || !(attr_mask & (1u << dev_id))) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_field_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      SF_FAIL(SF_ERR_LAUNCH, "ngp_field_bwd: cannot raise dynamic LDS limit to %zu", lds);
-    if (dev_id < 32) attr_mask |= 1u << dev_id;
-  }
   float* dfeat = g->g_embeddings ? drgb + 3 * M : nullptr;        // NULL table gradient = table frozen
-  static const bool use_valu = getenv("SF_NGP_BWD_VALU") != nullptr;     // A/B switch: the first-round VALU kernel
-  if (use_valu) {
-    const uint32_t n_tiles = sf_div_up(M, 256);
-    const uint32_t grid = n_tiles < 256 ? n_tiles : 256;      // one resident workgroup per CU (LDS-bound)
-    k_ngp_field_bwd<<<grid, 256, lds, st>>>(field_ptrs(f), fg, lv, rays_o, rays_d, aabb, z_sorted, dsig, drgb, dfeat,
-                                            (uint32_t)M, 2 * T);
-    SF_CHECK_LAUNCH("ngp_field_bwd");
-  } else {
+  {
     // matrix-core version: one wave per 32 points and trip, six fp32 GEMMs on v_mfma_f32_16x16x4_f32 (ngp_bwd_mfma.h)
     const size_t lds2 = (size_t)FB_LDS_FLOATS * sizeof(float);
     static unsigned attr3_mask = 0;
@@ -712,6 +426,30 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
     while (cached < lv.L && lv.scale[cached] <= sc_cutoff) ++cached;
     const uint32_t last = sc_split ? cached : lv.L;
     const uint32_t grid_sc = sf_div_up(N, SC_RAYS);
+    // The two scatter launches touch disjoint levels and stress different units (cached levels: LDS atomics, one 1024-thread
+    // workgroup per CU; fine levels: the memory-side atomic unit, no LDS): the fine levels run on a side stream forked here and
+    // joined before this call returns in stream order, so the atomic unit works while the LDS-bound kernel occupies the CUs.
+    static const bool overlap = !(getenv("SF_NGP_OVERLAP") && atoi(getenv("SF_NGP_OVERLAP")) == 0);
+    hipStream_t st_fine = st;
+    struct Side { hipStream_t s; hipEvent_t fork, join; };
+    static Side side[32] = {};
+    const bool fork = overlap && last > 0 && last < lv.L && dev_id < 32;
+    if (fork) {
+      Side& sd = side[dev_id];
+      if (!sd.s && (hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess))
+        SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: cannot create the side stream");
+      if (hipEventRecord(sd.fork, st) != hipSuccess || hipStreamWaitEvent(sd.s, sd.fork, 0) != hipSuccess)
+        SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: fork failed");
+      st_fine = sd.s;
+    }
+    if (last < lv.L) {
+      const uint64_t items = (uint64_t)4 * M * (lv.L - last);
+      const uint32_t grid_f = (uint32_t)(items / 256 < 16384 ? (items + 255) / 256 : 16384);
+      k_ngp_scatter_fine<<<grid_f, 256, 0, st_fine>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, 2 * T, last);
+      SF_CHECK_LAUNCH("ngp_scatter_fine");
+    }
     if (last > 0) {
       if (sc_threads == 256)
         k_ngp_scatter<256><<<grid_sc, 256, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, 2 * T, rays_per_row, cached, last, sc_run);
@@ -721,11 +459,10 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
         k_ngp_scatter<1024><<<grid_sc, 1024, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, 2 * T, rays_per_row, cached, last, sc_run);
       SF_CHECK_LAUNCH("ngp_scatter");
     }
-    if (last < lv.L) {
-      const uint64_t items = (uint64_t)4 * M * (lv.L - last);
-      const uint32_t grid_f = (uint32_t)(items / 256 < 16384 ? (items + 255) / 256 : 16384);
-      k_ngp_scatter_fine<<<grid_f, 256, 0, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, 2 * T, last);
-      SF_CHECK_LAUNCH("ngp_scatter_fine");
+    if (fork) {
+      Side& sd = side[dev_id];
+      if (hipEventRecord(sd.join, sd.s) != hipSuccess || hipStreamWaitEvent(st, sd.join, 0) != hipSuccess)
+        SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: join failed");
     }
   }
   return SF_OK;

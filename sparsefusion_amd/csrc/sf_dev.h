@@ -8,22 +8,6 @@
 #ifndef SF_KA_TOUCH
 #define SF_KA_TOUCH 1          // 0: A/B switch of sf_touch_kernarg
 #endif
-#ifndef SF_PDL
-#define SF_PDL 0               // 1: variant build with software dependent launch; see SfPdl below
-#endif
-#ifndef SF_PDL_BOUNDED
-#define SF_PDL_BOUNDED 0
-#endif
-// Software dependent launch (EXPERIMENTAL variant build, -DSF_PDL=1, never the default library): a kernel is launched with a
-// graph edge to its PRE-predecessor only, fetches what does not depend on its predecessor (weights, kernel arguments), and
-// waits here until every workgroup of the predecessor has arrived -- 8 arrival counters, one per XCD (blockIdx & 7), each on
-// its own 128-byte line.
-struct SfPdl {
-  const unsigned* wait;        // predecessor's counters [8][32] or null (plain stream order)
-  unsigned wait_grid;          // workgroups of the predecessor
-  unsigned* arrive;            // this launch's counters or null
-  unsigned* timeouts;          // incremented by a wait that gave up (SF_PDL_BOUNDED builds only)
-};
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -41,8 +25,6 @@ static inline T sf_shfl_xor(T v, int m) { return hipemu::shfl_xor(v, m); }
 template <class T>
 static inline T sf_shfl(T v, int src) { return hipemu::shfl_xor(v, (src ^ hipemu::t_lane) & 63); }
 static inline uint32_t sf_readlane(uint32_t v, uint32_t src) { return sf_shfl(v, (int)src); }      // src is wave-uniform
-static inline void sf_pdl_wait(const SfPdl&) {}
-static inline void sf_pdl_arrive(const SfPdl&) {}
 static inline int sf_uniform(int v) { return v; }
 static inline float sf_exp(float v) { return expf(v); }
 static inline float sf_exp2(float v) { return exp2f(v); }
@@ -116,44 +98,6 @@ template <class T>
 SF_DEV T sf_shfl_xor(T v, int m) { return __shfl_xor(v, m, 64); }
 template <class T>
 SF_DEV T sf_shfl(T v, int src) { return __shfl(v, src, 64); }
-// every thread of the workgroup calls these (workgroup barriers inside).  Counters of one launch: word 32 x of its 1 KB block
-// = arrivals of the workgroups with blockIdx & 7 == x (one 128-byte line per XCD: arrivals of one XCD do not queue behind the
-// others'), word 16 = shards that are complete.  The last arriver of a shard bumps word 16, so a waiting workgroup polls ONE word
-// with ONE thread (256 pollers on the fabric per hand-off, as the XCD-hierarchical barrier of MI355X_MICROARCH.md).
-SF_DEV void sf_pdl_wait(const SfPdl& p) {
-  if (p.wait) {
-    if (threadIdx.x == 0) {
-      const unsigned want = p.wait_grid < 8u ? p.wait_grid : 8u;       // non-empty shards of the predecessor
-#if SF_PDL_BOUNDED
-      // bounded by the 100 MHz wall clock (30 ms), a wait that gave up is counted.  NOTE: any loop-carried bound in this poll
-      // (spin counter, clock, out-of-line helper) crashed the register allocator of ROCm 7.2 on k_conv_fused_pair<1,1,12,1,1,8>,
-      // so the bounded form is opt-in and the experiment script bounds the PROCESS instead (tools/pdl_try.py: timeout per child).
-      const long long t0 = (long long)wall_clock64();
-      bool ok = true;
-      while (__hip_atomic_load(&p.wait[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        __builtin_amdgcn_s_sleep(2);
-        if ((long long)wall_clock64() - t0 > 3000000LL) { ok = false; break; }
-      }
-      if (!ok) __hip_atomic_fetch_add(p.timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-      while (__hip_atomic_load(&p.wait[16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2);
-#endif
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-}
-SF_DEV void sf_pdl_arrive(const SfPdl& p) {
-  if (p.arrive) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      const unsigned x = blockIdx.x & 7, in_shard = (gridDim.x + 7 - x) >> 3;      // workgroups of this launch in shard x
-      const unsigned n = __hip_atomic_fetch_add(&p.arrive[x * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (n + 1 == in_shard) __hip_atomic_fetch_add(&p.arrive[16], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
 SF_DEV int sf_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }      // tell the compiler v is wave-uniform (scalar registers)
 SF_DEV uint32_t sf_readlane(uint32_t v, uint32_t src) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src)); }   // src wave-uniform
 SF_DEV float sf_exp(float v) { return __expf(v); }

@@ -3,14 +3,6 @@
 #include "plan_ops.h"
 #include "fused_host.h"
 
-#if SF_PDL
-// Software dependent launch (variant build): the plan executor (unet_ops.hip) describes the hand-off of the NEXT launch here;
-// the launchers below copy it into the kernel arguments and report the grid they used.
-SfPdlHost g_sf_pdl = {nullptr, 0, nullptr, 0, nullptr};
-#define SF_PDL_SET(args, grid_) do { (args).pdl = SfPdl{g_sf_pdl.wait, g_sf_pdl.wait_grid, g_sf_pdl.arrive, g_sf_pdl.timeouts}; g_sf_pdl.last_grid = (grid_); } while (0)
-#else
-#define SF_PDL_SET(args, grid_) do { } while (0)
-#endif
 
 // Dynamic LDS above 64 KiB must be enabled per kernel AND per device (a process may drive several GPUs).
 template <class K>
@@ -47,7 +39,6 @@ static int run_fconv(const sf_op& op, hipStream_t st) {
   int WM, WN;
   uint32_t grid, lds;
   if (fconv_setup(op, a, WM, WN, grid, lds, sf_err_buf, sizeof(sf_err_buf))) return SF_ERR_INVALID;
-  SF_PDL_SET(a, grid);
   if (op.flags & 32) {
     const int EPT = fconv_pipe_ept(a);
 #define SF_TRYP(wm, wn, ept) if (WM == wm && WN == wn && EPT == ept) return launch_fconv_pipe<wm, wn, ept>(a, grid, lds, st);
@@ -85,8 +76,6 @@ int sf_plan_fused_pair(const sf_op* op1, const sf_op* op2, void* stream) {
   int WM, WN;
   uint32_t grid, lds;
   if (fconv_pair_setup(*op1, *op2, p, WM, WN, grid, lds, sf_err_buf, sizeof(sf_err_buf))) return SF_ERR_INVALID;
-  SF_PDL_SET(p.a, grid);
-  SF_PDL_SET(p.b, grid);
   if (op1->flags & 32) {
     const int EPT = fconv_pipe_ept(p.a);
 #define SF_TRYP(wm, wn, ept) if (WM == wm && WN == wn && EPT == ept) return launch_fconv_pipe_pair<wm, wn, ept>(p, grid, lds, (hipStream_t)stream);
@@ -115,22 +104,11 @@ static int run_slots(const sf_op& op, hipStream_t st) {
 }
 
 static int run_gca(const sf_op& op, hipStream_t st) {
-  if (op.flags == 4) {
-    GcaPoolNetArgs pn;
-    uint32_t g;
-    if (gca_poolnet_setup(op, pn, g, sf_err_buf, sizeof(sf_err_buf))) return SF_ERR_INVALID;
-    k_gca_poolnet<<<g, 256, 0, st>>>(pn);
-    SF_CHECK_LAUNCH("gca_poolnet");
-    return SF_OK;
-  }
   GcaPoolArgs pa;
   GcaNetArgs na;
   GcaGateArgs ga;
   uint32_t grid;
   if (gca_setup(op, pa, na, ga, grid, sf_err_buf, sizeof(sf_err_buf))) return SF_ERR_INVALID;
-  SF_PDL_SET(pa, grid);
-  SF_PDL_SET(na, grid);
-  SF_PDL_SET(ga, grid);
   if (op.flags == 1) k_gca_pool<<<grid, 256, 0, st>>>(pa);
   else if (op.flags == 2) k_gca_net0<<<grid, 256, 0, st>>>(na);
   else k_gca_gate<<<grid, 256, 0, st>>>(ga);

@@ -737,91 +737,12 @@ static int run_eltwise(const sf_op& op, hipStream_t st) {
   return SF_OK;
 }
 
-#if SF_PDL
-// ---- software dependent launch (EXPERIMENTAL variant build).  Fused convs and the three GlobalContext
-// kernels can wait for their predecessor on a device-side flag; two such launches in a row go to ALTERNATING streams, so the
-// second has a stream-order edge to the launch before its predecessor only and overlaps its weight prefetch with the predecessor.
-// Everything else keeps plain stream order (it continues on the stream of its predecessor).
-struct PdlRun {
-  bool on = false;
-  hipStream_t s[2];
-  int idx = 0;                 // stream of the previous launch
-  bool prev_sup = false;
-  unsigned prev_grid = 0;
-  uint32_t prev_k = 0;
-  bool aux_used = false;
-};
-static unsigned* g_pdl_flags = nullptr;                      // [SF_PDL_MAX_OPS][8][32] arrival counters
-static hipStream_t g_pdl_aux = nullptr;
-static hipEvent_t g_pdl_fork = nullptr, g_pdl_join = nullptr;
-#define SF_PDL_MAX_OPS 4096
-static bool pdl_supported(const sf_op& op) { return op.type == SF_OP_FCONV || (op.type == SF_OP_GCA && op.flags >= 1 && op.flags <= 3); }
-static int pdl_begin(PdlRun& pr, hipStream_t st, uint32_t n_ops) {
-  static const bool enabled = !(getenv("SF_PDL") && atoi(getenv("SF_PDL")) == 0);
-  if (!enabled || n_ops > SF_PDL_MAX_OPS) return SF_OK;
-  if (!g_pdl_flags) {
-    if (hipMalloc(&g_pdl_flags, (size_t)(SF_PDL_MAX_OPS + 1) * 1024) != hipSuccess ||
-        hipMemset(g_pdl_flags, 0, (size_t)(SF_PDL_MAX_OPS + 1) * 1024) != hipSuccess || hipStreamCreateWithFlags(&g_pdl_aux, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&g_pdl_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g_pdl_join, hipEventDisableTiming) != hipSuccess)
-      SF_FAIL(SF_ERR_LAUNCH, "pdl: cannot create the flag buffer / auxiliary stream");
-  }
-  if (hipMemsetAsync(g_pdl_flags, 0, (size_t)n_ops * 1024, st) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "pdl: memset failed");
-  if (hipEventRecord(g_pdl_fork, st) != hipSuccess || hipStreamWaitEvent(g_pdl_aux, g_pdl_fork, 0) != hipSuccess)
-    SF_FAIL(SF_ERR_LAUNCH, "pdl: fork failed");
-  pr.on = true; pr.s[0] = st; pr.s[1] = g_pdl_aux;
-  g_sf_pdl.timeouts = g_pdl_flags + (size_t)SF_PDL_MAX_OPS * 256;        // never reset: a run that timed out anywhere is suspect
-  return SF_OK;
-}
-// waits that gave up since the library was loaded (synchronises); 0 = every hand-off completed
-extern "C" int sf_pdl_timeouts(void) {
-  unsigned v = 0;
-  if (g_pdl_flags && hipMemcpy(&v, g_pdl_flags + (size_t)SF_PDL_MAX_OPS * 256, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  return (int)v;
-}
-static hipStream_t pdl_pick(PdlRun& pr, const sf_op& op, uint32_t k) {
-  const bool sup = pdl_supported(op);
-  // The predecessor must be fully RESIDENT before this launch may take CU slots and spin: with more workgroups than the chip
-  // holds at once, its tail could be locked out by our pollers (two hardware queues, no ordering between them) -- a deadlock.
-  // One workgroup per CU is always resident for these kernels: 256 (SF_PDL_MAX_PREV overrides).
-  static const unsigned max_prev = getenv("SF_PDL_MAX_PREV") ? (unsigned)atoi(getenv("SF_PDL_MAX_PREV")) : 256u;
-  if (sup && pr.prev_sup && pr.prev_grid <= max_prev) {
-    pr.idx ^= 1;
-    g_sf_pdl.wait = g_pdl_flags + (size_t)pr.prev_k * 256;
-    g_sf_pdl.wait_grid = pr.prev_grid;
-  } else {
-    g_sf_pdl.wait = nullptr;
-    g_sf_pdl.wait_grid = 0;
-  }
-  g_sf_pdl.arrive = sup ? g_pdl_flags + (size_t)k * 256 : nullptr;
-  g_sf_pdl.last_grid = 0;
-  if (pr.idx) pr.aux_used = true;
-  return pr.s[pr.idx];
-}
-static void pdl_after(PdlRun& pr, const sf_op& op, uint32_t k) {
-  pr.prev_sup = pdl_supported(op) && g_sf_pdl.last_grid > 0;
-  pr.prev_grid = g_sf_pdl.last_grid;
-  pr.prev_k = k;
-}
-static int pdl_end(PdlRun& pr) {
-  if (pr.on && (hipEventRecord(g_pdl_join, pr.s[1]) != hipSuccess || hipStreamWaitEvent(pr.s[0], g_pdl_join, 0) != hipSuccess))
-    SF_FAIL(SF_ERR_LAUNCH, "pdl: join failed");
-  return SF_OK;
-}
-#endif
 
 static int plan_run_impl(const sf_op* ops, uint32_t n_ops, hipStream_t st_main, hipEvent_t* ev) {
-#if SF_PDL
-  PdlRun pdl;
-  if (!ev) { if (int rc0 = pdl_begin(pdl, st_main, n_ops)) return rc0; }
-#endif
   for (uint32_t k = 0; k < n_ops; ++k) {
     const sf_op& op = ops[k];
     int rc = SF_OK;
     hipStream_t st = st_main;
-#if SF_PDL
-    const uint32_t k_first = k;
-    if (pdl.on) st = pdl_pick(pdl, op, k);
-#endif
     if (ev && hipEventRecord(ev[k], st) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "plan: hipEventRecord failed");
     switch (op.type) {
       case SF_OP_CONV: rc = run_conv(op, st); break;
@@ -882,13 +803,7 @@ static int plan_run_impl(const sf_op* ops, uint32_t n_ops, hipStream_t st_main, 
       snprintf(sf_err_buf, sizeof(sf_err_buf), "plan op %u (type %d): %s", k, op.type, tmp);
       return rc;
     }
-#if SF_PDL
-    if (pdl.on) pdl_after(pdl, ops[k_first], k_first);
-#endif
   }
-#if SF_PDL
-  if (int rc1 = pdl_end(pdl)) return rc1;
-#endif
   if (ev && hipEventRecord(ev[n_ops], st_main) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "plan: hipEventRecord failed");
   return SF_OK;
 }
@@ -957,9 +872,11 @@ extern "C" int sf_conv_pack_weights(const float* h_w, uint32_t Cout, uint32_t Ci
 // PLMS latent updates (external/plms.py:122-214, imagen_pytorch.py:242-297)
 // ---------------------------------------------------------------------------------------------
 struct Coef6 { float alpha, sigma, alpha_next, c, noise_scale, clip; };
-__global__ __launch_bounds__(256) void k_plms_update(const float* __restrict__ x, const float* __restrict__ eps,
+// x and x_prev may ALIAS (plms.py keeps the latents in place in the plan's input buffer): neither is __restrict__, and every
+// element is read before it is written by the same thread.
+__global__ __launch_bounds__(256) void k_plms_update(const float* x, const float* __restrict__ eps,
                                                      const float* __restrict__ noise, Coef6 k, long n,
-                                                     float* __restrict__ x_prev, float* __restrict__ x0) {
+                                                     float* x_prev, float* __restrict__ x0) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float xv = x[i];
     float s = __fdiv_rn(__fsub_rn(xv, __fmul_rn(k.sigma, eps[i])), fmaxf(k.alpha, 1e-8f));   // predict_start_from_noise
@@ -989,8 +906,8 @@ __global__ __launch_bounds__(256) void k_plms_combine(const float* __restrict__ 
 // combine + update in ONE launch (the steady state of the sampler: every step after the first)
 __global__ __launch_bounds__(256) void k_plms_step(const float* __restrict__ e0, const float* __restrict__ e1,
                                                    const float* __restrict__ e2, const float* __restrict__ e3, float c0, float c1,
-                                                   float c2, float c3, float* __restrict__ keep, const float* __restrict__ x,
-                                                   const float* __restrict__ noise, Coef6 k, long n, float* __restrict__ x_prev) {
+                                                   float c2, float c3, float* __restrict__ keep, const float* x,
+                                                   const float* __restrict__ noise, Coef6 k, long n, float* x_prev) {   // x may alias x_prev
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     if (keep) keep[i] = e0[i];
     float v = c0 * e0[i];                        // same expression order as k_plms_combine

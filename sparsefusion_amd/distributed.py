@@ -55,19 +55,47 @@ class FlatGradBucket:
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
+        if not self.params:
+            raise ValueError("FlatGradBucket: no parameter requires a gradient")
         ref = self.params[0]
+        for p in self.params:                                       # one collective on one buffer: one dtype, one device
+            if p.dtype != ref.dtype or p.device != ref.device:
+                raise ValueError(f"FlatGradBucket: parameters must share dtype and device (got {p.dtype} on {p.device} and "
+                                 f"{ref.dtype} on {ref.device})")
+        n = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        self.offsets = []
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.offsets.append(off)
             off += p.numel()
+        self.bind()
+
+    def bind(self):
+        """(Re-)attach every .grad to its slice of the flat buffer.  Needed again after anything that REBINDS .grad:
+        optimizer.zero_grad() (set_to_none=True is the torch default), `p.grad = None`, module.to() / _apply."""
+        for p, off in zip(self.params, self.offsets):
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+
+    def check_bound(self):
+        """Raise if some .grad is no longer the bucket's view: the collective would then reduce a stale buffer while the
+        optimizer steps on un-reduced per-rank gradients -- replicas would diverge without any error."""
+        isz = self.flat.element_size()
+        base = self.flat.data_ptr()
+        for k, (p, off) in enumerate(zip(self.params, self.offsets)):
+            g = p.grad
+            if g is None or g.data_ptr() != base + off * isz or g.shape != p.shape or not g.is_contiguous():
+                raise RuntimeError(f"FlatGradBucket: .grad of parameter {k} (shape {tuple(p.shape)}) was re-bound away from the flat "
+                                   "buffer (optimizer.zero_grad(set_to_none=True)? module.to()?): use bucket.zero() instead of "
+                                   "zero_grad(), or call bucket.bind() after moving the module")
 
     def zero(self):
+        self.check_bound()
         self.flat.zero_()
 
     def all_reduce(self, group=None, average=True, async_op=False):
         """In-place sum (mean) over the group; returns the work handle when async_op (wait before optimizer.step)."""
+        self.check_bound()
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
             return None
         if average:

@@ -254,8 +254,14 @@ class NeRFRenderer(nn.Module):
         restructured for the GPU:
           * evaluation is ONE launch (sf_ngp_render_occ_eval): every lane walks its ray through the density bitfield and
             evaluates the fused field at the occupied samples until it is opaque / leaves the box.  The reference's rounds of
-            march_rays -> network -> composite_rays over a shrinking alive list need a host read per round; the samples of
-            a ray and the arithmetic on them do not depend on that batching, so the result is the same;
+            march_rays -> network -> composite_rays over a shrinking alive list need a host read per round; with
+            perturb=False (the reference's evaluation setting, renderer_df.py:653-717 via render_batched) the samples of a
+            ray and the arithmetic on them do not depend on that batching, so the result is the same.  DEVIATION with
+            perturb=True: the reference restarts every round from rays_t = near + sum of the deltas it composited, which
+            lags the jittered t by step * noise (raymarching.cu:736-748, renderer_df.py:548), so later rounds re-jitter
+            from a slightly earlier t; this kernel keeps marching from the true t.  The sample sets differ by less than
+            one step per round; also the unused `light_d` randn(3) draw of the reference is not consumed (RNG stream
+            differs).  Use the raymarching.march_rays / composite_rays entry points for the round-exact behaviour;
           * training keeps the three stages (the samples must exist as tensors for autograd): slot assignment by a block
             scan (raymarching.march_rays_train), field query through the differentiable grid-encode op, compositing with
             its own backward kernel.

@@ -571,14 +571,9 @@ class _Plan:
             h2.lazy = None
             self.ws_owners[wi] = None
         self.need(res)
-        if HW in (16, 64) and cout <= 2048 and cout % 8 == 0 and groups <= 8 and getattr(self.u, "gca_poolnet", False):
-            # small maps: pooling + first 1x1 conv in one launch (every workgroup re-derives the pooled context: k_gca_poolnet)
-            self.op(OP_GCA, 4, p=(h2.ptr, ws, bias, lpart.ptr, self.wptr(f"{name}.gca.net.0.weight"), self.wptr(f"{name}.gca.net.0.bias"),
-                                  hid.ptr), i=(rows, cout, HW, nparts, groups, npad, (cout + 7) // 8 * 8, hidc))
-        else:
-            self.op(OP_GCA, 1, p=(h2.ptr, ws, bias, lpart.ptr, part_pool.ptr, part_ms.ptr), i=(rows, cout, HW, CH, chunks, nparts, groups, npad))
-            self.op(OP_GCA, 2, p=(part_pool.ptr, part_ms.ptr, self.wptr(f"{name}.gca.net.0.weight"), self.wptr(f"{name}.gca.net.0.bias"),
-                                  hid.ptr), i=(B, cout, (cout + 7) // 8 * 8, hidc, chunks))
+        self.op(OP_GCA, 1, p=(h2.ptr, ws, bias, lpart.ptr, part_pool.ptr, part_ms.ptr), i=(rows, cout, HW, CH, chunks, nparts, groups, npad))
+        self.op(OP_GCA, 2, p=(part_pool.ptr, part_ms.ptr, self.wptr(f"{name}.gca.net.0.weight"), self.wptr(f"{name}.gca.net.0.bias"),
+                              hid.ptr), i=(B, cout, (cout + 7) // 8 * 8, hidc, chunks))
         if want_slots:
             out.slots = self.misc.alloc(rows // 16 * (cout // 16) * 2 * 4)
         self.op(OP_GCA, 3, p=(h2.ptr, res.ptr, hid.ptr, self.wptr(f"{name}.gca.net.2.weight"), self.wptr(f"{name}.gca.net.2.bias"),
@@ -993,7 +988,6 @@ class Unet(nn.Module):
         # GroupNorm inside the conv launches (k_conv_fused) wherever the layer fits; SF_UNET_FUSED=0 = the first-round plan (A/B runs)
         self.fused = os.environ.get("SF_UNET_FUSED", "1") != "0"
         self.pair_res_conv = os.environ.get("SF_PAIR", "1") != "0"      # conv1 || res_conv of a ResnetBlock in one launch
-        self.gca_poolnet = os.environ.get("SF_POOLNET", "0") != "0"     # GlobalContext pooling + net.0 in one launch on the 4x4 / 8x8 maps: measured SLOWER (1.428 vs 1.367 ms per eval: every workgroup re-reads the whole map), kept as an A/B switch
         self.initx_direct = os.environ.get("SF_INITX", "1") != "0"      # latent half of the init conv as one direct-convolution launch
         self.fconv_pipe = os.environ.get("SF_PIPE", "1") != "0"         # slot-GroupNorm 3x3 convs on k_conv_fused_pipe (staging || matrix work)
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches
@@ -1064,8 +1058,13 @@ class Unet(nn.Module):
         self.invalidate()
         return r
 
+    MAX_TIME_PLANS = 4                   # ("time", T) plans kept per module: one per distinct trajectory length, LRU
+
     def invalidate(self):
-        """Forget packed weights / plans (call after mutating parameters in place)."""
+        """Forget packed weights / plans (call after mutating parameters in place).  Contexts of `begin_sampling` that still
+        point at a dropped plan are refused by `eval_prepared` (their plan's generation is retired)."""
+        for plan in self._plans.values():
+            plan.generation = -1
         self._pack_cache, self._plans = None, {}
 
     def _apply(self, fn, *a, **k):
@@ -1145,6 +1144,7 @@ class Unet(nn.Module):
             sizing = _Plan(self, B, device).build()
             plan = _Plan(self, B, device, (sizing.zero.off, sizing.misc.off + sizing.ws_bytes + sizing.ws2_bytes + 512,
                                            sizing.ws_bytes, sizing.ws2_bytes)).build()
+            plan.generation = 0
             self._plans[key] = plan
         return self._plans[key]
 
@@ -1170,7 +1170,8 @@ class Unet(nn.Module):
                 keep = torch.zeros(B, device=x.device).float().uniform_(0, 1) < (1 - cond_drop_prob)
             cond_images = cond_images * keep.view(B, 1, 1, 1)
         plan = self._plan(B, x.device)
-        plan.x_view.copy_(x.reshape(B, -1))
+        plan.generation += 1                                # the plan's arena is about to be overwritten: any sampler context
+        plan.x_view.copy_(x.reshape(B, -1))                 # of this batch size is dead from here on (eval_prepared checks)
         plan.t_view.copy_(time.reshape(-1).expand(B).reshape(B, 1))
         plan.cond_view.copy_(cond_images.reshape(B, -1))
         if self.use_hip_graph and not torch.cuda.is_current_stream_capturing():
@@ -1197,8 +1198,13 @@ class Unet(nn.Module):
     def _time_plan(self, T, device):
         key = ("time", T, str(device))
         if key not in self._plans:
+            old = [k for k in self._plans if k[0] == "time"]
+            for k in old[:max(0, len(old) + 1 - self.MAX_TIME_PLANS)]:          # dicts keep insertion order: oldest first
+                del self._plans[k]
             sizing = _TimePlan(self, T, device).build()
             self._plans[key] = _TimePlan(self, T, device, (sizing.zero.off, sizing.misc.off + 512, 0, 0)).build()
+        else:
+            self._plans[key] = self._plans.pop(key)                             # most recently used last
         return self._plans[key]
 
     @torch.no_grad()
@@ -1222,11 +1228,12 @@ class Unet(nn.Module):
         if cond_images.shape[-1] != self.image_size:
             cond_images = torch.nn.functional.interpolate(cond_images, self.image_size, mode='nearest')
         plan = self._plan(B, cond_images.device)
-        plan.cond_view.copy_(cond_images.reshape(B, -1))
+        plan.generation += 1                                   # ONE trajectory per (batch size, device) at a time: the latents,
+        plan.cond_view.copy_(cond_images.reshape(B, -1))       # `base` and the time rows of a trajectory live in the plan's arena
         plan.x_view.zero_()                                    # init conv of the conditioning image alone (+ bias) -> base
         _lib.check(_lib.lib().sf_plan_run(plan.init_array, plan.n_init_run, _lib.stream_ptr()), "unet init conv")
         plan.base_view.copy_(plan.x0_view)
-        return {"plan": plan, "table": self.time_table(log_snrs), "B": B}
+        return {"plan": plan, "table": self.time_table(log_snrs), "B": B, "generation": plan.generation}
 
     @torch.no_grad()
     def eval_prepared(self, ctx, x, row):
@@ -1234,6 +1241,10 @@ class Unet(nn.Module):
         sampler that writes its latents there saves the copy).  Returns a VIEW of the plan's output buffer: consume or clone
         it before the next eval."""
         plan, B = ctx["plan"], ctx["B"]
+        if ctx.get("generation") != plan.generation:
+            raise RuntimeError("Unet.eval_prepared: this sampling context is stale -- a later forward() / begin_sampling() with the same "
+                               "batch size, or invalidate() / .to(), took over the plan that held its latents and time rows; "
+                               "call begin_sampling() again")
         if x.data_ptr() != plan.x_view.data_ptr():
             plan.x_view.copy_(x.reshape(B, -1))
         plan.tb_view.copy_(ctx["table"][row].expand(B, -1))

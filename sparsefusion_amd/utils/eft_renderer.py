@@ -22,4 +22,4 @@ class CustomImplicitRenderer(torch.nn.Module):
         images = self.raymarcher(rays_densities=rays_densities, rays_features=rays_features, ray_bundle=ray_bundle, **kwargs)
         if self.reg is not None:
             return images, ray_bundle, reg_term
-        return images, ray_bundle
+        return images, ray_bundle, 0                    # utils/eft_renderer.py:164-167: always a 3-tuple

@@ -192,7 +192,7 @@ def run_slots_case(backend):
     assert torch.allclose(sl2.cpu(), slots_of(x, M, C), rtol=1e-5, atol=1e-4)
 
 
-def run_gca_case(backend, B, H, C, lazy=False, seed=0, poolnet=False):
+def run_gca_case(backend, B, H, C, lazy=False, seed=0):
     """k_gca_pool -> k_gca_net0 -> k_gca_gate against GlobalContext + gated residual (imagen_pytorch.py:916-941, :727-729)."""
     dev = "cpu" if backend == "emu" else "cuda:0"
     g = torch.Generator().manual_seed(seed)
@@ -227,8 +227,7 @@ def run_gca_case(backend, B, H, C, lazy=False, seed=0, poolnet=False):
     b0_d, b2_d = dv(b0), dv(b2)
     hid_d, out = torch.zeros(B, HID, device=dev), torch.zeros(M, C, device=dev)
     slots = torch.zeros(M // 16, C // 16, 2, device=dev)
-    head = [fused.mkop(OP_GCA, 4, p=(h2_d, ws_d, bias_d, lp_d, W0p, b0_d, hid_d), i=(M, C, HW, nparts, groups, npad, Kp, HID))] if poolnet else \
-        [fused.mkop(OP_GCA, 1, p=(h2_d, ws_d, bias_d, lp_d, part_pool, part_ms), i=(M, C, HW, CH, chunks, nparts, groups, npad)),
+    head = [fused.mkop(OP_GCA, 1, p=(h2_d, ws_d, bias_d, lp_d, part_pool, part_ms), i=(M, C, HW, CH, chunks, nparts, groups, npad)),
          fused.mkop(OP_GCA, 2, p=(part_pool, part_ms, W0p, b0_d, hid_d), i=(B, C, Kp, HID, chunks))]
     ops = head + [
            fused.mkop(OP_GCA, 3, p=(h2_d, res_d, hid_d, W2p, b2_d, out, slots), i=(M, C, HW, HID, Kp2))]
@@ -241,9 +240,8 @@ def run_gca_case(backend, B, H, C, lazy=False, seed=0, poolnet=False):
 
 
 GCA_CASES = {"4x4_lazy": dict(B=2, H=4, C=128, lazy=True), "8x8": dict(B=1, H=8, C=64, seed=1), "16x16": dict(B=1, H=16, C=64, seed=2),
-             "poolnet_4x4_lazy": dict(B=2, H=4, C=128, lazy=True, seed=7, poolnet=True), "poolnet_8x8": dict(B=2, H=8, C=192, seed=8, poolnet=True)}
-GCA_CASES_FULL = {"unet_poolnet_4x4": dict(B=1, H=4, C=1024, lazy=True, seed=9, poolnet=True), "unet_poolnet_8x8": dict(B=1, H=8, C=1024, seed=10, poolnet=True),
-                  "unet_4x4": dict(B=1, H=4, C=1024, lazy=True, seed=3), "unet_8x8": dict(B=1, H=8, C=1024, seed=4),
+             "8x8_c192_b2": dict(B=2, H=8, C=192, seed=8)}
+GCA_CASES_FULL = {"unet_4x4": dict(B=1, H=4, C=1024, lazy=True, seed=3), "unet_8x8": dict(B=1, H=8, C=1024, seed=4),
                   "unet_32x32": dict(B=1, H=32, C=256, seed=5), "unet_b4_16x16": dict(B=4, H=16, C=512, seed=6)}
 
 
@@ -251,6 +249,9 @@ GCA_CASES_FULL = {"unet_poolnet_4x4": dict(B=1, H=4, C=1024, lazy=True, seed=9, 
 CONV_CASES = {
     # the 4x4 level: whole image per tile, input-channel slices, lazy split-K source, partial slabs out
     "gn_self_sliced_lazy_splitk_4x4": dict(B=2, H=4, W=4, C1=64, C2=0, Cout=48, k=3, norm=GN_SELF, WM=1, WN=1, S=2, lazy=1, logits=True),
+    # 12 channels per group (not a power of two), 24 channel chunks per pixel (512 threads % 24 != 0): the fixed-order fallback
+    # of the GN_SELF statistics (r02: LDS float atomics, order dependent)
+    "gn_self_odd_groups_fallback_4x4": dict(B=2, H=4, W=4, C1=96, C2=0, Cout=32, k=3, norm=GN_SELF, WM=1, WN=1, seed=41),
     "gn_self_concat_gate_lazy_4x4": dict(B=1, H=4, W=4, C1=64, C2=64, Cout=32, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=2, seed=1),
     # 8x8 level: 2-row tiles with halo rows from neighbouring tiles, statistics from producer slots, final epilogue + slots
     "gn_slots_concat_8x8": dict(B=1, H=8, W=8, C1=128, C2=128, Cout=32, k=3, norm=GN_SLOTS, WM=1, WN=1, resid=True, seed=2),

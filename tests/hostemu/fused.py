@@ -10,8 +10,7 @@ from sparsefusion_amd import _lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "..", "..", "sparsefusion_amd", "csrc")
-# SF_EMU_DEFINES="SF_PDL=1": the kernels as the software-dependent-launch variant compiles them (flag waits are no-ops on CPU
-# threads; what is checked is the re-ordered prologue: weight ring first, every other load behind the wait)
+# SF_EMU_DEFINES="A=1,B": extra -D flags for an A/B harness build (its own .so)
 _DEFS = [d for d in os.environ.get("SF_EMU_DEFINES", "").split(",") if d]
 _SO = os.path.join(_HERE, "_build", "libfused_emu" + "".join("_" + d.replace("=", "") for d in _DEFS) + ".so")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"

@@ -80,13 +80,6 @@ extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
     });
     return 0;
   }
-  if (op->type == SF_OP_GCA && op->flags == 4) {
-    GcaPoolNetArgs pn;
-    uint32_t g;
-    if (gca_poolnet_setup(*op, pn, g, err, (size_t)errn)) return 1;
-    hipemu::launch(g, 256, 0, [&] { k_gca_poolnet(pn); });
-    return 0;
-  }
   if (op->type == SF_OP_GCA) {
     GcaPoolArgs pa;
     GcaNetArgs na;

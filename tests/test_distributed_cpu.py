@@ -56,6 +56,37 @@ def _worker(rank, world, port, ret):
             bucket.all_reduce()
             opt2.step()
             assert sfd.replicas_identical(net2)
+        # a re-bound .grad (torch's zero_grad(set_to_none=True) default) is refused instead of reducing a stale buffer
+        opt2.zero_grad()
+        for fn in (bucket.all_reduce, bucket.zero):
+            try:
+                fn()
+                raise AssertionError("re-bound gradients accepted")
+            except RuntimeError as e:
+                assert "re-bound" in str(e)
+        bucket.bind()
+        bucket.zero()
+        # the bucket on the REAL field's parameter list (CPU tensors: shapes and layout only) with the 8-GPU view split of
+        # BASELINE configs[3] (32 novel views, 4 per GPU): one 7.46 MB collective, identical layout on every rank
+        from sparsefusion_amd.nerf import NeRFNetwork, get_default_torch_ngp_opt
+        torch.manual_seed(0)
+        field = NeRFNetwork(get_default_torch_ngp_opt())
+        fb = sfd.FlatGradBucket(field.parameters())
+        assert fb.flat.numel() == sum(p.numel() for p in field.parameters()) == 929336 * 2 + 6532
+        assert [len(sfd.shard_views(32, r, 8)) for r in range(8)] == [4] * 8
+        assert sum((sfd.shard_views(32, r, 8) for r in range(8)), []) == list(range(32))
+        fb.zero()
+        for k, p_ in enumerate(field.parameters()):
+            p_.grad.add_(float(rank + 1) * (k + 1))                  # "backward": accumulates INTO the views
+        fb.all_reduce()
+        for k, p_ in enumerate(field.parameters()):
+            assert torch.all(p_.grad == 1.5 * (k + 1))                # mean over the two ranks, in place, still the same views
+        fb.check_bound()
+        try:
+            sfd.FlatGradBucket([torch.nn.Parameter(torch.zeros(2)), torch.nn.Parameter(torch.zeros(2, dtype=torch.float64))])
+            raise AssertionError("mixed dtypes accepted")
+        except ValueError:
+            pass
         # a diverged replica is detected
         if rank == 1:
             with torch.no_grad():

@@ -91,13 +91,32 @@ def test_sampler_fast_path_equals_forward():
         x = torch.randn(B, 4, 32, 32, generator=g).to(DEV)
         cond = torch.randn(B, 256, 32, 32, generator=g).to(DEV)
         ls = unet_ref.log_snr(torch.tensor([0.9, 0.5, 0.1, 0.02])).to(DEV)
-        ctx = net.begin_sampling(cond, ls)
         for row in (2, 0, 3):
+            ctx = net.begin_sampling(cond, ls)                   # forward() below takes the plan over: one trajectory at a time
             y_fast = net.eval_prepared(ctx, x, row).clone()
             y_full = net.forward(x, ls[row].expand(B), cond_images=cond)
+            with pytest.raises(RuntimeError, match="stale"):     # the context's latents / time rows lived in that plan's arena
+                net.eval_prepared(ctx, x, row)
             assert rel_err(y_fast.cpu(), y_full.cpu()) < TOL_REL, (B, row, rel_err(y_fast.cpu(), y_full.cpu()))
             y_again = net.forward(x, ls[row].expand(B), cond_images=cond)
             print(f"B={B} row={row}: fast vs full {rel_err(y_fast.cpu(), y_full.cpu()):.2e}, full vs full {rel_err(y_again.cpu(), y_full.cpu()):.2e}")
+
+
+@pytest.mark.parametrize("name", ["canonical", "small"])
+def test_unet_eval_is_bitwise_reproducible(name):
+    """Two evals of the same input give the same BITS: every reduction of the eval has a fixed order (GroupNorm statistics by
+    shuffle trees + fixed-order LDS sums at 4x4, slot sums elsewhere, split-K slabs reduced in slab order, no float atomics),
+    so a seeded PLMS trajectory is reproducible run to run on the same build."""
+    net = _unet(name)
+    x, ls, cond = inputs(CONFIGS[name], 2, 5)
+    x, ls, cond = x.to(DEV), ls.to(DEV), cond.to(DEV)
+    y0 = net.forward(x, ls, cond_images=cond)
+    for _ in range(3):
+        assert torch.equal(net.forward(x, ls, cond_images=cond), y0)
+    ctx = net.begin_sampling(cond, ls[:1].expand(3).contiguous())
+    z0 = net.eval_prepared(ctx, x, 1).clone()
+    for _ in range(3):
+        assert torch.equal(net.eval_prepared(ctx, x, 1), z0)
 
 
 def test_unet_state_dict_roundtrip_and_errors():

@@ -347,6 +347,12 @@ def test_plms_update_kernels():
         mean, _, logvar = unet_ref.q_posterior(xs, x, tb, tnb)
         ref = mean + (0.0 if tn == 0 else 1.0) * (0.5 * logvar).exp() * nz
         assert torch.allclose(x0.cpu(), xs, rtol=1e-6, atol=1e-6) and torch.allclose(xp.cpu(), ref, rtol=1e-5, atol=1e-6)
+        # in place (x_prev aliases x), as plms.py runs it on the plan's input buffer: same values bit for bit
+        xa, x0a = xd.clone(), torch.empty_like(x0)
+        _lib.check(_lib.lib().sf_plms_update(_lib.ptr(xa), _lib.ptr(ed), _lib.ptr(nd), coef.ctypes.data, x.numel(), _lib.ptr(xa),
+                                             _lib.ptr(x0a), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.equal(xa, xp) and torch.equal(x0a, x0)
 
 
 @pytest.mark.parametrize("B,R,Cx,cws", [(1, 32, 4, (128, 64, 64)), (2, 16, 3, (64, 32, 32))])

@@ -53,17 +53,3 @@ def test_whole_fused_plan_against_oracle(dim):
 @pytest.mark.parametrize("name", sorted(fc.GCA_CASES))
 def test_gca_chain_on_cpu_threads(name):
     fc.run_gca_case("emu", **(fc.GCA_CASES)[name])
-
-
-@pytest.mark.skipif(os.environ.get("SF_TEST_EXPERIMENTAL") != "1", reason="experimental variant: set SF_TEST_EXPERIMENTAL=1 (compiles a second harness)")
-def test_kernels_in_the_dependent_launch_order():
-    """The software-dependent-launch variant (-DSF_PDL=1) re-orders the prologues: weight ring first, every
-    load that depends on the predecessor behind the flag wait.  The waits are no-ops on CPU threads; what this checks is that the
-    re-ordered kernels still compute the same results (a child process: the harness library is chosen at import)."""
-    import subprocess
-    import sys
-    sel = "pipe_gn_slots_concat_8x8 or pair_gn_self_lazy_splitk_4x4 or pipe_pair_gn_slots_concat_8x8 or gn_self_concat_gate_lazy_4x4 or 4x4_lazy or 16x16"
-    env = dict(os.environ, SF_EMU_DEFINES="SF_PDL=1")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", sel, "-p", "no:cacheprovider"],
-                       env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]

@@ -86,7 +86,8 @@ def test_sampler_factories_and_renderer_plumbing():
     assert reg == 7 and img.shape == (2, 32, 32, 4) and isinstance(rb, RayBundle)
     pts = ray_bundle_to_ray_points(rb)
     assert torch.allclose(img[..., 0], 2.0 * pts[..., 0].mean(-1), atol=1e-6) and torch.allclose(img[..., 1:], pts.mean(-2), atol=1e-6)
-    img2, _ = CustomImplicitRenderer(raysampler=grid, raymarcher=LightFieldRaymarcher())(cameras=cams, volumetric_function=field)
+    img2, _, reg0 = CustomImplicitRenderer(raysampler=grid, raymarcher=LightFieldRaymarcher())(cameras=cams, volumetric_function=field)
+    assert reg0 == 0                                  # reg=None: the reference still returns a 3-tuple, (images, bundle, 0)
     assert img2.shape == (2, 32, 32, 4)
     try:
         CustomImplicitRenderer(raysampler=None, raymarcher=LightFieldRaymarcher())
