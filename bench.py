@@ -11,6 +11,11 @@ Everything runs on this repo's HIP path: NGP render, UNet/PLMS, the SD-VAE (SURV
 term (row 2; VGG16 / lin weights are synthetic, the `lpips` package is not available).  fp32 everywhere except the
 conv / linear MFMA operands of the UNet, VAE and VGG (bf16, fp32 accumulate).
 
+`--config 2` (BASELINE configs[2]): 6 input views, and the 256-channel view features of every novel view are NOT cached: each
+step first renders them through the Epipolar Feature Transformer (`renderer_feat(cameras=, volumetric_function=
+eft.batched_forward, n_batches=16, input_cameras=, input_rgb=)`, distillation.py:99-109: 32x32 rays x 20 depths x 6 views).
+`--config 3` = `--views-per-gpu 4` (BASELINE configs[3], 4 novel views per GPU and step).
+
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): every rank distils its own novel
 view (weak scaling); the ranks all-gather the rendered latents and all-reduce (mean) the NGP gradients
@@ -58,7 +63,7 @@ def huber(x, y, scaling=0.1):
 
 
 class HotPath:
-    def __init__(self, device, rank, world, max_thres, views=1, seed=0):
+    def __init__(self, device, rank, world, max_thres, views=1, seed=0, n_input_views=2, eft_features=False):
         from sparsefusion_amd.nerf import NeRFNetwork, get_default_torch_ngp_opt
         from sparsefusion_amd.unet import Unet
         from sparsefusion_amd.vldm import DDPM
@@ -74,7 +79,8 @@ class HotPath:
         self.optim = FusedAdam(self.ngp.get_params(lr=5e-4))              # torch.optim.Adam arithmetic, one launch per step
         from sparsefusion_amd.distributed import FlatGradBucket
         self.grads = FlatGradBucket(self.ngp.parameters())       # .grad = views of one flat buffer: zero-copy all-reduce
-        self.check_replicas = False
+        self.check_replicas = world > 1                          # cheap (two 4-element collectives per step): on by default
+        self.time_collectives = False
         unet = Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2),
                     layer_attns=(False, False, False, True), layer_cross_attns=(False, False, False, False),
                     cond_images_channels=256, attn_pool_text=False)
@@ -103,6 +109,36 @@ class HotPath:
         self.target_mask = (torch.rand(1, 1, 128, 128, generator=g) > 0.5).float().to(device)
         self.features = torch.randn(views, 256, 32, 32, generator=g).to(device)  # cached EFT features of the novel views
         self.flat_grads = None
+        self.n_input_views, self.eft = n_input_views, None
+        self.coll_us = {"all_gather_latents": [], "all_reduce_grads": []}     # host-timed collectives (multi-rank runs)
+        if eft_features:
+            # BASELINE configs[2]: the view features come from the EFT pre-pass over n_input_views input images every step
+            from sparsefusion_amd.eft import EpipolarFeatureTransformer
+            from sparsefusion_amd.utils.cameras import PinholeCameras
+            from sparsefusion_amd.utils.render_utils import init_light_field_renderer
+            self.eft = EpipolarFeatureTransformer(use_r=True, encoder='resnet18', return_features=True, remove_unused_layers=False).to(device)
+            self.in_rgb = torch.rand(n_input_views, 3, 256, 256, generator=g).to(device)
+            self.in_cams = self._circle_cameras([0.45 * i - 0.3 for i in range(n_input_views)], PinholeCameras).to(device)
+            self.novel_cams = [self._circle_cameras([0.25 + 0.2 * (rank * views + v)], PinholeCameras).to(device) for v in range(views)]
+            _, _, self.renderer_feat = init_light_field_renderer(device, 256, 256, min=1.0, max=8.0, scale_factor=8.0)   # distillation.py:86
+            self.eft.encode(self.in_cams, self.in_rgb)           # once per scene (distillation.py:92-98)
+
+    @staticmethod
+    def _circle_cameras(angles, cls):
+        import math
+        Rs = [torch.tensor([[math.cos(a), 0, -math.sin(a)], [0, 1, 0], [math.sin(a), 0, math.cos(a)]], dtype=torch.float32) for a in angles]
+        Ts = [torch.tensor([0.02 * i, -0.01 * i, 4.0]) for i in range(len(angles))]
+        return cls(torch.stack(Rs), torch.stack(Ts), torch.full((len(angles), 2), 2.2))
+
+    @torch.no_grad()
+    def render_features(self):
+        """distillation.py:99-117 for this rank's novel views: EFT feature render -> [V, 256, 32, 32] UNet conditioning."""
+        out = []
+        for cam in self.novel_cams:
+            feats, _, _ = self.renderer_feat(cameras=cam, volumetric_function=self.eft.batched_forward, n_batches=16,
+                                             input_cameras=self.in_cams, input_rgb=self.in_rgb)
+            out.append(feats[..., 3:].permute(0, 3, 1, 2))
+        return torch.cat(out, 0).contiguous()
 
     def sampler_ctx(self):
         """a prepared trajectory context (time table + conditioning part of the init conv) for timing single evals"""
@@ -120,13 +156,25 @@ class HotPath:
         return img, sil
 
     def sync_grads(self):
-        """mean all-reduce of the NGP gradients over the replicas: ONE in-place RCCL call on the flat gradient buffer."""
-        self.grads.all_reduce()
+        """mean all-reduce of the NGP gradients over the replicas: ONE in-place RCCL call on the flat gradient buffer.  It
+        cannot overlap the novel-view render: that render reads the parameters the optimiser step behind this reduce writes
+        (distillation.py:247 -> :282), so the collective is issued asynchronously only to keep the host ahead, and waited
+        on the stream right before the step."""
+        if self.world > 1 and self.time_collectives:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        work = self.grads.all_reduce(async_op=True)
+        if work is not None:
+            work.wait()                                          # stream-side wait for RCCL (host returns at once)
+        if self.world > 1 and self.time_collectives:
+            torch.cuda.synchronize()
+            self.coll_us["all_reduce_grads"].append((time.perf_counter() - t0) * 1e6)
 
     def after_step(self):
         if self.check_replicas and self.world > 1:
             from sparsefusion_amd.distributed import replicas_identical
-            assert replicas_identical(self.ngp), "NGP replicas diverged"
+            self.replicas_ok = replicas_identical(self.ngp)
+            assert self.replicas_ok, "NGP replicas diverged"
 
     def step(self):
         # A: input view
@@ -139,13 +187,21 @@ class HotPath:
         self.optim.step()
         # B: novel view(s) + diffusion distillation (V views per GPU share one batched PLMS call)
         self.grads.zero()
+        if self.eft is not None:
+            self.features = self.render_features()
         imgs, sils = zip(*[self.render(r) for r in self.rays_novel])
         img, sil = torch.cat(imgs, 0), torch.cat(sils, 0)
         img256, sil256 = upsample2x(img), upsample2x(sil)                       # :287-288 (bilinear x2) on the HIP kernel + its adjoint
         with torch.no_grad():
             latents = self.vae.encode(img256 * 2 - 1).mode() * self.z_scale          # distillation.py:299
             from sparsefusion_amd.distributed import all_gather_latents
+            if self.world > 1 and self.time_collectives:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
             self.step_latents = all_gather_latents(latents)        # latents of all novel views of this step (8(e))
+            if self.world > 1 and self.time_collectives:
+                torch.cuda.synchronize()
+                self.coll_us["all_gather_latents"].append((time.perf_counter() - t0) * 1e6)
             pred_x0, x_noisy, noise, acp = self.plms.sample(latents, cond_images=self.features, use_tqdm=False,
                                                             return_noise=True, max_thres=self.max_thres)
             pred_img = ((self.vae.decode(pred_x0 / self.z_scale) + 1) * 0.5).clip(0.0, 1.0)   # distillation.py:309
@@ -170,6 +226,9 @@ def time_region(fn, iters):
     return e0.elapsed_time(e1) / iters
 
 
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 (MI355X_MICROARCH.md; AMD's 2:1-sparsity figures are not priced against)
+
+
 def _op_weight_bytes(o):
     """bf16 weight bytes one conv / linear op streams (each read once per eval)."""
     from sparsefusion_amd.unet import OP_CONV, OP_FCONV
@@ -180,73 +239,69 @@ def _op_weight_bytes(o):
     return 0
 
 
-def unet_roofline(hp):
-    """Per-op HIP-event timing of ONE UNet eval as the PLMS sampler runs it (plan body: the time path and the conditioning
-    half of the init conv are evaluated once per trajectory) on its launch stream -> roofline of the conv kernels."""
-    import ctypes as C
+def _fconv_flops(o):
+    """algorithmic 2 * M * N * K of a fused conv op: i = (B, H, W, C1, C2, Cout, ldc, co_off, k, ...)."""
+    return 2.0 * o.i[0] * o.i[1] * o.i[2] * o.i[5] * (o.i[3] + o.i[4]) * o.i[8] * o.i[8]
+
+
+def _graph_time_ms(op_array, n_ops, reps=30):
+    """Milliseconds per replay of a hipGraph holding exactly `op_array[:n_ops]`, ONE event pair around `reps` replays on the
+    launch stream: no per-op events inside the timed region (an event pair around a kernel costs more than a kernel boundary)."""
     from sparsefusion_amd import _lib
-    from sparsefusion_amd.unet import OP_CONV, OP_FCONV, OP_ELTWISE
-    unet = hp.unet
-    ctx = unet.begin_sampling(hp.features[:1], torch.linspace(-3, 3, 4, device=hp.dev))
-    unet.eval_prepared(ctx, torch.zeros(1, 4, 32, 32, device=hp.dev), 0)
-    plan = ctx["plan"]
-    n_ops = plan.n_body_ops
-    ops = [plan.body_array[k] for k in range(n_ops)]
-    ms = (C.c_float * n_ops)()
     lib = _lib.lib()
-    acc = np.zeros(n_ops)
-    reps = 5
-    for it in range(reps + 1):
-        _lib.check(lib.sf_plan_profile(plan.body_array, n_ops, _lib.stream_ptr(), ms))
-        if it > 0:                                                 # first pass = warm-up, discarded
-            acc += np.array(list(ms))
-    acc /= reps
-    conv = [(o, m) for o, m in zip(ops, acc) if o.type in (OP_CONV, OP_FCONV)]
-    fconv = [(o, m) for o, m in conv if o.type == OP_FCONV]
-    n_conv, conv_ms = len(conv), float(sum(m for _, m in conv))
-    conv_bytes = int(sum(_op_weight_bytes(o) for o, _ in conv))
-    fconv_bytes, fconv_ms = int(sum(_op_weight_bytes(o) for o, _ in fconv)), float(sum(m for _, m in fconv))
+    run = lambda: _lib.check(lib.sf_plan_run(op_array, n_ops, _lib.stream_ptr()), "bench sub-plan")
+    run()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        run()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def unet_roofline(hp, B=1):
+    """Roofline of the UNet's dominant kernel family -- the fused GroupNorm | LayerNorm + conv launches (k_conv_fused,
+    k_conv_fused_pipe and their _pair forms) -- measured IN THIS RUN: the fused-conv launches of one eval (batch B), and only
+    those, are captured into a hipGraph in plan order and replayed; time per launch = graph time / launches.  Units are
+    consistent: everything is per LAUNCH (a conv1 || res_conv pair is two ops in one launch).  Both rooflines are stated
+    (SURVEY.md 8(d) "governing roofline"): weight bytes / HBM peak and 2MNK / dense bf16 MFMA peak."""
+    from sparsefusion_amd import _lib
+    from sparsefusion_amd.unet import OP_CONV, OP_FCONV
+    unet = hp.unet
+    ctx = unet.begin_sampling(hp.features[:B], torch.linspace(-3, 3, 4, device=hp.dev))
+    unet.eval_prepared(ctx, torch.zeros(B, 4, 32, 32, device=hp.dev), 0)
+    plan = ctx["plan"]
+    ops = [plan.body_array[k] for k in range(plan.n_body_ops)]
+    idx = [k for k, o in enumerate(ops) if o.type == OP_FCONV]
+    sub = (_lib.SfOp * len(idx))(*[ops[k] for k in idx])            # pairs stay adjacent: both halves are FCONV ops
+    n_launch = len(idx) - sum(1 for k in idx if ops[k].flags & 16)
+    fconv_bytes = int(sum(_op_weight_bytes(ops[k]) for k in idx))
+    fconv_flops = float(sum(_fconv_flops(ops[k]) for k in idx))
+    fconv_ms = _graph_time_ms(sub, len(idx))
+    eval_ms = _graph_time_ms(plan.body_array, plan.n_body_ops)
+    all_conv_bytes = int(sum(_op_weight_bytes(o) for o in ops if o.type in (OP_CONV, OP_FCONV)))
     achieved = fconv_bytes / (fconv_ms * 1e-3) / 1e9
-    total_ms = float(acc.sum())
-    # what an event pair adds around ANY op (record + kernel boundary + a near-empty kernel): 64 one-element adds
-    scratch = torch.zeros(64, device=hp.dev)
-    tiny = (_lib.SfOp * 64)()
-    for o in tiny:
-        o.type, o.flags = OP_ELTWISE, 4
-        o.p[0], o.p[3], o.i[0] = scratch.data_ptr(), scratch.data_ptr() + 128, 1
-    tms = (C.c_float * 64)()
-    for _ in range(2):
-        _lib.check(lib.sf_plan_profile(tiny, 64, _lib.stream_ptr(), tms))
-    event_floor_us = float(np.median(np.array(list(tms)))) * 1e3
-    rocprof_us, launches = None, None                              # trace-timed fused-conv time per launch
-    stats_csv = os.path.join(ROOT, "profiles", "r02_unet_eval_b1_kernel_stats.csv")
-    if os.path.exists(stats_csv):
-        import csv
-        rows = list(csv.DictReader(open(stats_csv)))
-        evals = max(int(r["Calls"]) for r in rows if r["Name"].startswith("k_unpack_out"))       # one per eval
-        fr = [r for r in rows if "k_conv_fused" in r["Name"]]
-        rocprof_us = round(sum(float(r["TotalDurationNs"]) for r in fr) / max(sum(int(r["Calls"]) for r in fr), 1) / 1e3, 2)
-        launches = round(sum(int(r["Calls"]) for r in rows if "rocclr" not in r["Name"]) / evals, 1)
-    traffic = mfma_busy = None                                     # counters from the committed PMC passes
-    pmc = os.path.join(ROOT, "profiles", "r02_unet_eval_b1_pmc.json")
-    if os.path.exists(pmc):
-        j = json.load(open(pmc))
-        traffic = j.get("fconv_fetch_bytes_per_launch_corrected")
-        mfma_busy = j.get("fconv_mfma_busy_frac")
-    return {"bound": "hbm", "kernel": "k_conv_fused / k_conv_fused_pipe / _pair (GroupNorm | LayerNorm + conv in one launch; 80 conv ops in 71 launches)", "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "mfma_busy_frac": mfma_busy,
-            "traffic_note": "avg HBM fetch bytes per k_conv_fused launch: rocprofv3 --pmc FETCH_SIZE pass (x2 gfx950 correction), "
-                            "profiles/r02_unet_eval_b1_pmc.json; algorithmic = %d B/launch" % (fconv_bytes // max(len(fconv), 1)),
-            "launches_per_eval": len(fconv), "avg_launch_us": round(fconv_ms / max(len(fconv), 1) * 1e3, 2),
-            "event_floor_us": round(event_floor_us, 2), "avg_launch_us_rocprof": rocprof_us,
-            "timing_note": "avg_launch_us = HIP events on the launch stream around each fused-conv op (one event / boundary each, whose "
-                           "floor is event_floor_us for a one-element kernel); avg_launch_us_rocprof = same kernels from the committed "
-                           "rocprofv3 kernel trace (profiles/r02_unet_eval_b1_kernel_stats.csv)",
-            "algorithmic_bytes_per_eval": fconv_bytes, "all_conv_ops": n_conv, "all_conv_bytes": conv_bytes,
-            "all_conv_avg_launch_us": round(conv_ms / n_conv * 1e3, 2),
-            "unet_eval_event_ms": round(total_ms, 3), "unet_ops_per_eval": n_ops, "unet_launches_per_eval_rocprof": launches,
-            "unet_eval_weight_stream_GBs": round(conv_bytes / (total_ms * 1e-3) / 1e9, 1)}
+    tflops = fconv_flops / (fconv_ms * 1e-3) / 1e12
+    return {"bound": "hbm", "kernel": "k_conv_fused / k_conv_fused_pipe / _pair (GroupNorm | LayerNorm + conv in one launch)",
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "traffic_note": "HBM counters need separate rocprofv3 --pmc passes; not collected inside bench.py (see profiles/r03_*_pmc.json)",
+            "batch": B, "launches": n_launch, "ops": len(idx), "avg_launch_us": round(fconv_ms / n_launch * 1e3, 2),
+            "algorithmic_bytes_per_launch": fconv_bytes // n_launch, "algorithmic_bytes_per_eval": fconv_bytes,
+            "fused_conv_ms_per_eval": round(fconv_ms, 4),
+            "timing_note": "one HIP-event pair on the launch stream around 30 replays of a hipGraph that holds ONLY these launches, in plan order",
+            "mfma": {"achieved": round(tflops, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / MFMA_PEAK_TFLOPS, 5),
+                     "gflop_per_eval": round(fconv_flops / 1e9, 1)},
+            "whole_eval": {"ms": round(eval_ms, 4), "ops": plan.n_body_ops, "weight_bytes": all_conv_bytes,
+                           "GBs": round(all_conv_bytes / (eval_ms * 1e-3) / 1e9, 1),
+                           "frac": round(all_conv_bytes / (eval_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
 
 
 def lds_conv_roofline(hp):
@@ -334,9 +389,15 @@ def main():
     ap.add_argument("--views-per-gpu", type=int, default=1, help="novel views distilled per GPU and step (BASELINE config 4: 4)")
     ap.add_argument("--total-views", type=int, default=0,
                     help="strong scaling: this many novel views per step in total, block-sharded over the ranks (overrides --views-per-gpu)")
-    ap.add_argument("--check-replicas", action="store_true", help="assert after every step that all ranks hold bit-identical NGP parameters")
+    ap.add_argument("--check-replicas", action="store_true", help="(default when N > 1) assert after every step that all ranks hold bit-identical NGP parameters")
+    ap.add_argument("--no-check-replicas", action="store_true")
+    ap.add_argument("--config", type=int, default=1, choices=(1, 2, 3),
+                    help="BASELINE configs[k]: 1 = 2 input views, cached features (default); 2 = 6 input views, EFT feature render every step; "
+                         "3 = 4 novel views per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.config == 3 and args.views_per_gpu == 1:
+        args.views_per_gpu = 4
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -360,8 +421,9 @@ def main():
         if args.total_views % world:
             raise SystemExit("--total-views must be a multiple of the number of ranks (equal shards for the latent all-gather)")
         args.views_per_gpu = len(shard_views(args.total_views, rank, world))
-    hp = HotPath(dev, rank, world, args.max_thres, args.views_per_gpu)
-    hp.check_replicas = args.check_replicas
+    n_in = 6 if args.config == 2 else 2
+    hp = HotPath(dev, rank, world, args.max_thres, args.views_per_gpu, n_input_views=n_in, eft_features=args.config == 2)
+    hp.check_replicas = (world > 1 or args.check_replicas) and not args.no_check_replicas
     for _ in range(args.warmup):
         hp.step()
 
@@ -379,6 +441,19 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
     ms_per_step = float(dt) / args.steps * 1e3
+    multi = None
+    if world > 1:                                                   # after the timed region: what the collectives cost, on every rank
+        import torch.distributed as dist
+        hp.time_collectives = True
+        for _ in range(2):
+            hp.step()
+        barrier()
+        med = lambda v: float(np.median(v)) if v else None
+        multi = {"world_size_seen": dist.get_world_size(), "backend": dist.get_backend(),
+                 "all_gather_latents_us": med(hp.coll_us["all_gather_latents"]), "all_reduce_grads_us": med(hp.coll_us["all_reduce_grads"]),
+                 "all_reduce_bytes": int(hp.grads.flat.numel() * hp.grads.flat.element_size()), "collectives_per_step": {"all_gather": 1, "all_reduce": 2},
+                 "replicas_identical": bool(getattr(hp, "replicas_ok", None)) if hp.check_replicas else None,
+                 "timing_note": "host wall time between device synchronisations around each collective, median over 2 extra steps after the timed region"}
 
     if rank == 0:
         n_evals = min(int(args.max_thres * 100), 50) + 1
@@ -388,9 +463,11 @@ def main():
             "value": round(world * args.views_per_gpu / (ms_per_step * 1e-3), 4), "unit": "views/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "bf16 MFMA operands / f32 accumulate (UNet); f32 (NGP render)", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: single MI355X" if args.views_per_gpu == 1 and world == 1 else
+            "config": {"workload": ("BASELINE configs[2]: single MI355X, 6 input views, EFT feature render (32x32 rays x 20 depths x 6 views) of every novel view inside the step"
+                                    if args.config == 2 else
+                                    "BASELINE configs[1]: single MI355X" if args.views_per_gpu == 1 and world == 1 else
                                     "BASELINE configs[3]-style view sharding: %d GPU(s) x %d novel views per step" % (world, args.views_per_gpu)) +
-                                   ", 256^2 hydrant-like synthetic scene, 2 input views, "
+                                   ", 256^2 hydrant-like synthetic scene, %d input views, " % n_in +
                                    "32x32 latent UNet (400.68M params, B=%d per GPU) + NGP render 128x128 rays x (64+64) samples; "
                                    "SD-VAE encode 256^2 -> 32x32x4 and decode back (83.65M params) and LPIPS-VGG16 fwd+bwd at 256^2 every step; "
                                    "max_thres=%.2f" % (args.views_per_gpu, args.max_thres),
@@ -408,8 +485,17 @@ def main():
             "vae_decode": round(time_region(lambda: hp.vae.decode(torch.zeros(1, 4, 32, 32, device=dev)), 5), 3),
             "lpips_fwd_bwd": round(time_region(lambda: hp.percep(lp_a, lp_b).sum().backward(), 5), 3),
         }
-        res["roofline"] = unet_roofline(hp)
+        if hp.eft is not None:
+            res["breakdown_ms"]["eft_feature_render_per_view"] = round(time_region(lambda: hp.render_features(), 5) / args.views_per_gpu, 3)
+        if args.views_per_gpu > 1:
+            Bv = args.views_per_gpu
+            ctx_b = hp.unet.begin_sampling(hp.features[:Bv], torch.linspace(-3, 3, 4, device=dev))
+            x_b = torch.zeros(Bv, 4, 32, 32, device=dev)
+            res["breakdown_ms"]["unet_eval_in_sampler_B%d" % Bv] = round(time_region(lambda: hp.unet.eval_prepared(ctx_b, x_b, 1), 20), 3)
+        res["roofline"] = unet_roofline(hp, args.views_per_gpu)    # the batch the step ran the UNet at (configs[3]: B = 4: both rooflines)
         res["roofline_mfma"] = lds_conv_roofline(hp)
+        if multi is not None:
+            res["multi_gpu"] = multi
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.max_thres)
         print(json.dumps(res))

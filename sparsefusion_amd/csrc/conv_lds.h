@@ -30,7 +30,7 @@ struct ConvArgs {
 #undef CONV_LDS_NAME
 #undef CONV_LDS_GN
 
-// k_conv_lds_gn (EXPERIMENTAL, SF_VAE_GN_EPI=1, not yet measured): the same kernel whose epilogue also leaves per-(pixel tile, GroupNorm group) partial sums (sum, sum of squares) of the values it
+// k_conv_lds_gn (the VAE default since r03; SF_VAE_GN_EPI=0 plans the statistics pass instead): the same kernel whose epilogue also leaves per-(pixel tile, GroupNorm group) partial sums (sum, sum of squares) of the values it
 // writes, in double, at gn_part[(mt * (Cout / gn_cg) + group) * 2] -- no atomics; k_gn_finalize adds the tiles of an image up
 // into the statistics k_gn_apply reads, which makes the separate statistics pass over the tensor (k_gn_stats_px) unnecessary.
 // Needs: the conv writes whole rows of the tensor (co_off = 0, Cout = ldc), gn_cg in {4, 8, 16}, 128 | Ho * Wo.

@@ -37,9 +37,10 @@ struct FBArgs {
   float* g_w0; float* g_b0; float* g_w1; float* g_b1; float* g_w2; float* g_b2;
   NgpLevels lv;
   const float* rays_o; const float* rays_d; const float* aabb; const float* z_s; const float* dsig; const float* drgb;
-  float* dfeat_out;          // level-major [L][P][2] or null (table frozen)
+  float* dfeat_out;          // level-major [L][dfeat_P][2] or null (table frozen)
   uint32_t P, T2;
-};
+  uint32_t dfeat_P, p_off;   // a launch may cover the chunk [p_off, p_off + P) of a larger point set (ray / sample pointers are
+};                           // pre-offset by the host): dfeat keeps the layout of the WHOLE set, level stride dfeat_P
 
 SF_KERNEL(256) void k_ngp_field_bwd_mfma(FBArgs a) {
   SF_DYN_LDS(lds_raw);
@@ -302,7 +303,7 @@ SF_KERNEL(256) void k_ngp_field_bwd_mfma(FBArgs a) {
             const int q = mt * 16 + 4 * kq + r, f = ft * 16 + li;
             const uint32_t pp = p0 + q;
             if (pp < a.P && (uint32_t)(f >> 1) < a.lv.L)
-              a.dfeat_out[((size_t)(f >> 1) * a.P + pp) * 2 + (f & 1)] = INS[q] != 0.0f ? c[mt][ft][r] : 0.0f;
+              a.dfeat_out[((size_t)(f >> 1) * a.dfeat_P + a.p_off + pp) * 2 + (f & 1)] = INS[q] != 0.0f ? c[mt][ft][r] : 0.0f;
           }
     }
     sf_wave_sync();                                      // before the next trip restages F / H1 / H2 / DO / INS

@@ -215,7 +215,9 @@ __global__ __launch_bounds__(NT) void k_ngp_scatter(
 __global__ __launch_bounds__(256) void k_ngp_scatter_fine(
     NgpLevels lv, float bound, float* __restrict__ gtable, const float* __restrict__ rays_o,
     const float* __restrict__ rays_d, const float* __restrict__ aabb, const float* __restrict__ z_s,
-    const float* __restrict__ dfeat, uint32_t N, uint32_t T2, uint32_t first_level) {
+    const float* __restrict__ dfeat, uint32_t N, uint32_t T2, uint32_t first_level, uint32_t P_stride, uint32_t p_off) {
+  // this launch walks the N rays behind the (pre-offset) ray / sample pointers = points [p_off, p_off + N * T2) of a set of
+  // P_stride points, whose level-major layout dfeat keeps
   const uint32_t P = N * T2;
   float box[6];
 #pragma unroll
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(256) void k_ngp_scatter_fine(
     const uint32_t ch = (uint32_t)it & 1, xb = ((uint32_t)it >> 1) & 1;
     const uint64_t q = it >> 2;
     const uint32_t l = first_level + (uint32_t)(q / P), p = (uint32_t)(q % P);
-    const float dfc = dfeat[((size_t)l * P + p) * 2 + ch];
+    const float dfc = dfeat[((size_t)l * P_stride + p_off + p) * 2 + ch];
     if (dfc == 0.0f) continue;
     const uint32_t n = p / T2;
     const float o[3] = {rays_o[n * 3], rays_o[n * 3 + 1], rays_o[n * 3 + 2]};
@@ -384,86 +386,93 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
   int dev_id = 0;                                  // raised dynamic-LDS limits are per-device function attributes
   if (hipGetDevice(&dev_id) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "hipGetDevice failed");
   float* dfeat = g->g_embeddings ? drgb + 3 * M : nullptr;        // NULL table gradient = table frozen
-  {
-    // matrix-core version: one wave per 32 points and trip, six fp32 GEMMs on v_mfma_f32_16x16x4_f32 (ngp_bwd_mfma.h)
-    const size_t lds2 = (size_t)FB_LDS_FLOATS * sizeof(float);
-    static unsigned attr3_mask = 0;
-    if (dev_id >= 32 || !(attr3_mask & (1u << dev_id))) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_field_bwd_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds2) != hipSuccess)
-        SF_FAIL(SF_ERR_LAUNCH, "ngp_field_bwd_mfma: cannot raise dynamic LDS limit to %zu", lds2);
-      if (dev_id < 32) attr3_mask |= 1u << dev_id;
-    }
+  const size_t lds2 = (size_t)FB_LDS_FLOATS * sizeof(float);
+  const size_t lds_sc = (size_t)SC_SLOTS * 3 * sizeof(float);
+  static unsigned attr_mask = 0;
+  if (dev_id >= 32 || !(attr_mask & (1u << dev_id))) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_field_bwd_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_scatter<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_scatter<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_scatter<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess)
+      SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: cannot raise the dynamic LDS limits");
+    if (dev_id < 32) attr_mask |= 1u << dev_id;
+  }
+  // tuning knobs (A/B on the GPU box): threads per cached-level workgroup, scale cutoff of the LDS cache, fine levels in
+  // their own high-occupancy launch
+  static const int sc_threads = getenv("SF_SC_THREADS") ? atoi(getenv("SF_SC_THREADS")) : 1024;
+  static const float sc_cutoff = getenv("SF_SC_CUTOFF") ? (float)atof(getenv("SF_SC_CUTOFF")) : 640.0f;
+  static const bool sc_split = getenv("SF_SC_SPLIT") ? atoi(getenv("SF_SC_SPLIT")) != 0 : true;
+  static const uint32_t sc_run = getenv("SF_SC_RUN") && atoi(getenv("SF_SC_RUN")) > 0 ? (uint32_t)atoi(getenv("SF_SC_RUN")) : 32u;   // measured 4 / 8 / 16 / 32: 6.95 / 6.85 / 6.81 / 6.76 ms render fwd+bwd
+  // levels up to scale ~640 profit from the LDS cache (measured r02: cut-off 160 / 320 / 640 / none = 7.82 / 7.63 / 7.51 / 8.27 ms render fwd+bwd)
+  uint32_t cached = 0;
+  while (cached < lv.L && lv.scale[cached] <= sc_cutoff) ++cached;
+  const uint32_t last = (dfeat && sc_split) ? cached : lv.L;     // levels [0, last): k_ngp_scatter, [last, L): k_ngp_scatter_fine
+
+  // ---- the pipeline (r03).  Three kernels with three different bottlenecks: the field backward (fp32 MFMA + 113 KB of LDS,
+  // one workgroup per CU), the fine-level scatter (memory-side atomic unit, no LDS, VALU idle) and the cached-level scatter
+  // (LDS atomics, 96 KB).  The rays are cut into chunks; the fine-level scatter of chunk c runs on a side stream while the
+  // field backward of chunk c + 1 occupies the CUs, and the last one runs beside the cached-level scatter (one launch over
+  // all rays, its LDS cache wants every ray of an 8x8 patch).  dfeat keeps the level-major layout of the whole ray set.
+  // SF_NGP_OVERLAP=0: everything on the caller's stream in one chunk (A/B).
+  static const bool overlap = !(getenv("SF_NGP_OVERLAP") && atoi(getenv("SF_NGP_OVERLAP")) == 0);
+  static const uint32_t want_chunks = getenv("SF_NGP_CHUNKS") && atoi(getenv("SF_NGP_CHUNKS")) > 0 ? (uint32_t)atoi(getenv("SF_NGP_CHUNKS")) : 4u;
+  struct Side { hipStream_t s; hipEvent_t fork, join; };
+  static Side side[32] = {};
+  const bool fork = overlap && dfeat && last < lv.L && dev_id < 32;
+  uint32_t n_chunks = 1;
+  if (fork) {
+    n_chunks = want_chunks;
+    while (n_chunks > 1 && (N % n_chunks || (N / n_chunks) % 256 || N / n_chunks < 2048)) --n_chunks;
+    Side& sd = side[dev_id];
+    if (!sd.s && (hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) != hipSuccess ||
+                  hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
+                  hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess))
+      SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: cannot create the side stream");
+  }
+  const uint32_t Nc = N / n_chunks, T2 = 2 * T;
+  const uint32_t Pc = Nc * T2;
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    // matrix-core field backward of chunk c: one wave per 32 points and trip, six fp32 GEMMs on v_mfma_f32_16x16x4_f32 (ngp_bwd_mfma.h)
     FBArgs a;
     a.table = f->embeddings; a.w0 = f->w0; a.b0 = f->b0; a.w1 = f->w1; a.b1 = f->b1; a.w2 = f->w2; a.b2 = f->b2; a.bound = f->bound;
     a.g_w0 = g->g_w0; a.g_b0 = g->g_b0; a.g_w1 = g->g_w1; a.g_b1 = g->g_b1; a.g_w2 = g->g_w2; a.g_b2 = g->g_b2;
     a.lv = lv;
-    a.rays_o = rays_o; a.rays_d = rays_d; a.aabb = aabb; a.z_s = z_sorted; a.dsig = dsig; a.drgb = drgb; a.dfeat_out = dfeat;
-    a.P = (uint32_t)M; a.T2 = 2 * T;
-    const uint32_t trips = sf_div_up(M, FB_PTS);
+    a.rays_o = rays_o + (size_t)c * Nc * 3; a.rays_d = rays_d + (size_t)c * Nc * 3; a.aabb = aabb;
+    a.z_s = z_sorted + (size_t)c * Pc; a.dsig = dsig + (size_t)c * Pc; a.drgb = drgb + (size_t)c * Pc * 3; a.dfeat_out = dfeat;
+    a.P = Pc; a.T2 = T2; a.dfeat_P = (uint32_t)M; a.p_off = c * Pc;
+    const uint32_t trips = sf_div_up(Pc, FB_PTS);
     const uint32_t grid = trips < 1024 ? sf_div_up(trips, 4) : 256;   // one resident workgroup per CU (LDS-bound), 4 waves each
     k_ngp_field_bwd_mfma<<<grid, 256, lds2, st>>>(a);
     SF_CHECK_LAUNCH("ngp_field_bwd_mfma");
-  }
-  if (dfeat) {
-    const size_t lds_sc = (size_t)SC_SLOTS * 3 * sizeof(float);
-    // tuning knobs (A/B on the GPU box): threads per cached-level workgroup, scale cutoff of the LDS cache, fine levels in
-    // their own high-occupancy launch
-    static const int sc_threads = getenv("SF_SC_THREADS") ? atoi(getenv("SF_SC_THREADS")) : 1024;
-    static const float sc_cutoff = getenv("SF_SC_CUTOFF") ? (float)atof(getenv("SF_SC_CUTOFF")) : 640.0f;
-    static const bool sc_split = getenv("SF_SC_SPLIT") ? atoi(getenv("SF_SC_SPLIT")) != 0 : true;
-    static const uint32_t sc_run = getenv("SF_SC_RUN") && atoi(getenv("SF_SC_RUN")) > 0 ? (uint32_t)atoi(getenv("SF_SC_RUN")) : 32u;   // measured 4 / 8 / 16 / 32: 6.95 / 6.85 / 6.81 / 6.76 ms render fwd+bwd
-    static unsigned attr2_mask = 0;
-    if (dev_id >= 32 || !(attr2_mask & (1u << dev_id))) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_scatter<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_scatter<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_scatter<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess)
-        SF_FAIL(SF_ERR_LAUNCH, "ngp_scatter: cannot raise dynamic LDS limit");
-      if (dev_id < 32) attr2_mask |= 1u << dev_id;
-    }
-    // levels up to scale ~640 profit from the LDS cache (measured r02: cut-off 160 / 320 / 640 / none = 7.82 / 7.63 / 7.51 / 8.27 ms render fwd+bwd)
-    uint32_t cached = 0;
-    while (cached < lv.L && lv.scale[cached] <= sc_cutoff) ++cached;
-    const uint32_t last = sc_split ? cached : lv.L;
-    const uint32_t grid_sc = sf_div_up(N, SC_RAYS);
-    // The two scatter launches touch disjoint levels and stress different units (cached levels: LDS atomics, one 1024-thread
-    // workgroup per CU; fine levels: the memory-side atomic unit, no LDS): the fine levels run on a side stream forked here and
-    // joined before this call returns in stream order, so the atomic unit works while the LDS-bound kernel occupies the CUs.
-    static const bool overlap = !(getenv("SF_NGP_OVERLAP") && atoi(getenv("SF_NGP_OVERLAP")) == 0);
-    hipStream_t st_fine = st;
-    struct Side { hipStream_t s; hipEvent_t fork, join; };
-    static Side side[32] = {};
-    const bool fork = overlap && last > 0 && last < lv.L && dev_id < 32;
-    if (fork) {
-      Side& sd = side[dev_id];
-      if (!sd.s && (hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) != hipSuccess ||
-                    hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess))
-        SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: cannot create the side stream");
-      if (hipEventRecord(sd.fork, st) != hipSuccess || hipStreamWaitEvent(sd.s, sd.fork, 0) != hipSuccess)
-        SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: fork failed");
-      st_fine = sd.s;
-    }
-    if (last < lv.L) {
-      const uint64_t items = (uint64_t)4 * M * (lv.L - last);
+    if (dfeat && last < lv.L) {
+      hipStream_t sf = st;
+      if (fork) {
+        Side& sd = side[dev_id];
+        if (hipEventRecord(sd.fork, st) != hipSuccess || hipStreamWaitEvent(sd.s, sd.fork, 0) != hipSuccess)
+          SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: fork failed");
+        sf = sd.s;
+      }
+      const uint64_t items = (uint64_t)4 * Pc * (lv.L - last);
       const uint32_t grid_f = (uint32_t)(items / 256 < 16384 ? (items + 255) / 256 : 16384);
-      k_ngp_scatter_fine<<<grid_f, 256, 0, st_fine>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, 2 * T, last);
+      k_ngp_scatter_fine<<<grid_f, 256, 0, sf>>>(lv, f->bound, g->g_embeddings, a.rays_o, a.rays_d, aabb, a.z_s, dfeat, Nc, T2, last,
+                                                 (uint32_t)M, c * Pc);
       SF_CHECK_LAUNCH("ngp_scatter_fine");
     }
-    if (last > 0) {
-      if (sc_threads == 256)
-        k_ngp_scatter<256><<<grid_sc, 256, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, 2 * T, rays_per_row, cached, last, sc_run);
-      else if (sc_threads == 512)
-        k_ngp_scatter<512><<<grid_sc, 512, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, 2 * T, rays_per_row, cached, last, sc_run);
-      else
-        k_ngp_scatter<1024><<<grid_sc, 1024, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, 2 * T, rays_per_row, cached, last, sc_run);
-      SF_CHECK_LAUNCH("ngp_scatter");
-    }
-    if (fork) {
-      Side& sd = side[dev_id];
-      if (hipEventRecord(sd.join, sd.s) != hipSuccess || hipStreamWaitEvent(st, sd.join, 0) != hipSuccess)
-        SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: join failed");
-    }
+  }
+  if (dfeat && last > 0) {
+    const uint32_t grid_sc = sf_div_up(N, SC_RAYS);
+    if (sc_threads == 256)
+      k_ngp_scatter<256><<<grid_sc, 256, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, T2, rays_per_row, cached, last, sc_run);
+    else if (sc_threads == 512)
+      k_ngp_scatter<512><<<grid_sc, 512, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, T2, rays_per_row, cached, last, sc_run);
+    else
+      k_ngp_scatter<1024><<<grid_sc, 1024, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, T2, rays_per_row, cached, last, sc_run);
+    SF_CHECK_LAUNCH("ngp_scatter");
+  }
+  if (fork) {
+    Side& sd = side[dev_id];
+    if (hipEventRecord(sd.join, sd.s) != hipSuccess || hipStreamWaitEvent(st, sd.join, 0) != hipSuccess)
+      SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: join failed");
   }
   return SF_OK;
 }

@@ -534,7 +534,7 @@ static int run_conv(const sf_op& op, hipStream_t st) {
     a.m_tiles = (a.m_frags + 7) / 8;
     a.n_tiles = (a.n_frags + bnf - 1) / bnf;
     const int nblk = a.m_tiles * a.n_tiles;
-    if (op.flags & 128) {                                // EXPERIMENTAL: epilogue leaves GroupNorm partial sums (conv_lds.h)
+    if (op.flags & 128) {                                // the epilogue also leaves GroupNorm partial sums (conv_lds.h)
       double* part = (double*)op.p[6];
       const int cg = op.i[15];
       if (!part || (cg != 4 && cg != 8 && cg != 16) || a.Cout % cg || a.co_off || a.ldc != a.Cout || (a.Ho * a.Wo) % 128)

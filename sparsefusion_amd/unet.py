@@ -349,7 +349,7 @@ class _Plan:
         cg = (C1 // groups) if not skip else 0
         if (getattr(self.u, "gn_epilogue", False) and wr is not None and not (wr.flags & 128) and li[0] == 0 and cg in (4, 8, 16)
                 and x.HW and x.HW % 128 == 0 and x.rows == self.B * x.HW):
-            # EXPERIMENTAL (SF_VAE_GN_EPI=1): the producing k_conv_lds leaves per-tile partial sums, k_gn_finalize adds them up,
+            # (VAE plans; SF_VAE_GN_EPI=0 disables) the producing k_conv_lds leaves per-tile partial sums, k_gn_finalize adds them up,
             # and the statistics pass over the tensor (k_gn_stats_px) is skipped
             part = self.misc.alloc(x.rows // 128 * groups * 2 * 8)
             wr.flags |= 128
@@ -1014,6 +1014,9 @@ class Unet(nn.Module):
         slices go through the workspace + k_splitk_reduce.  Terms: weight streaming from HBM (needs ~4 waves/CU
         to saturate), fragment traffic from L2 (1 KiB per fragment, amortised over the tile), MFMA issue, and the
         partial-tile round trip of split-K."""
+        ov = getattr(self, "tile_override", None)               # {(m_frags, n_frags, KS, pixshuf): (WM, WN, groups)}: measured picks
+        if ov and (m_frags, n_frags, KS, bool(pixshuf)) in ov:  # (TILE_PICKS below) and tools/tile_sweep.py
+            return ov[(m_frags, n_frags, KS, bool(pixshuf))]
         best = None
         mfma = m_frags * n_frags * KS
         w_bytes = n_frags * KS * 1024
@@ -1057,6 +1060,12 @@ class Unet(nn.Module):
         r = super().load_state_dict(*args, **kwargs)
         self.invalidate()
         return r
+
+    def drop_plans(self):
+        """Retire the launch plans but keep the packed weights (plan-level tuning: tools/tile_sweep.py)."""
+        for plan in self._plans.values():
+            plan.generation = -1
+        self._plans = {}
 
     MAX_TIME_PLANS = 4                   # ("time", T) plans kept per module: one per distinct trajectory length, LRU
 

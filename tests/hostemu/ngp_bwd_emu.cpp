@@ -32,7 +32,7 @@ extern "C" void emu_field_bwd(const float* table, const int32_t* h_offsets, uint
   a.table = table; a.w0 = w0; a.b0 = b0; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.bound = bound;
   a.g_w0 = g_w0; a.g_b0 = g_b0; a.g_w1 = g_w1; a.g_b1 = g_b1; a.g_w2 = g_w2; a.g_b2 = g_b2;
   fill_levels(&a.lv, h_offsets, L, S, H, gridtype);
-  a.rays_o = rays_o; a.rays_d = rays_d; a.aabb = aabb; a.z_s = z_s; a.dsig = dsig; a.drgb = drgb; a.dfeat_out = dfeat;
+  a.rays_o = rays_o; a.rays_d = rays_d; a.aabb = aabb; a.z_s = z_s; a.dsig = dsig; a.drgb = drgb; a.dfeat_out = dfeat; a.dfeat_P = P; a.p_off = 0;
   a.P = P; a.T2 = T2;
   if (!use_ref) {
     hipemu::launch(grid, 256, FB_LDS_FLOATS * sizeof(float), [&] { k_ngp_field_bwd_mfma(a); });

@@ -24,3 +24,20 @@ def test_two_ranks_strong_scaling_dry_run():
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["config"]["views_per_gpu"] == 1
     assert res["value"] > 0 and res["steps"] == 2
+    # the run verifies itself: the world size the process group saw, the collectives' cost and the replica check are in the line
+    mg = res["multi_gpu"]
+    assert mg["world_size_seen"] == 2 and mg["backend"] == "gloo" and mg["replicas_identical"] is True
+    assert mg["all_gather_latents_us"] > 0 and mg["all_reduce_grads_us"] > 0 and mg["all_reduce_bytes"] == (929336 * 2 + 6532) * 4
+    rf = res["roofline"]                                            # measured in this run, per launch, both rooflines
+    assert rf["traffic"] is None and rf["launches"] <= rf["ops"] and rf["avg_launch_us"] > 0 and rf["mfma"]["frac"] > 0
+    assert abs(rf["algorithmic_bytes_per_launch"] * rf["launches"] - rf["algorithmic_bytes_per_eval"]) < rf["launches"]
+
+
+def test_config2_eft_feature_render_in_the_step():
+    """BASELINE configs[2] as a bench workload: 6 input views, the EFT feature render of the novel view inside every step."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "2", "--steps", "1", "--warmup", "1", "--max-thres", "0.06",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert "configs[2]" in res["config"]["workload"] and res["breakdown_ms"]["eft_feature_render_per_view"] > 0 and res["value"] > 0

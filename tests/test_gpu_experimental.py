@@ -65,12 +65,12 @@ def test_vae_gn_statistics_from_the_conv_epilogue():
     """SF_VAE_GN_EPI=1 (k_conv_lds_gn + k_gn_finalize) gives the same encode / decode as the statistics pass up to the bf16
     decorrelation of the path (a last-ulp difference in a GroupNorm statistic re-rounds the bf16 operands downstream: measured
     4.8e-3 on the first GPU run, r3a; the path itself sits 7e-3 from the fp32 reference, tests/test_gpu_vae.py)."""
-    ref, got = _run(VAE_SNIPPET, {"SF_VAE_GN_EPI": "0"}), _run(VAE_SNIPPET, {"SF_VAE_GN_EPI": "1"})
+    ref, got = _run(VAE_SNIPPET, {"SF_VAE_GN_EPI": "0"}), _run(VAE_SNIPPET, {"SF_VAE_GN_EPI": "1"})    # 1 is the default since r03
     for k in ("lat", "dec"):
         assert torch.isfinite(got[k]).all() and _rel(got[k], ref[k]) < 1e-2, (k, _rel(got[k], ref[k]))
 
 
-@pytest.mark.parametrize("knob", ["SF_NGP_OVERLAP", "SF_NGP_FWD_MFMA"])
+@pytest.mark.parametrize("knob", ["SF_NGP_OVERLAP", "SF_NGP_FWD_MFMA"])      # overlap: 1 is the default (chunked backward + side stream)
 def test_ngp_render_variants_match_default(knob):
     ref, got = _run(NGP_SNIPPET, {knob: "0"}), _run(NGP_SNIPPET, {knob: "1"})
     assert torch.allclose(got["image"], ref["image"], atol=2e-6) and torch.allclose(got["ws"], ref["ws"], atol=2e-6)

@@ -94,7 +94,7 @@ def test_conv_lds_matches_conv2d(B, H, Cin, Cout, k, stride, pad, bnf, a_f32, up
     (1, 32, 32, 64, 4, False, False, False),      # 64-channel tile; a 32-group norm of 64 channels has 2 per group: 4-wide groups tested here
 ])
 def test_conv_lds_gn_epilogue_statistics(B, H, Cin, Cout, bnf, a_f32, resid, accum):
-    """k_conv_lds_gn + k_gn_finalize (EXPERIMENTAL, SF_VAE_GN_EPI=1): same output as k_conv_lds, and stats[b][g] = (sum, sum of
+    """k_conv_lds_gn + k_gn_finalize (the VAE default since r03): same output as k_conv_lds, and stats[b][g] = (sum, sum of
     squares) of the written tensor per image and GroupNorm group -- what k_gn_stats_px computes in a separate pass."""
     lib = _lib()
     g = torch.Generator().manual_seed(3 * Cin + Cout + H)

@@ -183,14 +183,15 @@ def test_vae_lpips_eft_plan_invariants():
 
 
 def test_vae_gn_epilogue_plan(monkeypatch):
-    """EXPERIMENTAL SF_VAE_GN_EPI=1: every GroupNorm whose input was last written by a whole-tensor k_conv_lds launch takes its
-    statistics from that conv's epilogue (flag 128 + partials buffer + group width on the conv, OP_GN_FINALIZE, flag 2 on the
-    GroupNorm); the others keep the statistics pass.  Off by default: the default plans are unchanged."""
+    """Every GroupNorm whose input was last written by a whole-tensor k_conv_lds launch takes its statistics from that conv's
+    epilogue (flag 128 + partials buffer + group width on the conv, OP_GN_FINALIZE, flag 2 on the GroupNorm); the others keep
+    the statistics pass.  Default since r03 (measured on the GPU); SF_VAE_GN_EPI=0 restores the statistics pass everywhere."""
     from sparsefusion_amd import unet as unet_mod
     from sparsefusion_amd.vae import AutoencoderKL, _VaePlan
+    monkeypatch.setenv("SF_VAE_GN_EPI", "0")
     base = _VaePlan(AutoencoderKL(), "dec", 1, CPU).build()
     assert not any(o.type == unet_mod.OP_GN_FINALIZE or (o.type == unet_mod.OP_CONV and o.flags & 128) for o in base.ops)
-    monkeypatch.setenv("SF_VAE_GN_EPI", "1")
+    monkeypatch.delenv("SF_VAE_GN_EPI")
     vae = AutoencoderKL()
     for kind, B in (("enc", 1), ("dec", 2)):
         s = _VaePlan(vae, kind, B, CPU).build()

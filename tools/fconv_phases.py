@@ -17,7 +17,11 @@ for name in names:
     if kw.get("accum"):
         continue
     dbg = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda:0")
-    wall = fc.run_conv_case("gpu", **kw, dbg=dbg, reps=20)
+    try:
+        wall = fc.run_conv_case("gpu", **kw, dbg=dbg, reps=20)
+    except Exception as e:                                       # paired launches carry no stamps
+        print(f"{name:28s} skipped ({e})")
+        continue
     d = dbg.view(-1, 8).cpu()
     d = d[d[:, 5] != 0].double()
     if d.shape[0] == 0:                                        # a library without the stamps (counter runs)
@@ -29,7 +33,9 @@ for name in names:
     end = (d[:, 5] - t0) / 100.0
     print(f"{name:28s} WGs {d.shape[0]:4d}  wall/launch {wall * 1e6:6.1f} us  kernel span {float(end.max()):6.2f} us  "
           f"WG start spread {float(start.max()):5.2f}")
-    for k, lab in enumerate(["prefetch-issue", "statistics", "staging", "main loop", "epilogue"]):
+    pipe = bool(kw.get("pipe"))       # k_conv_fused_pipe stamps: 1 = slot statistics + table done, 2 = first chunk staged, 3 = 4 = pipeline drained
+    for k, lab in enumerate(["entry->statistics", "first chunk staged", "pipelined chunks", "(-)", "epilogue"] if pipe else
+                            ["prefetch-issue", "statistics", "staging", "main loop", "epilogue"]):
         print(f"      {lab:15s} mean {float(ph[:, k].mean()):6.2f}  max {float(ph[:, k].max()):6.2f}")
     if float(d[:, 6].max()) > 0:                               # finer stamps inside "prefetch-issue": entry -> s6 -> s7 -> stamp 1
         a6, a7 = (d[:, 6] - d[:, 0]) / 100.0, (d[:, 7] - d[:, 6]) / 100.0
