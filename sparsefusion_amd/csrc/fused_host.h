@@ -18,6 +18,7 @@
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/sparsefusion_hip.h"
 #include "fused_kernels.h"
 #include "fused_pipe.h"
@@ -160,7 +161,18 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   lds_bytes = a.misc_off + 640 + 2048;      // misc: 160 floats of statistics + 512 floats of reduction partials
   if (lds_bytes > SF_LDS_MAX) FC_FAIL("fconv: tile needs %u bytes of LDS", lds_bytes);
   const int MT = a.B * a.mt_per_img;
-  a.xcd_map = (a.n_tiles % 8 == 0 && MT > 1) ? 1 : 0;
+  // XCD-aware tile map (fconv_tile_of): R row groups x 8 / R channel groups.  R = 1 (every XCD owns n-tiles == x mod 8 of ALL
+  // rows: each weight byte crosses the fabric once, the activation map is fetched by all 8 L2s) is the measured best on every
+  // layer: sharing rows instead (R = 2 / 4, each XCD then pulls 1 / R of the activations and R x the weights) was slower even
+  // on the 32x32 layers whose activations outweigh their weights (r03: eval 1.311 / 1.335 / 1.402 ms for R = 1 / 2 / 4;
+  // choosing R per layer by fabric bytes: 1.314).  SF_XCD_R forces another R for A/B.
+  a.xcd_map = 0;
+  if (MT > 1 && a.S == 1) {
+    static const int force_r = getenv("SF_XCD_R") ? atoi(getenv("SF_XCD_R")) : 1;
+    const int R = (force_r == 2 || force_r == 4 || force_r == 8) ? force_r : 1;
+    if (MT % R == 0 && a.n_tiles % (8 / R) == 0) a.xcd_map = R;
+    else if (a.n_tiles % 8 == 0) a.xcd_map = 1;
+  }
   grid = (uint32_t)a.S * MT * a.n_tiles;
   a.buf_bytes = 0;
   a.inv_n = (a.norm == FNORM_GN_SELF || a.norm == FNORM_GN_SLOTS) ? 1.0 / ((double)a.H * a.W * (a.C / a.G)) : 0.0;

@@ -195,6 +195,25 @@ struct FGather {
 // (the all-in-one version was 49 k instructions and spilled 190 SGPRs).  NW = waves per workgroup: the prologue is VALU
 // and latency bound (SiLU per element, one workgroup per CU because of the LDS frame), so it wants 2 waves per SIMD;
 // the same 8 waves then split K eight ways and keep 8 x D KiB of weight fragments in flight per CU.
+// Tile of workgroup t (within its K-slice).  Workgroups t, t + 8, ... run on one XCD (observed round-robin placement; only
+// speed depends on it) and every XCD's L2 fetches what its workgroups read through the fabric: with R row groups x Q = 8 / R
+// channel groups, XCD x = (rg = x % R, qg = x / R) owns the contiguous m-tiles [rg, rg + 1) * MT / R (neighbouring rows share
+// their halo in L2) and the n-tiles == qg (mod Q): it pulls 1 / R of the activations and 1 / Q of the weights.  R = 1 is the
+// r02 map (every XCD reads the whole activation map, each weight byte crosses the fabric once); the host picks R by bytes.
+SF_DEV void fconv_tile_of(const FConvArgs& a, int t, int MT, int& mt, int& nt) {
+  if (a.xcd_map) {
+    const int R = a.xcd_map, Q = 8 / R;
+    const int x = t & 7, j = t >> 3;
+    const int rg = x % R, qg = x / R;
+    const int MTg = MT / R;
+    mt = rg * MTg + j % MTg;
+    nt = qg + Q * (j / MTg);
+  } else {
+    nt = t % a.n_tiles;
+    mt = t / a.n_tiles;
+  }
+}
+
 template <int WM, int WN, int D, int NORM, int LAZY, int NW>
 SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
   constexpr int NT = NW * 64;
@@ -212,14 +231,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
   const int s = bid / tiles;
   const int t = bid - s * tiles;
   int mt, nt;
-  if (a.xcd_map) {                       // workgroups b, b+8, ... run on one XCD: give them the m-tiles of ONE n-tile (weights hit in L2)
-    const int x = t & 7, j = t >> 3;
-    mt = j % MT;
-    nt = (j / MT) * 8 + x;
-  } else {
-    nt = t % a.n_tiles;
-    mt = t / a.n_tiles;
-  }
+  fconv_tile_of(a, t, MT, mt, nt);
   const int b = mt / a.mt_per_img;
   const int row0 = (mt - b * a.mt_per_img) * a.TR;
   const int h = a.k >> 1;

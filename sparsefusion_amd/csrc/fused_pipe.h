@@ -31,14 +31,7 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
   // ---- which tile (S == 1)
   const int MT = a.B * a.mt_per_img;
   int mt, nt;
-  if (a.xcd_map) {
-    const int x = bid & 7, j = bid >> 3;
-    mt = j % MT;
-    nt = (j / MT) * 8 + x;
-  } else {
-    nt = bid % a.n_tiles;
-    mt = bid / a.n_tiles;
-  }
+  fconv_tile_of(a, bid, MT, mt, nt);
   const int b = mt / a.mt_per_img;
   const int row0 = (mt - b * a.mt_per_img) * a.TR;
   const int FW = a.W + 2, FR = a.TR + 2;
@@ -117,7 +110,8 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       f32x4 y = pool[vo + e] * A + Bv;
-      const f32x4 t = y * -1.4426950408889634f;
+#if !defined(SF_STAGE_EXPERIMENT) || SF_STAGE_EXPERIMENT == 0          // 1: no SiLU, 2: no arithmetic at all (measurement builds of
+      const f32x4 t = y * -1.4426950408889634f;                         // tools/fconv_phases.py only: where does the staging time go?)
       f32x4 ex;
 #pragma unroll
       for (int j = 0; j < 4; ++j) ex[j] = sf_exp2(t[j]);
@@ -125,6 +119,9 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) ex[j] = sf_rcp(ex[j]);
       y = y * ex;
+#elif SF_STAGE_EXPERIMENT == 2
+      y = pool[vo + e];
+#endif
       bf16x4 o;
       o[0] = (__bf16)y[0]; o[1] = (__bf16)y[1]; o[2] = (__bf16)y[2]; o[3] = (__bf16)y[3];
       *reinterpret_cast<bf16x4*>(buf + (long)fpx[e] * pstr) = o;

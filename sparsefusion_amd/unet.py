@@ -26,6 +26,14 @@ PAIR_TILES = {(1, 1, 1), (1, 1, 2), (1, 2, 2), (2, 2, 2)}
 # (WM, WN, (TR + 2) * W / 8) for which k_conv_fused_pipe is instantiated (SF_FCONV_PIPE_VARIANTS)
 PIPE_TILES = {(1, 1, 4), (1, 1, 6), (1, 2, 6), (2, 1, 12), (2, 2, 12)}
 FNORM_NONE, FNORM_GN_SELF, FNORM_GN_SLOTS, FNORM_LN = range(4)      # csrc/fused_kernels.h
+# Measured (WM, WN, split-K groups) of implicit-GEMM launches where the cost model of Unet.conv_tiling picks a slower tile
+# (tools/tile_sweep.py on MI355X, whole-eval time, r03: B = 1 eval 1.3246 -> 1.3004 ms): key = (m_frags, n_frags, KS, pixshuf).
+# The up-sampling 1x1 convs (PixelShuffle epilogue, no split-K) want ONE 16-row fragment per wave: a (4, 1) tile left 128
+# workgroups pulling 256 KB of fp32 activations each.
+TILE_PICKS = {(4, 32, 128, False): (1, 2, 8),      # Downsample 16x16 -> 8x8, 256 -> 512, k 4 s 2
+              (4, 128, 32, True): (1, 1, 1),       # Upsample 8x8 -> 16x16: 1x1 conv 1024 -> 2048 + PixelShuffle
+              (16, 64, 16, True): (1, 2, 1),       # Upsample 16x16 -> 32x32: 1x1 conv 512 -> 1024 + PixelShuffle
+              (64, 1, 72, False): (1, 1, 4)}       # final 3x3 conv 256 -> 4 at 32x32
 LDS_MAX = 163840
 SKIP_SCALE = 2 ** -0.5            # scale_skip_connection (imagen_pytorch.py:1283)
 
@@ -993,6 +1001,7 @@ class Unet(nn.Module):
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches
         self._pack_cache = None
         self._plans = {}
+        self.tile_override = dict(TILE_PICKS)
 
     @staticmethod
     def _default_init(name, shape, g):
