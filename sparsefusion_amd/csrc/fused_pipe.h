@@ -11,6 +11,13 @@
 // with one workgroup barrier per chunk.  A SIMD then issues VALU for its staging wave while its matrix wave waits on
 // weights or feeds the matrix pipe: the launch costs ~max(staging, main) instead of their sum.  Statistics, affine table,
 // epilogue, slots and context logits are those of k_conv_fused.
+//
+// What bounds the chunk loop (r03, measurement builds -DSF_STAGE_EXPERIMENT=1..4 of tools/fconv_phases.py,
+// profiles/r03_stage_experiment.log): the CU's vector-memory path, 64 B / clk shared by all 8 waves.  A chunk moves 48 KB of
+// fp32 activations (3 haloed rows x 128 channels) and 72 KB of weights (36 k-steps x WN KiB) through it = 0.8 us of its 1.3-1.9 us;
+// without the SiLU arithmetic the 512-channel 32x32 layer's loop falls 7.4 -> 5.3 us, without ANY arithmetic 5.2, without the
+// weight stream 3.7, with every activation load hitting L1 (same instruction count) only 4.9.  An L2 prefetch of the weight slab
+// at kernel entry changes nothing (the loads are not waiting on HBM), nor does sharing rows instead of n-tiles per XCD.
 #pragma once
 #include "fused_kernels.h"
 
@@ -98,8 +105,13 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
     const bool first = cg < a.s1.C;
     const float* srcp = first ? a.s1.p + cg : a.s2.p + (cg - a.s1.C);
     const int srcld = first ? a.s1.C : a.s2.C;
+#if defined(SF_STAGE_EXPERIMENT) && SF_STAGE_EXPERIMENT == 4           // 4: every element re-reads ONE pixel (L1 hits: no activation traffic)
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) pool[vo + e] = *reinterpret_cast<const f32x4*>(srcp + mxo[0] * srcld);
+#else
 #pragma unroll
     for (int e = 0; e < EPT; ++e) pool[vo + e] = *reinterpret_cast<const f32x4*>(srcp + mxo[e] * srcld);
+#endif
   };
   auto consume = [&](int c, const int vo) {
     const int cg = c * CC + tcx * 4;
@@ -119,7 +131,7 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) ex[j] = sf_rcp(ex[j]);
       y = y * ex;
-#elif SF_STAGE_EXPERIMENT == 2
+#elif SF_STAGE_EXPERIMENT >= 2
       y = pool[vo + e];
 #endif
       bf16x4 o;
@@ -278,8 +290,10 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
         for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
           for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = sf_mfma16(fa[mi], __builtin_bit_cast(bf16x8, pool[i * WN + ni]), acc[mi][ni]);
+#if !defined(SF_STAGE_EXPERIMENT) || SF_STAGE_EXPERIMENT != 3        // 3: no weight stream after the first ring fill (measurement build)
 #pragma unroll
         for (int ni = 0; ni < WN; ++ni) pool[i * WN + ni] = __builtin_bit_cast(f32x4, wload(cn, i, ni));
+#endif
       }
       sf_sync();
     }
