@@ -4,7 +4,9 @@ import csv, glob, sys
 from collections import defaultdict
 trace = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'k_pack_in' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'k_init_x' in r['Kernel_Name']]          # one per eval of the sampler path
+if len(idx) < 2:
+    idx = [i for i, r in enumerate(rows) if 'k_pack_in' in r['Kernel_Name']]     # the stand-alone forward
 seg = rows[idx[-2]:idx[-1]] if len(idx) > 1 else rows[idx[-1]:]
 out = open(sys.argv[2], "w") if len(sys.argv) > 2 else sys.stdout
 t0 = int(seg[0]['Start_Timestamp'])
