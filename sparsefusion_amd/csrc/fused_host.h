@@ -36,6 +36,10 @@
   X(1, 2, 8, FNORM_GN_SLOTS, 0) \
   X(2, 2, 8, FNORM_GN_SLOTS, 0) \
   X(2, 1, 12, FNORM_GN_SLOTS, 0) \
+  X(4, 1, 12, FNORM_GN_SLOTS, 0) \
+  X(4, 2, 8, FNORM_GN_SLOTS, 0) \
+  X(4, 1, 12, FNORM_NONE, 0) \
+  X(4, 2, 8, FNORM_NONE, 0) \
   X(2, 1, 12, FNORM_NONE, 0) \
   X(1, 1, 12, FNORM_NONE, 0) \
   X(1, 2, 8, FNORM_NONE, 0) \
@@ -45,12 +49,23 @@
   X(1, 2, 8, FNORM_LN, 0)
 
 // Pipelined slot-GroupNorm 3x3 convs (k_conv_fused_pipe, op flag 32): (WM, WN, EPT = (TR + 2) * W / 8 staging elements per thread and chunk)
+// (2, *, 8), (2, *, 6) and (4, *, 16): the 32-pixel tiles of the 16x16 (TR = 2) and 8x8 (TR = 4) maps and the 64-pixel tile of the
+// 32x32 map (TR = 2) that the planner picks
+// from B = 4 on -- 32 pixels per workgroup re-read each weight byte half as often as 16 (the chunk loop is bound by the CU's
+// vector-memory path, fused_pipe.h), and there are still >= 256 workgroups.
 #define SF_FCONV_PIPE_VARIANTS(X) \
   X(1, 1, 4) \
+  X(1, 2, 4) \
   X(1, 1, 6) \
   X(1, 2, 6) \
+  X(2, 1, 6) \
+  X(2, 2, 6) \
+  X(2, 1, 8) \
+  X(2, 2, 8) \
   X(2, 1, 12) \
-  X(2, 2, 12)
+  X(2, 2, 12) \
+  X(4, 1, 16) \
+  X(4, 2, 16)
 
 // Pairs (conv1 || res_conv in one launch, k_conv_fused_pair): (WM, WN, D, NORM of the first conv, LAZY of both)
 #define SF_FCONV_PAIR_VARIANTS(X) \
@@ -59,7 +74,8 @@
   X(1, 1, 12, FNORM_GN_SELF, 2) \
   X(1, 1, 12, FNORM_GN_SLOTS, 0) \
   X(1, 2, 8, FNORM_GN_SLOTS, 0) \
-  X(2, 2, 8, FNORM_GN_SLOTS, 0)
+  X(2, 2, 8, FNORM_GN_SLOTS, 0) \
+  X(4, 2, 8, FNORM_GN_SLOTS, 0)
 
 static inline int fconv_pix_stride(int Cs) {
   const int raw = Cs * 2;
@@ -97,7 +113,7 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   if (a.C % 32 || a.s1.C % 32 || a.s1.C <= 0 || a.s2.C < 0) FC_FAIL("fconv: channel counts must be multiples of 32");
   if (a.s2.C && !a.s2.p) FC_FAIL("fconv: second source missing");
   if (a.TR < 1 || a.H % a.TR || a.TR * a.W != 16 * WM) FC_FAIL("fconv: tile of %d rows x %d != 16*WM (WM=%d)", a.TR, a.W, WM);
-  if (!((WM == 1 || WM == 2) && (WN == 1 || WN == 2))) FC_FAIL("fconv: unsupported wave tile %dx%d", WM, WN);
+  if (!((WM == 1 || WM == 2 || WM == 4) && (WN == 1 || WN == 2))) FC_FAIL("fconv: unsupported wave tile %dx%d", WM, WN);
   a.cchunks = a.C / 32;
   if (a.cchunks % a.S) FC_FAIL("fconv: %d chunks do not split into %d slices", a.cchunks, a.S);
   a.cps = a.cchunks / a.S;
@@ -159,7 +175,7 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   a.tab_off = a.red_off + 1024 * SF_FCONV_WAVES * WM * WN;
   a.misc_off = a.tab_off + 2 * Cs * 4;
   lds_bytes = a.misc_off + 640 + 2048;      // misc: 160 floats of statistics + 512 floats of reduction partials
-  if (lds_bytes > SF_LDS_MAX) FC_FAIL("fconv: tile needs %u bytes of LDS", lds_bytes);
+  if (lds_bytes > SF_LDS_MAX && !(op.flags & 32)) FC_FAIL("fconv: tile needs %u bytes of LDS", lds_bytes);   // pipe: its own (chunked) frame below
   const int MT = a.B * a.mt_per_img;
   // XCD-aware tile map (fconv_tile_of): R row groups x 8 / R channel groups.  R = 1 (every XCD owns n-tiles == x mod 8 of ALL
   // rows: each weight byte crosses the fabric once, the activation map is fetched by all 8 L2s) is the measured best on every

@@ -22,9 +22,9 @@ from . import _lib
 OP_CONV, OP_GN_ACT, OP_LN, OP_GEMV, OP_ATTN, OP_GCA_POOL, OP_ELTWISE, OP_MEMSET, OP_TIME_EMB, OP_SPLITK_REDUCE = range(1, 11)
 OP_FCONV, OP_SLOTS, OP_GCA, OP_INITX, OP_GN_FINALIZE = 14, 15, 16, 17, 18
 # (WM, WN, norm of conv1) for which k_conv_fused_pair is instantiated (csrc/fused_host.h SF_FCONV_PAIR_VARIANTS); FNORM_GN_SELF = 1, _SLOTS = 2
-PAIR_TILES = {(1, 1, 1), (1, 1, 2), (1, 2, 2), (2, 2, 2)}
+PAIR_TILES = {(1, 1, 1), (1, 1, 2), (1, 2, 2), (2, 2, 2), (4, 2, 2)}
 # (WM, WN, (TR + 2) * W / 8) for which k_conv_fused_pipe is instantiated (SF_FCONV_PIPE_VARIANTS)
-PIPE_TILES = {(1, 1, 4), (1, 1, 6), (1, 2, 6), (2, 1, 12), (2, 2, 12)}
+PIPE_TILES = {(1, 1, 4), (1, 2, 4), (1, 1, 6), (1, 2, 6), (2, 1, 6), (2, 2, 6), (2, 1, 8), (2, 2, 8), (2, 1, 12), (2, 2, 12), (4, 1, 16), (4, 2, 16)}
 FNORM_NONE, FNORM_GN_SELF, FNORM_GN_SLOTS, FNORM_LN = range(4)      # csrc/fused_kernels.h
 # Measured (WM, WN, split-K groups) of implicit-GEMM launches where the cost model of Unet.conv_tiling picks a slower tile
 # (tools/tile_sweep.py on MI355X, whole-eval time, r03: B = 1 eval 1.3246 -> 1.3004 ms): key = (m_frags, n_frags, KS, pixshuf).
@@ -407,11 +407,28 @@ class _Plan:
         if not getattr(self.u, "fused", False) or H not in (4, 8, 16, 32) or C % 32 or Cout % 16:
             return None
         TR, WM = {4: (4, 1), 8: (2, 1), 16: (1, 1), 32: (1, 2)}[H]
+        if B >= getattr(self.u, "big_tile_min_batch", 2) and H in (8, 16, 32):
+            # twice the pixels per workgroup (32 at 8x8 / 16x16, 64 at 32x32) once the batch fills the chip: half the weight
+            # re-reads per pixel, a smaller halo share.  conv1 || res_conv of a
+            # ResnetBlock share a launch and must agree on the tile: the 1x1 half decides as its 3x3 partner (same C) does.
+            fit3 = self._fused_geometry(H, C, Cout, norm if k == 3 else FNORM_GN_SLOTS, 3, 2 * TR, 2 * WM)
+            g = self._fused_geometry(H, C, Cout, norm, k, 2 * TR, 2 * WM)
+            if fit3 is not None and g is not None:
+                return g
+        return self._fused_geometry(H, C, Cout, norm, k, TR, WM)
+
+    def _fused_geometry(self, H, C, Cout, norm, k, TR, WM):
+        B = self.B
         n_frags = Cout // 16
         MT = B * (H // TR)
         h = k // 2
 
+        pipe_ok = (getattr(self.u, "fconv_pipe", False) and norm == FNORM_GN_SLOTS and k == 3 and C % 128 == 0
+                   and ((TR + 2) * H) % 8 == 0)
+
         def lds_bytes(S_, WN_):
+            if pipe_ok and S_ == 1 and (WM, WN_, (TR + 2) * H // 8) in PIPE_TILES:      # k_conv_fused_pipe: two 128-channel frames
+                return 2 * (((TR + 2) * (H + 2) + 1) * 288 + 15) // 16 * 16 + 4096 * WM * WN_ + 2 * C * 4 + 2688
             Cs = C // S_
             stride = Cs * 2 + ((32 - (Cs * 2) % 256) + 256) % 256
             return ((TR + 2 * h) * (H + 2 * h) + 1) * stride + 8192 * WM * WN_ + 2 * Cs * 4 + 2688
@@ -997,6 +1014,7 @@ class Unet(nn.Module):
         self.fused = os.environ.get("SF_UNET_FUSED", "1") != "0"
         self.pair_res_conv = os.environ.get("SF_PAIR", "1") != "0"      # conv1 || res_conv of a ResnetBlock in one launch
         self.initx_direct = os.environ.get("SF_INITX", "1") != "0"      # latent half of the init conv as one direct-convolution launch
+        self.big_tile_min_batch = int(os.environ.get("SF_BIG_TILE_B", "2"))   # batch from which the 8x8 / 16x16 / 32x32 maps use 32- / 32- / 64-pixel tiles (r03: B = 2 eval 1.70 -> 1.50 ms, B = 4 2.62 -> 2.02, B = 32 16.4 -> 11.5; at B = 1 they would leave half the CUs idle; 999 = never)
         self.fconv_pipe = os.environ.get("SF_PIPE", "1") != "0"         # slot-GroupNorm 3x3 convs on k_conv_fused_pipe (staging || matrix work)
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches
         self._pack_cache = None

@@ -270,6 +270,15 @@ CONV_CASES = {
     "pipe_gn_slots_16x16_wn2": dict(B=1, H=16, W=16, C1=256, C2=128, Cout=64, k=3, norm=GN_SLOTS, WM=1, WN=2, seed=32, pipe=True, logits=True),
     "pipe_gn_slots_wm2_wn2_accum": dict(B=2, H=4, W=32, C1=128, C2=0, Cout=64, k=3, norm=GN_SLOTS, WM=2, WN=2, accum=True, seed=33, pipe=True),
     "pipe_pair_gn_slots_concat_8x8": dict(B=1, H=8, W=8, C1=128, C2=128, Cout=32, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=38, pipe=True, pair=True),
+    # 32-pixel tiles of the 16x16 / 8x8 maps (the B >= 4 geometry): two row pairs / four rows per workgroup
+    "pipe_gn_slots_16x16_tr2_wn2": dict(B=2, H=16, W=16, C1=256, C2=128, Cout=64, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=42, pipe=True, logits=True),
+    "pipe_gn_slots_wide_rows_wm4_wn2": dict(B=2, H=4, W=32, C1=128, C2=128, Cout=64, k=3, norm=GN_SLOTS, WM=4, WN=2, seed=47, pipe=True, logits=True),
+    "pipe_pair_gn_slots_wide_rows_wm4": dict(B=1, H=4, W=32, C1=128, C2=0, Cout=64, k=3, norm=GN_SLOTS, WM=4, WN=2, seed=48, pipe=True, pair=True),
+    "gn_slots_wide_rows_wm4_wn1": dict(B=1, H=4, W=32, C1=128, C2=0, Cout=48, k=3, norm=GN_SLOTS, WM=4, WN=1, seed=49),
+    "pipe_gn_slots_8x8_wn2": dict(B=2, H=8, W=8, C1=128, C2=128, Cout=64, k=3, norm=GN_SLOTS, WM=1, WN=2, seed=46, pipe=True),
+    "pipe_gn_slots_8x8_tr4_resid": dict(B=2, H=8, W=8, C1=128, C2=128, Cout=48, k=3, norm=GN_SLOTS, WM=2, WN=1, resid=True, seed=43, pipe=True),
+    "pipe_pair_gn_slots_16x16_tr2": dict(B=2, H=16, W=16, C1=128, C2=128, Cout=64, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=44, pipe=True, pair=True),
+    "raw_1x1_res_conv_8x8_tr4": dict(B=2, H=8, W=8, C1=64, C2=64, Cout=32, k=1, norm=NONE, WM=2, WN=2, silu=False, slots=False, seed=45),
     "layernorm_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=1, silu=False, seed=6, out_gelu=True),
     "layernorm_lazy_splitk_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=1, silu=False, lazy=1, seed=7),
     "gelu_layernorm_bias_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=2, silu=False, pre_gelu=True,
@@ -293,5 +302,11 @@ CONV_CASES_FULL = {
     "unet_pipe_32x32_512": dict(B=1, H=32, W=32, C1=256, C2=256, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=36, pipe=True),
     "unet_pipe_32x32_256": dict(B=1, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=37, pipe=True, logits=True),
     "unet_pipe_pair_16x16_768": dict(B=1, H=16, W=16, C1=512, C2=256, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=2, seed=39, pipe=True, pair=True),
+    # B = 4 geometry (r03): 32-pixel tiles at 8x8 / 16x16, 64-pixel tiles at 32x32; the 1536-channel frame only fits the chunked
+    # (pipelined) kernel
+    "unet_b4_pipe_pair_8x8_1536": dict(B=4, H=8, W=8, C1=1024, C2=512, Cout=1024, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=50, pipe=True, pair=True),
+    "unet_b4_pipe_16x16_768": dict(B=4, H=16, W=16, C1=512, C2=256, Cout=512, k=3, norm=GN_SLOTS, WM=2, WN=2, resid=True, seed=51, pipe=True),
+    "unet_b4_pipe_32x32_512": dict(B=4, H=32, W=32, C1=256, C2=256, Cout=256, k=3, norm=GN_SLOTS, WM=4, WN=2, seed=52, pipe=True, logits=True),
+    "unet_b4_pipe_pair_32x32_512": dict(B=4, H=32, W=32, C1=256, C2=256, Cout=256, k=3, norm=GN_SLOTS, WM=4, WN=2, seed=53, pipe=True, pair=True),
     "unet_b4_4x4": dict(B=4, H=4, W=4, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SELF, WM=1, WN=1, S=1, seed=16),
 }

@@ -70,7 +70,7 @@ def _audit(ops, name, sized=False):
             if second_of_pair:
                 assert norm == unet.FNORM_NONE and list(o.p)[1:4] == list(ops[kk - 1].p)[1:4], where + ": pair halves read the same source"
             assert C % 32 == 0 and C1 % 32 == 0 and k in (1, 3) and TR * W == 16 * WM and H % TR == 0, where
-            assert (C // 32) % S == 0 and WM in (1, 2) and WN in (1, 2), where
+            assert (C // 32) % S == 0 and WM in (1, 2, 4) and WN in (1, 2), where
             if S > 1:
                 assert (o.p[11] or not sized) and not (o.flags & 4) and not o.p[12], where + ": sliced convs write slabs only"
             if norm in (unet.FNORM_GN_SELF, unet.FNORM_GN_SLOTS):
