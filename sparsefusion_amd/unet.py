@@ -886,8 +886,11 @@ class _Plan:
                 H //= 2
             else:
                 y = self.zf32(B * H * H, do, H * H)
-                self.conv(x, True, H, H, f"downs.{lv}.4.fns.0.weight", f"downs.{lv}.4.fns.0.bias", y, do, 0, do, 3, 1, 1)
-                self.conv(x, True, H, H, f"downs.{lv}.4.fns.1.weight", f"downs.{lv}.4.fns.1.bias", y, do, 0, do, 1)
+                # Parallel(conv3x3, conv1x1) of the last level (imagen_pytorch.py:1294-1297: the two outputs are summed) = ONE 3x3
+                # conv whose centre tap carries the 1x1 weights too (merged at pack time, Unet._packed): one launch and one
+                # 18.9 MB weight stream instead of two launches + a split-K reduction; its partials stay lazy for mid_block1
+                self.conv(x, True, H, H, f"downs.{lv}.4.__merged__.weight", f"downs.{lv}.4.__merged__.bias", y, do, 0, do, 3, 1, 1,
+                          defer=bool(u.fused))
             x = y
         mid = x.C
         x = self.resnet("mid_block1", x, None, mid, H, cross=True)
@@ -1150,6 +1153,15 @@ class Unet(nn.Module):
                 buf = torch.empty(lib.sf_conv_packed_elems(co, ci, 1, 1), dtype=torch.int16)
                 _lib.check(lib.sf_conv_pack_weights(w4.data_ptr(), co, ci, ci, 1, 1, buf.data_ptr()), "pack qkv " + name)
                 packed[name + ".__qkv__"] = buf.to(device)
+        for name in [k[:-len(".fns.0.weight")] for k in sd if k.endswith(".fns.0.weight")]:      # Parallel(3x3, 1x1) -> one 3x3 conv
+            w3, w1 = sd[name + ".fns.0.weight"].float().cpu().clone(), sd[name + ".fns.1.weight"].float().cpu()
+            w3[:, :, 1, 1] += w1[:, :, 0, 0]
+            co, ci, kh, kw = w3.shape
+            cpad = (ci + 31) // 32 * 32
+            buf = torch.empty(lib.sf_conv_packed_elems(co, cpad, kh, kw), dtype=torch.int16)
+            _lib.check(lib.sf_conv_pack_weights(w3.contiguous().data_ptr(), co, ci, cpad, kh, kw, buf.data_ptr()), "pack merged " + name)
+            packed[name + ".__merged__.weight"] = buf.to(device)
+            packed[name + ".__merged__.bias"] = (sd[name + ".fns.0.bias"].float().cpu() + sd[name + ".fns.1.bias"].float().cpu()).to(device)
         for i in range(3):                                      # latent-channel slices of the init conv (sampler path)
             w4 = sd[f"init_conv.convs.{i}.weight"].float().cpu()[:, self.cond_images_channels:].contiguous()
             co, ci, kh, kw = w4.shape

@@ -184,6 +184,8 @@ def test_k_distillation_steps_match_the_oracle(size):
     d_psnr = abs(psnr(in_gpu, sc.target_rgb) - psnr(in_ref, sc.target_rgb))
     print(f"after {K_STEPS} steps: PSNR(gpu, oracle) novel {between_nv:.1f} dB / input {between_in:.1f} dB; "
           f"|dPSNR vs target| {d_psnr:.4f} dB; PSNR(initial, trained) {moved:.1f} dB")
-    assert moved < 40.0, "the optimisation did not move the field: vacuous comparison"
+    # not vacuous: the K steps changed the render by far more than the two paths differ (2 steps at the benchmark's size move
+    # it less than 10 steps at the small one: 46.7 dB vs the 113 dB agreement measured in r03)
+    assert moved < (40.0 if size == "small" else 60.0) and between_nv - moved >= 30.0, "the optimisation did not move the field: vacuous comparison"
     assert between_nv >= 40.0 and between_in >= 40.0
     assert d_psnr <= 0.1
