@@ -130,11 +130,12 @@ struct GcaNetArgs {
   int B, C, Kp, HID, chunks;
 };
 
-// grid = B * ceil(HID / 16); 4 waves x 4 rows each
-SF_KERNEL(256) void k_gca_net0(GcaNetArgs a) {
-  sf_touch_kernarg<(int)sizeof(GcaNetArgs)>();
-  SF_SHARED float pooled[2048];
-  SF_SHARED float wgt[8];
+// grid = B * ceil(HID / 16); 4 waves x 4 rows each.  NCK = chunk capacity of the instantiation (8 | 16 | 32 | 64): every phase
+// issues its loads as ONE batch -- all NCK pooled partials of a channel in flight together (a loop of 8-chunk trips would be up
+// to 8 dependent round trips), those of the thread's first channel ahead of the merge weights they do not depend on.  More than 8
+// chunks = the 16-pixel fragments the producing conv's epilogue pools (fused_pipe.h, POOL).
+template <int NCK>
+SF_DEV void gca_net0_body(const GcaNetArgs& a, float* pooled, float* wgt) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int rb = (a.HID + 15) / 16;
   const int b = blockIdx.x / rb, r0 = (blockIdx.x - b * rb) * 16;
@@ -149,28 +150,27 @@ SF_KERNEL(256) void k_gca_net0(GcaNetArgs a) {
       w[rr][it] = (r < a.HID && k < a.C) ? *reinterpret_cast<const bf16x8*>(a.W0 + (long)r * a.Kp + k) : sf_zero8();
     }
   }
-  // the pooled partials of this thread's first channel: independent of the merge weights, so in flight with them
-  float pj0[8];
+  const float* pp = a.part_pool + (long)b * a.chunks * a.C;
+  float pj0[NCK];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) pj0[j] = a.part_pool[((long)b * a.chunks + (j < a.chunks ? j : a.chunks - 1)) * a.C + (tid < a.C ? tid : 0)];
-  if (wave == 0) {                                        // online-softmax merge weights of the chunks (lanes = chunks)
+  for (int j = 0; j < NCK; ++j) pj0[j] = pp[(long)(j < a.chunks ? j : a.chunks - 1) * a.C + (tid < a.C ? tid : 0)];
+  if (wave == 0) {                                        // online-softmax merge weights of the chunks (lanes = chunks, <= 64)
     const bool on = lane < a.chunks;
     const float mj = on ? a.part_ms[((long)b * a.chunks + lane) * 2] : -INFINITY;
     const float sj = on ? a.part_ms[((long)b * a.chunks + lane) * 2 + 1] : 0.0f;
     const float M = sf_wave_max(mj);
     const float wj = on ? sf_exp(mj - M) : 0.0f;
     const float Z = sf_wave_sum(wj * sj);
-    if (on) wgt[lane] = wj / Z;
+    wgt[lane] = on ? wj / Z : 0.0f;                       // 0 beyond the last chunk
   }
   sf_sync();
   for (int c = tid; c < a.C; c += 256) {
-    float pj[8];
+    float pj[NCK];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) pj[j] = c == tid ? pj0[j] : a.part_pool[((long)b * a.chunks + (j < a.chunks ? j : a.chunks - 1)) * a.C + c];
+    for (int j = 0; j < NCK; ++j) pj[j] = c == tid ? pj0[j] : pp[(long)(j < a.chunks ? j : a.chunks - 1) * a.C + c];
     float s = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (j < a.chunks) s = fmaf(wgt[j], pj[j], s);
+    for (int j = 0; j < NCK; ++j) s = fmaf(wgt[j], pj[j], s);
     pooled[c] = s;
   }
   sf_sync();
@@ -189,6 +189,14 @@ SF_KERNEL(256) void k_gca_net0(GcaNetArgs a) {
     acc = sf_wave_sum(acc);
     if (lane == 0 && r < a.HID) a.hid[(long)b * a.HID + r] = sf_silu(acc + a.b0[r]);
   }
+}
+
+template <int NCK>
+SF_KERNEL(256) void k_gca_net0(GcaNetArgs a) {
+  sf_touch_kernarg<(int)sizeof(GcaNetArgs)>();
+  SF_SHARED float pooled[2048];
+  SF_SHARED float wgt[64];
+  gca_net0_body<NCK>(a, pooled, wgt);
 }
 
 struct GcaGateArgs {

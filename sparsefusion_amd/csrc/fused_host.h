@@ -93,6 +93,12 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   a.ws = (float*)op.p[11]; a.slots_out = (float*)op.p[12];
   a.dbg = (long long*)op.p[16];
   a.wk = (const float*)op.p[17]; a.logit_part = (float*)op.p[18];
+  a.weff = nullptr; a.pool_part = nullptr; a.weff_off = 0;
+  if (op.flags & 64) {                 // epilogue pooling (k_conv_fused_pipe<.., POOL>): p 17 = w_eff bf16 [KS * 32], p 18 = pooled fragments
+    a.weff = (const __bf16*)op.p[17]; a.pool_part = (float*)op.p[18];
+    a.wk = nullptr; a.logit_part = nullptr;
+    if (!(op.flags & 32) || !a.weff || !a.pool_part) FC_FAIL("fconv: epilogue pooling needs the pipelined kernel, w_eff and a pooled-fragment buffer");
+  }
   if ((a.wk == nullptr) != (a.logit_part == nullptr)) FC_FAIL("fconv: context logits need both to_k weight and the partial buffer");
   a.gamma = (const float*)op.p[13]; a.beta = (const float*)op.p[14]; a.ss = (const float*)op.p[15];
   a.B = op.i[0]; a.H = op.i[1]; a.W = op.i[2];
@@ -199,9 +205,14 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
     a.pix_stride = fconv_pix_stride(128);
     a.buf_bytes = (int)((((uint32_t)(a.TR + 2) * (a.W + 2) + 1) * a.pix_stride + 15) & ~15u);
     a.red_off = 2 * a.buf_bytes;
-    a.tab_off = a.red_off + 1024 * (SF_FCONV_WAVES / 2) * WM * WN;
+    a.tab_off = a.red_off + 1024 * (SF_FCONV_WAVES / 2) * (WM * WN + (a.weff ? WM : 0));
     a.misc_off = a.tab_off + 2 * a.C * 4;
     lds_bytes = a.misc_off + 640 + 2048;
+    if (a.weff) {
+      if (a.accum || a.resid || a.out_gelu || a.co_off || a.ldc != a.Cout) FC_FAIL("fconv: epilogue pooling wants a plain conv output");
+      a.weff_off = (int)lds_bytes;
+      lds_bytes += (uint32_t)a.KS * 64;
+    }
     if (lds_bytes > SF_LDS_MAX) FC_FAIL("fconv pipe: tile needs %u bytes of LDS", lds_bytes);
   }
   return 0;
@@ -251,7 +262,7 @@ static inline int gca_setup(const sf_op& op, GcaPoolArgs& pa, GcaNetArgs& na, Gc
     na.b0 = (const float*)op.p[3]; na.hid = (float*)op.p[4];
     na.B = op.i[0]; na.C = op.i[1]; na.Kp = op.i[2]; na.HID = op.i[3]; na.chunks = op.i[4];
     if (!na.part_pool || !na.part_ms || !na.W0 || !na.b0 || !na.hid) GC_FAIL("gca net0: missing operand");
-    if (na.C > 2048 || na.C % 8 || na.Kp < na.C || na.chunks < 1 || na.chunks > 8) GC_FAIL("gca net0: C <= 2048, 1..8 chunks");
+    if (na.C > 2048 || na.C % 8 || na.Kp < na.C || na.chunks < 1 || na.chunks > 64) GC_FAIL("gca net0: C <= 2048, 1..64 chunks");
     grid = (uint32_t)na.B * ((na.HID + 15) / 16);
     return 0;
   }

@@ -75,6 +75,12 @@ struct FConvArgs {
   const float* wk;                   // GlobalContext to_k weight [Cout] or null: the epilogue also emits partial context logits
   float* logit_part;                 //   logit_part[(s * n_frags + n_frag) * M + m] = sum over the fragment's 16 channels of value * wk
   long long* dbg;                    // optional [grid][8] phase timestamps (tools/fconv_phases.py), null in production
+  // k_conv_fused_pipe<.., POOL = true> (r03): the GlobalContext softmax pooling of this conv's OUTPUT in its own epilogue.
+  const __bf16* weff;                // [KS * 32] = (tap, channel) in k-step order: w_eff = sum_n wk[n] * W[n][channel][tap] -- the
+                                     // context logit of a pixel is a 1-output-channel conv of the SAME staged input (bias terms cancel)
+  float* pool_part;                  // [M / 16][Cout] un-normalised pooled fragments sum_p exp(l_p - max_frag) * out[p, n];
+                                     // directly behind it [M / 16][2] = (max_frag, sum_p exp(l_p - max_frag)): one chunk = 16 pixels
+  int weff_off;                      // LDS byte offset of the w_eff table
 };
 
 template <int MODE>

@@ -21,7 +21,7 @@
 #pragma once
 #include "fused_kernels.h"
 
-template <int WM, int WN, int EPT, int NW>
+template <int WM, int WN, int EPT, int NW, bool POOL = false>
 SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
   constexpr int NT = NW * 64, NWM = NW / 2;             // NWM matrix waves, NT - 64 * NWM staging threads
   constexpr int CC = 128;                               // input channels per pipeline chunk (4 k-steps per tap)
@@ -269,6 +269,9 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
   for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
     for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 accl[POOL ? WM : 1];                            // POOL: context-logit fragment of every m-fragment (column 0 = the logit)
+#pragma unroll
+  for (int mi = 0; mi < (POOL ? WM : 1); ++mi) accl[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (mx_role) {
     int abase[WM];
 #pragma unroll
@@ -276,6 +279,14 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
       const int p = mi * 16 + (lane & 15);
       const int ty = p >> a.logW, tx = p - (ty << a.logW);
       abase[mi] = (ty * FW + tx) * pstr + (lane >> 4) * 16;
+    }
+    // POOL: B fragment of step i = w_eff[k-step][8 * (lane >> 4) .. + 7] in column 0 (lanes with lane & 15 == 0), zero elsewhere
+    const char* weffL = lds + a.weff_off + (lane >> 4) * 16;
+    const bool col0 = (lane & 15) == 0;
+    if (POOL) {                                          // the w_eff table (KS x 32 bf16) into LDS, by the matrix waves while they
+      const bf16x8* src = reinterpret_cast<const bf16x8*>(a.weff);      // wait for chunk 0 anyway; visible behind the phase-0 barrier
+      bf16x8* dst = reinterpret_cast<bf16x8*>(lds + a.weff_off);
+      for (int i = tid; i < a.KS * 4; i += NWM * 64) dst[i] = src[i];
     }
     sf_sync();                                           // phase 0: chunk 0 is being staged
     for (int c = 0; c < NCH; ++c) {
@@ -294,6 +305,12 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
 #pragma unroll
         for (int ni = 0; ni < WN; ++ni) pool[i * WN + ni] = __builtin_bit_cast(f32x4, wload(cn, i, ni));
 #endif
+        if (POOL) {                                        // one more MFMA per m-fragment, BEHIND the ring refill (the weight stream
+          bf16x8 wl = *reinterpret_cast<const bf16x8*>(weffL + (woff[i] + c * (CC / 32) * 64));   // is what this loop waits on);
+          if (!col0) wl = sf_zero8();                                                               // woff = k-step * 64 bytes as well
+#pragma unroll
+          for (int mi = 0; mi < WM; ++mi) accl[mi] = sf_mfma16(fa[mi], wl, accl[mi]);
+        }
       }
       sf_sync();
     }
@@ -317,6 +334,7 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
   FP_STAMP(4);
 
   // ---- epilogue: the NWM K-slices meet in LDS; wave f < F finalises fragment f
+  constexpr int FT = POOL ? F + WM : F;                           // POOL: + one context-logit fragment per m-fragment
   float* red = reinterpret_cast<float*>(lds + a.red_off);         // [matrix wave][frag][r][lane]
   if (mx_role) {
 #pragma unroll
@@ -324,7 +342,13 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
 #pragma unroll
       for (int ni = 0; ni < WN; ++ni)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[((wave * F + mi * WN + ni) * 4 + r) * 64 + lane] = acc[mi][ni][r];
+        for (int r = 0; r < 4; ++r) red[((wave * FT + mi * WN + ni) * 4 + r) * 64 + lane] = acc[mi][ni][r];
+    if (POOL) {
+#pragma unroll
+      for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * FT + F + mi) * 4 + r) * 64 + lane] = accl[mi][r];
+    }
   }
   sf_sync();
   if (fin) {
@@ -335,7 +359,7 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
       const int idx = (f * 4 + r) * 64 + lane;
       float sacc = 0.0f;
 #pragma unroll
-      for (int w = 0; w < NWM; ++w) sacc += red[idx + w * F * 256];
+      for (int w = 0; w < NWM; ++w) sacc += red[idx + w * FT * 256];
       v[r] = sacc;
     }
     if (a.logit_part) {
@@ -347,12 +371,14 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
       }
     }
     float sm = 0.0f, sq = 0.0f;
+    float y4[4] = {0.f, 0.f, 0.f, 0.f};
     if (n < a.Cout) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float y = v[r] + bv + rv[r];
         if (a.out_gelu) y = sf_gelu(y);
         a.out[(mrow + r) * a.ldc + a.co_off + n] = y;
+        y4[r] = y;
         sm += y;
         sq = fmaf(y, y, sq);
       }
@@ -366,15 +392,48 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
         slo[1] = sq;
       }
     }
+    if (POOL) {
+      // GlobalContext pooling of this fragment (imagen_pytorch.py:916-941): its 16 pixels are one softmax chunk.  The logit
+      // fragment's column 0 sits in lanes 0 / 16 / 32 / 48 (rows 4 g .. 4 g + 3): every lane fetches the logits of ITS rows
+      // from lane (lane & 48); max and sums over the 16 pixels = over r and the four 16-lane groups.
+      float l[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = ((F + my_mi) * 4 + r) * 64 + lane;
+        float sacc = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NWM; ++w) sacc += red[idx + w * FT * 256];
+        l[r] = sf_shfl(sacc, lane & 48);
+      }
+      float mx = fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3]));
+      mx = fmaxf(mx, sf_shfl_xor(mx, 16));
+      mx = fmaxf(mx, sf_shfl_xor(mx, 32));
+      float es = 0.0f, pv = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = sf_exp(l[r] - mx);
+        es += e;
+        pv = fmaf(e, y4[r], pv);
+      }
+      es += sf_shfl_xor(es, 16); es += sf_shfl_xor(es, 32);
+      pv += sf_shfl_xor(pv, 16); pv += sf_shfl_xor(pv, 32);
+      const long mfrag = (m0 >> 4) + my_mi;
+      if (lane < 16 && n < a.Cout) a.pool_part[mfrag * a.Cout + n] = pv;
+      if (lane == 0 && my_nf == 0) {
+        float* ms = a.pool_part + (long)(a.M >> 4) * a.Cout + mfrag * 2;
+        ms[0] = mx;
+        ms[1] = es;
+      }
+    }
   }
   FP_STAMP(5);
 #undef FP_STAMP
 }
 
-template <int WM, int WN, int EPT, int NW>
+template <int WM, int WN, int EPT, int NW, bool POOL = false>
 SF_KERNEL(NW * 64) void k_conv_fused_pipe(FConvArgs a) {
   sf_touch_kernarg<(int)sizeof(FConvArgs)>();
-  conv_fused_pipe_body<WM, WN, EPT, NW>(a, (int)blockIdx.x);
+  conv_fused_pipe_body<WM, WN, EPT, NW, POOL>(a, (int)blockIdx.x);
 }
 
 // conv1 (pipelined) || res_conv (plain 1x1, k_conv_fused body) of one ResnetBlock in one launch: see k_conv_fused_pair.

@@ -25,11 +25,11 @@ static int launch_fconv(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStre
   return SF_OK;
 }
 
-template <int WM, int WN, int EPT>
+template <int WM, int WN, int EPT, bool POOL>
 static int launch_fconv_pipe(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStream_t st) {
   static unsigned mask = 0;
-  if (int rc = allow_big_lds(k_conv_fused_pipe<WM, WN, EPT, SF_FCONV_WAVES>, lds, mask)) return rc;
-  k_conv_fused_pipe<WM, WN, EPT, SF_FCONV_WAVES><<<grid, SF_FCONV_WAVES * 64, lds, st>>>(a);
+  if (int rc = allow_big_lds(k_conv_fused_pipe<WM, WN, EPT, SF_FCONV_WAVES, POOL>, lds, mask)) return rc;
+  k_conv_fused_pipe<WM, WN, EPT, SF_FCONV_WAVES, POOL><<<grid, SF_FCONV_WAVES * 64, lds, st>>>(a);
   SF_CHECK_LAUNCH("conv_fused_pipe");
   return SF_OK;
 }
@@ -41,7 +41,7 @@ static int run_fconv(const sf_op& op, hipStream_t st) {
   if (fconv_setup(op, a, WM, WN, grid, lds, sf_err_buf, sizeof(sf_err_buf))) return SF_ERR_INVALID;
   if (op.flags & 32) {
     const int EPT = fconv_pipe_ept(a);
-#define SF_TRYP(wm, wn, ept) if (WM == wm && WN == wn && EPT == ept) return launch_fconv_pipe<wm, wn, ept>(a, grid, lds, st);
+#define SF_TRYP(wm, wn, ept) if (WM == wm && WN == wn && EPT == ept) return a.weff ? launch_fconv_pipe<wm, wn, ept, true>(a, grid, lds, st) : launch_fconv_pipe<wm, wn, ept, false>(a, grid, lds, st);
     SF_FCONV_PIPE_VARIANTS(SF_TRYP)
 #undef SF_TRYP
     SF_FAIL(SF_ERR_INVALID, "fconv pipe: no kernel variant for tile %dx%d, %d staging elements", WM, WN, EPT);
@@ -110,7 +110,12 @@ static int run_gca(const sf_op& op, hipStream_t st) {
   uint32_t grid;
   if (gca_setup(op, pa, na, ga, grid, sf_err_buf, sizeof(sf_err_buf))) return SF_ERR_INVALID;
   if (op.flags == 1) k_gca_pool<<<grid, 256, 0, st>>>(pa);
-  else if (op.flags == 2) k_gca_net0<<<grid, 256, 0, st>>>(na);
+  else if (op.flags == 2) {
+    if (na.chunks <= 8) k_gca_net0<8><<<grid, 256, 0, st>>>(na);
+    else if (na.chunks <= 16) k_gca_net0<16><<<grid, 256, 0, st>>>(na);
+    else if (na.chunks <= 32) k_gca_net0<32><<<grid, 256, 0, st>>>(na);
+    else k_gca_net0<64><<<grid, 256, 0, st>>>(na);
+  }
   else k_gca_gate<<<grid, 256, 0, st>>>(ga);
   SF_CHECK_LAUNCH("gca");
   return SF_OK;

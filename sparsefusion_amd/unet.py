@@ -475,7 +475,7 @@ class _Plan:
 
     def fconv(self, x, skip, H, wname, bname, out, Cout, k, norm, geom, gname=None, ss_ptr=0, silu=True, resid=None,
               want_slots=False, pre_gelu=False, beta_name=None, ldc=None, co_off=0, logit=None, out_gelu=False,
-              pair_first=False, pair_lazy=None):
+              pair_first=False, pair_lazy=None, pool=None):
         """One k_conv_fused launch: out = conv_k(act(norm(concat(x, skip * 2^-1/2)))).  With S > 1 input-channel slices the
         output stays a lazy split-K tensor (slabs + bias + resid) that the next fused conv / GroupNorm / gca pass reduces."""
         TR, WM, WN, S = geom
@@ -518,11 +518,12 @@ class _Plan:
         bet = self.wptr(gname + ".bias") if norm in (FNORM_GN_SELF, FNORM_GN_SLOTS) else (self.wptr(beta_name) if beta_name else 0)
         assert not (out_gelu and S > 1)
         # staging and matrix work overlapped inside the workgroup (k_conv_fused_pipe) where the layer fits that kernel
-        pipe = (getattr(self.u, "fconv_pipe", False) and norm == FNORM_GN_SLOTS and k == 3 and S == 1 and li[0] == 0 and silu
-                and (C1 + C2) % 128 == 0 and C1 % 4 == 0 and ((TR + 2) * H) % 8 == 0 and (WM, WN, (TR + 2) * H // 8) in PIPE_TILES
-                and pair_lazy is None)
+        pipe = self.pipe_ok(C1, C2, H, geom, norm, k, silu) and li[0] == 0 and pair_lazy is None
+        if pool is not None:                                    # GlobalContext pooling in the epilogue: (w_eff ptr, pooled-fragment buffer)
+            assert pipe and logit is None and not accum and resid is None and ldc == Cout and co_off == 0
+            logit = pool
         self.op(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0) | (8 if out_gelu else 0) | (16 if pair_first else 0)
-                | (32 if pipe else 0),
+                | (32 if pipe else 0) | (64 if pool is not None else 0),
                 p=(x_ptr, lp[0], lp[1], lp[2], x.slots or 0, skip.ptr if skip else 0, (skip.slots or 0) if skip else 0,
                    self.wptr(wname), 0 if S > 1 else bias, out.ptr, 0 if S > 1 else res, ws, slots_out, gam, bet, ss_ptr, 0,
                    logit[0] if logit else 0, logit[1] if logit else 0),
@@ -533,6 +534,12 @@ class _Plan:
             self.ws_owners[wi] = out
             out.slots = None
         return lp, li
+
+    def pipe_ok(self, C1, C2, H, geom, norm, k, silu=True):
+        """A slot-GroupNorm 3x3 conv with a plain source runs on k_conv_fused_pipe (staging || matrix work) when its tile exists."""
+        TR, WM, WN, S = geom
+        return bool(getattr(self.u, "fconv_pipe", False) and norm == FNORM_GN_SLOTS and k == 3 and S == 1 and silu
+                    and (C1 + C2) % 128 == 0 and C1 % 4 == 0 and ((TR + 2) * H) % 8 == 0 and (WM, WN, (TR + 2) * H // 8) in PIPE_TILES)
 
     def resnet_fused(self, name, x, skip, cout, H, gca=False, cross=False):
         """ResnetBlock (imagen_pytorch.py:665-729) with both GroupNorms inside their convs: 2 launches (+ res_conv, + gca)
@@ -568,6 +575,14 @@ class _Plan:
             self.fconv(h, None, H, w2, b2, out, cout, 3, norm, g2, gname=gn2, ss_ptr=ss_ptr, resid=res, want_slots=slots)
             return out
         h2 = self.zf32(rows, cout, HW)
+        if (getattr(self.u, "gca_epilogue_pool", True) and cout % 64 == 0 and cout <= 2048 and HW % 16 == 0 and HW // 16 <= 64
+                and self.pipe_ok(cout, 0, H, g2, norm, 3) and h.lazy is None and f"{name}.__weff__" in self.w):
+            # r03: the softmax pooling of the GlobalContext rides in conv2's epilogue (k_conv_fused_pipe<.., POOL>: context logits
+            # from the conv's own staged input through w_eff, one pooled fragment per 16 pixels) -> net0 -> gate: 2 launches
+            pbuf = self.f32(rows // 16, cout + 2)                 # [M/16][cout] pooled fragments, then [M/16][2] (max, sum of exp)
+            self.fconv(h, None, H, w2, b2, h2, cout, 3, norm, g2, gname=gn2, ss_ptr=ss_ptr, pool=(self.wptr(f"{name}.__weff__"), pbuf.ptr))
+            self.gca_fused(name, h2, cout, res, out, None, 0, slots, pooled=(pbuf.ptr, pbuf.ptr + rows // 16 * cout * 4, HW // 16))
+            return out
         if cout % 64 == 0 and cout <= 2048 and HW % 16 == 0:
             # fused GlobalContext: conv2's epilogue leaves partial context logits, then pool -> net0 -> gate (+ residual, + slots)
             nparts = g2[3] * (cout // 16)
@@ -581,7 +596,7 @@ class _Plan:
         out.lazy = ("gate", h2.ptr, gate.ptr, res.ptr)
         return out
 
-    def gca_fused(self, name, h2, cout, res, out, lpart, nparts, want_slots):
+    def gca_fused(self, name, h2, cout, res, out, lpart, nparts, want_slots, pooled=None):
         """GlobalContext + gated residual in three launches (csrc/fused_gca.h): out = h2 * gca(h2) + res, materialised, with
         its statistics slots when the consumer is a slot-GroupNorm conv."""
         B, HW, rows = self.B, h2.HW, h2.rows
@@ -596,8 +611,12 @@ class _Plan:
             h2.lazy = None
             self.ws_owners[wi] = None
         self.need(res)
-        self.op(OP_GCA, 1, p=(h2.ptr, ws, bias, lpart.ptr, part_pool.ptr, part_ms.ptr), i=(rows, cout, HW, CH, chunks, nparts, groups, npad))
-        self.op(OP_GCA, 2, p=(part_pool.ptr, part_ms.ptr, self.wptr(f"{name}.gca.net.0.weight"), self.wptr(f"{name}.gca.net.0.bias"),
+        if pooled is not None:                                  # the producing conv's epilogue already pooled 16-pixel fragments
+            pp, pm, chunks = pooled
+        else:
+            pp, pm = part_pool.ptr, part_ms.ptr
+            self.op(OP_GCA, 1, p=(h2.ptr, ws, bias, lpart.ptr, pp, pm), i=(rows, cout, HW, CH, chunks, nparts, groups, npad))
+        self.op(OP_GCA, 2, p=(pp, pm, self.wptr(f"{name}.gca.net.0.weight"), self.wptr(f"{name}.gca.net.0.bias"),
                               hid.ptr), i=(B, cout, (cout + 7) // 8 * 8, hidc, chunks))
         if want_slots:
             out.slots = self.misc.alloc(rows // 16 * (cout // 16) * 2 * 4)
@@ -1018,6 +1037,7 @@ class Unet(nn.Module):
         self.pair_res_conv = os.environ.get("SF_PAIR", "1") != "0"      # conv1 || res_conv of a ResnetBlock in one launch
         self.initx_direct = os.environ.get("SF_INITX", "1") != "0"      # latent half of the init conv as one direct-convolution launch
         self.big_tile_min_batch = int(os.environ.get("SF_BIG_TILE_B", "2"))   # batch from which the 8x8 / 16x16 / 32x32 maps use 32- / 32- / 64-pixel tiles (r03: B = 2 eval 1.70 -> 1.50 ms, B = 4 2.62 -> 2.02, B = 32 16.4 -> 11.5; at B = 1 they would leave half the CUs idle; 999 = never)
+        self.gca_epilogue_pool = os.environ.get("SF_GCA_EPI_POOL", "1") != "0"   # GlobalContext pooling in conv2's epilogue (0 = k_gca_pool launch, A/B)
         self.fconv_pipe = os.environ.get("SF_PIPE", "1") != "0"         # slot-GroupNorm 3x3 convs on k_conv_fused_pipe (staging || matrix work)
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches
         self._pack_cache = None
@@ -1162,6 +1182,13 @@ class Unet(nn.Module):
             _lib.check(lib.sf_conv_pack_weights(w3.contiguous().data_ptr(), co, ci, cpad, kh, kw, buf.data_ptr()), "pack merged " + name)
             packed[name + ".__merged__.weight"] = buf.to(device)
             packed[name + ".__merged__.bias"] = (sd[name + ".fns.0.bias"].float().cpu() + sd[name + ".fns.1.bias"].float().cpu()).to(device)
+        for name in [k[:-len(".gca.to_k.weight")] for k in sd if k.endswith(".gca.to_k.weight")]:
+            # w_eff[tap][channel] = sum_n wk[n] * W2[n][channel][tap]: the context logit as a 1-output-channel conv of conv2's input
+            w2c = sd.get(name + ".block2.project.weight")
+            if w2c is not None and w2c.shape[1] % 32 == 0 and tuple(w2c.shape[2:]) == (3, 3):
+                wk = sd[name + ".gca.to_k.weight"].float().cpu().reshape(-1)
+                weff = torch.einsum("n,ncyx->yxc", wk, w2c.float().cpu()).reshape(-1).to(torch.bfloat16).contiguous()
+                packed[name + ".__weff__"] = weff.to(device)
         for i in range(3):                                      # latent-channel slices of the init conv (sampler path)
             w4 = sd[f"init_conv.convs.{i}.weight"].float().cpu()[:, self.cond_images_channels:].contiguous()
             co, ci, kh, kw = w4.shape

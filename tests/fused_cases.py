@@ -53,7 +53,7 @@ def run_ops(ops, backend):
 
 def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, silu=True, ss=True, accum=False, resid=False,
                   slots=True, pre_gelu=False, ln_bias=False, seed=0, G=8, scale2=2 ** -0.5, tol=4e-3, dbg=None, reps=1, logits=False,
-                  out_gelu=False, pair=False, pipe=False):
+                  out_gelu=False, pair=False, pipe=False, pool=False):
     dev = "cpu" if backend == "emu" else "cuda:0"
     d = lambda t: None if t is None else t.to(dev)
     g = torch.Generator().manual_seed(seed)
@@ -95,7 +95,7 @@ def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, 
     bias = rn(Cout)
     ref = to_rows(F.conv2d(bf(y), bf(w), None, padding=k // 2))
     # ---- op
-    ldc, co_off = Cout + 32, 16
+    ldc, co_off = (Cout, 0) if pool else (Cout + 32, 16)     # epilogue pooling wants the bare conv output
     out0 = rn(M, ldc)
     out = d(out0.clone())
     res = rn(M, ldc) if resid else None
@@ -108,10 +108,16 @@ def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, 
     x2_d, bias_d, gamma_d, ssv_d = d(x2), d(bias), d(gamma), d(ssv)
     beta_d = d(beta) if (norm != LN or ln_bias) else None
     n_frags = (Cout + 15) // 16
-    wk = rn(Cout) if logits else None
+    wk = rn(Cout) if (logits or pool) else None
     wk_d = d(wk)
     lpart = d(torch.full((S * n_frags, M), float("nan"))) if logits else None
-    op = fused.mkop(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0) | (8 if out_gelu else 0) | (32 if pipe else 0),
+    if pool:          # GlobalContext pooling in the epilogue: w_eff[tap][channel] = sum_n wk[n] * W[n][channel][tap], k-step order, bf16
+        assert pipe and not logits and k == 3
+        weff = torch.einsum("n,ncyx->yxc", wk, bf(w)).reshape(-1).to(torch.bfloat16).contiguous()
+        wk_d = d(weff)
+        lpart = d(torch.full((M // 16 * Cout + M // 16 * 2,), float("nan")))
+    op = fused.mkop(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0) | (8 if out_gelu else 0) | (32 if pipe else 0)
+                    | (64 if pool else 0),
                     p=(s1["p"], s1["a"], s1["b"], s1["r"], sl1, x2_d, sl2, wp, bias_d, out, res_d, wsl, slots_out, gamma_d, beta_d, ssv_d, dbg, wk_d, lpart),
                     i=(B, H, W, C1, C2, Cout, ldc, co_off, k, s1["mode"], s1["groups"], s1["npad"], norm, G, TR, WM, WN, S, 2 * C),
                     f=(1e-5, 1.0, scale2))
@@ -161,6 +167,18 @@ def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, 
         assert not (accum or resid)                      # the GlobalContext input is the bare conv output (bias is pixel-constant)
         val = got if S > 1 else out[:, co_off:co_off + Cout] - bias
         assert torch.allclose(lpart.cpu().sum(0), val @ wk, rtol=1e-3, atol=2e-3), "context logits wrong"
+    if pool:                                             # merged over the 16-pixel chunks of an image = softmax(out . wk) pooling of out
+        buf = lpart.cpu()
+        part, ms = buf[:M // 16 * Cout].view(B, HW // 16, Cout), buf[M // 16 * Cout:].view(B, HW // 16, 2)
+        assert torch.isfinite(buf).all()
+        mx = ms[..., 0].max(1, keepdim=True).values
+        wj = (ms[..., 0] - mx).exp()
+        pooled = (wj[..., None] * part).sum(1) / (wj * ms[..., 1]).sum(1, keepdim=True)
+        val = out[:, :Cout]
+        lg = ((val - bias) @ wk).view(B, HW)
+        want_pool = torch.einsum("bp,bpc->bc", torch.softmax(lg, 1), val.view(B, HW, Cout))
+        ep = rel(pooled, want_pool)
+        assert ep < 2e-2, f"epilogue pooling mismatch rel {ep}"
     if slots_out is not None:
         sl = slots_of(out[:, co_off:co_off + Cout].contiguous(), M, Cout)
         got_sl = slots_out.cpu()[:, co_off // 16:co_off // 16 + Cout // 16]
@@ -192,7 +210,7 @@ def run_slots_case(backend):
     assert torch.allclose(sl2.cpu(), slots_of(x, M, C), rtol=1e-5, atol=1e-4)
 
 
-def run_gca_case(backend, B, H, C, lazy=False, seed=0):
+def run_gca_case(backend, B, H, C, lazy=False, seed=0, epilogue_chunks=False):
     """k_gca_pool -> k_gca_net0 -> k_gca_gate against GlobalContext + gated residual (imagen_pytorch.py:916-941, :727-729)."""
     dev = "cpu" if backend == "emu" else "cuda:0"
     g = torch.Generator().manual_seed(seed)
@@ -229,6 +247,15 @@ def run_gca_case(backend, B, H, C, lazy=False, seed=0):
     slots = torch.zeros(M // 16, C // 16, 2, device=dev)
     head = [fused.mkop(OP_GCA, 1, p=(h2_d, ws_d, bias_d, lp_d, part_pool, part_ms), i=(M, C, HW, CH, chunks, nparts, groups, npad)),
          fused.mkop(OP_GCA, 2, p=(part_pool, part_ms, W0p, b0_d, hid_d), i=(B, C, Kp, HID, chunks))]
+    if epilogue_chunks:            # the pooled 16-pixel fragments as the producing conv's epilogue leaves them (fused_pipe.h POOL):
+        assert not lazy            # HW / 16 chunks per image, net0 merges up to 64 of them
+        chunks = HW // 16
+        lg = (h2 @ wk).view(B * chunks, 16)
+        mj = lg.max(1, keepdim=True).values
+        e = (lg - mj).exp()
+        part_pool = dv(torch.einsum("jp,jpc->jc", e, h2.view(B * chunks, 16, C)).contiguous())
+        part_ms = dv(torch.cat([mj, e.sum(1, keepdim=True)], 1).contiguous())
+        head = [fused.mkop(OP_GCA, 2, p=(part_pool, part_ms, W0p, b0_d, hid_d), i=(B, C, Kp, HID, chunks))]
     ops = head + [
            fused.mkop(OP_GCA, 3, p=(h2_d, res_d, hid_d, W2p, b2_d, out, slots), i=(M, C, HW, HID, Kp2))]
     run_ops(ops, backend)
@@ -240,8 +267,13 @@ def run_gca_case(backend, B, H, C, lazy=False, seed=0):
 
 
 GCA_CASES = {"4x4_lazy": dict(B=2, H=4, C=128, lazy=True), "8x8": dict(B=1, H=8, C=64, seed=1), "16x16": dict(B=1, H=16, C=64, seed=2),
-             "8x8_c192_b2": dict(B=2, H=8, C=192, seed=8)}
-GCA_CASES_FULL = {"unet_4x4": dict(B=1, H=4, C=1024, lazy=True, seed=3), "unet_8x8": dict(B=1, H=8, C=1024, seed=4),
+             "8x8_c192_b2": dict(B=2, H=8, C=192, seed=8),
+             "32x32_epilogue_chunks": dict(B=2, H=32, C=64, seed=11, epilogue_chunks=True),
+             "16x16_epilogue_chunks": dict(B=1, H=16, C=320, seed=12, epilogue_chunks=True),
+             "8x8_epilogue_chunks": dict(B=2, H=8, C=128, seed=13, epilogue_chunks=True)}
+GCA_CASES_FULL = {"unet_32x32_epilogue_chunks": dict(B=1, H=32, C=256, seed=14, epilogue_chunks=True),
+                  "unet_b4_16x16_epilogue_chunks": dict(B=4, H=16, C=512, seed=15, epilogue_chunks=True),
+                  "unet_4x4": dict(B=1, H=4, C=1024, lazy=True, seed=3), "unet_8x8": dict(B=1, H=8, C=1024, seed=4),
                   "unet_32x32": dict(B=1, H=32, C=256, seed=5), "unet_b4_16x16": dict(B=4, H=16, C=512, seed=6)}
 
 
@@ -270,6 +302,11 @@ CONV_CASES = {
     "pipe_gn_slots_16x16_wn2": dict(B=1, H=16, W=16, C1=256, C2=128, Cout=64, k=3, norm=GN_SLOTS, WM=1, WN=2, seed=32, pipe=True, logits=True),
     "pipe_gn_slots_wm2_wn2_accum": dict(B=2, H=4, W=32, C1=128, C2=0, Cout=64, k=3, norm=GN_SLOTS, WM=2, WN=2, accum=True, seed=33, pipe=True),
     "pipe_pair_gn_slots_concat_8x8": dict(B=1, H=8, W=8, C1=128, C2=128, Cout=32, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=38, pipe=True, pair=True),
+    # GlobalContext pooling in the conv's epilogue (context logits from the conv's own input through w_eff)
+    "pipe_pool_8x8": dict(B=2, H=8, W=8, C1=128, C2=0, Cout=64, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=54, pipe=True, pool=True),
+    "pipe_pool_16x16_wn2": dict(B=1, H=16, W=16, C1=256, C2=0, Cout=64, k=3, norm=GN_SLOTS, WM=1, WN=2, seed=55, pipe=True, pool=True),
+    "pipe_pool_16x16_tr2": dict(B=2, H=16, W=16, C1=128, C2=0, Cout=96, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=56, pipe=True, pool=True),
+    "pipe_pool_wide_rows_wm4": dict(B=2, H=4, W=32, C1=128, C2=0, Cout=64, k=3, norm=GN_SLOTS, WM=4, WN=2, seed=57, pipe=True, pool=True),
     # 32-pixel tiles of the 16x16 / 8x8 maps (the B >= 4 geometry): two row pairs / four rows per workgroup
     "pipe_gn_slots_16x16_tr2_wn2": dict(B=2, H=16, W=16, C1=256, C2=128, Cout=64, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=42, pipe=True, logits=True),
     "pipe_gn_slots_wide_rows_wm4_wn2": dict(B=2, H=4, W=32, C1=128, C2=128, Cout=64, k=3, norm=GN_SLOTS, WM=4, WN=2, seed=47, pipe=True, logits=True),
@@ -308,5 +345,8 @@ CONV_CASES_FULL = {
     "unet_b4_pipe_16x16_768": dict(B=4, H=16, W=16, C1=512, C2=256, Cout=512, k=3, norm=GN_SLOTS, WM=2, WN=2, resid=True, seed=51, pipe=True),
     "unet_b4_pipe_32x32_512": dict(B=4, H=32, W=32, C1=256, C2=256, Cout=256, k=3, norm=GN_SLOTS, WM=4, WN=2, seed=52, pipe=True, logits=True),
     "unet_b4_pipe_pair_32x32_512": dict(B=4, H=32, W=32, C1=256, C2=256, Cout=256, k=3, norm=GN_SLOTS, WM=4, WN=2, seed=53, pipe=True, pair=True),
+    "unet_pipe_pool_32x32_256": dict(B=1, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=58, pipe=True, pool=True),
+    "unet_pipe_pool_8x8_1024": dict(B=1, H=8, W=8, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=59, pipe=True, pool=True),
+    "unet_b4_pipe_pool_16x16_512": dict(B=4, H=16, W=16, C1=512, C2=0, Cout=512, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=60, pipe=True, pool=True),
     "unet_b4_4x4": dict(B=4, H=4, W=4, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SELF, WM=1, WN=1, S=1, seed=16),
 }

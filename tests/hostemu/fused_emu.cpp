@@ -55,7 +55,8 @@ extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
       const int EPT = fconv_pipe_ept(a);
 #define SF_TRYP(wm, wn, ept) \
       if (WM == wm && WN == wn && EPT == ept) { \
-        hipemu::launch(grid, SF_FCONV_WAVES * 64, lds, [&] { k_conv_fused_pipe<wm, wn, ept, SF_FCONV_WAVES>(a); }); \
+        if (a.weff) hipemu::launch(grid, SF_FCONV_WAVES * 64, lds, [&] { k_conv_fused_pipe<wm, wn, ept, SF_FCONV_WAVES, true>(a); }); \
+        else hipemu::launch(grid, SF_FCONV_WAVES * 64, lds, [&] { k_conv_fused_pipe<wm, wn, ept, SF_FCONV_WAVES, false>(a); }); \
         return 0; \
       }
       SF_FCONV_PIPE_VARIANTS(SF_TRYP)
@@ -87,7 +88,12 @@ extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
     uint32_t grid;
     if (gca_setup(*op, pa, na, ga, grid, err, (size_t)errn)) return 1;
     if (op->flags == 1) hipemu::launch(grid, 256, 0, [&] { k_gca_pool(pa); });
-    else if (op->flags == 2) hipemu::launch(grid, 256, 0, [&] { k_gca_net0(na); });
+    else if (op->flags == 2) {
+      if (na.chunks <= 8) hipemu::launch(grid, 256, 0, [&] { k_gca_net0<8>(na); });
+      else if (na.chunks <= 16) hipemu::launch(grid, 256, 0, [&] { k_gca_net0<16>(na); });
+      else if (na.chunks <= 32) hipemu::launch(grid, 256, 0, [&] { k_gca_net0<32>(na); });
+      else hipemu::launch(grid, 256, 0, [&] { k_gca_net0<64>(na); });
+    }
     else hipemu::launch(grid, 256, 0, [&] { k_gca_gate(ga); });
     return 0;
   }
