@@ -25,6 +25,7 @@
 #include "ngp_composite_wave.h"
 #include "ngp_fwd_mfma.h"
 #include <stdlib.h>
+#include <mutex>
 
 struct GridLevels;  // gridencoder.hip
 int sf_fill_levels(GridLevels* lv, const int32_t* offsets_dev, const int32_t* h_offsets, uint32_t L, float S,
@@ -424,6 +425,8 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
     n_chunks = want_chunks;
     while (n_chunks > 1 && (N % n_chunks || (N / n_chunks) % 256 || N / n_chunks < 2048)) --n_chunks;
     Side& sd = side[dev_id];
+    static std::mutex side_mu;                               // two host threads may render on one device
+    std::lock_guard<std::mutex> lk(side_mu);
     if (!sd.s && (hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) != hipSuccess ||
                   hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
                   hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess))
