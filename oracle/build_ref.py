@@ -88,7 +88,8 @@ def build(force=False, verbose=False, unfused=False):
             print(f"{s}: {n} launches rewritten -> {obj}")
         subprocess.run([CXX] + CXXFLAGS + contract + ["-x", "c++", "-c", "-", "-o", obj], input=text.encode(), check=True)
         objs.append(obj)
-    subprocess.check_call([CXX] + CXXFLAGS + contract + ["-shared", os.path.join(HERE, "ref_exports.cpp")] + objs + ["-o", OUT, "-lm"])
+    incs = ["-I" + os.path.join(REF, os.path.dirname(s_)) for s_ in SOURCES]          # the reference's own headers, where they lie
+    subprocess.check_call([CXX] + CXXFLAGS + contract + incs + ["-shared", os.path.join(HERE, "ref_exports.cpp")] + objs + ["-o", OUT, "-lm"])
     for o in objs:
         os.remove(o)
     return OUT
