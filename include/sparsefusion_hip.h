@@ -28,6 +28,9 @@ extern "C" {
 
 const char* sf_last_error(void);
 int sf_abi_version(void);
+/* 1 when this build multiplies IEEE-half operands (libsparsefusion_hip_f16.so, -DSF_OPERAND_F16=1), 0 for bf16 (default): host-side
+ * weight tables handed to the library must be rounded to that type. */
+int sf_operand_is_f16(void);
 
 /* ------------------------------------------------------------------------ */
 /* _gridencoder  (external/gridencoder/src/bindings.cpp:6-7)                 */

@@ -11,7 +11,9 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SF_HIP_LIB: an A/B build of the SAME library (sparsefusion_amd/build.py::build_variant), for tuning runs on the GPU box
-LIB_PATH = os.environ.get("SF_HIP_LIB") or os.path.join(_HERE, "libsparsefusion_hip.so")
+# SF_OPERAND=f16: the build with IEEE-half MFMA operands (csrc/sf_operand.h; build.build_f16) instead of bf16, for the whole process
+_DEFAULT_LIB = "libsparsefusion_hip_f16.so" if os.environ.get("SF_OPERAND", "bf16").lower() in ("f16", "fp16", "half") else "libsparsefusion_hip.so"
+LIB_PATH = os.environ.get("SF_HIP_LIB") or os.path.join(_HERE, _DEFAULT_LIB)
 
 _lib = None
 
@@ -56,6 +58,7 @@ class SfOp(C.Structure):
 SIGNATURES = {
     "sf_last_error": (C.c_char_p, []),
     "sf_abi_version": (C.c_int, []),
+    "sf_operand_is_f16": (C.c_int, []),
     "sf_grid_encode_forward": (C.c_int, [c_f32p, c_f32p, c_i32p, c_f32p, u32, u32, u32, u32, C.c_float, u32,
                                          c_f32p, u32, C.c_int, C.c_void_p, C.c_void_p]),
     "sf_grid_encode_backward": (C.c_int, [c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, u32, u32, u32, u32, C.c_float,
@@ -106,26 +109,49 @@ SIGNATURES = {
 }
 
 
-def lib():
-    """Load the HIP library (once).  Raises if it has not been built."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+_handles = {}
+
+
+def _load(path):
+    if path not in _handles:
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} is missing: build it with `python -m sparsefusion_amd.build` "
-                "(there is no CPU fallback for the sparsefusion_amd hot path)")
-        handle = C.CDLL(LIB_PATH)
+                f"{path} is missing: build it with `python -m sparsefusion_amd.build` (`--f16` for the IEEE-half operand build; "
+                "there is no CPU fallback for the sparsefusion_amd hot path)")
+        handle = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)   # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        _lib = handle
-    return _lib
+        _handles[path] = handle
+    return _handles[path]
 
 
-def check(rc, what=""):
+def lib(operand=None):
+    """The HIP library (loaded once).  operand=None: the process default (LIB_PATH: bf16 operands unless SF_OPERAND=f16);
+    "f16" / "bf16": that operand build explicitly -- a module (Unet.half()) may run on IEEE-half operands while the rest of the
+    process stays on bf16.  Raises if the library has not been built."""
+    global _lib
+    if operand is None:
+        if _lib is None:
+            _lib = _load(LIB_PATH)
+        return _lib
+    if operand == "f16":
+        return _load(os.path.join(_HERE, "libsparsefusion_hip_f16.so"))
+    if operand == "bf16":
+        return _load(os.path.join(_HERE, "libsparsefusion_hip.so"))
+    raise ValueError(f"unknown MFMA operand type {operand!r} (bf16 | f16)")
+
+
+def operand_dtype(handle=None):
+    """torch dtype of the MFMA operands of a library handle (default: the process library): bfloat16 or float16.  Host-side
+    weight tables that are handed to the library as raw 16-bit values must be rounded to THIS type."""
+    return torch.float16 if (handle or lib()).sf_operand_is_f16() else torch.bfloat16
+
+
+def check(rc, what="", handle=None):
     if rc != 0:
-        msg = lib().sf_last_error().decode("utf-8", "replace")
+        msg = (handle or lib()).sf_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what}: {msg}" if what else msg)
 
 

@@ -90,6 +90,34 @@ def build_variant(tag, defines, verbose=True, timing=False, sources=("unet_fused
     return out
 
 
+LIB_F16 = os.path.join(HERE, "libsparsefusion_hip_f16.so")
+
+
+def build_f16(verbose=True, force=False):
+    """libsparsefusion_hip_f16.so: the whole library with IEEE-half MFMA operands instead of bf16 (-DSF_OPERAND_F16=1,
+    csrc/sf_operand.h), selected per process with SF_OPERAND=f16 (BASELINE configs[4]: "fp16 UNet").  Objects are cached by
+    source mtime like the default build's."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdr_m = _deps_mtime()
+
+    def comp(src):
+        obj = os.path.join(OBJ_DIR, src[:-4] + "_f16.o")
+        sp = os.path.join(CSRC, src)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(sp), hdr_m):
+            return obj, False
+        cmd = [HIPCC] + FLAGS + ["-DSF_OPERAND_F16=1", "-c", sp, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj, True
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        res = list(ex.map(comp, _sources()))
+    if any(c for _, c in res) or not os.path.exists(LIB_F16):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_F16] + [o for o, _ in res])
+    return LIB_F16
+
+
 def build_timing(verbose=True):
     """libsf_fused_timing.so: unet_fused.hip with in-kernel phase timestamps (-DSF_FCONV_TIMING), a measurement aid for
     tools/fconv_phases.py -- never loaded by the package."""
@@ -107,6 +135,8 @@ def build_timing(verbose=True):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    if "--f16" in sys.argv:
+        print(build_f16(force="--force" in sys.argv))
     if "--timing" in sys.argv:
         print(build_timing())
     print(LIB)

@@ -40,7 +40,7 @@ SF_KERNEL(256) void k_layernorm(const float* __restrict__ in, const float* __res
         if (resid) y += resid[(long)row * C + c];
         reinterpret_cast<float*>(out)[(long)row * C + c] = y;
       } else {
-        reinterpret_cast<__bf16*>(out)[(long)row * C + c] = (__bf16)y;
+        reinterpret_cast<sf_opnd*>(out)[(long)row * C + c] = (sf_opnd)y;
       }
     }
   }
@@ -93,6 +93,6 @@ SF_KERNEL(256) void k_attn16(const float* __restrict__ q, void* __restrict__ out
     for (int j = 0; j < J; ++j) a = fmaf(sim[i][j], sv[j][t], a);
     const long o = ((long)b * 16 + i) * (heads * 64) + h * 64 + t;
     if (out_f32) reinterpret_cast<float*>(out)[o] = a;          // consumed by a fused linear (fp32 A operand prologue)
-    else reinterpret_cast<__bf16*>(out)[o] = (__bf16)a;
+    else reinterpret_cast<sf_opnd*>(out)[o] = (sf_opnd)a;
   }
 }

@@ -64,11 +64,11 @@ SF_KERNEL(256) void k_conv_igemm(ConvArgs a) {
     // free, unconditionally) before the MFMAs of trip t, so a wave keeps U*(WM+WN) KiB in flight while the
     // matrix pipe works -- weight streaming on the small-M layers is latency x bytes-in-flight bound.
     // Out-of-image taps read a clamped in-bounds pixel and are zeroed by a select, never by a branch.
-    const __bf16* abase16[WM];
+    const sf_opnd* abase16[WM];
     const float* abase32[WM];
 #pragma unroll
     for (int mi = 0; mi < WM; ++mi) {
-      abase16[mi] = reinterpret_cast<const __bf16*>(a.in) + aoff[mi];
+      abase16[mi] = reinterpret_cast<const sf_opnd*>(a.in) + aoff[mi];
       abase32[mi] = reinterpret_cast<const float*>(a.in) + aoff[mi];
     }
     auto load_a = [&](int mi, int cc) -> bf16x8 {
@@ -76,8 +76,8 @@ SF_KERNEL(256) void k_conv_igemm(ConvArgs a) {
       if (A_FP32) {
         const f32x4 lo = *reinterpret_cast<const f32x4*>(abase32[mi] + cc * 32);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(abase32[mi] + cc * 32 + 4);
-        v[0] = (__bf16)lo[0]; v[1] = (__bf16)lo[1]; v[2] = (__bf16)lo[2]; v[3] = (__bf16)lo[3];
-        v[4] = (__bf16)hi[0]; v[5] = (__bf16)hi[1]; v[6] = (__bf16)hi[2]; v[7] = (__bf16)hi[3];
+        v[0] = (sf_opnd)lo[0]; v[1] = (sf_opnd)lo[1]; v[2] = (sf_opnd)lo[2]; v[3] = (sf_opnd)lo[3];
+        v[4] = (sf_opnd)hi[0]; v[5] = (sf_opnd)hi[1]; v[6] = (sf_opnd)hi[2]; v[7] = (sf_opnd)hi[3];
       } else {
         v = *reinterpret_cast<const bf16x8*>(abase16[mi] + cc * 32);
       }

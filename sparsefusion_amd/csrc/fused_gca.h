@@ -124,7 +124,7 @@ SF_KERNEL(256) void k_gca_pool(GcaPoolArgs a) {
 struct GcaNetArgs {
   const float* part_pool;    // [B * chunks][C]
   const float* part_ms;      // [B * chunks][2]
-  const __bf16* W0;          // [hid][Kp] (Kp = C padded to 8)
+  const sf_opnd* W0;          // [hid][Kp] (Kp = C padded to 8)
   const float* b0;
   float* hid;                // [B][hid]
   int B, C, Kp, HID, chunks;
@@ -203,7 +203,7 @@ struct GcaGateArgs {
   const float* h2;
   const float* res;
   const float* hid;          // [B][HID]
-  const __bf16* W2;          // [C][Kp2]
+  const sf_opnd* W2;          // [C][Kp2]
   const float* b2;
   float* out;
   float* slots;              // [M/16][C/16][2] or null
@@ -251,7 +251,7 @@ SF_KERNEL(256) void k_gca_gate(GcaGateArgs a) {
         for (int j = 0; j < 4; ++j) g = fmaf((float)w[u][4 + j], h1[u][j], g);
       } else {
         for (int j = 0; j < 8; ++j)
-          if (k + j < a.HID) g = fmaf((float)(reinterpret_cast<const __bf16*>(a.W2)[(long)ch * a.Kp2 + k + j]), a.hid[(long)b * a.HID + k + j], g);
+          if (k + j < a.HID) g = fmaf((float)(reinterpret_cast<const sf_opnd*>(a.W2)[(long)ch * a.Kp2 + k + j]), a.hid[(long)b * a.HID + k + j], g);
       }
     }
   }

@@ -95,7 +95,7 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   a.wk = (const float*)op.p[17]; a.logit_part = (float*)op.p[18];
   a.weff = nullptr; a.pool_part = nullptr; a.weff_off = 0;
   if (op.flags & 64) {                 // epilogue pooling (k_conv_fused_pipe<.., POOL>): p 17 = w_eff bf16 [KS * 32], p 18 = pooled fragments
-    a.weff = (const __bf16*)op.p[17]; a.pool_part = (float*)op.p[18];
+    a.weff = (const sf_opnd*)op.p[17]; a.pool_part = (float*)op.p[18];
     a.wk = nullptr; a.logit_part = nullptr;
     if (!(op.flags & 32) || !a.weff || !a.pool_part) FC_FAIL("fconv: epilogue pooling needs the pipelined kernel, w_eff and a pooled-fragment buffer");
   }
@@ -258,7 +258,7 @@ static inline int gca_setup(const sf_op& op, GcaPoolArgs& pa, GcaNetArgs& na, Gc
     return 0;
   }
   if (op.flags == 2) {
-    na.part_pool = (const float*)op.p[0]; na.part_ms = (const float*)op.p[1]; na.W0 = (const __bf16*)op.p[2];
+    na.part_pool = (const float*)op.p[0]; na.part_ms = (const float*)op.p[1]; na.W0 = (const sf_opnd*)op.p[2];
     na.b0 = (const float*)op.p[3]; na.hid = (float*)op.p[4];
     na.B = op.i[0]; na.C = op.i[1]; na.Kp = op.i[2]; na.HID = op.i[3]; na.chunks = op.i[4];
     if (!na.part_pool || !na.part_ms || !na.W0 || !na.b0 || !na.hid) GC_FAIL("gca net0: missing operand");
@@ -268,7 +268,7 @@ static inline int gca_setup(const sf_op& op, GcaPoolArgs& pa, GcaNetArgs& na, Gc
   }
   if (op.flags == 3) {
     ga.h2 = (const float*)op.p[0]; ga.res = (const float*)op.p[1]; ga.hid = (const float*)op.p[2];
-    ga.W2 = (const __bf16*)op.p[3]; ga.b2 = (const float*)op.p[4]; ga.out = (float*)op.p[5]; ga.slots = (float*)op.p[6];
+    ga.W2 = (const sf_opnd*)op.p[3]; ga.b2 = (const float*)op.p[4]; ga.out = (float*)op.p[5]; ga.slots = (float*)op.p[6];
     ga.M = op.i[0]; ga.C = op.i[1]; ga.HW = op.i[2]; ga.HID = op.i[3]; ga.Kp2 = op.i[4];
     if (!ga.h2 || !ga.res || !ga.hid || !ga.W2 || !ga.b2 || !ga.out) GC_FAIL("gca gate: missing operand");
     if (ga.M % 16 || ga.C % 16 || ga.HW % 16 || ga.Kp2 % 8 || ga.Kp2 < ga.HID || ga.HID > 1024 || ga.HID < 8) GC_FAIL("gca gate: 16-aligned M, C, HW and 8 <= HID <= 1024 required");

@@ -76,7 +76,7 @@ struct FConvArgs {
   float* logit_part;                 //   logit_part[(s * n_frags + n_frag) * M + m] = sum over the fragment's 16 channels of value * wk
   long long* dbg;                    // optional [grid][8] phase timestamps (tools/fconv_phases.py), null in production
   // k_conv_fused_pipe<.., POOL = true> (r03): the GlobalContext softmax pooling of this conv's OUTPUT in its own epilogue.
-  const __bf16* weff;                // [KS * 32] = (tap, channel) in k-step order: w_eff = sum_n wk[n] * W[n][channel][tap] -- the
+  const sf_opnd* weff;                // [KS * 32] = (tap, channel) in k-step order: w_eff = sum_n wk[n] * W[n][channel][tap] -- the
                                      // context logit of a pixel is a 1-output-channel conv of the SAME staged input (bias terms cancel)
   float* pool_part;                  // [M / 16][Cout] un-normalised pooled fragments sum_p exp(l_p - max_frag) * out[p, n];
                                      // directly behind it [M / 16][2] = (max_frag, sum_p exp(l_p - max_frag)): one chunk = 16 pixels
@@ -390,7 +390,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
       v[j] = a.silu ? sv : v[j];
     }
     bf16x4 o;
-    o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+    o[0] = (sf_opnd)v[0]; o[1] = (sf_opnd)v[1]; o[2] = (sf_opnd)v[2]; o[3] = (sf_opnd)v[3];
     *reinterpret_cast<bf16x4*>(lds + (long)fp * a.pix_stride + cl * 2) = o;
   };
   auto affine_of = [&](int cl, f32x4& A, f32x4& Bv) {
@@ -561,7 +561,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
         if (a.beta) y += *reinterpret_cast<const f32x4*>(a.beta + c4 * 4);
         if (a.silu) { y[0] = sf_silu_fast(y[0]); y[1] = sf_silu_fast(y[1]); y[2] = sf_silu_fast(y[2]); y[3] = sf_silu_fast(y[3]); }
         bf16x4 o;
-        o[0] = (__bf16)y[0]; o[1] = (__bf16)y[1]; o[2] = (__bf16)y[2]; o[3] = (__bf16)y[3];
+        o[0] = (sf_opnd)y[0]; o[1] = (sf_opnd)y[1]; o[2] = (sf_opnd)y[2]; o[3] = (sf_opnd)y[3];
         *reinterpret_cast<bf16x4*>(lds + (long)row * a.pix_stride + c4 * 8) = o;
       }
     }
@@ -628,7 +628,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
           y = y * e;
         }
         bf16x4 o;
-        o[0] = (__bf16)y[0]; o[1] = (__bf16)y[1]; o[2] = (__bf16)y[2]; o[3] = (__bf16)y[3];
+        o[0] = (sf_opnd)y[0]; o[1] = (sf_opnd)y[1]; o[2] = (sf_opnd)y[2]; o[3] = (sf_opnd)y[3];
         *reinterpret_cast<bf16x4*>(lds + (long)fp * a.pix_stride + cl * 2) = o;
       }
     };

@@ -135,7 +135,7 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
       y = pool[vo + e];
 #endif
       bf16x4 o;
-      o[0] = (__bf16)y[0]; o[1] = (__bf16)y[1]; o[2] = (__bf16)y[2]; o[3] = (__bf16)y[3];
+      o[0] = (sf_opnd)y[0]; o[1] = (sf_opnd)y[1]; o[2] = (sf_opnd)y[2]; o[3] = (sf_opnd)y[3];
       *reinterpret_cast<bf16x4*>(buf + (long)fpx[e] * pstr) = o;
     }
   };

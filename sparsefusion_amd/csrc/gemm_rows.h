@@ -15,19 +15,19 @@
 
 struct GemmRowsArgs {
   const float* x;                  // [M][ldx]
-  const __bf16* W;                 // [N][Kp], Kp = K rounded up to 8, zero padded
+  const sf_opnd* W;                 // [N][Kp], Kp = K rounded up to 8, zero padded
   const float* bias;               // [N] or null
   float* y;                        // [M][ldy]
   int M, N, K, Kp, ldx, ldy, in_silu, out_act;     // out_act: 0 none, 1 SiLU, 2 sigmoid
 };
 
 SF_KERNEL(256) void k_gemm_rows(GemmRowsArgs a) {
-  SF_SHARED __attribute__((aligned(16))) __bf16 hi[64 * GR_LD];
-  SF_SHARED __attribute__((aligned(16))) __bf16 lo[64 * GR_LD];
+  SF_SHARED __attribute__((aligned(16))) sf_opnd hi[64 * GR_LD];
+  SF_SHARED __attribute__((aligned(16))) sf_opnd lo[64 * GR_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 15, g = lane >> 4;
   const int ncol = blockIdx.x * 64 + wave * 16 + n;
-  const __bf16* __restrict__ wrow = a.W + (long)min(ncol, a.N - 1) * a.Kp;
+  const sf_opnd* __restrict__ wrow = a.W + (long)min(ncol, a.N - 1) * a.Kp;
   const int MF = (a.M + 15) >> 4;
   f32x4 acc[4];
 #pragma unroll
@@ -47,9 +47,9 @@ SF_KERNEL(256) void k_gemm_rows(GemmRowsArgs a) {
       for (int j = 0; j < 8; ++j) {
         float t = (m < a.M && kc + k8 + j < a.K) ? v[j] : 0.0f;
         if (a.in_silu) t = sf_silu(t);
-        const __bf16 hb = (__bf16)t;
+        const sf_opnd hb = (sf_opnd)t;
         h[j] = hb;
-        l[j] = (__bf16)(t - (float)hb);
+        l[j] = (sf_opnd)(t - (float)hb);
       }
       *reinterpret_cast<bf16x8*>(&hi[m * GR_LD + k8]) = h;
       *reinterpret_cast<bf16x8*>(&lo[m * GR_LD + k8]) = l;

@@ -56,7 +56,7 @@ SF_DEV void initx_stage(const InitXArgs& a, char* __restrict__ patch, int tid, i
     const int i = tid + it * 256;
     ix_bf16x4 o;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) o[c] = (__bf16)((in[it] && c < a.Cx) ? v[it][c] : 0.0f);
+    for (int c = 0; c < 4; ++c) o[c] = (sf_opnd)((in[it] && c < a.Cx) ? v[it][c] : 0.0f);
     if (i < IX_PH * IX_PW) *reinterpret_cast<ix_bf16x4*>(patch + i * 8) = o;
   }
 }

@@ -12,7 +12,7 @@
 #include "plan_ops.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef sf_opnd bf16x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float lp_wave_sum(float v) {
 #pragma unroll
@@ -158,12 +158,12 @@ __global__ __launch_bounds__(256) void k_lpips_head_bwd(const float* __restrict_
 // ---- elementwise helpers ------------------------------------------------------------------------------------
 // out bf16 = dy * (y > 0)      (ReLU backward; y is the post-ReLU activation)
 __global__ __launch_bounds__(256) void k_relu_bwd(const float* __restrict__ dy, const float* __restrict__ y,
-                                                  __bf16* __restrict__ out, long n4) {
+                                                  sf_opnd* __restrict__ out, long n4) {
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     const f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4), a = *reinterpret_cast<const f32x4*>(y + i * 4);
     bf16x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (__bf16)(a[j] > 0.0f ? g[j] : 0.0f);
+    for (int j = 0; j < 4; ++j) o[j] = (sf_opnd)(a[j] > 0.0f ? g[j] : 0.0f);
     *reinterpret_cast<bf16x4*>(out + i * 4) = o;
   }
 }
@@ -230,7 +230,7 @@ int sf_plan_extra_op(const sf_op* opp, void* stream) {
       switch (op.flags) {
         case 7: {
           const long n4 = (long)(uint32_t)op.i[0] / 4;
-          k_relu_bwd<<<sf_grid_cap(sf_div_up(n4, 256)), 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (__bf16*)op.p[3], n4);
+          k_relu_bwd<<<sf_grid_cap(sf_div_up(n4, 256)), 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (sf_opnd*)op.p[3], n4);
           break;
         }
         case 8:

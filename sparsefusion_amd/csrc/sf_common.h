@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 #include "../../include/sparsefusion_hip.h"
+#include "sf_operand.h"
 
 extern thread_local char sf_err_buf[512];
 

@@ -4,12 +4,13 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include "sf_operand.h"
 
 #ifndef SF_KA_TOUCH
 #define SF_KA_TOUCH 1          // 0: A/B switch of sf_touch_kernarg
 #endif
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) sf_opnd bf16x8;
+typedef __attribute__((ext_vector_type(4))) sf_opnd bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
@@ -111,7 +112,11 @@ SF_DEV void sf_global_add(float* p, float v) { (void)__builtin_amdgcn_global_ato
 SF_DEV f32x4 sf_mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 SF_DEV float sf_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
 SF_DEV long long sf_clock() { return (long long)wall_clock64(); }      // 100 MHz constant clock
+#if SF_OPERAND_F16
+SF_DEV f32x4 sf_mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+#else
 SF_DEV f32x4 sf_mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+#endif
 // Touch every 64-byte line of the kernel-argument segment with independent scalar loads and wait ONCE.  The compiler
 // fetches a large by-value argument struct piecemeal, each piece right before its first use and each behind its own
 // s_waitcnt: ~8 serialised cold misses of the scalar cache (~0.4 us each) in front of the first vector load of a 460-byte

@@ -34,8 +34,8 @@
 #include "attn_ln.h"
 #include <math.h>
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) sf_opnd bf16x8;
+typedef __attribute__((ext_vector_type(4))) sf_opnd bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(1))) float gfloat;
 
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void k_gn_stats_px(const float* __restrict__ s
 __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ s1, const float* __restrict__ s2,
                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                   const float* __restrict__ ss, const double* __restrict__ stats,
-                                                  __bf16* __restrict__ out, __bf16* __restrict__ raw, int B, int HW, int C1,
+                                                  sf_opnd* __restrict__ out, sf_opnd* __restrict__ raw, int B, int HW, int C1,
                                                   int C2, int ss_stride, float eps, float s2_scale, int no_silu, int G) {
   const int C = C1 + C2, Cg = C / G, c4 = C / 4;
   const long total = (long)B * HW * c4;
@@ -231,8 +231,8 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ s1, 
       float y = (v[j] - mean) * rstd * ga[j] + be[j];
       if (ss) y = y * (ss[(long)b * ss_stride + c + j] + 1.0f) + ss[(long)b * ss_stride + C + c + j];
       if (!no_silu) y = silu_f(y);
-      o[j] = (__bf16)y;
-      r[j] = (__bf16)v[j];
+      o[j] = (sf_opnd)y;
+      r[j] = (sf_opnd)v[j];
     }
     *reinterpret_cast<bf16x4*>(out + ((long)b * HW + p) * C + c) = o;
     if (raw) *reinterpret_cast<bf16x4*>(raw + ((long)b * HW + p) * C + c) = r;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ s1, 
 // layers (the 33 792-row time-MLP GEMV streams 72 MB), 1 for the short ones (N <= 2048: gca nets, time tokens), which are a
 // single latency-bound phase and want as many workgroups as they have rows.
 template <int GEMV_ROWS>
-__global__ __launch_bounds__(256) void k_gemv(const float* __restrict__ x, const __bf16* __restrict__ W,
+__global__ __launch_bounds__(256) void k_gemv(const float* __restrict__ x, const sf_opnd* __restrict__ W,
                                               const float* __restrict__ bias, float* __restrict__ y, int M, int N, int K,
                                               int Kp, int ldx, int ldy, int in_silu, int out_act) {
   const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GEMV_ROWS, lane = threadIdx.x & 63;
@@ -437,14 +437,14 @@ __global__ __launch_bounds__(256) void k_pack_act(const float* __restrict__ src,
       const int c = c0 + j;
       float x = 0.0f;
       if (n < N && c < K) x = T ? src[(long)c * ld + n] : src[(long)n * ld + c];
-      v[j] = (__bf16)x;
+      v[j] = (sf_opnd)x;
     }
     out[i] = v;
   }
 }
 
 // SOFTMAX_ROWS: out bf16 [R, N] = softmax(scale * in f32 [R, N]) per row; one workgroup per row.
-__global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ in, __bf16* __restrict__ out, int N, float scale) {
+__global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ in, sf_opnd* __restrict__ out, int N, float scale) {
   __shared__ float red[8];
   const float* x = in + (long)blockIdx.x * N;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ 
   if (lane == 0) red[4 + wv] = s;
   __syncthreads();
   const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
-  for (int i = threadIdx.x; i < N; i += 256) out[(long)blockIdx.x * N + i] = (__bf16)(expf(x[i] * scale - mx) * inv);
+  for (int i = threadIdx.x; i < N; i += 256) out[(long)blockIdx.x * N + i] = (sf_opnd)(expf(x[i] * scale - mx) * inv);
 }
 
 __global__ __launch_bounds__(256) void k_unpack_out(const float* __restrict__ in, float* __restrict__ out, int B, int HW,
@@ -626,7 +626,7 @@ static int run_gn(const sf_op& op, hipStream_t st) {
   const long total = (long)B * HW * (C / 4);
   k_gn_apply<<<sf_grid_cap(sf_div_up(total, 256)), 256, 0, st>>>(
       (const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], (const float*)op.p[3], (const float*)op.p[4],
-      (const double*)op.p[7], (__bf16*)op.p[5], (__bf16*)op.p[6], B, HW, C1, C2, op.i[4], op.f[0], op.f[1], op.flags & 1, G);
+      (const double*)op.p[7], (sf_opnd*)op.p[5], (sf_opnd*)op.p[6], B, HW, C1, C2, op.i[4], op.f[0], op.f[1], op.flags & 1, G);
   SF_CHECK_LAUNCH("gn_apply");
   return SF_OK;
 }
@@ -644,7 +644,7 @@ static int run_gemv(const sf_op& op, hipStream_t st) {
   const int M = op.i[0], N = op.i[1];
   if (M > 64) SF_FAIL(SF_ERR_INVALID, "gemv: at most 64 rows");
   if (M > 8) {                                                  // many rows (a sampler's time table): rows on the MFMA M side, weights read once
-    GemmRowsArgs a{(const float*)op.p[0], (const __bf16*)op.p[1], (const float*)op.p[2], (float*)op.p[3], M, N, op.i[2], op.i[3], op.i[4],
+    GemmRowsArgs a{(const float*)op.p[0], (const sf_opnd*)op.p[1], (const float*)op.p[2], (float*)op.p[3], M, N, op.i[2], op.i[3], op.i[4],
                    op.i[5], (int)(op.flags & 1), (int)((op.flags >> 1) & 3)};
     if (a.Kp < 8 || a.Kp % 8) SF_FAIL(SF_ERR_INVALID, "gemv: padded K must be a multiple of 8");
     k_gemm_rows<<<sf_div_up(N, 64), 256, 0, st>>>(a);
@@ -652,10 +652,10 @@ static int run_gemv(const sf_op& op, hipStream_t st) {
     return SF_OK;
   }
   if (N <= 2048)
-    k_gemv<1><<<sf_div_up(N, 4), 256, 0, st>>>((const float*)op.p[0], (const __bf16*)op.p[1], (const float*)op.p[2], (float*)op.p[3], M,
+    k_gemv<1><<<sf_div_up(N, 4), 256, 0, st>>>((const float*)op.p[0], (const sf_opnd*)op.p[1], (const float*)op.p[2], (float*)op.p[3], M,
                                               N, op.i[2], op.i[3], op.i[4], op.i[5], op.flags & 1, (op.flags >> 1) & 3);
   else
-    k_gemv<4><<<sf_div_up(N, 16), 256, 0, st>>>((const float*)op.p[0], (const __bf16*)op.p[1], (const float*)op.p[2], (float*)op.p[3], M,
+    k_gemv<4><<<sf_div_up(N, 16), 256, 0, st>>>((const float*)op.p[0], (const sf_opnd*)op.p[1], (const float*)op.p[2], (float*)op.p[3], M,
                                                N, op.i[2], op.i[3], op.i[4], op.i[5], op.flags & 1, (op.flags >> 1) & 3);
   SF_CHECK_LAUNCH("gemv");
   return SF_OK;
@@ -728,7 +728,7 @@ static int run_eltwise(const sf_op& op, hipStream_t st) {
       break;
     }
     case 6:
-      k_softmax_rows<<<op.i[0], 256, 0, st>>>((const float*)op.p[0], (__bf16*)op.p[3], op.i[1], op.f[0]);
+      k_softmax_rows<<<op.i[0], 256, 0, st>>>((const float*)op.p[0], (sf_opnd*)op.p[3], op.i[1], op.f[0]);
       break;
     case 7: case 8: case 9: return sf_plan_extra_op(&op, st);      // LPIPS helpers (lpips_ops.hip)
     default: SF_FAIL(SF_ERR_INVALID, "eltwise: unknown mode %d", op.flags);
@@ -834,6 +834,14 @@ extern "C" int sf_plan_profile(const sf_op* ops, uint32_t n_ops, void* stream, f
 // ---------------------------------------------------------------------------------------------
 // host-side weight packing (round-to-nearest-even bf16)
 // ---------------------------------------------------------------------------------------------
+#if SF_OPERAND_F16
+static inline uint16_t f32_to_bf16_rne(float f) {            // operand = IEEE half in this build: the compiler's round-to-nearest-even
+  const _Float16 h = (_Float16)f;
+  uint16_t u;
+  memcpy(&u, &h, 2);
+  return u;
+}
+#else
 static inline uint16_t f32_to_bf16_rne(float f) {
   uint32_t u;
   memcpy(&u, &f, 4);
@@ -841,6 +849,7 @@ static inline uint16_t f32_to_bf16_rne(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
 }
+#endif
 
 extern "C" uint64_t sf_conv_packed_elems(uint32_t Cout, uint32_t cin_pad, uint32_t kh, uint32_t kw) {
   const uint64_t nfr = (Cout + 15) / 16;

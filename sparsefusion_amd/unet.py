@@ -38,7 +38,7 @@ LDS_MAX = 163840
 SKIP_SCALE = 2 ** -0.5            # scale_skip_connection (imagen_pytorch.py:1283)
 
 
-def init_x_weight_table(ws):
+def init_x_weight_table(ws, dtype=torch.bfloat16):
     """bf16 MFMA B-fragments of SF_OP_INITX (csrc/initx.hip) for the three CrossEmbed convs (k = 3 / 7 / 15), latent channels only:
     [k-step][n-frag][lane 64][8] with lane = (n = lane & 15, g = lane >> 4) and element j = (tap kx0 + j // 4, channel j % 4):
     k = 15: step s = (ky = s // 2, kx0 = 8 * (s % 2) + 2 g); k = 7: (ky = s, kx0 = 2 g); k = 3: (ky = 2 s + g // 2, kx0 = 2 * (g % 2)).
@@ -64,7 +64,7 @@ def init_x_weight_table(ws):
         parts.append(t.reshape(-1))
         offs.append(acc)
         acc += steps * nfr
-    return torch.cat(parts).to(torch.bfloat16).view(torch.int16).contiguous(), offs
+    return torch.cat(parts).to(dtype).view(torch.int16).contiguous(), offs       # dtype = the library's MFMA operand type
 
 
 def _cast_tuple(v, n):
@@ -1135,7 +1135,8 @@ class Unet(nn.Module):
     def _packed(self, device):
         if self._pack_cache is not None and self._pack_cache[0] == str(device):
             return self._pack_cache[1]
-        lib = _lib.lib()
+        lib = self.clib
+        odt = _lib.operand_dtype(lib)
         packed = {}
         sd = {k: v.detach() for k, v in self.named_parameters()}
         tm_w, tm_b = [], []
@@ -1187,7 +1188,7 @@ class Unet(nn.Module):
             w2c = sd.get(name + ".block2.project.weight")
             if w2c is not None and w2c.shape[1] % 32 == 0 and tuple(w2c.shape[2:]) == (3, 3):
                 wk = sd[name + ".gca.to_k.weight"].float().cpu().reshape(-1)
-                weff = torch.einsum("n,ncyx->yxc", wk, w2c.float().cpu()).reshape(-1).to(torch.bfloat16).contiguous()
+                weff = torch.einsum("n,ncyx->yxc", wk, w2c.float().cpu()).reshape(-1).to(odt).contiguous()
                 packed[name + ".__weff__"] = weff.to(device)
         for i in range(3):                                      # latent-channel slices of the init conv (sampler path)
             w4 = sd[f"init_conv.convs.{i}.weight"].float().cpu()[:, self.cond_images_channels:].contiguous()
@@ -1198,20 +1199,43 @@ class Unet(nn.Module):
         # the same slices as fp32 [tap = (ci, ky, kx)][channel] tables for the direct init-x conv (csrc/initx.hip)
         if self.channels <= 4:
             tab, self.initx_woffs = init_x_weight_table([sd[f"init_conv.convs.{i}.weight"].float().cpu()[:, self.cond_images_channels:]
-                                                         for i in range(3)])
+                                                         for i in range(3)], dtype=odt)
             packed["__init_xw__"] = tab.to(device)
         packed["__time_mlps__.weight"] = self._gemv_pack(torch.cat(tm_w, 0), device)
         packed["__time_mlps__.bias"] = torch.cat(tm_b, 0).to(device)
         self._pack_cache = (str(device), packed)
         return packed
 
-    @staticmethod
-    def _gemv_pack(w2, device):
+    def _gemv_pack(self, w2, device):
         K = w2.shape[1]
         Kp = (K + 7) // 8 * 8
         if Kp != K:
             w2 = torch.nn.functional.pad(w2, (0, Kp - K))
-        return w2.to(torch.bfloat16).contiguous().to(device)
+        return w2.to(_lib.operand_dtype(self.clib)).contiguous().to(device)
+
+    # ---- MFMA operand type: bf16 (default) or IEEE half.  `unet.half()` -- what a reference user does for fp16 inference --
+    # selects the IEEE-half build of the library for THIS module (libsparsefusion_hip_f16.so, csrc/sf_operand.h): weights are
+    # packed as fp16, activations are rounded to fp16 in front of every MFMA, accumulation / residual stream / norms / softmax
+    # stay fp32.  `set_operand("f16" | "bf16" | None)` overrides the parameter-dtype rule (None = follow the parameters, or
+    # SF_OPERAND for the whole process).
+    def set_operand(self, operand):
+        if operand not in (None, "bf16", "f16"):
+            raise ValueError("operand must be None, 'bf16' or 'f16'")
+        self._operand_override = operand
+        self.invalidate()
+        return self
+
+    @property
+    def operand(self):
+        ov = getattr(self, "_operand_override", None)
+        if ov is not None:
+            return ov
+        p = next(self.parameters(), None)
+        return "f16" if (p is not None and p.dtype == torch.float16) else None
+
+    @property
+    def clib(self):
+        return _lib.lib(self.operand)
 
     def _plan(self, B, device):
         key = (B, str(device))
@@ -1260,14 +1284,15 @@ class Unet(nn.Module):
             plan.graph.replay()
         else:
             self._run_plan(plan)
-        return plan.out_view.clone().view(B, self.channels, self.image_size, self.image_size)
+        y = plan.out_view.clone().view(B, self.channels, self.image_size, self.image_size)
+        return y if x.dtype == torch.float32 else y.to(x.dtype)          # a .half() model answers in half, as the reference's would
 
     @staticmethod
     def _run_plan(plan, body_only=False):
         if body_only:
-            _lib.check(_lib.lib().sf_plan_run(plan.body_array, plan.n_body_ops, _lib.stream_ptr()), "unet plan")
+            _lib.check(plan.u.clib.sf_plan_run(plan.body_array, plan.n_body_ops, _lib.stream_ptr()), "unet plan", plan.u.clib)
         else:
-            _lib.check(_lib.lib().sf_plan_run(plan.op_array, len(plan.ops), _lib.stream_ptr()), "unet plan")
+            _lib.check(plan.u.clib.sf_plan_run(plan.op_array, len(plan.ops), _lib.stream_ptr()), "unet plan", plan.u.clib)
 
     # ---- sampler fast path: the time path is evaluated once per trajectory, the eval replays the body only
     def _time_plan(self, T, device):
@@ -1291,7 +1316,7 @@ class Unet(nn.Module):
         T = log_snrs.numel()
         plan = self._time_plan(T, log_snrs.device)
         plan.t_view.copy_(log_snrs.reshape(T, 1))
-        _lib.check(_lib.lib().sf_plan_run(plan.op_array, len(plan.ops), _lib.stream_ptr()), "unet time plan")
+        _lib.check(self.clib.sf_plan_run(plan.op_array, len(plan.ops), _lib.stream_ptr()), "unet time plan", self.clib)
         return plan.table_view.clone()
 
     @torch.no_grad()
@@ -1306,7 +1331,7 @@ class Unet(nn.Module):
         plan.generation += 1                                   # ONE trajectory per (batch size, device) at a time: the latents,
         plan.cond_view.copy_(cond_images.reshape(B, -1))       # `base` and the time rows of a trajectory live in the plan's arena
         plan.x_view.zero_()                                    # init conv of the conditioning image alone (+ bias) -> base
-        _lib.check(_lib.lib().sf_plan_run(plan.init_array, plan.n_init_run, _lib.stream_ptr()), "unet init conv")
+        _lib.check(self.clib.sf_plan_run(plan.init_array, plan.n_init_run, _lib.stream_ptr()), "unet init conv", self.clib)
         plan.base_view.copy_(plan.x0_view)
         return {"plan": plan, "table": self.time_table(log_snrs), "B": B, "generation": plan.generation}
 

@@ -32,6 +32,11 @@ def test_library_built_and_exports_header_symbols():
     assert not missing, f"header declares symbols the .so lacks: {missing}"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     assert _lib.lib().sf_abi_version() >= 1
+    # the IEEE-half operand build (BASELINE configs[4] "fp16 UNet") is the same ABI: every symbol, and it says what it multiplies
+    f16 = ctypes.CDLL(build.build_f16(verbose=False))
+    assert not [n for n in sorted(declared) if not hasattr(f16, n)]
+    assert f16.sf_operand_is_f16() == 1 and handle.sf_operand_is_f16() == 0
+    assert _lib.lib("f16").sf_operand_is_f16() == 1 and _lib.lib("bf16").sf_operand_is_f16() == 0
 
 
 def test_product_never_imports_oracle_or_reference():

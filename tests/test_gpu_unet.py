@@ -36,6 +36,35 @@ def test_unet_forward_matches_reference_golden(name):
     assert rel_err(y0, y[:1]) < TOL_REL and rel_err(y0, g["y"][:1]) < TOL_REL
 
 
+def test_unet_fp16_operands_match_reference_golden():
+    """BASELINE configs[4] "fp16 UNet": the same plan on the IEEE-half operand build of the library (csrc/sf_operand.h,
+    libsparsefusion_hip_f16.so: v_mfma_f32_16x16x32_f16, fp32 accumulate) against the fp32 reference golden -- selected per module
+    with set_operand("f16") or, as a reference user would, with .half()."""
+    name = "canonical"
+    g = torch.load(f"{GOLD}/unet_forward.pt")[name]
+    net = _unet(name).set_operand("f16")
+    assert net.clib.sf_operand_is_f16() == 1
+    x, ls, cond = inputs(CONFIGS[name], g["B"], g["input_seed"])
+    y = net.forward_with_cond_scale(x.to(DEV), ls.to(DEV), cond_images=cond.to(DEV), cond_scale=1.).cpu()
+    r, c = rel_err(y, g["y"]), cosine(y, g["y"])
+    print(f"unet[{name}] fp16 operands: rel L2 err {r:.3e}  cosine {c:.6f}")
+    assert torch.isfinite(y).all() and r < TOL_REL and c > TOL_COS
+    net.set_operand("bf16")                                          # same module on the bf16 build: new plans, other roundings
+    yb = net.forward_with_cond_scale(x.to(DEV), ls.to(DEV), cond_images=cond.to(DEV), cond_scale=1.).cpu()
+    assert rel_err(yb, g["y"]) < TOL_REL and not torch.equal(yb, y)
+    # .half(): parameters in fp16 -> fp16 operands, half in, half out; the sampler fast path runs on the same build
+    name = "small"
+    gs = torch.load(f"{GOLD}/unet_forward.pt")[name]
+    small = _unet(name).half()
+    assert small.operand == "f16"
+    x, ls, cond = inputs(CONFIGS[name], gs["B"], gs["input_seed"])
+    yh = small.forward_with_cond_scale(x.to(DEV).half(), ls.to(DEV), cond_images=cond.to(DEV).half(), cond_scale=1.)
+    assert yh.dtype == torch.float16 and rel_err(yh.float().cpu(), gs["y"]) < TOL_REL
+    ctx = small.begin_sampling(cond.to(DEV), ls.to(DEV))
+    z = small.eval_prepared(ctx, x.to(DEV), 0).clone().cpu()
+    assert rel_err(z[:1], gs["y"][:1]) < TOL_REL
+
+
 def test_unet_layerwise_against_oracle():
     """Intermediate activations (down/mid/up stages) of the small config vs the oracle: localises errors."""
     name = "small"
