@@ -88,6 +88,28 @@ static inline f32x4 sf_mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   w->bar.wait();
   return d;
 }
+// LDS-DMA (global_load_lds_dwordx4) under emulation.  The copy is DEFERRED until the sf_vmcnt<N>() that retires it (the latest moment
+// the hardware may land it: a read that does not sit behind the right counted wait + barrier sees stale data and the test fails);
+// HIPEMU_GLDS_IMMEDIATE=1 lands it at issue instead (the earliest moment: a buffer restaged while another wave still reads it shows).
+struct SfGldsPending { char* dst; const char* src; };
+static thread_local SfGldsPending sf_glds_q[64];
+static thread_local int sf_glds_head = 0, sf_glds_n = 0;
+static inline bool sf_glds_immediate() { static const bool v = getenv("HIPEMU_GLDS_IMMEDIATE") && atoi(getenv("HIPEMU_GLDS_IMMEDIATE")); return v; }
+static inline void sf_glds16(char* lds_wave_base, const void* gsrc) {
+  char* dst = lds_wave_base + hipemu::t_lane * 16;
+  if (sf_glds_immediate()) { memcpy(dst, gsrc, 16); return; }
+  if (sf_glds_n == 64) { fprintf(stderr, "sf_glds16: more than 64 LDS-DMA loads in flight (vmcnt is 6 bits)\n"); abort(); }
+  sf_glds_q[(sf_glds_head + sf_glds_n++) & 63] = SfGldsPending{dst, (const char*)gsrc};
+}
+template <int N>
+static inline void sf_vmcnt() {
+  while (sf_glds_n > N) { memcpy(sf_glds_q[sf_glds_head].dst, sf_glds_q[sf_glds_head].src, 16); sf_glds_head = (sf_glds_head + 1) & 63; --sf_glds_n; }
+}
+static inline void sf_lds_barrier() { hipemu::syncthreads(); }
+#define SF_SCHED_GROUP(mask, n) do { } while (0)
+#define SF_LGKM0() do { } while (0)
+static inline void sf_glds_done() { if (sf_glds_n) { fprintf(stderr, "LDS-DMA loads still in flight at kernel end\n"); abort(); } }
+static const uint32_t sf_zero16[4] __attribute__((aligned(16))) = {0, 0, 0, 0};
 #else
 #include <hip/hip_runtime.h>
 #define SF_KERNEL(...) __global__ __launch_bounds__(__VA_ARGS__)
@@ -132,6 +154,26 @@ SF_DEV void sf_touch_kernarg() {
   asm volatile("" ::"s"(acc));
 #endif
 }
+// LDS-DMA: every lane's 16 bytes at gsrc land at lds_wave_base + lane * 16 (the base is wave-uniform and goes through M0).  As an
+// asm statement the load is INVISIBLE to hipcc's s_waitcnt bookkeeping -- that is the point: a builtin LDS-DMA makes the compiler
+// drain vmcnt(0) at every barrier and before every ds_read, which serialises the ring.  The caller counts: sf_vmcnt<N>() (in issue
+// order), then sf_lds_barrier(), then the ds_read.  No compiler-visible vector load may be in flight while these are.
+typedef __attribute__((address_space(3))) char sf_lds_char;
+SF_DEV void sf_glds16(char* lds_wave_base, const void* gsrc) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(sf_lds_char*)lds_wave_base);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+template <int N>
+SF_DEV void sf_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+// this wave's LDS reads have returned, then the workgroup meets (a raw s_barrier: __syncthreads() would drain the LDS-DMA queue)
+SF_DEV void sf_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+SF_DEV void sf_glds_done() {}
+// scheduling hint: the next n instructions of class `mask` (0x008 MFMA, 0x100 LDS read) go here, in program order of the groups
+#define SF_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#define SF_LGKM0() __builtin_amdgcn_s_waitcnt(0xc07f)      // lgkmcnt(0), visible to the compiler's own counting
+__device__ __attribute__((aligned(16))) static const uint32_t sf_zero16[4] = {0, 0, 0, 0};
 #endif
 
 SF_DEV float sf_silu(float v) { return v / (1.0f + sf_exp(-v)); }

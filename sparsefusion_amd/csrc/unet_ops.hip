@@ -29,7 +29,7 @@
 #include "plan_ops.h"
 #include "sf_dev.h"
 #include "gemm_rows.h"
-#include "conv_lds.h"
+#include "conv_glds.h"
 #include "conv_igemm.h"
 #include "attn_ln.h"
 #include <math.h>
@@ -500,6 +500,32 @@ static void launch_conv(const ConvArgs& a, bool a_fp32, int blocks, hipStream_t 
   else k_conv_igemm<WM, WN, false><<<blocks, 256, 0, st>>>(a);
 }
 
+// k_conv_glds (conv_glds.h): the LDS-tiled conv for operand-type activations, staged by LDS-DMA through a ring of NST buffers.
+// SF_CONV_GLDS = 0 keeps those layers on k_conv_lds (A/B), 3 / 4 picks the ring depth (default 4).
+static int conv_glds_depth() {
+  static const int v = [] { const char* e = getenv("SF_CONV_GLDS"); const int d = e ? atoi(e) : 4; return (d == 3 || d == 4) ? d : 0; }();
+  return v;
+}
+template <int BNF, int NST, bool GN>
+static int launch_conv_glds(const ConvArgs& a, int nblk, double* part, int cg, hipStream_t st) {
+  static unsigned mask = 0;
+  const uint32_t lds = conv_glds_lds_bytes(BNF, NST);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "hipGetDevice failed");
+  if (dev >= 32 || !(mask & (1u << dev))) {             // dynamic LDS above 64 KiB: per kernel and per device
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_glds<BNF, NST, GN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      SF_FAIL(SF_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
+    if (dev < 32) mask |= 1u << dev;
+  }
+  k_conv_glds<BNF, NST, GN><<<nblk, 512, lds, st>>>(a, part, cg);
+  SF_CHECK_LAUNCH("conv_glds");
+  return SF_OK;
+}
+template <int BNF, bool GN>
+static int launch_conv_glds_nst(const ConvArgs& a, int nblk, double* part, int cg, int nst, hipStream_t st) {
+  return nst == 3 ? launch_conv_glds<BNF, 3, GN>(a, nblk, part, cg, st) : launch_conv_glds<BNF, 4, GN>(a, nblk, part, cg, st);
+}
+
 static int run_conv(const sf_op& op, hipStream_t st) {
   ConvArgs a;
   a.in = op.p[0]; a.w = (const bf16x8*)op.p[1]; a.bias = (const float*)op.p[2]; a.out = (float*)op.p[3];
@@ -528,17 +554,22 @@ static int run_conv(const sf_op& op, hipStream_t st) {
   a.steps_per_wave = (a.KS + a.groups * 4 - 1) / (a.groups * 4);
   const int blocks = a.m_tiles * a.n_tiles * a.groups;
   const bool f32 = (op.flags & 1) != 0;
-  if (tile >= 256) {                                   // LDS-tiled large-M kernel: tile = 256 + n-fragments per workgroup
-    const int bnf = tile - 256;
+  if (tile >= 256) {                                   // LDS-tiled large-M kernel: tile = 256 + 16 * sel + n-fragments per workgroup
+    const int bnf = (tile - 256) & 15, sel = (tile - 256) >> 4;      // sel 0: the default kernel; 1: k_conv_lds; 3 / 4: k_conv_glds ring depth
+    if (sel != 0 && sel != 1 && sel != 3 && sel != 4) SF_FAIL(SF_ERR_INVALID, "conv: unknown LDS kernel selector %d", sel);
+    const bool glds_ok = !f32 && a.Cin % 64 == 0 && a.Cout % 4 == 0 && a.ldc % 4 == 0 && a.co_off % 4 == 0 && (bnf == 8 || bnf == 4);
+    if (sel >= 3 && !glds_ok) SF_FAIL(SF_ERR_INVALID, "conv: k_conv_glds takes operand-type activations with Cin %% 64 == 0 and float4-aligned output rows only");
     if (a.groups != 1 || a.pixshuf) SF_FAIL(SF_ERR_INVALID, "conv: the LDS-tiled kernel has no split-K / pixel-shuffle epilogue");
     a.m_tiles = (a.m_frags + 7) / 8;
     a.n_tiles = (a.n_frags + bnf - 1) / bnf;
     const int nblk = a.m_tiles * a.n_tiles;
+    const int glds = (glds_ok && sel != 1) ? (sel >= 3 ? sel : conv_glds_depth()) : 0;
     if (op.flags & 128) {                                // the epilogue also leaves GroupNorm partial sums (conv_lds.h)
       double* part = (double*)op.p[6];
       const int cg = op.i[15];
       if (!part || (cg != 4 && cg != 8 && cg != 16) || a.Cout % cg || a.co_off || a.ldc != a.Cout || (a.Ho * a.Wo) % 128)
         SF_FAIL(SF_ERR_INVALID, "conv: GroupNorm-partials epilogue needs whole rows, 128 | Ho*Wo, group width 4 / 8 / 16");
+      if (glds) return bnf == 8 ? launch_conv_glds_nst<8, true>(a, nblk, part, cg, glds, st) : launch_conv_glds_nst<4, true>(a, nblk, part, cg, glds, st);
       if (bnf == 8) {
         if (f32) k_conv_lds_gn<8, true><<<nblk, 256, 0, st>>>(a, part, cg); else k_conv_lds_gn<8, false><<<nblk, 256, 0, st>>>(a, part, cg);
       } else if (bnf == 4) {
@@ -549,6 +580,7 @@ static int run_conv(const sf_op& op, hipStream_t st) {
       SF_CHECK_LAUNCH("conv_lds_gn");
       return SF_OK;
     }
+    if (glds) return bnf == 8 ? launch_conv_glds_nst<8, false>(a, nblk, nullptr, 0, glds, st) : launch_conv_glds_nst<4, false>(a, nblk, nullptr, 0, glds, st);
     if (bnf == 8) {
       if (f32) k_conv_lds<8, true><<<nblk, 256, 0, st>>>(a); else k_conv_lds<8, false><<<nblk, 256, 0, st>>>(a);
     } else if (bnf == 4) {

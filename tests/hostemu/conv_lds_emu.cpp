@@ -8,12 +8,25 @@
 #include <algorithm>
 using std::min;
 using std::max;
-#include "../../sparsefusion_amd/csrc/conv_lds.h"
+#include "../../sparsefusion_amd/csrc/conv_glds.h"
 
 // gn_part != null: the GroupNorm-partials variant (k_conv_lds_gn) followed by k_gn_finalize into `stats` [B][G][2]
+// glds > 0: k_conv_glds (conv_glds.h) with a ring of `glds` stage buffers instead of k_conv_lds; bf16 activations only
+template <int BNF, int NST, bool GN>
+static void run_glds(const ConvArgs& a, unsigned nblk, double* gn_part, int gn_cg) {
+  hipemu::launch(nblk, 512, conv_glds_lds_bytes(BNF, NST), [&] { k_conv_glds<BNF, NST, GN>(a, gn_part, gn_cg); });
+}
+template <int BNF, bool GN>
+static int run_glds_nst(const ConvArgs& a, unsigned nblk, double* gn_part, int gn_cg, int nst) {
+  if (nst == 3) run_glds<BNF, 3, GN>(a, nblk, gn_part, gn_cg);
+  else if (nst == 4) run_glds<BNF, 4, GN>(a, nblk, gn_part, gn_cg);
+  else return 1;
+  return 0;
+}
+
 extern "C" int emu_conv_lds(const void* in, const uint16_t* w, const float* bias, float* out, const float* resid, int B, int H, int W,
                             int Cin, int Ho, int Wo, int Cout, int ldc, int co_off, int k, int stride, int pad, int bnf, int a_f32,
-                            int accum, int ups, int relu, double* gn_part, int gn_cg, double* stats) {
+                            int accum, int ups, int relu, double* gn_part, int gn_cg, double* stats, int glds) {
   ConvArgs a;
   a.in = in; a.w = reinterpret_cast<const bf16x8*>(w); a.bias = bias; a.out = out; a.resid = resid; a.ws = nullptr;
   a.accum = accum; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.ldc = ldc; a.co_off = co_off;
@@ -27,6 +40,20 @@ extern "C" int emu_conv_lds(const void* in, const uint16_t* w, const float* bias
   a.n_tiles = (a.n_frags + bnf - 1) / bnf;
   a.steps_per_wave = 0;
   const unsigned nblk = (unsigned)(a.m_tiles * a.n_tiles);
+  if (glds) {
+    if (a_f32 || Cin % 64 || Cout % 4 || ldc % 4 || co_off % 4) return 3;
+    if (gn_part && ((Ho * Wo) % 128 || co_off || ldc != Cout || (gn_cg != 4 && gn_cg != 8 && gn_cg != 16))) return 2;
+    int rc;
+    if (bnf == 8) rc = gn_part ? run_glds_nst<8, true>(a, nblk, gn_part, gn_cg, glds) : run_glds_nst<8, false>(a, nblk, nullptr, 0, glds);
+    else if (bnf == 4) rc = gn_part ? run_glds_nst<4, true>(a, nblk, gn_part, gn_cg, glds) : run_glds_nst<4, false>(a, nblk, nullptr, 0, glds);
+    else return 1;
+    if (rc) return rc;
+    if (gn_part) {
+      const int G = Cout / gn_cg, tiles_per_image = Ho * Wo / 128;
+      hipemu::launch((unsigned)B, 256, 0, [&] { k_gn_finalize(gn_part, stats, tiles_per_image, G); });
+    }
+    return 0;
+  }
   if (gn_part) {
     if ((Ho * Wo) % 128 || co_off || ldc != Cout || (gn_cg != 4 && gn_cg != 8 && gn_cg != 16)) return 2;
     if (bnf == 8) {

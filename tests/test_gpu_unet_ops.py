@@ -146,6 +146,57 @@ def test_conv_lds_tiled(case):
         assert torch.allclose(out.cpu()[..., co_off:co_off + Cout], 2 * ref, rtol=4e-4, atol=4e-4)
 
 
+GLDS_CASES = [
+    # B, H, Cin, Cout, k, stride, pad, bnf, resid, relu, ups, gn
+    (1, 64, 128, 128, 3, 1, 1, 8, True, False, False, True),      # SD-VAE 3x3 with GroupNorm partial sums, 32 tiles
+    (1, 128, 256, 256, 3, 1, 1, 8, False, False, False, True),    # 72 stages, 256 workgroups: one per CU, two channel tiles
+    (1, 64, 512, 512, 3, 1, 1, 4, False, False, False, False),    # 64-channel tiles (the 64x64 level), 144 stages
+    (1, 32, 64, 64, 3, 1, 1, 4, False, True, False, False),       # 9 stages, ReLU
+    (1, 40, 192, 200, 3, 1, 1, 8, False, False, False, False),    # ragged: M = 1600 (12.5 tiles), Cout = 200 (12.5 frags)
+    (1, 64, 128, 128, 3, 2, 0, 8, False, False, False, False),    # Downsample addressing: stride 2, pad right/bottom only
+    (1, 32, 128, 128, 3, 1, 1, 8, False, False, True, False),     # Upsample: nearest x2 folded into the addressing
+    (3, 16, 256, 384, 1, 1, 0, 8, True, False, False, False),     # 1x1 (4 stages), odd batch
+    (2, 16, 64, 64, 1, 1, 0, 4, False, False, False, False),      # ONE stage: shorter than the ring
+]
+
+
+@pytest.mark.parametrize("nst", [3, 4])
+@pytest.mark.parametrize("case", GLDS_CASES)
+def test_conv_glds_is_bitwise_conv_lds(case, nst):
+    """k_conv_glds (csrc/conv_glds.h: LDS-DMA ring of `nst` stage buffers, loader / matrix wave specialisation, counted vmcnt) against
+    k_conv_lds on the same operands, both selected explicitly by tile code (256 + 16 * selector + n-fragments): bit-identical output,
+    GroupNorm partial sums to summation order, repeated launches included (a race in the ring would show as run-to-run differences)."""
+    B, H, Cin, Cout, k, stride, pad, bnf, use_res, relu, ups, gn = case
+    g = torch.Generator().manual_seed(Cin + Cout + k + H + nst)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    wp, cpad = _pack_conv(w)
+    assert cpad == Cin
+    xd = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+    Hin = 2 * H if ups else H
+    Ho = Hin // 2 if stride == 2 else (Hin + 2 * pad - k) // stride + 1
+    M = B * Ho * Ho
+    ldc, co_off = (Cout, 0) if gn else (Cout + 8, 4)
+    res = torch.randn(B, Ho, Ho, ldc, generator=g).to(DEV) if use_res else None
+    cg = 4 if Cout <= 128 else 8
+    flags = (16 if ups else 0) | (32 if relu else 0) | (128 if gn else 0)
+    outs = []
+    for sel in (1, nst, nst, nst):
+        out = torch.zeros(B, Ho, Ho, ldc, device=DEV)
+        part = torch.full((max(M // 128, 1), Cout // cg, 2), float("nan"), dtype=torch.float64, device=DEV) if gn else None
+        _run([_op(1, flags, p=(xd, wp, bias.to(DEV), out, res, None, part),
+                  i=(B, Hin, Hin, cpad, Ho, Ho, Cout, ldc, co_off, k, k, stride, pad, 1, 256 + 16 * sel + bnf, cg if gn else 0))])
+        torch.cuda.synchronize()
+        outs.append((out.cpu(), part.cpu() if gn else None))
+    ref, rpart = outs[0]
+    assert ref.abs().max() > 0
+    for got, gpart in outs[1:]:
+        assert torch.equal(got, ref), float((got - ref).abs().max())
+        if gn:                                                        # another (fixed) summation order than k_conv_lds_gn; identical run to run
+            assert torch.allclose(gpart, rpart, rtol=1e-5, atol=1e-4) and torch.equal(gpart, outs[1][1])
+
+
 def test_conv_accumulates_and_pixel_shuffle():
     g = torch.Generator().manual_seed(3)
     B, H, C = 2, 8, 128

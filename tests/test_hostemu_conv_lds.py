@@ -19,7 +19,7 @@ pytestmark = pytest.mark.skipif(not fused.available(), reason="host clang not fo
 
 def _lib():
     srcs = [os.path.join(HERE, "conv_lds_emu.cpp"), os.path.join(HERE, "hip_emu.h")] + \
-           [os.path.join(HERE, "..", "..", "sparsefusion_amd", "csrc", f) for f in ("conv_lds.h", "sf_dev.h")]
+           [os.path.join(HERE, "..", "..", "sparsefusion_amd", "csrc", f) for f in ("conv_lds.h", "conv_lds_body.inc", "conv_glds.h", "sf_dev.h")]
     if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(s) for s in srcs):
         os.makedirs(os.path.dirname(SO), exist_ok=True)
         subprocess.check_call([fused.CLANG, "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + HERE, "-Wall", "-Wno-unused-function",
@@ -80,7 +80,7 @@ def test_conv_lds_matches_conv2d(B, H, Cin, Cout, k, stride, pad, bnf, a_f32, up
     xa = xn if a_f32 else xn.to(torch.bfloat16)
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
     rc = lib.emu_conv_lds(ptr(xa), ptr(wp), ptr(b), ptr(out), ptr(res), B, H, H, Cin, Ho, Ho, Cout, ldc, 0, k, stride, pad, bnf,
-                          int(a_f32), int(accum), ups, relu, None, 0, None)
+                          int(a_f32), int(accum), ups, relu, None, 0, None, 0)
     assert rc == 0
     got = out[:, :Cout]
     assert torch.allclose(got, want, rtol=1e-4, atol=2e-4), float((got - want).abs().max())
@@ -118,10 +118,80 @@ def test_conv_lds_gn_epilogue_statistics(B, H, Cin, Cout, bnf, a_f32, resid, acc
     stats = torch.full((B, G, 2), float("nan"), dtype=torch.float64)
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
     rc = lib.emu_conv_lds(ptr(xa), ptr(wp), ptr(b), ptr(out), ptr(res), B, H, H, Cin, H, H, Cout, Cout, 0, 3, 1, 1, bnf, int(a_f32),
-                          int(accum), 0, 0, ptr(part), cg, ptr(stats))
+                          int(accum), 0, 0, ptr(part), cg, ptr(stats), 0)
     assert rc == 0
     assert torch.allclose(out, want, rtol=1e-4, atol=2e-4)
     o = out.double().view(B, H * H, G, cg)                     # statistics of what the kernel WROTE
     ref = torch.stack([o.sum((1, 3)), (o * o).sum((1, 3))], -1)
     assert torch.allclose(stats, ref, rtol=2e-6, atol=1e-4), float((stats - ref).abs().max())
     assert not bool(torch.isnan(part).any())
+
+
+GLDS_CASES = [
+    # B, H, Cin, Cout, k, stride, pad, bnf, ups, resid, accum, relu, nst, gn
+    (1, 16, 128, 128, 3, 1, 1, 8, 0, False, False, 0, 4, False),    # 18 stages: the steady state of the 4-deep ring and its tail
+    (1, 16, 64, 128, 3, 1, 1, 8, 0, True, False, 0, 3, True),       # 3-deep ring, GroupNorm partial sums, residual
+    (1, 12, 64, 72, 3, 1, 1, 4, 0, True, False, 1, 4, False),       # ragged M = 144 and Cout = 72, ReLU
+    (2, 16, 64, 64, 1, 1, 0, 4, 0, False, True, 0, 4, False),       # 1x1: S = 1 stage, shorter than the ring (prologue and tail only)
+    (2, 16, 128, 64, 1, 1, 0, 4, 0, False, False, 0, 4, False),     # S = 2
+    (2, 16, 192, 64, 1, 1, 0, 4, 0, False, False, 0, 3, False),     # S = 3 on the 3-deep ring
+    (1, 17, 64, 64, 3, 2, 0, 4, 0, False, False, 0, 4, False),      # Downsample: stride 2, pad 0, explicit 8x8 output
+    (1, 16, 64, 128, 3, 1, 1, 8, 1, False, False, 0, 3, False),     # Upsample folded into the addressing (input 8x8)
+    (2, 16, 64, 256, 3, 1, 1, 8, 0, False, True, 0, 4, True),       # two images, two channel tiles, accumulate + partial sums
+    (1, 32, 64, 128, 3, 1, 1, 8, 0, False, False, 0, 4, False),     # 8 tiles: XCD-aware tile order
+]
+
+
+@pytest.mark.parametrize("immediate", [0, 1])
+@pytest.mark.parametrize("B,H,Cin,Cout,k,stride,pad,bnf,ups,resid,accum,relu,nst,gn", GLDS_CASES)
+def test_conv_glds_is_bitwise_k_conv_lds(B, H, Cin, Cout, k, stride, pad, bnf, ups, resid, accum, relu, nst, gn, immediate):
+    """k_conv_glds (conv_glds.h: the same implicit GEMM staged by LDS-DMA through a ring of `nst` buffers with counted waits)
+    against k_conv_lds on the same operands: bit-identical output, GroupNorm partial sums to summation order.  The emulated LDS-DMA lands either at
+    the wait that retires it (immediate = 0: a read ahead of its wait + barrier sees stale data) or at issue (1: a buffer restaged
+    while another wave still reads it shows) -- the two ends of what the hardware may do; run in a subprocess per mode because the
+    mode is read once."""
+    import sys
+    code = f"""
+import sys, ctypes as C, torch
+sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+import test_hostemu_conv_lds as T
+T.glds_vs_lds({B}, {H}, {Cin}, {Cout}, {k}, {stride}, {pad}, {bnf}, {ups}, {resid}, {accum}, {relu}, {nst}, {gn})
+"""
+    env = dict(os.environ, HIPEMU_GLDS_IMMEDIATE=str(immediate))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def glds_vs_lds(B, H, Cin, Cout, k, stride, pad, bnf, ups, resid, accum, relu, nst, gn):
+    lib = _lib()
+    g = torch.Generator().manual_seed(7 * Cin + Cout + H + nst)
+    Hin = H >> ups
+    x = torch.randn(B, Cin, Hin, Hin, generator=g).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    Ho = 8 if stride == 2 else H
+    M = B * Ho * Ho
+    ldc = Cout if gn else Cout + 8
+    res = torch.randn(M, ldc, generator=g) if resid else None
+    out0 = torch.randn(M, ldc, generator=g) if accum else torch.full((M, ldc), float("nan"))
+    wp, cpad = _pack(w)
+    assert cpad == Cin
+    cg = 4 if Cout <= 128 else 8
+    G = Cout // cg
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    outs = []
+    for glds in (0, nst):
+        out = out0.clone()
+        part = torch.full((max(M // 128, 1), G, 2), float("nan"), dtype=torch.float64) if gn else None
+        stats = torch.full((B, G, 2), float("nan"), dtype=torch.float64) if gn else None
+        rc = lib.emu_conv_lds(ptr(x), ptr(wp), ptr(b), ptr(out), ptr(res), B, H, H, Cin, Ho, Ho, Cout, ldc, 0, k, stride, pad, bnf, 0,
+                              int(accum), ups, relu, ptr(part), cg if gn else 0, ptr(stats), glds)
+        assert rc == 0, rc
+        outs.append((out, part, stats))
+    (o0, p0, s0), (o1, p1, s1) = outs
+    assert not bool(torch.isnan(o1[:, :Cout]).any())
+    assert torch.equal(o0[:, :Cout], o1[:, :Cout]), float((o0[:, :Cout] - o1[:, :Cout]).abs().max())
+    if not accum and not gn:
+        assert bool(torch.isnan(o1[:, Cout:]).all())
+    if gn:
+        assert torch.allclose(p0, p1, rtol=1e-5, atol=1e-4) and torch.allclose(s0, s1, rtol=1e-6, atol=1e-4)     # other (fixed) summation order

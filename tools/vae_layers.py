@@ -25,10 +25,8 @@ for kind, x, fn in (("enc", img, vae.encode), ("dec", z, vae.decode)):
         agg.setdefault(key, [0, 0.0])
         agg[key][0] += 1
         agg[key][1] += m / 3
-    for kk, (o, m) in enumerate(zip(plan.ops, acc)):
-        if o.type == 1 and o.i[1] == 128 and o.i[3] == 256 and o.i[6] == 256 and o.i[9] == 3:
-            print(f"   op {kk} flags {o.flags} i={list(o.i)[:16]} {m / 3 * 1e3:.1f} us   prev op type {plan.ops[kk - 1].type} flags {plan.ops[kk - 1].flags}")
-    print(f"== {kind}: conv layers (count, ms total, TFLOP/s)")
+    tot = sum(m for m in acc) / 3
+    print(f"== {kind}: plan {tot:.3f} ms event-timed per op; conv layers (count, ms total, TFLOP/s)")
     for key, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         H, W, Cin, Ho, Wo, Cout, k, tile, f32 = key
         fl = 2.0 * Ho * Wo * Cout * Cin * k * k * n
