@@ -17,7 +17,7 @@
 // A operand: line-shaped loads + source-side swizzle (see the loader below); Cin must be a multiple of 64 (else k_conv_lds).
 // The loads are asm statements hipcc does not count (sf_dev.h: sf_glds16); no compiler-visible vector load is in flight while they
 // are (the loaders have no other loads; the epilogue operands belong to the matrix waves).  Zero padding: a lane whose tap falls
-// outside the image (or whose pixel is past the end) reads 16 zero bytes from sf_zero16 instead -- the source address is
+// outside the image (or whose pixel is past the end) reads its 16 bytes of the zero line sf_zero128 instead -- the source address is
 // per lane, only the LDS destination is wave-linear.  bf16 (operand-type) activations only; fp32 inputs stay on k_conv_lds, which
 // converts in registers.  Same fragment order, same accumulation order, same epilogue as k_conv_lds: the results are bit-identical
 // (tests/test_hostemu_conv_lds.py, tests/test_gpu_unet_ops.py); the GroupNorm partial sums are taken in another (also fixed) order.
@@ -30,6 +30,80 @@
 #ifndef SF_GLDS_EXPERIMENT
 #define SF_GLDS_EXPERIMENT 0
 #endif
+
+// ---- epilogue of the 8-wave tiles (k_conv_glds, k_conv3_halo): the 128 x 16*BNF tile goes through LDS once so that every global
+// access is a full float4 of one row (the fragment layout gives a lane one column of four rows: 64-byte pieces per store
+// instruction, 64 stores per lane; measured 42 -> 33 us on the 128x128 256->256 layer).  All 8 waves write: thread t owns the
+// float4 column c4 = t % (COLS / 4) of rows t / (COLS / 4) + k * (512 / (COLS / 4)).  pix(row) = the row's pixel index in the
+// output tensor or -1.  Host-checked: Cout, ldc, co_off are multiples of 4.  SF_GLDS_EXPERIMENT 9: no epilogue (measurement).
+template <int BNF, int LDS_BYTES, bool GN, class Pix>
+SF_DEV void conv_tile_epilogue(const ConvArgs& a, char* lds, const f32x4 (&acc)[4][BNF / 2], const bool loader, const int wm, const int wn,
+                               const int lane, const int nt, const int mt, double* __restrict__ gn_part, const int gn_cg, Pix pix) {
+#if SF_GLDS_EXPERIMENT == 9
+  return;
+#endif
+  constexpr int WNF = BNF / 2;
+  constexpr int COLS = 16 * BNF, F4 = COLS / 4, RPP = 512 / F4, PITCH = COLS + 4;      // pitch = 4 mod 8 floats: the four row groups of a
+  static_assert(128 * PITCH * 4 <= LDS_BYTES, "the output tile fits the staging buffers");   // fragment store land on disjoint banks
+  float* ot = reinterpret_cast<float*>(lds);
+  sf_lds_barrier();                                // every read of the last stage has returned; no LDS-DMA is in flight
+  if (!loader) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int n = 0; n < WNF; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          ot[(wm * 64 + i * 16 + (lane >> 4) * 4 + r) * PITCH + (wn * WNF + n) * 16 + (lane & 15)] = acc[i][n][r];
+  }
+  sf_sync();
+  const int tid = threadIdx.x;
+  const int c4 = tid % F4, r0 = tid / F4;
+  const int col = nt * COLS + c4 * 4;
+  const bool cok = col < a.Cout;
+  f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (cok && a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + col);
+  float gs = 0.0f, gq = 0.0f;                      // (GN) sums of this thread's four columns over its rows
+#pragma unroll 4
+  for (int row = r0; row < 128; row += RPP) {
+    const long m = pix(row);
+    if (!cok || m < 0) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(ot + row * PITCH + c4 * 4) + bv;
+    const long o = m * a.ldc + a.co_off + col;
+    if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + o);
+    if (a.accum) v += *reinterpret_cast<const f32x4*>(a.out + o);
+    if (a.relu == 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+    } else if (a.relu == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = 0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752f));
+    }
+    *reinterpret_cast<f32x4*>(a.out + o) = v;
+    if (GN) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { gs += v[j]; gq = fmaf(v[j], v[j], gq); }
+    }
+  }
+  if (GN) {
+    // per (pixel tile, group) partial sums in a fixed order: the threads of one float4 column (same c4, RPP apart in t), then the
+    // gn_cg / 4 float4 columns of the group -- no atomics, reproducible bit for bit
+    SF_SHARED float red[2][512];
+    red[0][tid] = gs; red[1][tid] = gq;
+    sf_sync();
+    const int gpt = COLS / gn_cg;                  // groups in this channel tile
+    if (tid < gpt) {
+      const int gcol = nt * COLS + tid * gn_cg;
+      if (gcol < a.Cout) {
+        double s = 0.0, q = 0.0;
+        for (int f = tid * (gn_cg >> 2); f < (tid + 1) * (gn_cg >> 2); ++f)
+          for (int rr = 0; rr < RPP; ++rr) { s += (double)red[0][rr * F4 + f]; q += (double)red[1][rr * F4 + f]; }
+        double* o = gn_part + ((long)mt * (a.Cout / gn_cg) + gcol / gn_cg) * 2;
+        o[0] = s; o[1] = q;
+      }
+    }
+  }
+}
 
 template <int BNF, int NST, bool GN>
 SF_DEV void conv_glds_body(const ConvArgs& a, double* __restrict__ gn_part, const int gn_cg) {
@@ -117,9 +191,9 @@ SF_DEV void conv_glds_body(const ConvArgs& a, double* __restrict__ gn_part, cons
         const sf_opnd* p = in + ((pbase[q] + (long)cy * Ws + cx) * a.Cin + i_cc * 64 + coff[q & 1]);
 #endif
 #if SF_GLDS_EXPERIMENT == 4                     // 4: no A traffic (every lane reads the zero line)
-        const void* src = (ok && i_ks < 0) ? static_cast<const void*>(p) : static_cast<const void*>(sf_zero16);
+        const void* src = (ok && i_ks < 0) ? static_cast<const void*>(p) : static_cast<const void*>(sf_zero128 + (lane & 7) * 4);
 #else
-        const void* src = ok ? static_cast<const void*>(p) : static_cast<const void*>(sf_zero16);
+        const void* src = ok ? static_cast<const void*>(p) : static_cast<const void*>(sf_zero128 + (lane & 7) * 4);
 #endif
         sf_glds16(sb + (2 * lw) * 2048 + q * 1024, src);
       }
@@ -188,73 +262,8 @@ SF_DEV void conv_glds_body(const ConvArgs& a, double* __restrict__ gn_part, cons
       if (++r_buf == NST) r_buf = 0;
     }
   }
-  // ---- epilogue: the tile goes through LDS once so that every global access is a full float4 of one row (the fragment layout
-  // gives a lane one column of four rows: 64-byte pieces per store instruction, 64 stores per lane).  All 8 waves write: thread t
-  // owns the float4 column c4 = t % (COLS / 4) of rows t / (COLS / 4) + k * (512 / (COLS / 4)).  Host-checked: Cout, ldc, co_off
-  // are multiples of 4.  SF_GLDS_EXPERIMENT 9: no epilogue at all (measurement).
-#if SF_GLDS_EXPERIMENT == 9
-  return;
-#endif
-  constexpr int COLS = 16 * BNF, F4 = COLS / 4, RPP = 512 / F4, PITCH = COLS + 4;      // pitch = 4 mod 8 floats: the four row groups of a
-  static_assert(128 * PITCH * 4 <= NST * STAGE, "the output tile fits the ring");       // fragment store land on disjoint banks
-  float* ot = reinterpret_cast<float*>(lds);
-  sf_lds_barrier();                                // every read of the last stage has returned; no LDS-DMA is in flight
-  if (!loader) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int n = 0; n < WNF; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          ot[(wm * 64 + i * 16 + (lane >> 4) * 4 + r) * PITCH + (wn * WNF + n) * 16 + (lane & 15)] = acc[i][n][r];
-  }
-  sf_sync();
-  const int tid = threadIdx.x;
-  const int c4 = tid % F4, r0 = tid / F4;
-  const int col = nt * COLS + c4 * 4;
-  const bool cok = col < a.Cout;
-  f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (cok && a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + col);
-  float gs = 0.0f, gq = 0.0f;                      // (GN) sums of this thread's four columns over its rows
-#pragma unroll 4
-  for (int row = r0; row < 128; row += RPP) {
-    const int m = mt * 128 + row;
-    if (!cok || m >= M) continue;
-    f32x4 v = *reinterpret_cast<const f32x4*>(ot + row * PITCH + c4 * 4) + bv;
-    const long o = (long)m * a.ldc + a.co_off + col;
-    if (a.resid) v += *reinterpret_cast<const f32x4*>(a.resid + o);
-    if (a.accum) v += *reinterpret_cast<const f32x4*>(a.out + o);
-    if (a.relu == 1) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
-    } else if (a.relu == 2) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = 0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752f));
-    }
-    *reinterpret_cast<f32x4*>(a.out + o) = v;
-    if (GN) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { gs += v[j]; gq = fmaf(v[j], v[j], gq); }
-    }
-  }
-  if (GN) {
-    // per (pixel tile, group) partial sums in a fixed order: the threads of one float4 column (same c4, RPP apart in t), then the
-    // gn_cg / 4 float4 columns of the group -- no atomics, reproducible bit for bit
-    SF_SHARED float red[2][512];
-    red[0][tid] = gs; red[1][tid] = gq;
-    sf_sync();
-    const int gpt = COLS / gn_cg;                  // groups in this channel tile
-    if (tid < gpt) {
-      const int gcol = nt * COLS + tid * gn_cg;
-      if (gcol < a.Cout) {
-        double s = 0.0, q = 0.0;
-        for (int f = tid * (gn_cg >> 2); f < (tid + 1) * (gn_cg >> 2); ++f)
-          for (int rr = 0; rr < RPP; ++rr) { s += (double)red[0][rr * F4 + f]; q += (double)red[1][rr * F4 + f]; }
-        double* o = gn_part + ((long)mt * (a.Cout / gn_cg) + gcol / gn_cg) * 2;
-        o[0] = s; o[1] = q;
-      }
-    }
-  }
+  conv_tile_epilogue<BNF, NST * STAGE, GN>(a, lds, acc, loader, wm, wn, lane, nt, mt, gn_part, gn_cg,
+                                           [&](int row) -> long { const int m = mt * 128 + row; return m < M ? (long)m : -1L; });
 }
 
 template <int BNF, int NST, bool GN>

@@ -109,7 +109,7 @@ static inline void sf_lds_barrier() { hipemu::syncthreads(); }
 #define SF_SCHED_GROUP(mask, n) do { } while (0)
 #define SF_LGKM0() do { } while (0)
 static inline void sf_glds_done() { if (sf_glds_n) { fprintf(stderr, "LDS-DMA loads still in flight at kernel end\n"); abort(); } }
-static const uint32_t sf_zero16[4] __attribute__((aligned(16))) = {0, 0, 0, 0};
+static const uint32_t sf_zero128[32] __attribute__((aligned(128))) = {0};
 #else
 #include <hip/hip_runtime.h>
 #define SF_KERNEL(...) __global__ __launch_bounds__(__VA_ARGS__)
@@ -173,7 +173,7 @@ SF_DEV void sf_glds_done() {}
 // scheduling hint: the next n instructions of class `mask` (0x008 MFMA, 0x100 LDS read) go here, in program order of the groups
 #define SF_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #define SF_LGKM0() __builtin_amdgcn_s_waitcnt(0xc07f)      // lgkmcnt(0), visible to the compiler's own counting
-__device__ __attribute__((aligned(16))) static const uint32_t sf_zero16[4] = {0, 0, 0, 0};
+__device__ __attribute__((aligned(128))) static const uint32_t sf_zero128[32] = {0};      // one zero line: an out-of-image pixel's 8 lanes read it like any other line
 #endif
 
 SF_DEV float sf_silu(float v) { return v / (1.0f + sf_exp(-v)); }

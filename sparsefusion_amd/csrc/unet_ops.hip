@@ -29,7 +29,7 @@
 #include "plan_ops.h"
 #include "sf_dev.h"
 #include "gemm_rows.h"
-#include "conv_glds.h"
+#include "conv_halo.h"
 #include "conv_igemm.h"
 #include "attn_ln.h"
 #include <math.h>
@@ -521,6 +521,32 @@ static int launch_conv_glds(const ConvArgs& a, int nblk, double* part, int cg, h
   SF_CHECK_LAUNCH("conv_glds");
   return SF_OK;
 }
+// k_conv3_halo (conv_halo.h): 3x3 / stride 1 / pad 1 layers with the pixel tile's halo staged once per 64-channel chunk.
+// SF_CONV_HALO = 0 keeps them on k_conv_glds (A/B).
+static bool conv_halo_enabled() {
+  static const bool v = [] { const char* e = getenv("SF_CONV_HALO"); return !e || atoi(e) != 0; }();
+  return v;
+}
+template <int BNF, int NST, bool GN>
+static int launch_conv_halo(const ConvArgs& a, int nblk, double* part, int cg, hipStream_t st) {
+  static unsigned mask = 0;
+  const uint32_t lds = conv_halo_lds_bytes(BNF, NST);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "hipGetDevice failed");
+  if (dev >= 32 || !(mask & (1u << dev))) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_halo<BNF, NST, GN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      SF_FAIL(SF_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
+    if (dev < 32) mask |= 1u << dev;
+  }
+  k_conv3_halo<BNF, NST, GN><<<nblk, 512, lds, st>>>(a, part, cg);
+  SF_CHECK_LAUNCH("conv3_halo");
+  return SF_OK;
+}
+template <int BNF, bool GN>
+static int launch_conv_halo_nst(const ConvArgs& a, int nblk, double* part, int cg, int nst, hipStream_t st) {
+  return nst == 3 ? launch_conv_halo<BNF, 3, GN>(a, nblk, part, cg, st) : launch_conv_halo<BNF, 4, GN>(a, nblk, part, cg, st);
+}
+
 template <int BNF, bool GN>
 static int launch_conv_glds_nst(const ConvArgs& a, int nblk, double* part, int cg, int nst, hipStream_t st) {
   return nst == 3 ? launch_conv_glds<BNF, 3, GN>(a, nblk, part, cg, st) : launch_conv_glds<BNF, 4, GN>(a, nblk, part, cg, st);
@@ -555,20 +581,25 @@ static int run_conv(const sf_op& op, hipStream_t st) {
   const int blocks = a.m_tiles * a.n_tiles * a.groups;
   const bool f32 = (op.flags & 1) != 0;
   if (tile >= 256) {                                   // LDS-tiled large-M kernel: tile = 256 + 16 * sel + n-fragments per workgroup
-    const int bnf = (tile - 256) & 15, sel = (tile - 256) >> 4;      // sel 0: the default kernel; 1: k_conv_lds; 3 / 4: k_conv_glds ring depth
-    if (sel != 0 && sel != 1 && sel != 3 && sel != 4) SF_FAIL(SF_ERR_INVALID, "conv: unknown LDS kernel selector %d", sel);
+    const int bnf = (tile - 256) & 15, sel = (tile - 256) >> 4;      // sel 0: the default kernel; 1: k_conv_lds; 3 / 4: k_conv_glds ring depth;
+    if (sel != 0 && sel != 1 && sel != 3 && sel != 4 && sel != 6 && sel != 7)                       // 6 / 7: k_conv3_halo with a 3 / 4 deep weight ring
+      SF_FAIL(SF_ERR_INVALID, "conv: unknown LDS kernel selector %d", sel);
     const bool glds_ok = !f32 && a.Cin % 64 == 0 && a.Cout % 4 == 0 && a.ldc % 4 == 0 && a.co_off % 4 == 0 && (bnf == 8 || bnf == 4);
     if (sel >= 3 && !glds_ok) SF_FAIL(SF_ERR_INVALID, "conv: k_conv_glds takes operand-type activations with Cin %% 64 == 0 and float4-aligned output rows only");
     if (a.groups != 1 || a.pixshuf) SF_FAIL(SF_ERR_INVALID, "conv: the LDS-tiled kernel has no split-K / pixel-shuffle epilogue");
     a.m_tiles = (a.m_frags + 7) / 8;
     a.n_tiles = (a.n_frags + bnf - 1) / bnf;
     const int nblk = a.m_tiles * a.n_tiles;
-    const int glds = (glds_ok && sel != 1) ? (sel >= 3 ? sel : conv_glds_depth()) : 0;
+    const bool halo_ok = glds_ok && conv_halo_ok(a) && M % 128 == 0;
+    if (sel >= 6 && !halo_ok) SF_FAIL(SF_ERR_INVALID, "conv: k_conv3_halo takes 3x3 / stride 1 / pad 1 layers with W %% 16 == 0, H %% 8 == 0 only");
+    const int glds = (glds_ok && sel != 1 && sel < 6) ? (sel >= 3 ? sel : conv_glds_depth()) : 0;
+    const int halo = sel >= 6 ? sel - 3 : ((sel == 0 && halo_ok && glds && conv_halo_enabled()) ? glds : 0);      // ring depth of the halo kernel, 0 = not taken
     if (op.flags & 128) {                                // the epilogue also leaves GroupNorm partial sums (conv_lds.h)
       double* part = (double*)op.p[6];
       const int cg = op.i[15];
       if (!part || (cg != 4 && cg != 8 && cg != 16) || a.Cout % cg || a.co_off || a.ldc != a.Cout || (a.Ho * a.Wo) % 128)
         SF_FAIL(SF_ERR_INVALID, "conv: GroupNorm-partials epilogue needs whole rows, 128 | Ho*Wo, group width 4 / 8 / 16");
+      if (halo) return bnf == 8 ? launch_conv_halo_nst<8, true>(a, nblk, part, cg, halo, st) : launch_conv_halo_nst<4, true>(a, nblk, part, cg, halo, st);
       if (glds) return bnf == 8 ? launch_conv_glds_nst<8, true>(a, nblk, part, cg, glds, st) : launch_conv_glds_nst<4, true>(a, nblk, part, cg, glds, st);
       if (bnf == 8) {
         if (f32) k_conv_lds_gn<8, true><<<nblk, 256, 0, st>>>(a, part, cg); else k_conv_lds_gn<8, false><<<nblk, 256, 0, st>>>(a, part, cg);
@@ -580,6 +611,7 @@ static int run_conv(const sf_op& op, hipStream_t st) {
       SF_CHECK_LAUNCH("conv_lds_gn");
       return SF_OK;
     }
+    if (halo) return bnf == 8 ? launch_conv_halo_nst<8, false>(a, nblk, nullptr, 0, halo, st) : launch_conv_halo_nst<4, false>(a, nblk, nullptr, 0, halo, st);
     if (glds) return bnf == 8 ? launch_conv_glds_nst<8, false>(a, nblk, nullptr, 0, glds, st) : launch_conv_glds_nst<4, false>(a, nblk, nullptr, 0, glds, st);
     if (bnf == 8) {
       if (f32) k_conv_lds<8, true><<<nblk, 256, 0, st>>>(a); else k_conv_lds<8, false><<<nblk, 256, 0, st>>>(a);

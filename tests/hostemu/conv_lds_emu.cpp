@@ -8,7 +8,7 @@
 #include <algorithm>
 using std::min;
 using std::max;
-#include "../../sparsefusion_amd/csrc/conv_glds.h"
+#include "../../sparsefusion_amd/csrc/conv_halo.h"
 
 // gn_part != null: the GroupNorm-partials variant (k_conv_lds_gn) followed by k_gn_finalize into `stats` [B][G][2]
 // glds > 0: k_conv_glds (conv_glds.h) with a ring of `glds` stage buffers instead of k_conv_lds; bf16 activations only
@@ -16,11 +16,18 @@ template <int BNF, int NST, bool GN>
 static void run_glds(const ConvArgs& a, unsigned nblk, double* gn_part, int gn_cg) {
   hipemu::launch(nblk, 512, conv_glds_lds_bytes(BNF, NST), [&] { k_conv_glds<BNF, NST, GN>(a, gn_part, gn_cg); });
 }
+template <int BNF, int NST, bool GN>
+static void run_halo(const ConvArgs& a, unsigned nblk, double* gn_part, int gn_cg) {
+  hipemu::launch(nblk, 512, conv_halo_lds_bytes(BNF, NST), [&] { k_conv3_halo<BNF, NST, GN>(a, gn_part, gn_cg); });
+}
 template <int BNF, bool GN>
 static int run_glds_nst(const ConvArgs& a, unsigned nblk, double* gn_part, int gn_cg, int nst) {
   if (nst == 3) run_glds<BNF, 3, GN>(a, nblk, gn_part, gn_cg);
   else if (nst == 4) run_glds<BNF, 4, GN>(a, nblk, gn_part, gn_cg);
-  else return 1;
+  else if (nst == 6 || nst == 7) {                           // k_conv3_halo with a 3 / 4 deep weight ring
+    if (!conv_halo_ok(a) || (a.B * a.Ho * a.Wo) % 128) return 4;
+    if (nst == 6) run_halo<BNF, 3, GN>(a, nblk, gn_part, gn_cg); else run_halo<BNF, 4, GN>(a, nblk, gn_part, gn_cg);
+  } else return 1;
   return 0;
 }
 
