@@ -80,6 +80,11 @@ SF_DEV void conv_tile_epilogue(const ConvArgs& a, char* lds, const f32x4 (&acc)[
       for (int j = 0; j < 4; ++j) v[j] = 0.5f * v[j] * (1.0f + erff(v[j] * 0.70710678118654752f));
     }
     *reinterpret_cast<f32x4*>(a.out + o) = v;
+    if (a.ws) {                                    // operand-type twin of the output, dense [pixel][Cout]: the A operand of a following conv
+      bf16x4 tw;
+      tw[0] = (sf_opnd)v[0]; tw[1] = (sf_opnd)v[1]; tw[2] = (sf_opnd)v[2]; tw[3] = (sf_opnd)v[3];
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<sf_opnd*>(a.ws) + m * a.Cout + col) = tw;
+    }
     if (GN) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) { gs += v[j]; gq = fmaf(v[j], v[j], gq); }

@@ -16,7 +16,7 @@
 //   line-shaped LDS-DMA (8 lanes per 128-byte line, the permutation on the source address).
 // Waves: 0..3 multiply (2 x 2, four tile rows x 8*BNF channels each); 4, 5 stream the weight ring; 6, 7 stage the halo tile
 // of the NEXT chunk while the nine taps of the current one run.  One raw barrier per stage.
-// Needs: k = 3, stride 1, pad 1, no upsampling, W % 16 == 0, H % 8 == 0, Cin % 64 == 0, operand-type activations.
+// Needs: k = 3, stride 1, pad 1 (a nearest-x2 upsampled input view is fine), W % 16 == 0, H % 8 == 0, Cin % 64 == 0, operand-type activations.
 #pragma once
 #include "conv_glds.h"
 
@@ -61,7 +61,8 @@ SF_DEV void conv_halo_body(const ConvArgs& a, double* __restrict__ gn_part, cons
       const int y = y0 - 1 + hr, x = x0 - 1 + hc;
       const bool ok = (p < 10 * HW_) & (y >= 0) & (y < a.H) & (x >= 0) & (x < a.W);
       const int chunk = (lane & 7) ^ (p & 7);
-      const sf_opnd* in = reinterpret_cast<const sf_opnd*>(a.in) + (((long)b * a.H + (ok ? y : 0)) * a.W + (ok ? x : 0)) * a.Cin + chunk * 8;
+      const int ys = (ok ? y : 0) >> a.ups, xs = (ok ? x : 0) >> a.ups;       // nearest x2 upsampling folded into the addressing: (H, W) are the
+      const sf_opnd* in = reinterpret_cast<const sf_opnd*>(a.in) + (((long)b * (a.H >> a.ups) + ys) * (a.W >> a.ups) + xs) * a.Cin + chunk * 8;      // upsampled dims
       src[j] = ok ? in : reinterpret_cast<const sf_opnd*>(sf_zero128) + (lane & 7) * 8;
       step[j] = ok ? 64 : 0;
     }
@@ -171,6 +172,6 @@ SF_KERNEL(512, 1) void k_conv3_halo(ConvArgs a, double* __restrict__ gn_part, in
 
 static inline uint32_t conv_halo_lds_bytes(int bnf, int nst) { return 2u * 184 * 128 + (uint32_t)nst * bnf * 2 * 1024; }
 static inline bool conv_halo_ok(const ConvArgs& a) {
-  return a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && !a.ups && a.Ho == a.H && a.Wo == a.W && a.W % 16 == 0 && a.H % 8 == 0 &&
+  return a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H && a.Wo == a.W && a.W % 16 == 0 && a.H % 8 == 0 &&
          a.Cin % 64 == 0;
 }

@@ -840,7 +840,7 @@ static int plan_run_impl(const sf_op* ops, uint32_t n_ops, hipStream_t st_main, 
         const int G = op.i[2];
         if (!op.p[0] || !op.p[1] || op.i[0] < 1 || op.i[1] < 1 || G < 1 || G > 256 || 256 % G)
           SF_FAIL(SF_ERR_INVALID, "gn_finalize: bad operands");
-        k_gn_finalize<<<op.i[0], 256, 0, st>>>((const double*)op.p[0], (double*)op.p[1], op.i[1], G);
+        k_gn_finalize<<<op.i[0] * G, 256, 0, st>>>((const double*)op.p[0], (double*)op.p[1], op.i[1], G);
         SF_CHECK_LAUNCH("gn_finalize");
         rc = SF_OK;
         break;

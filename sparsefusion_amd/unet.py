@@ -195,7 +195,7 @@ class _Arena:
 
 class _T:
     """A planned activation: device pointer + logical shape [B, HW, C] (NHWC) or [rows, C]."""
-    __slots__ = ("ptr", "rows", "C", "HW", "lazy", "slots", "writer")
+    __slots__ = ("ptr", "rows", "C", "HW", "lazy", "slots", "writer", "twin")
 
     def __init__(self, ptr, rows, C, HW=None):
         self.ptr, self.rows, self.C, self.HW = ptr, rows, C, HW
@@ -205,6 +205,7 @@ class _T:
         # slots: device pointer of the [rows/16][C/16][2] (sum, sum of squares) table of the materialised values that a
         # GroupNorm-fused conv reads its statistics from (csrc/fused_kernels.h), or None
         self.slots = None
+        self.twin = None            # operand-type copy [rows][C] written by the producing conv's epilogue (_Plan.conv twin=), or None
         # writer: the OP_CONV op (k_conv_lds) that wrote the whole tensor last, or None (experimental GroupNorm-partials epilogue)
         self.writer = None
 
@@ -305,10 +306,12 @@ class _Plan:
 
     # -------- op emitters
     def conv(self, x, x_f32, H, W, wname, bname, out, ldc, co_off, Cout, k, stride=1, pad=0, resid=None, pixshuf=False,
-             defer=False, w_ptr=None, batch=None, out_hw=None, upsampled=False, relu=False, gelu=False):
+             defer=False, w_ptr=None, batch=None, out_hw=None, upsampled=False, relu=False, gelu=False, twin=None):
         """One implicit-GEMM launch.  `w_ptr` replaces the named weight by a device-packed B operand (attention),
         `batch` overrides the plan batch (per-sample GEMMs), `out_hw` the output size (asymmetric padding),
-        `upsampled` makes (H, W) the dims of a nearest-x2 view of the stored [H/2, W/2] input."""
+        `upsampled` makes (H, W) the dims of a nearest-x2 view of the stored [H/2, W/2] input.  `twin`: a dense operand-type
+        [M][Cout] buffer the epilogue of an LDS-tiled kernel also fills (the A operand of a following conv: no fp32 round trip);
+        out.twin is set when the chosen kernel writes it."""
         B = self.B if batch is None else batch
         self.need(x)
         self.need(resid)
@@ -331,8 +334,14 @@ class _Plan:
             blocks = ((m_frags + 7) // 8) * ((n_frags + bnf - 1) // bnf)
             if bnf == 8 and blocks < 256:                     # fewer tiles than CUs: halve the channel tile instead of idling CUs
                 bnf, blocks = 4, ((m_frags + 7) // 8) * ((n_frags + 3) // 4)
-            if blocks >= lds_min:
+            # 3x3 layers k_conv3_halo takes (csrc/conv_halo.h) beat the weight-streaming kernel from 64 tiles on (measured 21 vs 29 us
+            # on the 32x32 512->512 layer); everything else needs lds_min tiles
+            halo = (k == 3 and stride == 1 and pad == 1 and not x_f32 and x.C % 64 == 0 and W % 16 == 0 and H % 8 == 0 and M % 128 == 0
+                    and Cout % 4 == 0 and ldc % 4 == 0 and co_off % 4 == 0 and (Ho, Wo) == (H, W))
+            if blocks >= (min(lds_min, 64) if halo else lds_min):
                 tile, groups, ws = 256 + bnf, 1, 0
+                if twin is not None and ldc == Cout and co_off == 0:
+                    ws = twin.ptr
         defer = bool(defer and not relu and not gelu and 1 < groups <= 8 and not accum and not pixshuf and co_off == 0 and ldc == Cout == out.C and M == out.rows
                      and (self.u.lazy_consumers & 1))
         bias, res = self.wptr(bname) if bname else 0, resid.ptr if resid else 0
@@ -345,6 +354,7 @@ class _Plan:
             self.ws_owners[wi] = out
         out.slots = None
         out.writer = self.ops[-1] if (tile >= 256 and co_off == 0 and ldc == Cout == out.C and M == out.rows) else None
+        out.twin = twin if (twin is not None and tile >= 256 and ws == twin.ptr) else None
         return Ho, Wo
 
     def gn_act(self, x, skip, gname, ss_ptr, out, raw=None, silu=True, groups=8, eps=1e-5):

@@ -94,11 +94,12 @@ class _VaePlan(_Plan):
     def gn(self, x, name, out, silu=True):
         self.gn_act(x, None, name, 0, out, None, silu=silu, groups=32, eps=1e-6)
 
-    def conv3(self, x, x_f32, H, name, out, cout, resid=None):
-        self.conv(x, x_f32, H, H, name + ".weight", name + ".bias", out, cout, 0, cout, 3, 1, 1, resid=resid)
+    def conv3(self, x, x_f32, H, name, out, cout, resid=None, twin=None):
+        self.conv(x, x_f32, H, H, name + ".weight", name + ".bias", out, cout, 0, cout, 3, 1, 1, resid=resid, twin=twin)
 
-    def resnet_block(self, p, x, cout, H):
-        """model.py:119-141 (temb None, dropout 0)."""
+    def resnet_block(self, p, x, cout, H, twin=False):
+        """model.py:119-141 (temb None, dropout 0).  twin: conv2 also leaves its output in operand type (out.twin) for a conv that
+        reads the block output directly (Upsample)."""
         rows, HW, cin = x.rows, H * H, x.C
         a1 = self.bf16(rows, cin, HW)
         self.gn(x, p + ".norm1", a1)
@@ -107,11 +108,13 @@ class _VaePlan(_Plan):
         a2 = self.bf16(rows, cout, HW)
         self.gn(h, p + ".norm2", a2)
         out = self.zf32(rows, cout, HW)
+        tw = self.bf16(rows, cout, HW) if twin else None
         if cin != cout:                                   # out = nin_shortcut(x), then conv2 accumulates into it
-            self.conv(x, True, H, H, p + ".nin_shortcut.weight", p + ".nin_shortcut.bias", out, cout, 0, cout, 1)
-            self.conv3(a2, False, H, p + ".conv2", out, cout)
+            xs = x.twin if self.u.conv_twin else None    # (the producing conv left an operand-type copy: half the bytes, LDS-DMA kernel)
+            self.conv(xs if xs is not None else x, xs is None, H, H, p + ".nin_shortcut.weight", p + ".nin_shortcut.bias", out, cout, 0, cout, 1)
+            self.conv3(a2, False, H, p + ".conv2", out, cout, twin=tw)
         else:
-            self.conv3(a2, False, H, p + ".conv2", out, cout, resid=x)
+            self.conv3(a2, False, H, p + ".conv2", out, cout, resid=x, twin=tw)
         return out
 
     def attn_block(self, p, x, H):
@@ -163,11 +166,14 @@ class _VaePlan(_Plan):
             H = R
             for lv in range(n_lv):
                 for b in range(nres):
-                    h = self.resnet_block(f"encoder.down.{lv}.block.{b}", h, ch * mult[lv], H)
+                    h = self.resnet_block(f"encoder.down.{lv}.block.{b}", h, ch * mult[lv], H,
+                                          twin=(b == nres - 1 and lv != n_lv - 1 and v.conv_twin))
                 if lv != n_lv - 1:                        # Downsample: zero pad right/bottom, conv3x3 stride 2 (model.py:72-76)
                     y = self.zf32(B * (H // 2) ** 2, h.C, (H // 2) ** 2)
-                    self.conv(h, True, H, H, f"encoder.down.{lv}.downsample.conv.weight", f"encoder.down.{lv}.downsample.conv.bias",
-                              y, h.C, 0, h.C, 3, 2, 0, out_hw=(H // 2, H // 2))
+                    src = h.twin                          # operand-type copy from the block's conv2 epilogue, when it runs an LDS-tiled kernel
+                    ytw = self.bf16(y.rows, h.C, y.HW) if (v.conv_twin and ch * mult[lv + 1] != h.C) else None      # ... and one for the next nin_shortcut
+                    self.conv(src if src is not None else h, src is None, H, H, f"encoder.down.{lv}.downsample.conv.weight",
+                              f"encoder.down.{lv}.downsample.conv.bias", y, h.C, 0, h.C, 3, 2, 0, out_hw=(H // 2, H // 2), twin=ytw)
                     h, H = y, H // 2
             h = self.resnet_block("encoder.mid.block_1", h, h.C, H)
             h = self.attn_block("encoder.mid.attn_1", h, H)
@@ -200,11 +206,13 @@ class _VaePlan(_Plan):
             h = self.resnet_block("decoder.mid.block_2", h, block_in, H)
             for lv in reversed(range(n_lv)):
                 for b in range(nres + 1):
-                    h = self.resnet_block(f"decoder.up.{lv}.block.{b}", h, ch * mult[lv], H)
+                    h = self.resnet_block(f"decoder.up.{lv}.block.{b}", h, ch * mult[lv], H, twin=(b == nres and lv != 0 and v.conv_twin))
                 if lv != 0:                               # Upsample: nearest x2 folded into the conv's input addressing (:53-57)
                     y = self.zf32(B * 4 * H * H, h.C, 4 * H * H)
-                    self.conv(h, True, 2 * H, 2 * H, f"decoder.up.{lv}.upsample.conv.weight", f"decoder.up.{lv}.upsample.conv.bias",
-                              y, h.C, 0, h.C, 3, 1, 1, upsampled=True)
+                    src = h.twin                          # the block's conv2 left an operand-type copy: the 3x3 runs on k_conv3_halo
+                    ytw = self.bf16(y.rows, h.C, y.HW) if (v.conv_twin and ch * mult[lv - 1] != h.C) else None      # for the next nin_shortcut
+                    self.conv(src if src is not None else h, src is None, 2 * H, 2 * H, f"decoder.up.{lv}.upsample.conv.weight",
+                              f"decoder.up.{lv}.upsample.conv.bias", y, h.C, 0, h.C, 3, 1, 1, upsampled=True, twin=ytw)
                     h, H = y, 2 * H
             a = self.bf16(h.rows, h.C, H * H)
             self.gn(h, "decoder.norm_out", a)
@@ -276,6 +284,7 @@ class AutoencoderKL(nn.Module):
         self.lds_conv_min_blocks = 96
         # EXPERIMENTAL, not yet measured: GroupNorm statistics from the producing conv's epilogue (csrc/conv_lds.h) instead of a pass
         # over the tensor; parity-checked on CPU threads (tests/test_hostemu_conv_lds.py)
+        self.conv_twin = os.environ.get("SF_VAE_TWIN", "1") != "0"       # Upsample convs read an operand-type twin of the block output (r03) instead of the fp32 tensor; 0 = A/B
         self.gn_epilogue = os.environ.get("SF_VAE_GN_EPI", "1") != "0"   # GroupNorm statistics out of the producing conv's epilogue (r03: encode 1.80 -> 1.72 ms, decode 2.94 -> 2.76 ms); 0 = the statistics pass, A/B
         self._pack_cache, self._plans = None, {}
         if ckpt_path is not None:

@@ -57,7 +57,7 @@ extern "C" int emu_conv_lds(const void* in, const uint16_t* w, const float* bias
     if (rc) return rc;
     if (gn_part) {
       const int G = Cout / gn_cg, tiles_per_image = Ho * Wo / 128;
-      hipemu::launch((unsigned)B, 256, 0, [&] { k_gn_finalize(gn_part, stats, tiles_per_image, G); });
+      hipemu::launch((unsigned)(B * G), 256, 0, [&] { k_gn_finalize(gn_part, stats, tiles_per_image, G); });
     }
     return 0;
   }
@@ -73,7 +73,7 @@ extern "C" int emu_conv_lds(const void* in, const uint16_t* w, const float* bias
       return 1;
     }
     const int G = Cout / gn_cg, tiles_per_image = Ho * Wo / 128;
-    hipemu::launch((unsigned)B, 256, 0, [&] { k_gn_finalize(gn_part, stats, tiles_per_image, G); });
+    hipemu::launch((unsigned)(B * G), 256, 0, [&] { k_gn_finalize(gn_part, stats, tiles_per_image, G); });
     return 0;
   }
   if (bnf == 8) {

@@ -198,12 +198,13 @@ def test_conv_glds_is_bitwise_conv_lds(case, nst):
 
 
 HALO_CASES = [
-    # B, H, W, Cin, Cout, bnf, resid, relu, gn
+    # B, H, W, Cin, Cout, bnf, resid, relu, gn (+ optional: ups)
     (1, 64, 64, 128, 128, 8, True, False, True),       # SD-VAE 3x3 with GroupNorm partial sums: 32 tiles of 8 x 16 pixels
     (1, 128, 128, 256, 256, 8, False, False, True),    # 4 chunks x 9 taps, 256 workgroups, two channel tiles
     (1, 64, 64, 512, 512, 4, False, False, False),     # 64-channel tiles, 8 chunks
     (2, 32, 48, 192, 200, 8, True, True, False),       # two images, W = 48 (3 tile columns), ragged Cout, residual + ReLU
     (1, 8, 16, 64, 64, 4, False, False, False),        # ONE tile: every halo edge lies outside the image
+    (1, 64, 64, 256, 128, 8, False, False, True, 1),   # Upsample: stored 32 x 32, the halo tile of its nearest-x2 view; also fills the twin
 ]
 
 
@@ -212,23 +213,26 @@ HALO_CASES = [
 def test_conv3_halo_matches_conv_lds(case, sel):
     """k_conv3_halo (csrc/conv_halo.h: halo tile of a 64-channel chunk staged once, nine shifted window reads, chunk-major K) against
     k_conv_lds on the same operands: equal to fp32 reassociation, per-image GroupNorm sums equal, identical run to run."""
-    B, H, W, Cin, Cout, bnf, use_res, relu, gn = case
+    B, H, W, Cin, Cout, bnf, use_res, relu, gn = case[:9]
+    ups = case[9] if len(case) > 9 else 0
     g = torch.Generator().manual_seed(Cin + Cout + H + sel)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
     bias = torch.randn(Cout, generator=g)
-    x = torch.randn(B, Cin, H, W, generator=g)
+    x = torch.randn(B, Cin, H >> ups, W >> ups, generator=g)
     wp, cpad = _pack_conv(w)
     xd = x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
     M = B * H * W
     ldc, co_off = (Cout, 0) if gn else (Cout + 8, 4)
     res = torch.randn(B, H, W, ldc, generator=g).to(DEV) if use_res else None
     cg = 4 if Cout <= 128 else 8
-    flags = (32 if relu else 0) | (128 if gn else 0)
-    outs = []
+    flags = (16 if ups else 0) | (32 if relu else 0) | (128 if gn else 0)
+    outs, twins = [], []
     for s_ in (1, sel, sel, sel):
         out = torch.zeros(B, H, W, ldc, device=DEV)
         part = torch.full((M // 128, Cout // cg, 2), float("nan"), dtype=torch.float64, device=DEV) if gn else None
-        _run([_op(1, flags, p=(xd, wp, bias.to(DEV), out, res, None, part),
+        twin = torch.zeros(M, Cout, dtype=torch.bfloat16, device=DEV) if ups else None          # (the twin epilogue rides on the ups case)
+        twins.append(twin)
+        _run([_op(1, flags, p=(xd, wp, bias.to(DEV), out, res, twin, part),
                   i=(B, H, W, cpad, H, W, Cout, ldc, co_off, 3, 3, 1, 1, 1, 256 + 16 * s_ + bnf, cg if gn else 0))])
         torch.cuda.synchronize()
         outs.append((out.cpu(), part.cpu() if gn else None))
@@ -242,12 +246,17 @@ def test_conv3_halo_matches_conv_lds(case, sel):
             assert torch.allclose(gpart.view(B, tpi, -1, 2).sum(1), rpart.view(B, tpi, -1, 2).sum(1), rtol=1e-6, atol=1e-3)
             assert torch.equal(gpart, outs[1][1])
     xr, wr = bf(x), bf(w)
+    if ups:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
     want = F.conv2d(xr, wr, bias, padding=1).permute(0, 2, 3, 1)
     if use_res:
         want = want + res.cpu()[..., co_off:co_off + Cout]
     if relu:
         want = F.relu(want)
     assert torch.allclose(outs[1][0][..., co_off:co_off + Cout], want, rtol=2e-4, atol=2e-4)
+    if ups:                                                           # the operand-type twin = the written output, rounded; both kernels
+        for tw, (o_, _) in zip(twins, outs):
+            assert torch.equal(tw.cpu().view(B, H, W, Cout), o_.to(torch.bfloat16))
 
 
 def test_conv_accumulates_and_pixel_shuffle():

@@ -207,18 +207,19 @@ def glds_vs_lds(B, H, Cin, Cout, k, stride, pad, bnf, ups, resid, accum, relu, n
 
 
 HALO_CASES = [
-    # B, H, Cin, Cout, bnf, resid, accum, relu, nst(6: 3-deep weight ring, 7: 4-deep), gn
-    (1, 16, 128, 128, 8, False, False, 0, 7, False),     # 2 tiles (8 x 16 pixels each), 2 chunks x 9 taps: halo double buffer + ring tail
-    (1, 16, 64, 128, 8, True, False, 0, 6, True),        # one chunk, 3-deep ring, GroupNorm partial sums, residual
-    (2, 16, 192, 72, 4, True, False, 1, 7, False),       # two images, ragged Cout = 72, three chunks, ReLU
-    (1, 32, 64, 64, 4, False, True, 0, 7, True),         # 8 tiles (XCD order), interior tiles with full halos, accumulate + partial sums
-    (1, 8, 64, 256, 8, False, False, 0, 6, False),       # H = 8, W = 16... one tile per image row block: every halo edge is outside
+    # B, H, Cin, Cout, bnf, resid, accum, relu, nst(6: 3-deep weight ring, 7: 4-deep), gn, ups
+    (1, 16, 128, 128, 8, False, False, 0, 7, False, 0),  # 2 tiles (8 x 16 pixels each), 2 chunks x 9 taps: halo double buffer + ring tail
+    (1, 16, 64, 128, 8, True, False, 0, 6, True, 0),     # one chunk, 3-deep ring, GroupNorm partial sums, residual
+    (2, 16, 192, 72, 4, True, False, 1, 7, False, 0),    # two images, ragged Cout = 72, three chunks, ReLU
+    (1, 32, 64, 64, 4, False, True, 0, 7, True, 0),      # 8 tiles (XCD order), interior tiles with full halos, accumulate + partial sums
+    (1, 16, 128, 64, 4, False, False, 0, 7, False, 1),   # Upsample: the halo tile of the nearest-x2 view of a stored 8 x 8 map
+    (1, 8, 64, 256, 8, False, False, 0, 6, False, 0),    # H = 8, W = 16... one tile per image row block: every halo edge is outside
 ]
 
 
 @pytest.mark.parametrize("immediate", [0, 1])
-@pytest.mark.parametrize("B,H,Cin,Cout,bnf,resid,accum,relu,nst,gn", HALO_CASES)
-def test_conv3_halo_matches_k_conv_lds(B, H, Cin, Cout, bnf, resid, accum, relu, nst, gn, immediate):
+@pytest.mark.parametrize("B,H,Cin,Cout,bnf,resid,accum,relu,nst,gn,ups", HALO_CASES)
+def test_conv3_halo_matches_k_conv_lds(B, H, Cin, Cout, bnf, resid, accum, relu, nst, gn, ups, immediate):
     """k_conv3_halo (conv_halo.h: 8 x 16 pixel tiles, the 10 x 18 halo tile of a 64-channel chunk staged once by LDS-DMA and read as
     nine shifted windows, chunk-major K loop) against k_conv_lds: equal to fp32 reassociation, in both LDS-DMA landing modes of the
     emulation (see test_conv_glds_is_bitwise_k_conv_lds)."""
@@ -228,7 +229,7 @@ def test_conv3_halo_matches_k_conv_lds(B, H, Cin, Cout, bnf, resid, accum, relu,
 import sys
 sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
 import test_hostemu_conv_lds as T
-T.glds_vs_lds({B}, {H}, {Cin}, {Cout}, 3, 1, 1, {bnf}, 0, {resid}, {accum}, {relu}, {nst}, {gn}, bitwise=False, W={W})
+T.glds_vs_lds({B}, {H}, {Cin}, {Cout}, 3, 1, 1, {bnf}, {ups}, {resid}, {accum}, {relu}, {nst}, {gn}, bitwise=False, W={W})
 """
     env = dict(os.environ, HIPEMU_GLDS_IMMEDIATE=str(immediate))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)

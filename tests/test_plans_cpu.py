@@ -223,3 +223,33 @@ def test_lds_conv_selection_rule():
     dec = _VaePlan(AutoencoderKL(), "dec", 1, CPU).build()
     big = [o for o in dec.ops if o.type == OP_CONV and o.i[4] >= 128]
     assert big and all(o.i[14] >= 256 or o.i[6] < 64 for o in big)                 # every wide 128^2 / 256^2 conv is LDS-tiled
+
+
+def test_vae_upsample_reads_the_operand_twin(monkeypatch):
+    """r03: the decoder's three Upsample convs read an operand-type twin of the block output that the producing conv2 (an LDS-tiled
+    kernel from 64 tiles on when k_conv3_halo can take the layer, csrc/conv_halo.h) writes in its epilogue -- bf16 A operand, the
+    nearest-x2 view folded into the halo addressing -- instead of the fp32 tensor; SF_VAE_TWIN=0 restores the fp32 read."""
+    from sparsefusion_amd.unet import OP_CONV
+    from sparsefusion_amd.vae import AutoencoderKL, _VaePlan
+    ops = _VaePlan(AutoencoderKL(), "dec", 1, CPU).build().ops
+    ups = [k for k, o in enumerate(ops) if o.type == OP_CONV and o.flags & 16]
+    assert len(ups) == 3
+    for k in ups:
+        o = ops[k]
+        assert not (o.flags & 1) and o.i[14] >= 256                                             # operand-type input, LDS-tiled kernel
+        prod = [q for q in ops[:k] if q.type == OP_CONV and q.p[5] == o.p[0]]
+        assert len(prod) == 1 and prod[0].i[14] >= 256 and prod[0].i[13] == 1                   # written by one LDS-tiled conv (no split-K workspace)
+        assert prod[0].i[6] == prod[0].i[7] == o.i[3] and prod[0].i[8] == 0                     # dense [pixel][Cout] = the consumer's Cin
+        assert prod[0].i[4] * 2 == o.i[1] and prod[0].i[5] * 2 == o.i[2]                        # consumer dims are the upsampled view
+    assert sum(1 for q in ops if q.type == OP_CONV and q.i[14] >= 256 and q.p[5]) == 3 + 2     # + the Upsample convs' own twins for the two nin_shortcuts
+    nin = [o for o in ops if o.type == OP_CONV and o.i[9] == 1 and o.i[3] != o.i[6] and o.i[1] >= 128]
+    assert len(nin) == 2 and all(not (o.flags & 1) and o.i[14] >= 256 for o in nin)              # 1x1 shortcuts on the operand twin
+    enc = _VaePlan(AutoencoderKL(), "enc", 1, CPU).build().ops
+    down = [o for o in enc if o.type == OP_CONV and o.i[11] == 2]
+    assert len(down) == 3 and all(not (o.flags & 1) for o in down)                              # Downsample convs read the block's twin
+    assert all(any(q.type == OP_CONV and q.p[5] == o.p[0] for q in enc) for o in down)
+    assert all(q.i[14] >= 256 for q in ops if q.type == OP_CONV and q.i[9] == 3 and q.i[4] == 32 and q.i[3] == 512 and q.i[6] == 512)   # 32x32 layers: 64 tiles
+    monkeypatch.setenv("SF_VAE_TWIN", "0")
+    ops0 = _VaePlan(AutoencoderKL(), "dec", 1, CPU).build().ops
+    assert all(o.flags & 1 for o in ops0 if o.type == OP_CONV and o.flags & 16)
+    assert not any(q.p[5] for q in ops0 if q.type == OP_CONV and q.i[14] >= 256)
