@@ -651,13 +651,16 @@ class _Plan:
 
     # -------- blocks
     def resnet(self, name, x, skip, cout, H, gca=False, cross=False):
-        if getattr(self.u, "fused", False):
-            y = self.resnet_fused(name, x, skip, cout, H, gca, cross)
-            if y is not None:
-                return y
         B, HW = self.B, H * H
         cin = x.C + (skip.C if skip else 0)
         rows = B * HW
+        # large batches at the 32x32 / 16x16 levels: GroupNorm as its own pass + the 3x3 convs on k_conv3_halo (csrc/conv_halo.h, 700-950
+        # TFLOP/s from 128 tiles on) beat the GroupNorm-fused weight-streaming kernels, which are built for M of a few tiles
+        big = rows >= getattr(self.u, "unfused_min_rows", 1 << 30) and H % 16 == 0 and cin % 64 == 0 and cout % 64 == 0
+        if getattr(self.u, "fused", False) and not big:
+            y = self.resnet_fused(name, x, skip, cout, H, gca, cross)
+            if y is not None:
+                return y
         a1 = self.bf16(rows, cin, HW)
         raw = self.bf16(rows, cin, HW) if cin != cout else None
         self.gn_act(x, skip, f"{name}.block1.groupnorm", 0, a1, raw)
@@ -1041,6 +1044,7 @@ class Unet(nn.Module):
         self.tb_stride = (off + 63) // 64 * 64
         self.conv_waves_target = 1024       # waves wanted per conv launch (4 per CU) before split-K stops
         self.lds_conv_min_blocks = 96       # use k_conv_lds when a layer has at least this many 128 x 128 output tiles
+        self.unfused_min_rows = int(os.environ.get("SF_UNFUSED_ROWS", "8192"))     # ResnetBlocks with B*H*W >= this at the 32x32 / 16x16 levels leave the fused kernels (_Plan.resnet; measured r03: B = 8 eval 3.33 -> 2.96 ms, B = 32 11.5 -> 7.8 ms, B = 4 unchanged)
         self.lazy_consumers = 3             # bit 0: split-K reductions, bit 1: gated residuals are materialised by their first consumer
         # GroupNorm inside the conv launches (k_conv_fused) wherever the layer fits; SF_UNET_FUSED=0 = the first-round plan (A/B runs)
         self.fused = os.environ.get("SF_UNET_FUSED", "1") != "0"
