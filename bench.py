@@ -305,7 +305,8 @@ def unet_roofline(hp, B=1):
 
 
 def lds_conv_roofline(hp):
-    """MFMA-bound companion of `roofline`: the LDS-tiled large-M convs (k_conv_lds) of one SD-VAE decode, event-timed per op
+    """MFMA-bound companion of `roofline`: the LDS-tiled large-M convs of one SD-VAE decode (k_conv3_halo where the layer is a 3x3 /
+    stride 1 with operand-type input, k_conv_glds for the other operand-type layers, k_conv_lds for fp32 inputs), event-timed per op
     on the launch stream; FLOPs are the algorithmic 2*M*N*K of each layer (padding and out-of-image taps not counted)."""
     import ctypes as C
     from sparsefusion_amd import _lib
@@ -322,7 +323,7 @@ def lds_conv_roofline(hp):
     acc /= 3
     flops, t, n = 0.0, 0.0, 0
     for o, m in zip(plan.ops, acc):
-        if o.type == OP_CONV and o.i[14] >= 256:                   # tile code 256 + n-fragments = k_conv_lds
+        if o.type == OP_CONV and o.i[14] >= 256:                   # tile code 256 + n-fragments = the LDS-tiled kernels
             B, Cin, Ho, Wo, Cout, k = o.i[0], o.i[3], o.i[4], o.i[5], o.i[6], o.i[9]
             flops += 2.0 * B * Ho * Wo * Cout * Cin * k * k
             t += float(m)
@@ -330,7 +331,7 @@ def lds_conv_roofline(hp):
     if not n:
         return None
     achieved = flops / (t * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "k_conv_lds (SD-VAE decode, %d layers)" % n, "achieved": round(achieved, 1), "peak": 2500.0,
+    return {"bound": "mfma", "kernel": "k_conv3_halo / k_conv_glds / k_conv_lds (SD-VAE decode, %d LDS-tiled layers)" % n, "achieved": round(achieved, 1), "peak": 2500.0,
             "unit": "TFLOP/s", "frac": round(achieved / 2500.0, 4), "gflop": round(flops / 1e9, 1), "ms": round(t, 3)}
 
 
