@@ -14,6 +14,7 @@ Forward = 13 implicit-GEMM convs (bf16 MFMA operands, fp32 accumulate, ReLU in t
 epilogue.  No CPU fallback."""
 import math
 
+import os
 import torch
 import torch.nn as nn
 
@@ -65,7 +66,13 @@ class _LpipsPlan(_Plan):
                 h, H, cur = y, H // 2, sl
             y = self.zf32(B * H * H, cout, H * H)
             name = f"net.slice{sl}.{idx}"
-            self.conv(h, True, H, H, name + ".weight", name + ".bias", y, cout, 0, cout, 3, 1, 1, relu=True)
+            # a conv followed by a conv of the same slice also leaves its ReLU output in operand type (r03): the next conv then runs on
+            # k_conv3_halo (csrc/conv_halo.h) instead of converting fp32 in registers on k_conv_lds; same rounding, same operands
+            nxt = ci + 1 < len(VGG_CONVS) and VGG_CONVS[ci + 1][0] == sl and getattr(self.u, "conv_twin", True)
+            tw = self.bf16(B * H * H, cout, H * H) if nxt else None
+            src = h.twin if getattr(self.u, "conv_twin", True) else None
+            self.conv(src if src is not None else h, src is None, H, H, name + ".weight", name + ".bias", y, cout, 0, cout, 3, 1, 1,
+                      relu=True, twin=tw)
             self.conv_in.append(h)
             self.conv_out.append(y)
             h = y
@@ -160,6 +167,7 @@ class LPIPS(nn.Module):
         self.lazy_consumers = 0
         self.ss_total = 0
         self.lds_conv_min_blocks = 96
+        self.conv_twin = os.environ.get("SF_LPIPS_TWIN", "1") != "0"     # conv -> conv links of a VGG slice in operand type (r03); 0 = fp32 reads, A/B
         self._pack_cache, self._plans, self._serial = None, {}, 0
         # the `lpips` package ships pretrained VGG16 + learned lin heads; this module starts from a seeded random init and has
         # no network access: until load_state_dict() brings real weights the distance is NOT the LPIPS metric

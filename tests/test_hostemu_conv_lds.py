@@ -142,8 +142,12 @@ GLDS_CASES = [
 ]
 
 
-@pytest.mark.parametrize("immediate", [0, 1])
-@pytest.mark.parametrize("B,H,Cin,Cout,k,stride,pad,bnf,ups,resid,accum,relu,nst,gn", GLDS_CASES)
+def _glds_params(cases, early):
+    """Every case with the LDS-DMA landing late; the cases listed in `early` also with it landing at issue (suite time)."""
+    return [c + (0,) for c in cases] + [cases[i] + (1,) for i in early]
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,stride,pad,bnf,ups,resid,accum,relu,nst,gn,immediate", _glds_params(GLDS_CASES, (0, 1, 5)))
 def test_conv_glds_is_bitwise_k_conv_lds(B, H, Cin, Cout, k, stride, pad, bnf, ups, resid, accum, relu, nst, gn, immediate):
     """k_conv_glds (conv_glds.h: the same implicit GEMM staged by LDS-DMA through a ring of `nst` buffers with counted waits)
     against k_conv_lds on the same operands: bit-identical output, GroupNorm partial sums to summation order.  The emulated LDS-DMA lands either at
@@ -217,8 +221,7 @@ HALO_CASES = [
 ]
 
 
-@pytest.mark.parametrize("immediate", [0, 1])
-@pytest.mark.parametrize("B,H,Cin,Cout,bnf,resid,accum,relu,nst,gn,ups", HALO_CASES)
+@pytest.mark.parametrize("B,H,Cin,Cout,bnf,resid,accum,relu,nst,gn,ups,immediate", _glds_params(HALO_CASES, (0, 2)))
 def test_conv3_halo_matches_k_conv_lds(B, H, Cin, Cout, bnf, resid, accum, relu, nst, gn, ups, immediate):
     """k_conv3_halo (conv_halo.h: 8 x 16 pixel tiles, the 10 x 18 halo tile of a 64-channel chunk staged once by LDS-DMA and read as
     nine shifted windows, chunk-major K loop) against k_conv_lds: equal to fp32 reassociation, in both LDS-DMA landing modes of the
