@@ -137,8 +137,8 @@ GLDS_CASES = [
     (2, 16, 192, 64, 1, 1, 0, 4, 0, False, False, 0, 3, False),     # S = 3 on the 3-deep ring
     (1, 17, 64, 64, 3, 2, 0, 4, 0, False, False, 0, 4, False),      # Downsample: stride 2, pad 0, explicit 8x8 output
     (1, 16, 64, 128, 3, 1, 1, 8, 1, False, False, 0, 3, False),     # Upsample folded into the addressing (input 8x8)
-    (2, 16, 64, 256, 3, 1, 1, 8, 0, False, True, 0, 4, True),       # two images, two channel tiles, accumulate + partial sums
-    (1, 32, 64, 128, 3, 1, 1, 8, 0, False, False, 0, 4, False),     # 8 tiles: XCD-aware tile order
+    (2, 16, 64, 128, 3, 1, 1, 4, 0, False, True, 0, 4, True),       # two images, two channel tiles, accumulate + partial sums
+    (1, 32, 64, 64, 3, 1, 1, 4, 0, False, False, 0, 4, False),      # 8 tiles: XCD-aware tile order
 ]
 
 
@@ -214,14 +214,14 @@ HALO_CASES = [
     # B, H, Cin, Cout, bnf, resid, accum, relu, nst(6: 3-deep weight ring, 7: 4-deep), gn, ups
     (1, 16, 128, 128, 8, False, False, 0, 7, False, 0),  # 2 tiles (8 x 16 pixels each), 2 chunks x 9 taps: halo double buffer + ring tail
     (1, 16, 64, 128, 8, True, False, 0, 6, True, 0),     # one chunk, 3-deep ring, GroupNorm partial sums, residual
-    (2, 16, 192, 72, 4, True, False, 1, 7, False, 0),    # two images, ragged Cout = 72, three chunks, ReLU
+    (2, 16, 128, 72, 4, True, False, 1, 7, False, 0),    # two images, ragged Cout = 72, two chunks, ReLU
     (1, 32, 64, 64, 4, False, True, 0, 7, True, 0),      # 8 tiles (XCD order), interior tiles with full halos, accumulate + partial sums
     (1, 16, 128, 64, 4, False, False, 0, 7, False, 1),   # Upsample: the halo tile of the nearest-x2 view of a stored 8 x 8 map
     (1, 8, 64, 256, 8, False, False, 0, 6, False, 0),    # H = 8, W = 16... one tile per image row block: every halo edge is outside
 ]
 
 
-@pytest.mark.parametrize("B,H,Cin,Cout,bnf,resid,accum,relu,nst,gn,ups,immediate", _glds_params(HALO_CASES, (0, 2)))
+@pytest.mark.parametrize("B,H,Cin,Cout,bnf,resid,accum,relu,nst,gn,ups,immediate", _glds_params(HALO_CASES, (0, 1)))
 def test_conv3_halo_matches_k_conv_lds(B, H, Cin, Cout, bnf, resid, accum, relu, nst, gn, ups, immediate):
     """k_conv3_halo (conv_halo.h: 8 x 16 pixel tiles, the 10 x 18 halo tile of a 64-channel chunk staged once by LDS-DMA and read as
     nine shifted windows, chunk-major K loop) against k_conv_lds: equal to fp32 reassociation, in both LDS-DMA landing modes of the

@@ -13,8 +13,14 @@ from hostemu import fused
 pytestmark = pytest.mark.skipif(not fused.available(), reason="host clang not found")
 
 
+# 15-45 s of thread emulation each: by default only on the GPU (tests/test_gpu_fused.py runs every case); SF_SLOW_TESTS=1 runs them here too
+HEAVY_ON_CPU = {"pipe_pool_16x16_tr2", "gn_slots_xcd_map_16x16", "pipe_gn_slots_16x16_tr2_wn2", "pipe_pool_16x16_wn2", "pipe_pair_gn_slots_16x16_tr2"}
+
+
 @pytest.mark.parametrize("name", sorted(fc.CONV_CASES))
 def test_fused_conv_on_cpu_threads(name):
+    if name in HEAVY_ON_CPU and not os.environ.get("SF_SLOW_TESTS"):
+        pytest.skip("heavy emulation case: SF_SLOW_TESTS=1 (covered on the GPU by tests/test_gpu_fused.py)")
     fc.run_conv_case("emu", **fc.CONV_CASES[name])
 
 
