@@ -185,7 +185,7 @@ int sf_ngp_render_forward(const sf_ngp_field* f, const float* rays_o,
                           uint32_t u_fine_row_stride, float bg_color, float* nears,
                           float* fars, float* z_sorted, float* sigma_s,
                           float* rgb_s, float* image, float* depth,
-                          float* weights_sum, float* workspace,
+                          float* weights_sum, float* field_cache, float* workspace,
                           uint64_t workspace_bytes, void* stream);
 
 /* Backward of sf_ngp_render_forward w.r.t. the field parameters given
@@ -200,11 +200,18 @@ int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_grad* g,
                            const float* z_sorted, const float* sigma_s,
                            const float* rgb_s, float bg_color,
                            const float* grad_image, const float* grad_weights_sum,
-                           uint32_t rays_per_row,
+                           uint32_t rays_per_row, const float* field_cache,
                            float* workspace, uint64_t workspace_bytes,
                            void* stream);
 
 uint64_t sf_ngp_render_workspace_bytes(uint32_t N, uint32_t T);
+
+/* field_cache (both calls; NULL = none): sf_ngp_render_cache_bytes(N, T) bytes the forward fills with the hash-grid features of
+ * every sample ([N*T][32] coarse, [N*T][32] fine) and the sort permutation ([N][2T] u32); the backward then reads a sample's
+ * features back instead of re-gathering 16 levels x 8 corners (the reference's autograd keeps the encoder output alive the
+ * same way: external/gridencoder/grid.py:42-47 saves inputs / embeddings / dy_dx for its backward).  The caller keeps the
+ * buffer untouched between the two calls. */
+uint64_t sf_ngp_render_cache_bytes(uint32_t N, uint32_t T);
 
 /* Fused evaluation render through the occupancy grid (`cuda_ray=True`, eval mode): replaces the host loop
  * `while step < max_steps: march_rays -> network -> composite_rays` of external/nerf/renderer_df.py:543-584 by ONE

@@ -92,11 +92,12 @@ SIGNATURES = {
     "sf_ngp_density": (C.c_int, [C.POINTER(SfNgpField), c_f32p, u32, c_f32p, c_f32p, C.c_void_p]),
     "sf_ngp_render_forward": (C.c_int, [C.POINTER(SfNgpField), c_f32p, c_f32p, c_f32p, u32, u32, C.c_float,
                                         c_f32p, c_f32p, c_f32p, u32, C.c_float, c_f32p, c_f32p, c_f32p, c_f32p,
-                                        c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, u64, C.c_void_p]),
+                                        c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, u64, C.c_void_p]),
     "sf_ngp_render_backward": (C.c_int, [C.POINTER(SfNgpField), C.POINTER(SfNgpFieldGrad), c_f32p, c_f32p,
                                          c_f32p, u32, u32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
-                                         C.c_float, c_f32p, c_f32p, u32, c_f32p, u64, C.c_void_p]),
+                                         C.c_float, c_f32p, c_f32p, u32, c_f32p, c_f32p, u64, C.c_void_p]),
     "sf_ngp_render_workspace_bytes": (u64, [u32, u32]),
+    "sf_ngp_render_cache_bytes": (u64, [u32, u32]),
     "sf_ngp_render_occ_eval": (C.c_int, [C.POINTER(SfNgpField), c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_float, u32, u32, u32,
                                          c_f32p, C.c_float, u32, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "sf_plan_run": (C.c_int, [C.POINTER(SfOp), u32, C.c_void_p]),

@@ -20,7 +20,8 @@ struct CompositeArgs {
   float bg;
   float* z_s; float* sig_s; float* rgb_s;                        // sorted ray [N][2T], [N][2T], [N][2T][3] (kept for the backward)
   float* image; float* depth; float* weights_sum;                // [N][3], [N], [N]
-};
+  uint32_t* perm;                                                // or null: [N][2T] index in cat([coarse, fine]) of every sorted sample
+};                                                               // (the field backward finds a sample's cached features through it)
 
 SF_DEV uint32_t ngp_sort_key(float z) {
   const uint32_t b = __builtin_bit_cast(uint32_t, z);
@@ -59,6 +60,10 @@ SF_KERNEL(256) void k_ngp_composite_wave(CompositeArgs a) {
   if (have) {
     sz[rank0] = zv[0]; ss[rank0] = sv[0]; sr[rank0 * 3 + 0] = cv[0][0]; sr[rank0 * 3 + 1] = cv[0][1]; sr[rank0 * 3 + 2] = cv[0][2];
     sz[rank1] = zv[1]; ss[rank1] = sv[1]; sr[rank1 * 3 + 0] = cv[1][0]; sr[rank1 * 3 + 1] = cv[1][1]; sr[rank1 * 3 + 2] = cv[1][2];
+    if (a.perm) {
+      a.perm[(size_t)n * M + rank0] = lane;
+      a.perm[(size_t)n * M + rank1] = T + lane;
+    }
   }
   sf_wave_sync();                                              // LDS writes of this wave are read back by other lanes of it
   // ---- sorted positions 2 lane, 2 lane + 1

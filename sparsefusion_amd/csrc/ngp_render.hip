@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_ngp_field(
     const float* __restrict__ aabb, const float* __restrict__ nears, const float* __restrict__ fars,
     const float* __restrict__ lin, const float* __restrict__ u, const float* __restrict__ z_in,
     const float* __restrict__ xyz_in, uint32_t P, uint32_t T, float* __restrict__ z_out,
-    float* __restrict__ sigma, float* __restrict__ rgb) {
+    float* __restrict__ sigma, float* __restrict__ rgb, float* __restrict__ feat_out = nullptr) {
   __shared__ __attribute__((aligned(16))) float W[NGP_WTOTAL];
   load_weights_lds(W, f);
   __syncthreads();
@@ -71,6 +71,11 @@ __global__ __launch_bounds__(256) void k_ngp_field(
     const bool inside = ngp_unit(x, f.bound, x01);
     float feat[NGP_FEAT], h1[NGP_HID], h2[NGP_HID], out[NGP_OUT];
     ngp_encode(lv, f.table, x01, inside, feat);
+    if (feat_out) {                                   // field cache for the backward (sf_ngp_render_forward): one 128-byte row per point
+#pragma unroll
+      for (int j = 0; j < NGP_FEAT / 4; ++j)
+        *reinterpret_cast<float4*>(feat_out + (size_t)p * NGP_FEAT + 4 * j) = make_float4(feat[4 * j], feat[4 * j + 1], feat[4 * j + 2], feat[4 * j + 3]);
+    }
     ngp_mlp_forward(W, feat, h1, h2, out);
     sigma[p] = expf(out[0] + ngp_blob(x));
     rgb[p * 3 + 0] = ngp_sigmoid(out[1]);
@@ -295,12 +300,17 @@ extern "C" uint64_t sf_ngp_render_workspace_bytes(uint32_t N, uint32_t T) {
   return (uint64_t)(8 + 4 * NGP_MAX_LEVELS) * N * T * sizeof(float);
 }
 
+extern "C" uint64_t sf_ngp_render_cache_bytes(uint32_t N, uint32_t T) {
+  return ((uint64_t)2 * N * T * NGP_FEAT + (uint64_t)N * 2 * T) * sizeof(float);
+}
+
 extern "C" int sf_ngp_render_forward(const sf_ngp_field* f, const float* rays_o, const float* rays_d,
                                      const float* aabb, uint32_t N, uint32_t T, float min_near,
                                      const float* lin, const float* u_coarse, const float* u_fine,
                                      uint32_t u_fine_row_stride, float bg_color, float* nears, float* fars,
                                      float* z_sorted, float* sigma_s, float* rgb_s, float* image, float* depth,
-                                     float* weights_sum, float* workspace, uint64_t workspace_bytes, void* stream) {
+                                     float* weights_sum, float* field_cache, float* workspace, uint64_t workspace_bytes,
+                                     void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (N == 0) return SF_OK;
   if (T < 4 || T > 64) SF_FAIL(SF_ERR_INVALID, "ngp_render: T must be in [4,64]");
@@ -315,9 +325,14 @@ extern "C" int sf_ngp_render_forward(const sf_ngp_field* f, const float* rays_o,
   const FieldPtrs fp = field_ptrs(f);
   const uint32_t P = (uint32_t)NT;
   const uint32_t gridp = sf_grid_cap(sf_div_up(P, 256));
+  // field cache (or NULL): [N*T][32] coarse features | [N*T][32] fine features | [N][2T] u32 sort permutation
+  float* feat_c = field_cache;
+  float* feat_f = field_cache ? field_cache + NT * NGP_FEAT : nullptr;
+  uint32_t* perm = field_cache ? reinterpret_cast<uint32_t*>(field_cache + 2 * NT * NGP_FEAT) : nullptr;
   // EXPERIMENTAL (SF_NGP_FWD_MFMA=1): hidden layers of the field on the matrix cores (ngp_fwd_mfma.h); parity-green, measured
   // slower in its first shape (render forward 1.34 vs 1.12 ms) -- the default stays the VALU kernel.
   static const bool fwd_mfma = getenv("SF_NGP_FWD_MFMA") && atoi(getenv("SF_NGP_FWD_MFMA")) != 0;
+  if (fwd_mfma && field_cache) SF_FAIL(SF_ERR_INVALID, "ngp_render: the experimental MFMA forward does not fill the field cache (pass NULL)");
   FFArgs fa;
   uint32_t grid_ff = 0;
   const size_t lds_ff = (size_t)FF_LDS_FLOATS * sizeof(float);
@@ -341,7 +356,7 @@ extern "C" int sf_ngp_render_forward(const sf_ngp_field* f, const float* rays_o,
     k_ngp_field_fwd_mfma<<<grid_ff, 256, lds_ff, st>>>(fa);
   } else {
     k_ngp_field<0><<<gridp, 256, 0, st>>>(fp, lv, rays_o, rays_d, aabb, nears, fars, lin, u_coarse, nullptr, nullptr, P, T,
-                                          z_c, sig_c, rgb_c);
+                                          z_c, sig_c, rgb_c, feat_c);
   }
   SF_CHECK_LAUNCH("ngp_field_coarse");
   const uint32_t gridr = sf_div_up(N, 64);
@@ -353,13 +368,13 @@ extern "C" int sf_ngp_render_forward(const sf_ngp_field* f, const float* rays_o,
     k_ngp_field_fwd_mfma<<<grid_ff, 256, lds_ff, st>>>(fa);
   } else {
     k_ngp_field<1><<<gridp, 256, 0, st>>>(fp, lv, rays_o, rays_d, aabb, nears, fars, nullptr, nullptr, z_f, nullptr, P, T,
-                                          nullptr, sig_f, rgb_f);
+                                          nullptr, sig_f, rgb_f, feat_f);
   }
   SF_CHECK_LAUNCH("ngp_field_fine");
   // one WAVE per ray: rank sort of cat([coarse, fine]) by readlane keys + scans (ngp_composite_wave.h)
   k_ngp_composite_wave<<<sf_div_up(N, 4), 256, 4 * 5 * 2 * T * sizeof(float), st>>>(
       CompositeArgs{z_c, sig_c, rgb_c, z_f, sig_f, rgb_f, nears, fars, N, T, bg_color, z_sorted, sigma_s, rgb_s, image, depth,
-                    weights_sum});
+                    weights_sum, perm});
   SF_CHECK_LAUNCH("ngp_composite");
   return SF_OK;
 }
@@ -369,7 +384,7 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
                                       const float* nears, const float* fars, const float* z_sorted,
                                       const float* sigma_s, const float* rgb_s, float bg_color,
                                       const float* grad_image, const float* grad_weights_sum, uint32_t rays_per_row,
-                                      float* workspace, uint64_t workspace_bytes, void* stream) {
+                                      const float* field_cache, float* workspace, uint64_t workspace_bytes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (N == 0) return SF_OK;
   if (T < 4 || T > 64) SF_FAIL(SF_ERR_INVALID, "ngp_render: T must be in [4,64]");
@@ -436,13 +451,16 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
   const uint32_t Pc = Nc * T2;
   for (uint32_t c = 0; c < n_chunks; ++c) {
     // matrix-core field backward of chunk c: one wave per 32 points and trip, six fp32 GEMMs on v_mfma_f32_16x16x4_f32 (ngp_bwd_mfma.h)
-    FBArgs a;
+    FBArgs a{};
     a.table = f->embeddings; a.w0 = f->w0; a.b0 = f->b0; a.w1 = f->w1; a.b1 = f->b1; a.w2 = f->w2; a.b2 = f->b2; a.bound = f->bound;
     a.g_w0 = g->g_w0; a.g_b0 = g->g_b0; a.g_w1 = g->g_w1; a.g_b1 = g->g_b1; a.g_w2 = g->g_w2; a.g_b2 = g->g_b2;
     a.lv = lv;
     a.rays_o = rays_o + (size_t)c * Nc * 3; a.rays_d = rays_d + (size_t)c * Nc * 3; a.aabb = aabb;
     a.z_s = z_sorted + (size_t)c * Pc; a.dsig = dsig + (size_t)c * Pc; a.drgb = drgb + (size_t)c * Pc * 3; a.dfeat_out = dfeat;
     a.P = Pc; a.T2 = T2; a.dfeat_P = (uint32_t)M; a.p_off = c * Pc;
+    a.feat_c = field_cache;                           // (or all three null: the kernel re-gathers the features)
+    a.feat_f = field_cache ? field_cache + (size_t)N * T * NGP_FEAT : nullptr;
+    a.perm = field_cache ? reinterpret_cast<const uint32_t*>(field_cache + 2 * (size_t)N * T * NGP_FEAT) : nullptr;
     const uint32_t trips = sf_div_up(Pc, FB_PTS);
     const uint32_t grid = trips < 1024 ? sf_div_up(trips, 4) : 256;   // one resident workgroup per CU (LDS-bound), 4 waves each
     k_ngp_field_bwd_mfma<<<grid, 256, lds2, st>>>(a);

@@ -28,13 +28,34 @@ extern "C" void emu_field_bwd(const float* table, const int32_t* h_offsets, uint
                               float bound, const float* rays_o, const float* rays_d, const float* aabb, const float* z_s,
                               const float* dsig, const float* drgb, uint32_t P, uint32_t T2, uint32_t grid, int use_ref,
                               float* g_w0, float* g_b0, float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* dfeat) {
-  FBArgs a;
+  // use_ref == 2: the kernel on a field cache (features + permutation as the forward would leave them) instead of the re-gather
+  std::vector<float> fc, ff;
+  std::vector<uint32_t> perm;
+  if (use_ref == 2) {
+    NgpLevels lv0;
+    fill_levels(&lv0, h_offsets, L, S, H, gridtype);
+    const uint32_t T = T2 / 2, N = (P + T2 - 1) / T2;
+    fc.assign((size_t)N * T * NGP_FEAT, 0.f); ff.assign((size_t)N * T * NGP_FEAT, 0.f); perm.assign((size_t)N * T2, 0);
+    for (uint32_t p = 0; p < P; ++p) {
+      const uint32_t n = p / T2, m = p - n * T2;
+      const uint32_t src = (m * 7 + 3) % T2;                 // some permutation of the ray's samples (7 is odd, T2 a power of two... or coprime)
+      perm[p] = src;
+      float x[3], x01[3], feat[NGP_FEAT];
+      ngp_point(rays_o + n * 3, rays_d + n * 3, z_s[p], aabb, x);
+      const bool inside = ngp_unit(x, bound, x01);
+      ngp_encode(lv0, table, x01, inside, feat);
+      float* row = src < T ? &fc[((size_t)n * T + src) * NGP_FEAT] : &ff[((size_t)n * T + (src - T)) * NGP_FEAT];
+      for (int i = 0; i < NGP_FEAT; ++i) row[i] = feat[i];
+    }
+  }
+  FBArgs a{};                                      // (feat_c / feat_f / perm stay null: the re-gather path)
   a.table = table; a.w0 = w0; a.b0 = b0; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.bound = bound;
   a.g_w0 = g_w0; a.g_b0 = g_b0; a.g_w1 = g_w1; a.g_b1 = g_b1; a.g_w2 = g_w2; a.g_b2 = g_b2;
   fill_levels(&a.lv, h_offsets, L, S, H, gridtype);
   a.rays_o = rays_o; a.rays_d = rays_d; a.aabb = aabb; a.z_s = z_s; a.dsig = dsig; a.drgb = drgb; a.dfeat_out = dfeat; a.dfeat_P = P; a.p_off = 0;
   a.P = P; a.T2 = T2;
-  if (!use_ref) {
+  if (use_ref == 2) { a.feat_c = fc.data(); a.feat_f = ff.data(); a.perm = perm.data(); }
+  if (use_ref != 1) {
     hipemu::launch(grid, 256, FB_LDS_FLOATS * sizeof(float), [&] { k_ngp_field_bwd_mfma(a); });
     return;
   }

@@ -209,7 +209,7 @@ def test_render_backward_isolated_tight(golden):
     work = torch.empty(wb // 4, device=DEV)
     rc = lib.sf_ngp_render_backward(C.byref(f), C.byref(gs), _lib.ptr(o), _lib.ptr(dd), _lib.ptr(aabb), N, T, _lib.ptr(nears),
                                     _lib.ptr(fars), _lib.ptr(zs), _lib.ptr(ss), _lib.ptr(rs), 0.0, _lib.ptr(gi), _lib.ptr(gw),
-                                    0, _lib.ptr(work), wb, _lib.stream_ptr())
+                                    0, None, _lib.ptr(work), wb, _lib.stream_ptr())      # no field cache: the re-gather path
     _lib.check(rc)
     torch.cuda.synchronize()
     names = ["encoder.embeddings"] + [f"sigma_net.net.{i}.{w}" for i in range(3) for w in ("weight", "bias")]
@@ -261,6 +261,34 @@ def test_render_full_size_properties(golden):
         got = net.render(o2[None].to(DEV), d2[None].to(DEV), staged=False, perturb=True, bg_color=0, shading='albedo',
                          noise=dict(u_coarse=uc.to(DEV), u_fine=uf.to(DEV)), **vars(net.opt))
     assert psnr(got["image"][0].cpu(), ref["image"]) > 50.0
+
+
+def test_field_cache_equals_regather(golden, monkeypatch):
+    """r03: the forward's field cache (features of every sample + sort permutation, sf_ngp_render_forward's field_cache) against
+    the backward that re-gathers the features: same render, gradients equal to the last bits (the cached features ARE the values
+    the forward multiplied; the re-gather recomputes them with the same arithmetic)."""
+    from sparsefusion_amd.nerf import renderer as R
+    p = params_from_cfg(golden["teacher"]["cfg"])
+    net = _net(p).train()
+    o, d = ngp_ref.circle_rays(48, view=3)
+    o, d = o.to(DEV), d.to(DEV)
+    N = o.shape[0]
+    g = torch.Generator().manual_seed(5)
+    noise = dict(u_coarse=torch.rand(N, 64, generator=g).to(DEV), u_fine=torch.rand(N, 64, generator=g).to(DEV))
+    gi, gw = torch.randn(N, 3, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
+    kw = dict(staged=False, perturb=True, bg_color=0, shading='albedo', noise=noise, **vars(net.opt))
+    out = []
+    for cache in (True, False, True):
+        monkeypatch.setattr(R, "_FEAT_CACHE", cache)
+        net.zero_grad()
+        r = net.render(o[None], d[None], **kw)
+        ((r["image"][0] * gi).sum() + (r["weights_sum"] * gw).sum()).backward()
+        out.append((r["image"].clone(), [q.grad.clone() for q in net.parameters()]))
+    assert torch.equal(out[0][0], out[1][0])
+    for a, b, c in zip(out[0][1], out[1][1], out[2][1]):
+        assert a.abs().max() > 0
+        assert (a - b).norm() <= 1e-5 * b.norm() + 1e-9, float((a - b).norm() / b.norm())
+        assert (a - c).norm() <= 1e-5 * c.norm() + 1e-9                             # (atomics in the scatters: equal to summation order)
 
 
 def test_render_batched_eval_sizes(golden):

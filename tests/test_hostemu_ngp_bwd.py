@@ -60,3 +60,9 @@ def test_field_backward_mfma_matches_per_point_math():
             err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-20)
             assert err < 2e-5, (grid, name, err)
     assert float(ref[6].abs().max()) > 0 and float(ref[2].abs().max()) > 0
+    # r03: the same kernel reading the forward's field cache (features of every sample through the sort permutation) instead of
+    # re-gathering them
+    got = run(2, 3)
+    for name, a, b in zip(("g_w0", "g_b0", "g_w1", "g_b1", "g_w2", "g_b2", "dfeat"), got, ref):
+        err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-20)
+        assert err < 2e-5, ("cache", name, err)
