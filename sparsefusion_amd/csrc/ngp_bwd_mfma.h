@@ -318,6 +318,10 @@ SF_KERNEL(256) void k_ngp_field_bwd_mfma(FBArgs a) {
         c[1][0] = sf_mfma4(a1, b0, c[1][0]);
         c[1][1] = sf_mfma4(a1, b1, c[1][1]);
       }
+      // The fragment layout gives a lane one feature of four points: stored directly that is 32 eight-byte pieces per store
+      // instruction, scattered over 8 level planes.  Through the (now free) F tile instead: lane = (level lane >> 2, quarter
+      // lane & 3) owns 8 consecutive points of one level = 64 contiguous bytes of the level-major [L][P][2] image.
+      sf_wave_sync();                                    // phase H has read F
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -325,10 +329,27 @@ SF_KERNEL(256) void k_ngp_field_bwd_mfma(FBArgs a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int q = mt * 16 + 4 * kq + r, f = ft * 16 + li;
-            const uint32_t pp = p0 + q;
-            if (pp < a.P && (uint32_t)(f >> 1) < a.lv.L)
-              a.dfeat_out[((size_t)(f >> 1) * a.dfeat_P + a.p_off + pp) * 2 + (f & 1)] = INS[q] != 0.0f ? c[mt][ft][r] : 0.0f;
+            F[q * FB_SF + f] = INS[q] != 0.0f ? c[mt][ft][r] : 0.0f;
           }
+      sf_wave_sync();
+      {
+        const uint32_t l = lane >> 2, q0 = (lane & 3) * 8;
+        if (l < a.lv.L) {
+          float* dst = a.dfeat_out + ((size_t)l * a.dfeat_P + a.p_off + p0 + q0) * 2;
+          if (p0 + FB_PTS <= a.P && !((a.dfeat_P | a.p_off) & 1)) {      // whole trip, 16-byte aligned rows
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              f32x4 v;
+              v[0] = F[(q0 + 2 * j) * FB_SF + 2 * l];     v[1] = F[(q0 + 2 * j) * FB_SF + 2 * l + 1];
+              v[2] = F[(q0 + 2 * j + 1) * FB_SF + 2 * l]; v[3] = F[(q0 + 2 * j + 1) * FB_SF + 2 * l + 1];
+              *reinterpret_cast<f32x4*>(dst + 4 * j) = v;
+            }
+          } else {                                         // ragged last trip (or an odd point count)
+            for (int j = 0; j < 8; ++j)
+              if (p0 + q0 + j < a.P) { dst[2 * j] = F[(q0 + j) * FB_SF + 2 * l]; dst[2 * j + 1] = F[(q0 + j) * FB_SF + 2 * l + 1]; }
+          }
+        }
+      }
     }
     sf_wave_sync();                                      // before the next trip restages F / H1 / H2 / DO / INS
   }
