@@ -80,7 +80,7 @@ def test_conv_lds_matches_conv2d(B, H, Cin, Cout, k, stride, pad, bnf, a_f32, up
     xa = xn if a_f32 else xn.to(torch.bfloat16)
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
     rc = lib.emu_conv_lds(ptr(xa), ptr(wp), ptr(b), ptr(out), ptr(res), B, H, H, Cin, Ho, Ho, Cout, ldc, 0, k, stride, pad, bnf,
-                          int(a_f32), int(accum), ups, relu, None, 0, None, 0)
+                          int(a_f32), int(accum), ups, relu, None, 0, None, 0, None)
     assert rc == 0
     got = out[:, :Cout]
     assert torch.allclose(got, want, rtol=1e-4, atol=2e-4), float((got - want).abs().max())
@@ -118,7 +118,7 @@ def test_conv_lds_gn_epilogue_statistics(B, H, Cin, Cout, bnf, a_f32, resid, acc
     stats = torch.full((B, G, 2), float("nan"), dtype=torch.float64)
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
     rc = lib.emu_conv_lds(ptr(xa), ptr(wp), ptr(b), ptr(out), ptr(res), B, H, H, Cin, H, H, Cout, Cout, 0, 3, 1, 1, bnf, int(a_f32),
-                          int(accum), 0, 0, ptr(part), cg, ptr(stats), 0)
+                          int(accum), 0, 0, ptr(part), cg, ptr(stats), 0, None)
     assert rc == 0
     assert torch.allclose(out, want, rtol=1e-4, atol=2e-4)
     o = out.double().view(B, H * H, G, cg)                     # statistics of what the kernel WROTE
@@ -191,9 +191,12 @@ def glds_vs_lds(B, H, Cin, Cout, k, stride, pad, bnf, ups, resid, accum, relu, n
         out = out0.clone()
         part = torch.full((max(M // 128, 1), G, 2), float("nan"), dtype=torch.float64) if gn else None
         stats = torch.full((B, G, 2), float("nan"), dtype=torch.float64) if gn else None
+        twin = torch.zeros(M, Cout, dtype=torch.bfloat16) if ldc == Cout else None      # the epilogue's operand-type copy (dense rows only)
         rc = lib.emu_conv_lds(ptr(x), ptr(wp), ptr(b), ptr(out), ptr(res), B, H, W, Cin, Ho, Wo, Cout, ldc, 0, k, stride, pad, bnf, 0,
-                              int(accum), ups, relu, ptr(part), cg if gn else 0, ptr(stats), glds)
+                              int(accum), ups, relu, ptr(part), cg if gn else 0, ptr(stats), glds, ptr(twin))
         assert rc == 0, rc
+        if twin is not None:
+            assert torch.equal(twin, out.to(torch.bfloat16))
         outs.append((out, part, stats))
     (o0, p0, s0), (o1, p1, s1) = outs
     assert not bool(torch.isnan(o1[:, :Cout]).any())
