@@ -1,5 +1,6 @@
-// k_conv_glds: the large-M implicit GEMM of conv_lds.h (workgroup tile 128 pixels x 16*BNF channels, operand fragments in MFMA
-// lane order = 1 KiB of conflict-free LDS each) with its staging rebuilt around LDS-DMA and wave specialisation.
+// k_conv_glds: the large-M implicit GEMM of conv_lds.h (workgroup tile 128 pixels x 16*BNF channels; weight fragments in MFMA lane
+// order = 1 KiB of conflict-free LDS each, activation fragments as swizzled 128-byte pixel rows) with its staging rebuilt around
+// LDS-DMA and wave specialisation.
 //
 // Why: k_conv_lds prefetches ONE stage into registers, so every stage of 64 input channels ends in a full L2 round trip before
 // its ds_write (measured 1.3 us per stage against 0.1 us of MFMA work at one workgroup per CU: 200-320 TFLOP/s on the SD-VAE
@@ -22,9 +23,10 @@
 // converts in registers.  Same fragment order, same accumulation order, same epilogue as k_conv_lds: the results are bit-identical
 // (tests/test_hostemu_conv_lds.py, tests/test_gpu_unet_ops.py); the GroupNorm partial sums are taken in another (also fixed) order.
 // Dynamic LDS: NST * (16 + 2 * BNF) KiB (128 KiB at BNF = 8, NST = 4: one workgroup per CU, the ring is the latency hiding).
-// Bounds at this tile: per 32-deep k-step the matrix waves read 32 KiB of fragments (256 clk of the CU's 128 B/clk LDS port) and
-// the DMA writes 16 KiB (128 clk) against 256 clk of MFMA time, and the loaders pull 16 KiB through the 64 B/clk vector-memory
-// path (256 clk): LDS-port bound at about two thirds of the MFMA peak before any stall.
+// Bounds at this tile: per 32-deep k-step the matrix waves read 32 KiB of fragments (128 clk of the LDS port at ds_read_b128's
+// 256 B/clk) and the DMA writes 16 KiB against 256 clk of MFMA time -- neither is what was measured to bound it: the A operand's
+// 16 KiB per stage through the L2 -> L1 path is (profiles/r03_conv_glds_experiments.log), which is why 3x3 layers go to
+// k_conv3_halo (conv_halo.h) and this kernel keeps the 1x1 / stride-2 layers.
 #pragma once
 #include "conv_lds.h"
 #ifndef SF_GLDS_EXPERIMENT
