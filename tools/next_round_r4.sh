@@ -21,3 +21,10 @@ timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rpu -- 
 cp $(find /tmp/rpu -name "*kernel_stats.csv" | head -1) $O/r04_unet_eval_b32_kernel_stats.csv
 cd $GRAFT_REPO_ROOT
 head -12 $O/r04_unet_eval_b32_kernel_stats.csv | cut -c1-110
+# 5. what k_ngp_field_bwd_mfma (2.0 ms per render, 22 % MFMA busy) waits for: LDS counters (the 16-points-per-trip variant was slower,
+#    which points at the 4-byte fragment reads rather than at latency cover)
+cd /tmp
+timeout 150 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --output-format csv -d /tmp/q_ngp_l -- python $GRAFT_REPO_ROOT/tools/ngp_microbench.py > $O/q_ngp_l.log 2>&1
+cd $GRAFT_REPO_ROOT
+python tools/pmc_collect.py /tmp/q_ngp_l k_ngp_field_bwd_mfma > $O/r04_ngp_field_bwd_lds_pmc.json; python -c "
+import json; d=json.load(open('$O/r04_ngp_field_bwd_lds_pmc.json')); print({k: round(v['mean_per_dispatch']) for k, v in d.items()})"
