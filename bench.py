@@ -17,7 +17,8 @@ eft.batched_forward, n_batches=16, input_cameras=, input_rgb=)`, distillation.py
 `--config 3` = `--views-per-gpu 4` (BASELINE configs[3], 4 novel views per GPU and step).
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): every rank distils its own novel
+N > 1 runs one rank per GPU over RCCL -- under torch.distributed.run (RANK / WORLD_SIZE in the environment), or spawned by
+bench.py itself when it is started plainly (it re-execs under torch.distributed.run): every rank distils its own novel
 view (weak scaling); the ranks all-gather the rendered latents and all-reduce (mean) the NGP gradients
 before each optimiser step so the replicas stay identical."""
 import argparse
@@ -415,8 +416,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` spawns its own ranks, as the reference's demo does (demo.py:180 mp.spawn(fit, nprocs=gpus),
+        # :22 init_process_group): re-exec under torch.distributed.run on this node, one rank per GPU, rendezvous on 127.0.0.1
+        # (the container hostname may not resolve).  Under torchrun (WORLD_SIZE set) this branch is never taken.
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+    if args.gpus > 1 and args.gpus != world:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE=%d of the launcher" % (args.gpus, world))
     backend = os.environ.get("SF_BENCH_BACKEND", "nccl")         # "gloo": dry-run of the multi-rank path on fewer GPUs than ranks
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)

@@ -33,6 +33,20 @@ def test_two_ranks_strong_scaling_dry_run():
     assert abs(rf["algorithmic_bytes_per_launch"] * rf["launches"] - rf["algorithmic_bytes_per_eval"]) < rf["launches"]
 
 
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher (how the driver invokes the N = 1 bench): bench.py re-execs itself under
+    torch.distributed.run, one rank per GPU (the reference spawns its ranks itself too: demo.py:180, :22)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SF_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--max-thres", "0.06",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["multi_gpu"]["world_size_seen"] == 2
+    assert res["multi_gpu"]["replicas_identical"] is True and res["value"] > 0
+
+
 def test_config2_eft_feature_render_in_the_step():
     """BASELINE configs[2] as a bench workload: 6 input views, the EFT feature render of the novel view inside every step."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "2", "--steps", "1", "--warmup", "1", "--max-thres", "0.06",
