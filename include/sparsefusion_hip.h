@@ -333,10 +333,13 @@ int sf_plms_combine(const float* e0, const float* e1, const float* e2,
                     const float* e3, const float* h_c4, uint64_t n, float* out,
                     float* keep_e0, void* stream);
 /* sf_plms_combine followed by sf_plms_update on its result, in one launch (the steady-state step of
- * external/plms.py:137-152 + :122-135): x_prev = update(x, c0*e0 + .. + c3*e3, noise). */
+ * external/plms.py:137-152 + :122-135): x_prev = update(x, c0*e0 + .. + c3*e3, noise).
+ * row_n > 0: extra workgroups of the same launch copy row_n floats (a multiple of 4, 16-byte aligned) from row_src to
+ * row_dst -- the UNet's time-block row of the NEXT eval into the plan's arena (Unet.eval_prepared(.., row_ready=True)). */
 int sf_plms_step(const float* e0, const float* e1, const float* e2, const float* e3,
                  const float* h_c4, float* keep_e0, const float* x, const float* noise,
-                 const float* h_coef6, uint64_t n, float* x_prev, void* stream);
+                 const float* h_coef6, uint64_t n, float* x_prev,
+                 const float* row_src, float* row_dst, uint64_t row_n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -106,7 +106,7 @@ SIGNATURES = {
     "sf_conv_pack_weights": (C.c_int, [C.c_void_p, u32, u32, u32, u32, u32, C.c_void_p]),
     "sf_plms_update": (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_void_p, u64, c_f32p, c_f32p, C.c_void_p]),
     "sf_plms_combine": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, u64, c_f32p, c_f32p, C.c_void_p]),
-    "sf_plms_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_void_p, u64, c_f32p, C.c_void_p]),
+    "sf_plms_step": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_void_p, u64, c_f32p, c_f32p, c_f32p, u64, C.c_void_p]),
 }
 
 

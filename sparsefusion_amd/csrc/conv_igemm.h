@@ -168,6 +168,26 @@ SF_KERNEL(256) void k_conv_igemm(ConvArgs a) {
         }
         continue;
       }
+      if (a.pixshuf && a.slots_out) {             // (lanes beyond Cout / M contribute zeros; the host checks 16 | Cout / 4, 16 | M)
+        float sm = 0.0f, sq = 0.0f;
+        if (n < a.Cout) {
+          const float bq = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = (mt * WM + mi) * 16 + (lane >> 4) * 4 + r;
+            const float v = sf_silu(acc[mi][ni][r] + bq);
+            if (m < M) { sm += v; sq = fmaf(v, v, sq); }
+          }
+        }
+        sm = sf_wave_sum(sm);
+        sq = sf_wave_sum(sq);
+        if (lane == 0) {
+          const int nf = nt * WN + ni;
+          float* sl = a.slots_out + (((long)(mt * WM + mi) * 4 + (nf & 3)) * (a.ldc >> 4) + (a.co_off >> 4) + (nf >> 2)) * 2;
+          sl[0] = sm;
+          sl[1] = sq;
+        }
+      }
       if (n >= a.Cout) continue;
       const float bv = a.bias ? a.bias[n] : 0.0f;
 #pragma unroll

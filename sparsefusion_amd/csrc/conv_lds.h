@@ -9,6 +9,11 @@ struct ConvArgs {
   int B, H, W, Cin, Ho, Wo, Cout, ldc, co_off, kh, kw, stride, pad, groups;
   int KS, cchunks, m_frags, n_frags, m_tiles, n_tiles, steps_per_wave;
   int pixshuf, ups, relu;   // relu: 0 none, 1 ReLU, 2 GELU (erf)
+  float* slots_out;         // k_conv_igemm pixel-shuffle epilogue only, or null: (sum, sum of squares) slots [Mout/16][ldc/16][2] of the
+                            // written (shuffled, SiLU'd) tensor for the next GroupNorm-fused conv -- input fragment (m-frag, n-frag) -> slot
+                            // row 4 * m-frag + (n-frag & 3), column (co_off / 16) + n-frag / 4: its 16 conv channels are 4 output channels of
+                            // ONE 16-channel column, its pixels stay inside one image; the consumer sums all slots of an (image, group)
+  int out_nchw_hw;          // > 0: the split-K reduction writes out[(b * Cout + n) * hw + p] (plan output, NCHW) instead of rows
 };
 
 // ---------------------------------------------------------------------------------------------

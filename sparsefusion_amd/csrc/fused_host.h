@@ -12,6 +12,10 @@
 //          32 pipelined kernel (k_conv_fused_pipe: slot GroupNorm, k = 3, plain source, C % 128 == 0),
 //          16 pair: the NEXT op (an un-normalised fconv of the same tile shape) runs in the same launch (k_conv_fused_pair)
 //   f: 0 eps  1 s1.scale  2 s2.scale
+//   norm == FNORM_ATTN (the attention core as the prologue of its output projection; k = 1, 4x4 map, C1 = 512 = 8 heads x 64):
+//      p: 0 q rows [B * 16][ldq] (instead of a source tensor)  19..21 key pointers of the <= 3 key / value segments
+//      i: 19 ldq  20 + 4 s .. 23 + 4 s: rows, row_stride, batch_stride, head_stride of segment s (rows = 0: unused)
+//      f: 3 + s: value offset of segment s in floats (v = k + offset)  6: softmax scale
 // SF_OP_SLOTS operands
 //   p: 0 x (or h)  1 gate [B, C] or null  2 res  3 out (gate / split-K mode)  4 slots  5 split-K slabs or null  6 conv bias or null
 //   i: 0 M  1 C  2 HW  3 slab groups  4 slab row stride (npad)
@@ -46,7 +50,8 @@
   X(2, 2, 8, FNORM_NONE, 0) \
   X(1, 1, 12, FNORM_LN, 0) \
   X(1, 1, 12, FNORM_LN, 1) \
-  X(1, 2, 8, FNORM_LN, 0)
+  X(1, 2, 8, FNORM_LN, 0) \
+  X(1, 1, 12, FNORM_ATTN, 0)
 
 // Pipelined slot-GroupNorm 3x3 convs (k_conv_fused_pipe, op flag 32): (WM, WN, EPT = (TR + 2) * W / 8 staging elements per thread and chunk)
 // (2, *, 8), (2, *, 6) and (4, *, 16): the 32-pixel tiles of the 16x16 (TR = 2) and 8x8 (TR = 4) maps and the 64-pixel tile of the
@@ -94,6 +99,7 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   a.dbg = (long long*)op.p[16];
   a.wk = (const float*)op.p[17]; a.logit_part = (float*)op.p[18];
   a.weff = nullptr; a.pool_part = nullptr; a.weff_off = 0;
+  a.attn = FAttn{}; a.attn_off = 0;
   if (op.flags & 64) {                 // epilogue pooling (k_conv_fused_pipe<.., POOL>): p 17 = w_eff bf16 [KS * 32], p 18 = pooled fragments
     a.weff = (const sf_opnd*)op.p[17]; a.pool_part = (float*)op.p[18];
     a.wk = nullptr; a.logit_part = nullptr;
@@ -149,6 +155,21 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
     if (a.S != 1 || a.k != 1 || !a.gamma || a.s2.C) FC_FAIL("fconv: LayerNorm prologue needs S=1, k=1, one source, a gain");
     if ((a.C / 4) * 16 * WM > 16 * SF_FCONV_WAVES * 64) FC_FAIL("fconv: LayerNorm row too long for the register-resident prologue (C <= 2048)");
     if (a.s1.scale != 1.0f) FC_FAIL("fconv: LayerNorm source is unscaled");
+  } else if (a.norm == FNORM_ATTN) {
+    if (a.S != 1 || a.k != 1 || a.s2.C || a.s1.mode || a.C != 64 * SF_FCONV_WAVES || a.H * a.W != 16 || WM != 1 || (op.flags & (1 | 2 | 32)))
+      FC_FAIL("fconv: the attention prologue needs k=1, one plain source of 8 x 64 channels, a 16-token map, no activation");
+    FAttn& at = a.attn;
+    at.q = (const float*)op.p[0]; at.ldq = op.i[19]; at.scale = op.f[6]; at.J = 0; at.per_head = 0;
+    for (int sgi = 0; sgi < 3; ++sgi) {
+      FAttnSeg& sg = at.seg[sgi];
+      sg.k = (const float*)op.p[19 + sgi]; sg.v_off = (int)op.f[3 + sgi];
+      sg.rows = op.i[20 + 4 * sgi]; sg.row_stride = op.i[21 + 4 * sgi]; sg.batch_stride = op.i[22 + 4 * sgi]; sg.head_stride = op.i[23 + 4 * sgi];
+      if (sg.rows < 0 || (sg.rows && !sg.k)) FC_FAIL("fconv: attention segment %d without keys", sgi);
+      if (!sg.rows) sg.k = at.q;                                   // never dereferenced; keeps the struct free of null arithmetic
+      at.J += sg.rows;
+      if (sg.rows && sg.head_stride) at.per_head = 1;
+    }
+    if (at.ldq < a.C || at.J < 1 || at.J > (at.per_head ? 4 : SF_ATTN_MAX_KEYS)) FC_FAIL("fconv: attention wants 1..%d keys (%d given)", at.per_head ? 4 : SF_ATTN_MAX_KEYS, at.J);
   } else if (a.norm != FNORM_NONE) {
     FC_FAIL("fconv: unknown norm %d", a.norm);
   }
@@ -181,6 +202,8 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   a.tab_off = a.red_off + 1024 * SF_FCONV_WAVES * WM * WN;
   a.misc_off = a.tab_off + 2 * Cs * 4;
   lds_bytes = a.misc_off + 640 + 2048;      // misc: 160 floats of statistics + 512 floats of reduction partials
+  a.attn_off = 0;
+  if (a.norm == FNORM_ATTN) { a.attn_off = (int)((lds_bytes + 15) & ~15u); lds_bytes = a.attn_off + SF_ATTN_LDS_BYTES; }
   if (lds_bytes > SF_LDS_MAX && !(op.flags & 32)) FC_FAIL("fconv: tile needs %u bytes of LDS", lds_bytes);   // pipe: its own (chunked) frame below
   const int MT = a.B * a.mt_per_img;
   // XCD-aware tile map (fconv_tile_of): R row groups x 8 / R channel groups.  R = 1 (every XCD owns n-tiles == x mod 8 of ALL

@@ -36,7 +36,23 @@ SF_DEV uint32_t fdiv(uint32_t n, FDiv f) { return f.d == 1 ? n : (uint32_t)(((ui
 #ifndef SF_RING_POS
 #define SF_RING_POS 1          // weight-ring issue point of the slot / plain prologue: 0 before the first staging batch, 1 after it, 2 after staging
 #endif
-enum { FNORM_NONE = 0, FNORM_GN_SELF = 1, FNORM_GN_SLOTS = 2, FNORM_LN = 3 };
+enum { FNORM_NONE = 0, FNORM_GN_SELF = 1, FNORM_GN_SLOTS = 2, FNORM_LN = 3, FNORM_ATTN = 4 };
+
+// FNORM_ATTN: the A operand of an attention output projection IS the attention core's result, computed in the prologue
+// (r04; was its own k_attn16 launch): 16 query tokens x 8 heads x 64 dims against up to 3 key / value segments (null k/v, time
+// tokens, the 16 tokens' shared k/v head; external/imagen_pytorch.py:480-566, :731-805).  Key row r of segment s, head h, batch b:
+// k[b * batch_stride + r * row_stride + h * head_stride + d], value = the same address + v_off.
+#define SF_ATTN_MAX_KEYS 24
+#define SF_ATTN_PSTRIDE 28          /* floats per probability row (16-byte aligned rows of <= 24 keys) */
+#define SF_ATTN_KSTRIDE 68          /* floats per staged key / value row: 16-byte aligned, 4 consecutive rows on disjoint banks */
+#define SF_ATTN_LDS_BYTES (8 * 16 * SF_ATTN_PSTRIDE * 4 + 2 * 8 * 4 * SF_ATTN_KSTRIDE * 4)   /* >= 2 * 24 shared rows as well */
+struct FAttnSeg { const float* k; int v_off, rows, row_stride, batch_stride, head_stride; };
+struct FAttn {
+  const float* q;           // [B * 16][ldq], head h at columns [64 h, 64 h + 64)
+  FAttnSeg seg[3];
+  int ldq, J, per_head;     // J = total keys; per_head: some segment has its own k / v per head (then J <= 4)
+  float scale;
+};
 
 // fp32 NHWC source [M = B*HW, C].  mode 0: plain at p.  mode 1: v = b[c] + sum_g a[g][m][c (ld npad)] (+ r[m][c]).
 // mode 2: v = a[m][c] * b[batch][c] + r[m][c].  Lazy sources are written to p by the workgroups that own the element.
@@ -81,6 +97,8 @@ struct FConvArgs {
   float* pool_part;                  // [M / 16][Cout] un-normalised pooled fragments sum_p exp(l_p - max_frag) * out[p, n];
                                      // directly behind it [M / 16][2] = (max_frag, sum_p exp(l_p - max_frag)): one chunk = 16 pixels
   int weff_off;                      // LDS byte offset of the w_eff table
+  FAttn attn;                        // FNORM_ATTN only
+  int attn_off;                      //   LDS byte offset of its scratch (SF_ATTN_LDS_BYTES)
 };
 
 template <int MODE>
@@ -564,6 +582,83 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
         o[0] = (sf_opnd)y[0]; o[1] = (sf_opnd)y[1]; o[2] = (sf_opnd)y[2]; o[3] = (sf_opnd)y[3];
         *reinterpret_cast<bf16x4*>(lds + (long)row * a.pix_stride + c4 * 8) = o;
       }
+    }
+  } else if (NORM == FNORM_ATTN) {
+    // ---- (b1'') the attention core: wave = head (8 waves x 64 lanes = the 512 inner channels), the tile's 16 pixels = the 16
+    // query tokens.  Scores with lane = (query i, key quarter jq): the query row sits in registers, key rows are broadcast
+    // 16-byte LDS reads; softmax over the 4 lanes of a query by shuffles; P . V with lane = output dim, values in registers and
+    // probabilities as broadcast reads; the result goes straight into the frame as the conv's bf16 A operand.
+    const FAttn& at = a.attn;
+    float* sp = reinterpret_cast<float*>(lds + a.attn_off);                 // [8 heads][16 queries][SF_ATTN_PSTRIDE]
+    float* skv = sp + 8 * 16 * SF_ATTN_PSTRIDE;                             // keys [regions][J][KSTRIDE], then values
+    const int J = at.J, nreg = at.per_head ? 8 : 1;
+    const int qi = lane & 15, jq = lane >> 4;
+    const float* qp = at.q + ((long)b * 16 + qi) * at.ldq + wave * 64;
+    f32x4 q[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) q[u] = *reinterpret_cast<const f32x4*>(qp + 4 * u);
+    FC_PREFETCH();
+    FC_STAMP(1);
+    // key / value rows: per-head segments -> this wave stages the J rows of ITS head; shared head -> the 8 waves split the rows
+    {
+      const int j0 = at.per_head ? 0 : wave, jst = at.per_head ? 1 : NW;
+      const int reg = at.per_head ? wave : 0;
+      for (int j = j0; j < J; j += jst) {
+        const int r0 = at.seg[0].rows, r1 = at.seg[1].rows;
+        const int si = j < r0 ? 0 : (j < r0 + r1 ? 1 : 2);
+        const int r = j - (si == 0 ? 0 : (si == 1 ? r0 : r0 + r1));
+        const FAttnSeg sg = at.seg[si];
+        const long off = (long)b * sg.batch_stride + (long)r * sg.row_stride + (long)wave * (at.per_head ? sg.head_stride : 0) + lane;
+        const float kv = sg.k[off], vv = sg.k[off + sg.v_off];
+        skv[(reg * J + j) * SF_ATTN_KSTRIDE + lane] = kv;
+        skv[((nreg + reg) * J + j) * SF_ATTN_KSTRIDE + lane] = vv;
+      }
+    }
+    sf_sync();
+    const float* kb = skv + (at.per_head ? wave : 0) * J * SF_ATTN_KSTRIDE;
+    const float* vb = skv + (nreg + (at.per_head ? wave : 0)) * J * SF_ATTN_KSTRIDE;
+    constexpr int NU = SF_ATTN_MAX_KEYS / 4;
+    float sc[NU];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int j = jq + 4 * u;
+      const f32x4* kr = reinterpret_cast<const f32x4*>(kb + (j < J ? j : J - 1) * SF_ATTN_KSTRIDE);
+      float acc = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const f32x4 kk = kr[t];
+        acc = fmaf(q[t][0], kk[0], acc); acc = fmaf(q[t][1], kk[1], acc); acc = fmaf(q[t][2], kk[2], acc); acc = fmaf(q[t][3], kk[3], acc);
+      }
+      sc[u] = j < J ? acc * at.scale : -INFINITY;
+      mx = fmaxf(mx, sc[u]);
+    }
+    mx = fmaxf(mx, sf_shfl_xor(mx, 16));
+    mx = fmaxf(mx, sf_shfl_xor(mx, 32));
+    float den = 0.0f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) { sc[u] = (jq + 4 * u < J) ? expf(sc[u] - mx) : 0.0f; den += sc[u]; }
+    den += sf_shfl_xor(den, 16);
+    den += sf_shfl_xor(den, 32);
+    const float inv = 1.0f / den;
+    float* prow = sp + (wave * 16 + qi) * SF_ATTN_PSTRIDE;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) prow[jq + 4 * u] = sc[u] * inv;            // zeros beyond the last key
+    sf_wave_sync();
+    float vv[SF_ATTN_MAX_KEYS];
+#pragma unroll
+    for (int j = 0; j < SF_ATTN_MAX_KEYS; ++j) vv[j] = vb[(j < J ? j : J - 1) * SF_ATTN_KSTRIDE + lane];
+    FC_STAMP(2);
+#pragma unroll 4
+    for (int ii = 0; ii < 16; ++ii) {
+      const f32x4* pr = reinterpret_cast<const f32x4*>(sp + (wave * 16 + ii) * SF_ATTN_PSTRIDE);
+      float o = 0.0f;
+#pragma unroll
+      for (int t = 0; t < NU; ++t) {
+        const f32x4 pp = pr[t];
+        o = fmaf(pp[0], vv[4 * t], o); o = fmaf(pp[1], vv[4 * t + 1], o); o = fmaf(pp[2], vv[4 * t + 2], o); o = fmaf(pp[3], vv[4 * t + 3], o);
+      }
+      *reinterpret_cast<sf_opnd*>(lds + (long)ii * a.pix_stride + (wave * 64 + lane) * 2) = (sf_opnd)o;
     }
   } else {
     // ---- (b2) + (c): GroupNorm statistics from the producer's slots (or no normalisation), then the in-image frame rows

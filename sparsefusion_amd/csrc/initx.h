@@ -30,6 +30,9 @@ struct InitXArgs {
   const float* base;         // [B*H*W][ld]
   const ix_bf16x8* w;        // conv i at w + woff[i] (in fragments of 64 lanes x 8): [k-step][n-frag][lane]
   float* out;                // [B*H*W][ld]
+  float* slots;              // or null: [B*H*W/16][ld/16][2] (sum, sum of squares) of `out`, one slot per 16-pixel x 16-channel MFMA
+                             // fragment (16 pixels = two rows of the 8x8 tile, slot row = (image tile, row pair): the consuming GroupNorm
+                             // sums ALL slots of an (image, group), so any pixel partition with the right channel column serves)
   int B, H, W, Cx, ld;
   int cw[3], co[3], woff[3];
 };
@@ -65,7 +68,7 @@ SF_DEV void initx_stage(const InitXArgs& a, char* __restrict__ patch, int tid, i
 // its STEPS x NFW weight fragments fit in registers and are fetched FIRST, before the patch is staged, so the one global-memory
 // latency of the kernel overlaps the staging; the main loop is LDS reads and MFMAs only.
 template <int K, int NFW>
-SF_DEV void initx_conv(const InitXArgs& a, char* __restrict__ patch, int conv, int tid, int b, int y0, int x0) {
+SF_DEV void initx_conv(const InitXArgs& a, char* __restrict__ patch, int conv, int tid, int b, int y0, int x0, int slot_row0) {
   constexpr int OFF = IX_HALO - K / 2;
   constexpr int STEPS = K == 15 ? 30 : (K == 7 ? 7 : 2);
   const int lane = tid & 63, wave = sf_uniform(tid >> 6);
@@ -130,14 +133,34 @@ SF_DEV void initx_conv(const InitXArgs& a, char* __restrict__ patch, int conv, i
     }
   }
 #pragma unroll
-  for (int mf = 0; mf < 4; ++mf)
+  for (int mf = 0; mf < 4; ++mf) {
+    float sm[NFW], sq[NFW];
+#pragma unroll
+    for (int j = 0; j < NFW; ++j) sm[j] = sq[j] = 0.0f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = 4 * g + r;
       const long mm = m0 + (long)(2 * mf + (i >> 3)) * a.W + (i & 7);
 #pragma unroll
-      for (int j = 0; j < NFW; ++j) a.out[mm * a.ld + a.co[conv] + (wave + 4 * j) * 16 + n] = bv[mf][r][j] + acc[mf][j][r];
+      for (int j = 0; j < NFW; ++j) {
+        const float v = bv[mf][r][j] + acc[mf][j][r];
+        a.out[mm * a.ld + a.co[conv] + (wave + 4 * j) * 16 + n] = v;
+        sm[j] += v;
+        sq[j] = fmaf(v, v, sq[j]);
+      }
     }
+    if (a.slots) {                                            // the statistics slots of the next GroupNorm-fused conv (r04: was a k_slots launch)
+#pragma unroll
+      for (int j = 0; j < NFW; ++j) {
+        const float s1 = sf_wave_sum(sm[j]), s2 = sf_wave_sum(sq[j]);
+        if (lane == 0) {
+          float* sl = a.slots + ((long)(slot_row0 + mf) * (a.ld >> 4) + (a.co[conv] >> 4) + wave + 4 * j) * 2;
+          sl[0] = s1;
+          sl[1] = s2;
+        }
+      }
+    }
+  }
 }
 
 SF_KERNEL(256) void k_init_x(InitXArgs a) {
@@ -149,9 +172,10 @@ SF_KERNEL(256) void k_init_x(InitXArgs a) {
   const int b = bt / tiles, t = bt - b * tiles;
   const int ty = t / tiles_x, tx = t - ty * tiles_x;
   const int y0 = ty * IX_TILE, x0 = tx * IX_TILE;
-  if (conv == 2) initx_conv<15, 1>(a, patch, 2, tid, b, y0, x0);
-  else if (conv == 1) initx_conv<7, 1>(a, patch, 1, tid, b, y0, x0);
-  else if (a.cw[0] == 128) initx_conv<3, 2>(a, patch, 0, tid, b, y0, x0);
-  else initx_conv<3, 1>(a, patch, 0, tid, b, y0, x0);
+  const int srow = bt * 4;                                    // 4 fragment rows (row pairs) per 8x8 tile: (B * tiles) * 4 = B * H * W / 16
+  if (conv == 2) initx_conv<15, 1>(a, patch, 2, tid, b, y0, x0, srow);
+  else if (conv == 1) initx_conv<7, 1>(a, patch, 1, tid, b, y0, x0, srow);
+  else if (a.cw[0] == 128) initx_conv<3, 2>(a, patch, 0, tid, b, y0, x0, srow);
+  else initx_conv<3, 1>(a, patch, 0, tid, b, y0, x0, srow);
 }
 

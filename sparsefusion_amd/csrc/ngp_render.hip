@@ -439,13 +439,25 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
   if (fork) {
     n_chunks = want_chunks;
     while (n_chunks > 1 && (N % n_chunks || (N / n_chunks) % 256 || N / n_chunks < 2048)) --n_chunks;
+  }
+  // The side stream and its fork / join events are ONE set per device: two host threads (or two caller streams) rendering on the
+  // same device would re-record each other's events, so the whole fork .. join section runs under the lock (host-side enqueue only:
+  // microseconds).  The guard below joins the side stream into the caller's stream on EVERY exit path, error returns included.
+  static std::mutex side_mu;
+  std::unique_lock<std::mutex> side_lk(side_mu, std::defer_lock);
+  struct SideJoin {
+    Side* sd = nullptr; hipStream_t st = nullptr; bool forked = false;
+    int join() { const bool f = forked; forked = false; return (!f || (hipEventRecord(sd->join, sd->s) == hipSuccess && hipStreamWaitEvent(st, sd->join, 0) == hipSuccess)) ? 0 : 1; }
+    ~SideJoin() { (void)join(); }
+  } side_join;
+  if (fork) {
+    side_lk.lock();
     Side& sd = side[dev_id];
-    static std::mutex side_mu;                               // two host threads may render on one device
-    std::lock_guard<std::mutex> lk(side_mu);
     if (!sd.s && (hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) != hipSuccess ||
                   hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
                   hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess))
       SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: cannot create the side stream");
+    side_join.sd = &sd; side_join.st = st;
   }
   const uint32_t Nc = N / n_chunks, T2 = 2 * T;
   const uint32_t Pc = Nc * T2;
@@ -472,6 +484,7 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
         if (hipEventRecord(sd.fork, st) != hipSuccess || hipStreamWaitEvent(sd.s, sd.fork, 0) != hipSuccess)
           SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: fork failed");
         sf = sd.s;
+        side_join.forked = true;
       }
       const uint64_t items = (uint64_t)4 * Pc * (lv.L - last);
       const uint32_t grid_f = (uint32_t)(items / 256 < 16384 ? (items + 255) / 256 : 16384);
@@ -490,10 +503,6 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
       k_ngp_scatter<1024><<<grid_sc, 1024, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, T2, rays_per_row, cached, last, sc_run);
     SF_CHECK_LAUNCH("ngp_scatter");
   }
-  if (fork) {
-    Side& sd = side[dev_id];
-    if (hipEventRecord(sd.join, sd.s) != hipSuccess || hipStreamWaitEvent(st, sd.join, 0) != hipSuccess)
-      SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: join failed");
-  }
+  if (side_join.join()) SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: join failed");
   return SF_OK;
 }

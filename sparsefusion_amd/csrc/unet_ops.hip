@@ -67,6 +67,8 @@ __device__ __forceinline__ float wave_max(float v) {
 //          8 = split-K partials stay in the workspace; the consumer reduces them (LazySrc mode 1),
 //          16 = the input is a nearest x2 upsampling of a stored [B, H/2, W/2, Cin] map (H, W = upsampled dims),
 //          32 = ReLU, 64 = GELU(erf) in the epilogue (after bias / residual / accumulate)
+//          256 = the split-K reduction stores NCHW: out[(b * Cout + n) * Ho*Wo + pixel] (the plan's output tensor; groups > 1, not deferred)
+//   p[7] = (sum, sum of squares) slots of the pixel-shuffled output for the next GroupNorm-fused conv, or NULL (flag 2 only)
 // No atomics: with groups == 1 every output element is owned by one wave (plain store / read-modify-write);
 // with groups > 1 each K-slice group stores its partial tile to the workspace and k_splitk_reduce sums them
 // (fp32 L2 atomics top out at ~25 G lane-ops/s on MI355X, which made the atomic split-K epilogue 10x the
@@ -81,13 +83,15 @@ __device__ __forceinline__ float wave_max(float v) {
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ ws, const float* __restrict__ bias,
                                                        const float* __restrict__ resid, float* __restrict__ out, int M,
                                                        int Cout, int npad, int groups, int ldc, int co_off, int accum,
-                                                       int relu) {
+                                                       int relu, int nchw_hw) {
   const long total = (long)M * Cout;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int m = (int)(i / Cout), n = (int)(i - (long)m * Cout);
+    int m, n;
+    if (nchw_hw) { n = (int)((i / nchw_hw) % Cout); m = (int)(i / ((long)nchw_hw * Cout)) * nchw_hw + (int)(i % nchw_hw); }   // i = NCHW index: coalesced stores
+    else { m = (int)(i / Cout); n = (int)(i - (long)m * Cout); }
     float v = bias ? bias[n] : 0.0f;
     for (int g = 0; g < groups; ++g) v += ws[((long)g * M + m) * npad + n];
-    const long o = (long)m * ldc + co_off + n;
+    const long o = nchw_hw ? i : (long)m * ldc + co_off + n;      // NCHW [B][Cout][hw]: the plan's output layout (r04: was k_unpack_out)
     if (resid) v += resid[o];
     if (accum) v += out[o];
     if (relu == 1) v = fmaxf(v, 0.0f);
@@ -563,6 +567,8 @@ static int run_conv(const sf_op& op, hipStream_t st) {
   const int tile = op.i[14];
   const int WM = tile / 16, WN = tile % 16;
   a.pixshuf = (op.flags & 2) ? 1 : 0;
+  a.slots_out = (float*)op.p[7];
+  a.out_nchw_hw = (op.flags & 256) ? op.i[4] * op.i[5] : 0;
   a.ups = (op.flags & 16) ? 1 : 0;
   a.relu = (op.flags & 32) ? 1 : ((op.flags & 64) ? 2 : 0);
   if (a.ups && ((a.H | a.W) & 1)) SF_FAIL(SF_ERR_INVALID, "conv: upsampled input dims must be even");
@@ -577,6 +583,10 @@ static int run_conv(const sf_op& op, hipStream_t st) {
   a.n_tiles = (a.n_frags + WN - 1) / WN;
   a.npad = a.n_frags * 16;
   if (a.pixshuf) a.groups = 1;
+  if (a.slots_out && (!a.pixshuf || tile >= 256 || (a.Cout / 4) % 16 || a.ldc % 16 || a.co_off % 16 || M % 16 || (a.Ho * a.Wo) % 16))
+    SF_FAIL(SF_ERR_INVALID, "conv: output slots ride on the pixel-shuffle epilogue only (16 | Cout / 4, ldc, co_off, Ho * Wo)");
+  if (a.out_nchw_hw && (a.groups < 2 || (op.flags & (8 | 4)) || op.p[4] || tile >= 256 || a.co_off || a.ldc != a.Cout))
+    SF_FAIL(SF_ERR_INVALID, "conv: NCHW output is written by the (non-deferred) split-K reduction of a plain conv only");
   a.steps_per_wave = (a.KS + a.groups * 4 - 1) / (a.groups * 4);
   const int blocks = a.m_tiles * a.n_tiles * a.groups;
   const bool f32 = (op.flags & 1) != 0;
@@ -640,7 +650,7 @@ static int run_conv(const sf_op& op, hipStream_t st) {
     if (!a.ws) SF_FAIL(SF_ERR_INVALID, "conv: split-K needs a workspace");
     if (op.flags & 8) return SF_OK;      // reduction deferred to the consumer (LazySrc mode 1)
     k_splitk_reduce<<<sf_grid_cap(sf_div_up((long)M * a.Cout, 256)), 256, 0, st>>>(a.ws, a.bias, a.resid, a.out, M, a.Cout, a.npad,
-                                                                                  a.groups, a.ldc, a.co_off, a.accum, a.relu);
+                                                                                  a.groups, a.ldc, a.co_off, a.accum, a.relu, a.out_nchw_hw);
     SF_CHECK_LAUNCH("splitk_reduce");
   }
   return SF_OK;
@@ -823,7 +833,7 @@ static int plan_run_impl(const sf_op* ops, uint32_t n_ops, hipStream_t st_main, 
         const int M = op.i[0], Cout = op.i[1];
         if (!op.p[0] || !op.p[3] || op.i[3] < 1) SF_FAIL(SF_ERR_INVALID, "splitk_reduce: bad operands");
         k_splitk_reduce<<<sf_grid_cap(sf_div_up((long)M * Cout, 256)), 256, 0, st>>>(
-            (const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], (float*)op.p[3], M, Cout, op.i[2], op.i[3], Cout, 0, 0, 0);
+            (const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], (float*)op.p[3], M, Cout, op.i[2], op.i[3], Cout, 0, 0, 0, 0);
         if (hipGetLastError() != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "splitk_reduce launch failed");
         break;
       }
@@ -980,8 +990,15 @@ __global__ __launch_bounds__(256) void k_plms_combine(const float* __restrict__ 
 __global__ __launch_bounds__(256) void k_plms_step(const float* __restrict__ e0, const float* __restrict__ e1,
                                                    const float* __restrict__ e2, const float* __restrict__ e3, float c0, float c1,
                                                    float c2, float c3, float* __restrict__ keep, const float* x,
-                                                   const float* __restrict__ noise, Coef6 k, long n, float* x_prev) {   // x may alias x_prev
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+                                                   const float* __restrict__ noise, Coef6 k, long n, float* x_prev,   // x may alias x_prev
+                                                   int step_blocks, const float* __restrict__ row_src, float* __restrict__ row_dst, long row_n4) {
+  if ((int)blockIdx.x >= step_blocks) {          // the extra workgroups: the NEXT eval's time-block row into the plan (r04: was a copy launch per eval)
+    const long nb = gridDim.x - step_blocks;
+    for (long i = (blockIdx.x - step_blocks) * 256L + threadIdx.x; i < row_n4; i += nb * 256)
+      reinterpret_cast<float4*>(row_dst)[i] = reinterpret_cast<const float4*>(row_src)[i];
+    return;
+  }
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)step_blocks * 256) {
     if (keep) keep[i] = e0[i];
     float v = c0 * e0[i];                        // same expression order as k_plms_combine
     if (e1) v += c1 * e1[i];
@@ -998,12 +1015,16 @@ __global__ __launch_bounds__(256) void k_plms_step(const float* __restrict__ e0,
 }
 
 extern "C" int sf_plms_step(const float* e0, const float* e1, const float* e2, const float* e3, const float* h_c4, float* keep_e0,
-                            const float* x, const float* noise, const float* h_coef6, uint64_t n, float* x_prev, void* stream) {
+                            const float* x, const float* noise, const float* h_coef6, uint64_t n, float* x_prev,
+                            const float* row_src, float* row_dst, uint64_t row_n, void* stream) {
   if (!e0 || !h_c4 || !x || !h_coef6 || !x_prev) SF_FAIL(SF_ERR_INVALID, "plms_step: null argument");
   if (n == 0) return SF_OK;
+  if (row_n && (!row_src || !row_dst || row_n % 4 || ((uintptr_t)row_src | (uintptr_t)row_dst) % 16)) SF_FAIL(SF_ERR_INVALID, "plms_step: the row copy wants 16-byte aligned rows of 4 n floats");
   Coef6 k{h_coef6[0], h_coef6[1], h_coef6[2], h_coef6[3], h_coef6[4], h_coef6[5]};
-  k_plms_step<<<sf_grid_cap(sf_div_up(n, 256)), 256, 0, (hipStream_t)stream>>>(e0, e1, e2, e3, h_c4[0], h_c4[1], h_c4[2], h_c4[3], keep_e0, x,
-                                                                               noise, k, (long)n, x_prev);
+  const int sb = (int)sf_grid_cap(sf_div_up(n, 256));
+  const int rb = row_n ? (int)sf_grid_cap(sf_div_up(row_n / 4, 256)) : 0;
+  k_plms_step<<<sb + rb, 256, 0, (hipStream_t)stream>>>(e0, e1, e2, e3, h_c4[0], h_c4[1], h_c4[2], h_c4[3], keep_e0, x,
+                                                        noise, k, (long)n, x_prev, sb, row_src, row_dst, (long)(row_n / 4));
   SF_CHECK_LAUNCH("plms_step");
   return SF_OK;
 }

@@ -80,7 +80,7 @@ _FEAT_CACHE = os.environ.get("SF_NGP_FEAT_CACHE", "1") != "0" and not (os.enviro
 
 class _RenderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, handle, rays_o, rays_d, aabb, T, min_near, lin, u_coarse, u_fine, u_stride, bg, rays_per_row, *params):
+    def forward(ctx, handle, rays_o, rays_d, aabb, T, min_near, lin, u_coarse, u_fine, u_stride, bg, rays_per_row, grad_mode, *params):
         _lib.require_cuda(rays_o, rays_d, aabb, *params)
         params = [p.detach().contiguous() for p in params]
         N = rays_o.shape[0]
@@ -98,7 +98,9 @@ class _RenderFn(torch.autograd.Function):
         # permutation, so the backward reads 128 bytes per sample instead of re-gathering 16 levels x 8 corners (0.73 ms of a
         # 4.5 ms backward at 128^2 rays x 128 samples; 268 MB per render held until then).  SF_NGP_FEAT_CACHE=0: recompute (A/B).
         cache = None
-        if _FEAT_CACHE and any(ctx.needs_input_grad[12:]):
+        # `grad_mode` = torch.is_grad_enabled() at the call site: needs_input_grad mirrors requires_grad even under no_grad(), and
+        # grad mode is always off in here -- an eval render of a trainable field must not allocate / write the 268 MB cache
+        if _FEAT_CACHE and grad_mode and any(ctx.needs_input_grad[13:]):
             cache = torch.empty(lib.sf_ngp_render_cache_bytes(N, T) // 4, **f32)
         rc = lib.sf_ngp_render_forward(C.byref(f), _lib.ptr(rays_o), _lib.ptr(rays_d), _lib.ptr(aabb), N, T,
                                        float(min_near), _lib.ptr(lin), _lib.ptr(u_coarse), _lib.ptr(u_fine),
@@ -131,7 +133,7 @@ class _RenderFn(torch.autograd.Function):
                                         ctx.bg, _lib.ptr(g_image), _lib.ptr(g_ws), int(ctx.rays_per_row), _lib.ptr(cache),
                                         _lib.ptr(work), wbytes, _lib.stream_ptr())
         _lib.check(rc, "ngp_render_backward")
-        return (None,) * 12 + tuple(grads)
+        return (None,) * 13 + tuple(grads)
 
 
 class NeRFRenderer(nn.Module):
@@ -249,7 +251,7 @@ class NeRFRenderer(nn.Module):
             raise NotImplementedError("per-ray bg_color tensors are not on the distillation path (bg_color=0)")
         image, weights_sum, depth, nears, fars = _RenderFn.apply(
             self._field_handle(), o, d, aabb, T, self.min_near, lin, u_coarse, u_f, stride, float(bg_color),
-            self._rays_per_row(N, kwargs), *self._field_params())
+            self._rays_per_row(N, kwargs), torch.is_grad_enabled(), *self._field_params())
         return {'image': image.view(*prefix, 3), 'depth': depth.view(*prefix), 'weights_sum': weights_sum,
                 'mask': (nears < fars).view(*prefix)}
 

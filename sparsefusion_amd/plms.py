@@ -95,10 +95,13 @@ class PLMSSampler():
             ctx = unet.begin_sampling(cond_images, torch.stack([alpha_cosine_log_snr(_f(t)) for t in eval_times]).to(dev))
             x_slot = ctx["plan"].x_view.view(shape)                 # the plan's input buffer: latents live there between steps
 
+        row_ready = [None]          # the table row the last sf_plms_step already copied into the plan (one launch less per eval)
+
         def eps_model(x, t):
             """eps for latents x at time t.  Fast path: a VIEW of the plan's output buffer (valid until the next eval)."""
             if fast:
-                return unet.eval_prepared(ctx, x, row_of[t])
+                ready, row_ready[0] = row_ready[0] == row_of[t], None
+                return unet.eval_prepared(ctx, x, row_of[t], row_ready=ready)
             ls = torch.full((B,), float(alpha_cosine_log_snr(_f(t))), dtype=torch.float32, device=dev)
             return unet.forward_with_cond_scale(x, ls, cond_images=cond_images, cond_scale=cond_scale)
 
@@ -120,15 +123,21 @@ class PLMSSampler():
             return out
 
         def step(es, cs, keep, x, t, t_next, out):
-            """combine + update in ONE launch: x_prev = update(x, sum_k cs[k] * es[k]); `keep` receives es[0]."""
+            """combine + update in ONE launch: x_prev = update(x, sum_k cs[k] * es[k]); `keep` receives es[0].  On the fast path the
+            same launch also moves the NEXT eval's time-block row into the plan (its eps inputs are read before anything else runs)."""
             c4 = np.zeros(4, dtype=np.float32)
             c4[:len(cs)] = cs
             ptrs = [_lib.ptr(e) for e in es] + [None] * (4 - len(es))
             coef = step_coefficients(t, t_next, clip)
             nz = draw()
             x_prev = torch.empty_like(x) if out is None else out
+            rsrc = rdst = None
+            rn = 0
+            if fast and t_next in row_of and B == 1 and ctx["table"].shape[1] % 4 == 0:
+                rsrc, rdst, rn = ctx["table"][row_of[t_next]], ctx["plan"].tb_view, ctx["table"].shape[1]
+                row_ready[0] = row_of[t_next]
             _lib.check(lib.sf_plms_step(*ptrs, c4.ctypes.data, _lib.ptr(keep), _lib.ptr(x), _lib.ptr(nz), coef.ctypes.data, n,
-                                        _lib.ptr(x_prev), _lib.stream_ptr()), "plms_step")
+                                        _lib.ptr(x_prev), _lib.ptr(rsrc), _lib.ptr(rdst), rn, _lib.stream_ptr()), "plms_step")
             return x_prev
 
         ring = [torch.empty(shape, device=dev) for _ in range(4)]   # eps history (the eval's output buffer is reused)

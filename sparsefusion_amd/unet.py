@@ -25,7 +25,8 @@ OP_FCONV, OP_SLOTS, OP_GCA, OP_INITX, OP_GN_FINALIZE = 14, 15, 16, 17, 18
 PAIR_TILES = {(1, 1, 1), (1, 1, 2), (1, 2, 2), (2, 2, 2), (4, 2, 2)}
 # (WM, WN, (TR + 2) * W / 8) for which k_conv_fused_pipe is instantiated (SF_FCONV_PIPE_VARIANTS)
 PIPE_TILES = {(1, 1, 4), (1, 2, 4), (1, 1, 6), (1, 2, 6), (2, 1, 6), (2, 2, 6), (2, 1, 8), (2, 2, 8), (2, 1, 12), (2, 2, 12), (4, 1, 16), (4, 2, 16)}
-FNORM_NONE, FNORM_GN_SELF, FNORM_GN_SLOTS, FNORM_LN = range(4)      # csrc/fused_kernels.h
+FNORM_NONE, FNORM_GN_SELF, FNORM_GN_SLOTS, FNORM_LN, FNORM_ATTN = range(5)      # csrc/fused_kernels.h
+ATTN_LDS_BYTES = 8 * 16 * 28 * 4 + 2 * 8 * 4 * 68 * 4      # SF_ATTN_LDS_BYTES: scratch of the attention prologue (FNORM_ATTN)
 # Measured (WM, WN, split-K groups) of implicit-GEMM launches where the cost model of Unet.conv_tiling picks a slower tile
 # (tools/tile_sweep.py on MI355X, whole-eval time, r03: B = 1 eval 1.3246 -> 1.3004 ms): key = (m_frags, n_frags, KS, pixshuf).
 # The up-sampling 1x1 convs (PixelShuffle epilogue, no split-K) want ONE 16-row fragment per wave: a (4, 1) tile left 128
@@ -306,7 +307,8 @@ class _Plan:
 
     # -------- op emitters
     def conv(self, x, x_f32, H, W, wname, bname, out, ldc, co_off, Cout, k, stride=1, pad=0, resid=None, pixshuf=False,
-             defer=False, w_ptr=None, batch=None, out_hw=None, upsampled=False, relu=False, gelu=False, twin=None):
+             defer=False, w_ptr=None, batch=None, out_hw=None, upsampled=False, relu=False, gelu=False, twin=None, want_slots=False,
+             nchw=False):
         """One implicit-GEMM launch.  `w_ptr` replaces the named weight by a device-packed B operand (attention),
         `batch` overrides the plan batch (per-sample GEMMs), `out_hw` the output size (asymmetric padding),
         `upsampled` makes (H, W) the dims of a nearest-x2 view of the stored [H/2, W/2] input.  `twin`: a dense operand-type
@@ -345,14 +347,22 @@ class _Plan:
         defer = bool(defer and not relu and not gelu and 1 < groups <= 8 and not accum and not pixshuf and co_off == 0 and ldc == Cout == out.C and M == out.rows
                      and (self.u.lazy_consumers & 1))
         bias, res = self.wptr(bname) if bname else 0, resid.ptr if resid else 0
+        # r04: the SiLU + PixelShuffle epilogue of an Upsample also leaves the (sum, sum of squares) slots of its output for the next
+        # GroupNorm-fused conv (was a k_slots launch): one slot per MFMA fragment, filed under the right (image, 16-channel column)
+        slots = 0
+        if want_slots and pixshuf and tile < 256 and (Cout // 4) % 16 == 0 and ldc % 16 == 0 and co_off % 16 == 0 and (Ho * Wo) % 16 == 0 and not accum:
+            slots = self.misc.alloc(4 * M // 16 * (ldc // 16) * 2 * 4)
+        # nchw: the (non-deferred) split-K reduction of this conv writes the plan's NCHW output directly (was k_unpack_out)
+        nchw = bool(nchw and groups > 1 and not defer and not accum and not resid and tile < 256 and co_off == 0 and ldc == Cout)
         self.op(OP_CONV, (1 if x_f32 else 0) | (2 if pixshuf else 0) | (4 if accum else 0) | (8 if defer else 0) |
-                (16 if upsampled else 0) | (32 if relu else 0) | (64 if gelu else 0),
-                p=(x.ptr, w_ptr if w_ptr is not None else self.wptr(wname), bias, out.ptr, res, ws),
+                (16 if upsampled else 0) | (32 if relu else 0) | (64 if gelu else 0) | (256 if nchw else 0),
+                p=(x.ptr, w_ptr if w_ptr is not None else self.wptr(wname), bias, out.ptr, res, ws, 0, slots),
                 i=(B, H, W, x.C, Ho, Wo, Cout, ldc, co_off, k, k, stride, pad, groups, tile))
         if defer:
             out.lazy = ("splitk", ws, bias, res, groups, n_frags * 16, wi)
             self.ws_owners[wi] = out
-        out.slots = None
+        out.slots = slots or None
+        self.last_conv_nchw = nchw
         out.writer = self.ops[-1] if (tile >= 256 and co_off == 0 and ldc == Cout == out.C and M == out.rows) else None
         out.twin = twin if (twin is not None and tile >= 256 and ws == twin.ptr) else None
         return Ho, Wo
@@ -438,10 +448,10 @@ class _Plan:
 
         def lds_bytes(S_, WN_):
             if pipe_ok and S_ == 1 and (WM, WN_, (TR + 2) * H // 8) in PIPE_TILES:      # k_conv_fused_pipe: two 128-channel frames
-                return 2 * (((TR + 2) * (H + 2) + 1) * 288 + 15) // 16 * 16 + 4096 * WM * WN_ + 2 * C * 4 + 2688
+                return self.pipe_lds_bytes(H, C, TR, WM, WN_)
             Cs = C // S_
             stride = Cs * 2 + ((32 - (Cs * 2) % 256) + 256) % 256
-            return ((TR + 2 * h) * (H + 2 * h) + 1) * stride + 8192 * WM * WN_ + 2 * Cs * 4 + 2688
+            return ((TR + 2 * h) * (H + 2 * h) + 1) * stride + 8192 * WM * WN_ + 2 * Cs * 4 + 2688 + (ATTN_LDS_BYTES + 16 if norm == FNORM_ATTN else 0)
 
         cand = [1]
         if norm in (FNORM_GN_SELF, FNORM_GN_SLOTS):
@@ -461,6 +471,14 @@ class _Plan:
         S = next((d for d in cand if MT * n_frags * d >= 256), cand[-1])
         WN = 2 if (n_frags % 2 == 0 and MT * (n_frags // 2) * S >= 256 and lds_bytes(S, 2) <= LDS_MAX and norm != FNORM_GN_SELF) else 1
         return TR, WM, WN, S
+
+    @staticmethod
+    def pipe_lds_bytes(H, C, TR, WM, WN, pool=False):
+        """LDS bytes of a k_conv_fused_pipe launch (csrc/fused_host.h fconv_setup, pipe branch): two 128-channel frames, the K-slice
+        reduction buffer of the 4 matrix waves, the affine table, statistics; POOL adds one logit fragment per m-fragment to the
+        reduction buffer and the w_eff table (9 * C / 32 k-steps x 64 bytes)."""
+        buf = (((TR + 2) * (H + 2) + 1) * 288 + 15) // 16 * 16
+        return 2 * buf + 4096 * (WM * WN + (WM if pool else 0)) + 2 * C * 4 + 2688 + (9 * (C // 32) * 64 if pool else 0)
 
     def ensure_slots(self, t):
         """Make `t` a materialised tensor with a (sum, sum of squares) slot table (one launch when it has none)."""
@@ -485,7 +503,7 @@ class _Plan:
 
     def fconv(self, x, skip, H, wname, bname, out, Cout, k, norm, geom, gname=None, ss_ptr=0, silu=True, resid=None,
               want_slots=False, pre_gelu=False, beta_name=None, ldc=None, co_off=0, logit=None, out_gelu=False,
-              pair_first=False, pair_lazy=None, pool=None):
+              pair_first=False, pair_lazy=None, pool=None, attn=None):
         """One k_conv_fused launch: out = conv_k(act(norm(concat(x, skip * 2^-1/2)))).  With S > 1 input-channel slices the
         output stays a lazy split-K tensor (slabs + bias + resid) that the next fused conv / GroupNorm / gca pass reduces."""
         TR, WM, WN, S = geom
@@ -532,13 +550,22 @@ class _Plan:
         if pool is not None:                                    # GlobalContext pooling in the epilogue: (w_eff ptr, pooled-fragment buffer)
             assert pipe and logit is None and not accum and resid is None and ldc == Cout and co_off == 0
             logit = pool
+        ap, ai, af = (), (), ()
+        if attn is not None:                                    # FNORM_ATTN: x.ptr = the q rows; <= 3 key / value segments (csrc/fused_host.h)
+            segs, ldq, scale = attn
+            assert norm == FNORM_ATTN and len(segs) <= 3 and not silu and x.lazy is None and lp == (0, 0, 0)
+            segs = list(segs) + [(0, 0, 0, 0, 0, 0)] * (3 - len(segs))
+            assert all((sv - sk) % 4 == 0 and 0 <= (sv - sk) // 4 < (1 << 24) for sk, sv, *_ in segs)
+            ap = tuple(sk for sk, *_ in segs)
+            ai = (ldq,) + tuple(v for _, _, rows, rs, bs, hs in segs for v in (rows, rs, bs, hs))
+            af = tuple((sv - sk) // 4 for sk, sv, *_ in segs) + (scale,)
         self.op(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0) | (8 if out_gelu else 0) | (16 if pair_first else 0)
                 | (32 if pipe else 0) | (64 if pool is not None else 0),
                 p=(x_ptr, lp[0], lp[1], lp[2], x.slots or 0, skip.ptr if skip else 0, (skip.slots or 0) if skip else 0,
                    self.wptr(wname), 0 if S > 1 else bias, out.ptr, 0 if S > 1 else res, ws, slots_out, gam, bet, ss_ptr, 0,
-                   logit[0] if logit else 0, logit[1] if logit else 0),
-                i=(B, H, H, C1, C2, Cout, ldc, co_off, k, li[0], li[1], li[2], norm, 8, TR, WM, WN, S, self.u.tb_stride),
-                f=(1e-5, 1.0, SKIP_SCALE))
+                   logit[0] if logit else 0, logit[1] if logit else 0) + ap,
+                i=(B, H, H, C1, C2, Cout, ldc, co_off, k, li[0], li[1], li[2], norm, 8, TR, WM, WN, S, self.u.tb_stride) + ai,
+                f=(1e-5, 1.0, SKIP_SCALE) + af)
         if S > 1:
             out.lazy = ("splitk", ws, bias, res, S, n_frags * 16, wi)
             self.ws_owners[wi] = out
@@ -586,7 +613,8 @@ class _Plan:
             return out
         h2 = self.zf32(rows, cout, HW)
         if (getattr(self.u, "gca_epilogue_pool", True) and cout % 64 == 0 and cout <= 2048 and HW % 16 == 0 and HW // 16 <= 64
-                and self.pipe_ok(cout, 0, H, g2, norm, 3) and h.lazy is None and f"{name}.__weff__" in self.w):
+                and self.pipe_ok(cout, 0, H, g2, norm, 3) and h.lazy is None and f"{name}.__weff__" in self.w
+                and self.pipe_lds_bytes(H, cout, g2[0], g2[1], g2[2], pool=True) <= LDS_MAX):      # else: the k_gca_pool plan below
             # r03: the softmax pooling of the GlobalContext rides in conv2's epilogue (k_conv_fused_pipe<.., POOL>: context logits
             # from the conv's own staged input through w_eff, one pooled fragment per 16 pixels) -> net0 -> gate: 2 launches
             pbuf = self.f32(rows // 16, cout + 2)                 # [M/16][cout] pooled fragments, then [M/16][2] (max, sum of exp)
@@ -728,7 +756,7 @@ class _Plan:
         if g1 is None or d % 32:
             return None
         att = _T(self.misc.alloc(rows * inner * 4), rows, inner, 16)
-        g2 = self.lin_geometry(att, d, FNORM_NONE)
+        g2 = self.lin_geometry(att, d, FNORM_ATTN)            # the larger LDS frame of the two forms of the output projection
         if g2 is None:
             return None
         self.need(x)       # split-K slabs: one reduce launch beats re-reducing them in each of the projection's 40 workgroups
@@ -746,9 +774,15 @@ class _Plan:
                 segs.append((ckvp, ckvp + dh * 4, 2, 2 * dh, self.u.tb_stride, 0))
             kp = qkv.ptr + inner * 4                           # one shared k/v head right of the 8 query heads
             segs += [(nk, nk + dh * 4, 1, 0, 0, 0), (kp, kp + dh * 4, 16, nq, 16 * nq, 0)]
-        self.attn(qkv, att, segs, heads, nq, dh ** -0.5, out_f32=True)
         o = self.zf32(rows, d, 16)
-        self.fconv(att, None, 4, f"{name}.to_out.0.weight", None, o, d, 1, FNORM_NONE, g2, silu=False)
+        if getattr(self.u, "attn_in_out_proj", True) and heads == 8 and dh == 64 and all(sg[2] <= (4 if sg[5] else 24) for sg in segs):
+            # r04: the attention core runs in the prologue of its output projection (k_conv_fused<.., FNORM_ATTN>: wave = head, the 64
+            # workgroups each redo the 16-token core -- 0.3 MFLOP -- instead of one more dependent launch)
+            qv = _T(qkv.ptr, rows, inner, 16)
+            self.fconv(qv, None, 4, f"{name}.to_out.0.weight", None, o, d, 1, FNORM_ATTN, g2, silu=False, attn=(segs, nq, dh ** -0.5))
+        else:
+            self.attn(qkv, att, segs, heads, nq, dh ** -0.5, out_f32=True)
+            self.fconv(att, None, 4, f"{name}.to_out.0.weight", None, o, d, 1, FNORM_NONE, g2, silu=False)
         y = self.f32(rows, d, x.HW)
         self.ln(o, f"{name}.to_out.1.g", None, y, d, rows, out_f32=True, resid=x)
         return y
@@ -937,14 +971,27 @@ class _Plan:
                 x = self.transformer(f"ups.{ui}.2", x)
             if ui < n_lv - 1:
                 y = self.f32(B * 4 * H * H, di, 4 * H * H)
-                self.conv(x, True, H, H, f"ups.{ui}.3.net.0.weight", f"ups.{ui}.3.net.0.bias", y, di, 0, di * 4, 1, pixshuf=True)
+                self.conv(x, True, H, H, f"ups.{ui}.3.net.0.weight", f"ups.{ui}.3.net.0.bias", y, di, 0, di * 4, 1, pixshuf=True,
+                          want_slots=bool(u.fused and getattr(u, "producer_slots", True)))
                 H *= 2
                 x = y
         x = self.resnet("final_res_block", x, None, u.dim, H, gca=True)
-        o = self.zf32(B * HW, u.channels, HW)
-        self.conv(x, True, R, R, "final_conv.weight", "final_conv.bias", o, u.channels, 0, u.channels, 3, 1, 1)
         self.out = self.f32(B, u.channels * HW)
-        self.op(OP_ELTWISE, 3, p=(o.ptr, 0, 0, self.out.ptr), i=(B, HW, u.channels, u.channels))
+        o = _T(self.out.ptr, B * HW, u.channels, HW)
+        self.conv(x, True, R, R, "final_conv.weight", "final_conv.bias", o, u.channels, 0, u.channels, 3, 1, 1,
+                  nchw=getattr(u, "producer_slots", True))
+        if not self.last_conv_nchw:                                  # the conv was not split-K (or the switch is off): rows, then unpack
+            o = self.zf32(B * HW, u.channels, HW)
+            self.ops.pop()
+            self.conv(x, True, R, R, "final_conv.weight", "final_conv.bias", o, u.channels, 0, u.channels, 3, 1, 1)
+            self.op(OP_ELTWISE, 3, p=(o.ptr, 0, 0, self.out.ptr), i=(B, HW, u.channels, u.channels))
+        # r04: the sampler's init conv (k_init_x) leaves the statistics slots of x0 itself.  The full plan's k_slots pass over x0 --
+        # emitted by the first GroupNorm-fused conv, i.e. the first op behind the init convs -- then belongs to the init part only.
+        first = self.ops[self.n_init_ops] if self.n_init_ops < len(self.ops) else None
+        if (getattr(u, "producer_slots", True) and first is not None and first.type == OP_SLOTS and first.p[0] == self.x0.ptr and not first.p[1]
+                and not first.p[5] and self.x0.slots and len(self.init_x_ops) == 1 and self.init_x_ops[0].type == OP_INITX):
+            self.init_x_ops[0].p[4] = self.x0.slots
+            self.n_init_ops += 1
         memset_op.i[0] = (self.zero.off + 3) // 4
         if self.zero.off == 0:                          # nothing accumulates with atomics in this plan: no memset launch
             self.ops.remove(memset_op)
@@ -1053,6 +1100,8 @@ class Unet(nn.Module):
         self.big_tile_min_batch = int(os.environ.get("SF_BIG_TILE_B", "2"))   # batch from which the 8x8 / 16x16 / 32x32 maps use 32- / 32- / 64-pixel tiles (r03: B = 2 eval 1.70 -> 1.50 ms, B = 4 2.62 -> 2.02, B = 32 16.4 -> 11.5; at B = 1 they would leave half the CUs idle; 999 = never)
         self.gca_epilogue_pool = os.environ.get("SF_GCA_EPI_POOL", "1") != "0"   # GlobalContext pooling in conv2's epilogue (0 = k_gca_pool launch, A/B)
         self.fconv_pipe = os.environ.get("SF_PIPE", "1") != "0"         # slot-GroupNorm 3x3 convs on k_conv_fused_pipe (staging || matrix work)
+        self.producer_slots = True          # r04: k_init_x / the Upsample epilogue leave their consumers' statistics slots, the final conv's split-K reduction writes NCHW (False: the r03 k_slots / k_unpack_out launches; parity tests)
+        self.attn_in_out_proj = True        # the 16-token attention core in the prologue of its output projection (False: k_attn16 launch; parity tests)
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches
         self._pack_cache = None
         self._plans = {}
@@ -1350,9 +1399,9 @@ class Unet(nn.Module):
         return {"plan": plan, "table": self.time_table(log_snrs), "B": B, "generation": plan.generation}
 
     @torch.no_grad()
-    def eval_prepared(self, ctx, x, row):
+    def eval_prepared(self, ctx, x, row, row_ready=False):
         """eps = unet(x, time = log_snrs[row]) for a context of `begin_sampling`.  `x` may be ctx['plan'].x_view itself (a
-        sampler that writes its latents there saves the copy).  Returns a VIEW of the plan's output buffer: consume or clone
+        sampler that writes its latents there saves the copy); `row_ready`: ctx['table'][row] already sits in ctx['plan'].tb_view.  Returns a VIEW of the plan's output buffer: consume or clone
         it before the next eval."""
         plan, B = ctx["plan"], ctx["B"]
         if ctx.get("generation") != plan.generation:
@@ -1361,7 +1410,8 @@ class Unet(nn.Module):
                                "call begin_sampling() again")
         if x.data_ptr() != plan.x_view.data_ptr():
             plan.x_view.copy_(x.reshape(B, -1))
-        plan.tb_view.copy_(ctx["table"][row].expand(B, -1))
+        if not row_ready:                                       # (a sampler whose step kernel already moved the row there skips the copy launch)
+            plan.tb_view.copy_(ctx["table"][row].expand(B, -1))
         if self.use_hip_graph and not torch.cuda.is_current_stream_capturing():
             if getattr(plan, "body_graph", None) is None:
                 self._run_plan(plan, True)

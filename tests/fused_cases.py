@@ -9,7 +9,7 @@ from hostemu import fused
 from sparsefusion_amd import _lib
 
 OP_FCONV, OP_SLOTS, OP_GCA = 14, 15, 16
-NONE, GN_SELF, GN_SLOTS, LN = 0, 1, 2, 3
+NONE, GN_SELF, GN_SLOTS, LN, ATTN = 0, 1, 2, 3, 4
 
 
 def bf(x):
@@ -265,6 +265,76 @@ def run_gca_case(backend, B, H, C, lazy=False, seed=0, epilogue_chunks=False):
     if lazy:
         assert torch.allclose(h2_d.cpu(), h2, atol=1e-5)
 
+
+def run_attn_case(backend, B=2, cross=False, context=True, Cout=48, seed=0, tol=4e-3):
+    """k_conv_fused<.., FNORM_ATTN>: the 16-token attention core (8 heads x 64, keys = [context tokens,] null k/v, the tokens' one
+    shared k/v head -- or, cross-attention, null + 2 per-head time tokens; imagen_pytorch.py:480-566, :731-805) as the prologue of
+    its output projection, against softmax(q k^T scale) v -> bf16 -> linear in torch."""
+    dev = "cpu" if backend == "emu" else "cuda:0"
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    heads, dh, inner = 8, 64, 512
+    scale = dh ** -0.5
+    nq = inner if cross else inner + 2 * dh
+    qkv = rn(B * 16, nq) * 1.3
+    null_kv = rn(2, dh)
+    q = qkv[:, :inner].view(B, 16, heads, dh)
+    if cross:                                            # time block row per batch: [.. | k (2 tokens x 8 heads x 64) | v (same)]
+        st = 3000
+        tb = rn(B, st)
+        off = 700
+        kt = tb[:, off:off + 2 * inner].view(B, 2, heads, dh)
+        vt = tb[:, off + 2 * inner:off + 4 * inner].view(B, 2, heads, dh)
+        k = torch.cat([null_kv[0].expand(B, 1, heads, dh), kt], 1)                      # [B, 3, heads, dh]
+        v = torch.cat([null_kv[1].expand(B, 1, heads, dh), vt], 1)
+        tb_d, nk_d = tb.to(dev), null_kv.reshape(-1).contiguous().to(dev)
+        # layout of the plan: k of token t, head h at off + t * (2 * inner) ... the plan's own strides: row = 2 * inner, head = dh, v = k + inner
+        kt2 = torch.stack([kt, vt], 2).reshape(B, 2, 2 * inner)                          # [B, token, (k heads | v heads)]
+        tb2 = tb.clone()
+        tb2[:, off:off + 4 * inner] = kt2.reshape(B, -1)
+        tb_d = tb2.to(dev)
+        segs = [(nk_d.data_ptr(), nk_d.data_ptr() + dh * 4, 1, 0, 0, 0),
+                (tb_d.data_ptr() + off * 4, tb_d.data_ptr() + (off + inner) * 4, 2, 2 * inner, st, dh)]
+    else:
+        ks = qkv[:, inner:inner + dh].view(B, 16, 1, dh).expand(B, 16, heads, dh)
+        vs = qkv[:, inner + dh:].view(B, 16, 1, dh).expand(B, 16, heads, dh)
+        parts_k, parts_v, segs = [], [], []
+        nk_d = null_kv.reshape(-1).contiguous().to(dev)
+        if context:
+            st, off = 1000, 300
+            tb = rn(B, st)
+            ck = tb[:, off:off + 4 * dh].view(B, 2, 2, dh)                               # token t: [k | v]
+            parts_k.append(ck[:, :, 0].view(B, 2, 1, dh).expand(B, 2, heads, dh))
+            parts_v.append(ck[:, :, 1].view(B, 2, 1, dh).expand(B, 2, heads, dh))
+            tb_d = tb.to(dev)
+            segs.append((tb_d.data_ptr() + off * 4, tb_d.data_ptr() + (off + dh) * 4, 2, 2 * dh, st, 0))
+        parts_k += [null_kv[0].expand(B, 1, heads, dh), ks]
+        parts_v += [null_kv[1].expand(B, 1, heads, dh), vs]
+        k, v = torch.cat(parts_k, 1), torch.cat(parts_v, 1)
+    qkv_d = qkv.to(dev)
+    if not cross:
+        kp = qkv_d.data_ptr() + inner * 4
+        segs += [(nk_d.data_ptr(), nk_d.data_ptr() + dh * 4, 1, 0, 0, 0), (kp, kp + dh * 4, 16, nq, 16 * nq, 0)]
+    sim = torch.einsum("bihd,bjhd->bhij", q, k) * scale
+    att = torch.einsum("bhij,bjhd->bihd", torch.softmax(sim, -1), v).reshape(B * 16, inner)
+    w = rn(Cout, inner, 1, 1) / inner ** 0.5
+    bias, res = rn(Cout), rn(B * 16, Cout)
+    want = bf(att) @ bf(w.view(Cout, inner)).t() + bias + res
+    out = torch.full((B * 16, Cout), float("nan")).to(dev)
+    wp, bias_d, res_d = fused.pack_conv_weights(w).to(dev), bias.to(dev), res.to(dev)
+    segs = segs + [(0, 0, 0, 0, 0, 0)] * (3 - len(segs))
+    op = fused.mkop(OP_FCONV, 0,
+                    p=(qkv_d, None, None, None, None, None, None, wp, bias_d, out, res_d, None, None, None, None, None, None, None, None) + tuple(sg[0] for sg in segs),
+                    i=(B, 4, 4, inner, 0, Cout, Cout, 0, 1, 0, 0, 0, ATTN, 8, 4, 1, 1, 1, 0, nq) + tuple(x for sg in segs for x in sg[2:]),
+                    f=(1e-5, 1.0, 1.0) + tuple((sg[1] - sg[0]) // 4 for sg in segs) + (scale,))
+    run_ops([op], backend)
+    e = rel(out.cpu(), want)
+    assert torch.isfinite(out.cpu()).all() and e < tol, f"attention + projection mismatch rel {e}"
+    return e
+
+
+ATTN_CASES = {"self_context": dict(B=2, cross=False, context=True, seed=61), "self_plain": dict(B=1, cross=False, context=False, seed=62),
+              "cross_time_tokens": dict(B=2, cross=True, seed=63, Cout=64)}
 
 GCA_CASES = {"4x4_lazy": dict(B=2, H=4, C=128, lazy=True), "8x8": dict(B=1, H=8, C=64, seed=1), "16x16": dict(B=1, H=16, C=64, seed=2),
              "8x8_c192_b2": dict(B=2, H=8, C=192, seed=8),

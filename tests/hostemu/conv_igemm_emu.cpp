@@ -18,8 +18,9 @@ static void go(const ConvArgs& a, int a_f32, unsigned blocks) {
 
 extern "C" int emu_conv_igemm(const void* in, const uint16_t* w, const float* bias, float* out, const float* resid, float* ws, int B, int H,
                               int W, int Cin, int Ho, int Wo, int Cout, int ldc, int co_off, int k, int stride, int pad, int groups,
-                              int WM, int WN, int a_f32, int accum, int ups, int relu, int pixshuf) {
-  ConvArgs a;
+                              int WM, int WN, int a_f32, int accum, int ups, int relu, int pixshuf, float* slots) {
+  ConvArgs a{};
+  a.slots_out = slots;
   a.in = in; a.w = reinterpret_cast<const bf16x8*>(w); a.bias = bias; a.out = out; a.resid = resid; a.ws = ws;
   a.accum = accum; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.ldc = ldc; a.co_off = co_off;
   a.kh = a.kw = k; a.stride = stride; a.pad = pad; a.groups = groups; a.pixshuf = pixshuf; a.ups = ups; a.relu = relu;

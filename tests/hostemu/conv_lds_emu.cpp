@@ -34,7 +34,7 @@ static int run_glds_nst(const ConvArgs& a, unsigned nblk, double* gn_part, int g
 extern "C" int emu_conv_lds(const void* in, const uint16_t* w, const float* bias, float* out, const float* resid, int B, int H, int W,
                             int Cin, int Ho, int Wo, int Cout, int ldc, int co_off, int k, int stride, int pad, int bnf, int a_f32,
                             int accum, int ups, int relu, double* gn_part, int gn_cg, double* stats, int glds, uint16_t* twin) {
-  ConvArgs a;
+  ConvArgs a{};
   a.in = in; a.w = reinterpret_cast<const bf16x8*>(w); a.bias = bias; a.out = out; a.resid = resid;
   a.ws = reinterpret_cast<float*>(twin);          // operand-type twin of the output (dense [M][Cout]) or null
   a.accum = accum; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout; a.ldc = ldc; a.co_off = co_off;

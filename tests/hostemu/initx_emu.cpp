@@ -10,8 +10,9 @@ using std::max;
 #include "../../sparsefusion_amd/csrc/initx.h"
 
 extern "C" void emu_init_x(const float* x, const float* base, const uint16_t* w, float* out, int B, int H, int W, int Cx, int ld,
-                           const int* cw, const int* co, const int* woff) {
+                           const int* cw, const int* co, const int* woff, float* slots) {
   InitXArgs a;
+  a.slots = slots;
   a.x = x; a.base = base; a.w = reinterpret_cast<const ix_bf16x8*>(w); a.out = out;
   a.B = B; a.H = H; a.W = W; a.Cx = Cx; a.ld = ld;
   for (int k = 0; k < 3; ++k) { a.cw[k] = cw[k]; a.co[k] = co[k]; a.woff[k] = woff[k]; }

@@ -186,6 +186,13 @@ def run_op(o):
         if fl & 2:                                               # SiLU + PixelShuffle(2)
             y = F.silu(y).view(B, Ho, Wo, Cout // 4, 2, 2).permute(0, 1, 4, 2, 5, 3).reshape(B * 4 * Ho * Wo, Cout // 4)
             f32(p[3], B * 4 * Ho * Wo, ldc)[:, co_off:co_off + Cout // 4] = y
+            if p[7]:                                             # output slots: any fragment partition with the right (image, column) sums serves
+                Mo, Co = B * 4 * Ho * Wo, Cout // 4
+                t = y.reshape(Mo // 16, 16, Co // 16, 16).permute(0, 2, 1, 3).reshape(Mo // 16, Co // 16, 256)
+                f32(p[7], Mo // 16, ldc // 16, 2)[:, co_off // 16:co_off // 16 + Co // 16] = torch.stack([t.sum(-1), (t * t).sum(-1)], -1)
+            return
+        if fl & 256:                                             # split-K reduction straight into the plan's NCHW output
+            f32(p[3], B, Cout, Ho * Wo)[:] = y.view(B, Ho * Wo, Cout).permute(0, 2, 1)
             return
         out = f32(p[3], M, ldc)
         if p[4]:

@@ -108,6 +108,45 @@ def test_lazy_consumers_do_not_change_the_result(B):
         assert r < TOL_REL and c > TOL_COS
 
 
+@pytest.mark.parametrize("switch", ["hybrid_rows", "no_big_tiles", "cost_model_tiles"])
+def test_plan_switches_match_oracle(switch):
+    """Every planner switch that changes which kernels an eval runs has its own parity case (the default suite runs B = 1, 2, 4 on
+    the default plan only): `unfused_min_rows` (ResnetBlocks with >= that many pixel rows at 32x32 / 16x16 leave the GroupNorm-fused
+    kernels for GroupNorm + k_conv3_halo: the default threshold 8192 is first reached at B = 8; forced here at B = 2),
+    `big_tile_min_batch` (the 32- / 64-pixel tiles from B = 2 on, here switched off) and `tile_override` (measured implicit-GEMM tile
+    picks, here the cost model's).  Each plan is compared with the fp32 oracle and with the default plan."""
+    name = "canonical"
+    sd = state(name)
+    net = _unet(name, sd)
+    B = 2
+    g = torch.Generator().manual_seed(91)
+    x, cond = torch.randn(B, 4, 32, 32, generator=g), torch.randn(B, 256, 32, 32, generator=g)
+    ls = unet_ref.log_snr(torch.tensor([0.7, 0.15]))
+    with torch.no_grad():
+        y_ref = unet_ref.unet_forward(sd, x, ls, cond)
+    y_def = net.forward_with_cond_scale(x.to(DEV), ls.to(DEV), cond_images=cond.to(DEV)).cpu()
+    n_def = [o.type for o in net._plan(B, torch.device(DEV)).ops]
+    if switch == "hybrid_rows":
+        net.unfused_min_rows = 512
+    elif switch == "no_big_tiles":
+        net.big_tile_min_batch = 999
+    else:
+        net.tile_override = {}
+    net.drop_plans()
+    y = net.forward_with_cond_scale(x.to(DEV), ls.to(DEV), cond_images=cond.to(DEV)).cpu()
+    ops = net._plan(B, torch.device(DEV)).ops
+    if switch == "hybrid_rows":                    # the plan really changed: GroupNorm passes + LDS-tiled convs appeared
+        from sparsefusion_amd.unet import OP_CONV, OP_GN_ACT
+        assert sum(o.type == OP_GN_ACT for o in ops) >= 16 and sum(o.type == OP_CONV and o.i[14] >= 256 for o in ops) >= 12
+        assert [o.type for o in ops] != n_def
+    elif switch == "no_big_tiles":
+        from sparsefusion_amd.unet import OP_FCONV
+        assert max(o.i[15] for o in ops if o.type == OP_FCONV) <= 2          # WM: no 64-pixel tiles
+    r, c = rel_err(y, y_ref), cosine(y, y_ref)
+    print(f"{switch}: rel L2 vs oracle {r:.3e} cosine {c:.6f}; vs default plan {rel_err(y, y_def):.3e}")
+    assert torch.isfinite(y).all() and r < TOL_REL and c > TOL_COS and rel_err(y, y_def) < TOL_REL
+
+
 def test_sampler_fast_path_equals_forward():
     """Unet.begin_sampling / eval_prepared (time table once per trajectory + plan body per eval) is the same computation as
     Unet.forward: same kernels on the same operands.  Not bit-identical: the GroupNorm statistics of the 4x4 level meet
@@ -205,7 +244,7 @@ def test_plms_sampler_matches_reference_golden(max_thres, evals):
     assert torch.allclose(acp.cpu(), r["alpha_cumprod"], atol=1e-6)
     rr, cc = rel_err(img.cpu(), r["img"]), cosine(img.cpu(), r["img"])
     print(f"plms[{max_thres}] rel {rr:.3e} cos {cc:.6f}")
-    assert rr < (1e-6 if evals == 0 else 5e-2) and cc > 0.998
+    assert rr < (1e-6 if evals == 0 else 3e-2) and cc > 0.9995       # measured 1.0e-3 (7 evals) / 1.8e-2 (51 evals, dim-64 config)
     assert float(img.abs().max()) <= 10.0
 
 
@@ -213,7 +252,7 @@ def test_plms_canonical_config_trajectory_matches_reference_golden():
     """The headline configuration end to end: the reference's own PLMSSampler.sample on the 400.68 M-parameter UNet at
     max_thres = 0.5 (50 steps = 51 evals, B = 1: sparsefusion/distillation.py:304, external/plms.py:54-119), golden from
     tests/golden/make_golden_unet.py --canonical-plms.  51 chained bf16-operand evals: stated trajectory tolerance
-    relative L2 < 5e-2 and cosine > 0.998 (measured ~1.5e-2 / 0.9999)."""
+    relative L2 < 3e-2 and cosine > 0.9995 (measured 4e-3 ... 1.5e-2 / 0.9999: a 2x regression fails)."""
     from sparsefusion_amd.vldm import DDPM
     from sparsefusion_amd.plms import PLMSSampler
     r = torch.load(f"{GOLD}/plms_sample_canonical.pt")
@@ -241,7 +280,7 @@ def test_plms_canonical_config_trajectory_matches_reference_golden():
     assert torch.allclose(acp.cpu(), r["alpha_cumprod"], atol=1e-6)
     rr, cc = rel_err(img.cpu(), r["img"]), cosine(img.cpu(), r["img"])
     print(f"plms canonical (51 evals) rel {rr:.3e} cos {cc:.6f}")
-    assert rr < 5e-2 and cc > 0.998 and float(img.abs().max()) <= 10.0
+    assert rr < 3e-2 and cc > 0.9995 and float(img.abs().max()) <= 10.0
 
 
 def test_plms_internal_draws_match_injected_ones():

@@ -195,6 +195,25 @@ def test_conv_glds_is_bitwise_conv_lds(case, nst):
         assert torch.equal(got, ref), float((got - ref).abs().max())
         if gn:                                                        # another (fixed) summation order than k_conv_lds_gn; identical run to run
             assert torch.allclose(gpart, rpart, rtol=1e-5, atol=1e-4) and torch.equal(gpart, outs[1][1])
+    # ... and both against torch itself (kernel-vs-kernel alone would pass a bug the two share on a shape LDS_CASES lacks)
+    xr = bf(x)
+    if ups:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    if stride == 2:
+        xr = F.pad(xr, (0, 1, 0, 1))
+    want = F.conv2d(xr, bf(w), bias, stride=stride, padding=pad).permute(0, 2, 3, 1)
+    if use_res:
+        want = want + res.cpu()[..., co_off:co_off + Cout]
+    if relu:
+        want = F.relu(want)
+    got = outs[1][0]
+    assert torch.allclose(got[..., co_off:co_off + Cout], want, rtol=2e-4, atol=2e-4), float((got[..., co_off:co_off + Cout] - want).abs().max())
+    assert got[..., :co_off].abs().max() == 0 and got[..., co_off + Cout:].abs().max() == 0
+    if gn:                                                            # per-image, per-group (sum, sum of squares) of the written output
+        tpi = max(Ho * Ho // 128, 1)
+        v = got.double().view(B, Ho * Ho, Cout // cg, cg)
+        direct = torch.stack([v.sum((1, 3)), (v * v).sum((1, 3))], -1)
+        assert torch.allclose(outs[1][1].view(B, tpi, Cout // cg, 2).sum(1), direct, rtol=1e-6, atol=1e-3)
 
 
 HALO_CASES = [

@@ -46,6 +46,7 @@ CASES = [
     (2, 8, 64, 64, 1, 1, 0, 1, (2, 2), False, False, True, 2, False),       # 1x1, accumulate, GELU
     (1, 8, 32, 64, 4, 2, 1, 1, (1, 2), True, False, False, 0, False),       # Downsample conv 4x4 stride 2 pad 1 (imagen)
     (1, 4, 64, 128, 3, 1, 1, 1, (1, 2), True, False, False, 0, True),       # Upsample: conv -> SiLU -> PixelShuffle(2)
+    (2, 4, 64, 256, 1, 1, 0, 1, (1, 1), True, False, False, 0, True),       # the UNet's Upsample: 1x1 conv, two images, + output slots
     (1, 10, 32, 40, 3, 1, 1, 1, (4, 2), False, False, False, 1, False),     # ragged M = 100 (6.25 fragments), ReLU
 ]
 
@@ -70,9 +71,17 @@ def test_conv_igemm_matches_conv2d(B, H, Cin, Cout, k, stride, pad, groups, tile
     if pixshuf:                                                 # [B, 2Ho, 2Ho, Cout/4] = PixelShuffle(2)(SiLU(conv))
         want = F.pixel_shuffle(F.silu(conv), 2).permute(0, 2, 3, 1).reshape(B * 4 * Ho * Ho, Cout // 4)
         out = torch.full((B * 4 * Ho * Ho, Cout // 4), float("nan"))
+        Co, Mo = Cout // 4, B * 4 * Ho * Ho
+        slots = torch.full((Mo // 16, Co // 16, 2), float("nan")) if Co % 16 == 0 else None
         rc = lib.emu_conv_igemm(ptr(xa), ptr(wp), ptr(b), ptr(out), None, None, B, H, H, Cin, Ho, Ho, Cout, Cout // 4, 0, k, stride, pad, 1,
-                                WM, WN, int(a_f32), 0, 0, 0, 1)
+                                WM, WN, int(a_f32), 0, 0, 0, 1, ptr(slots))
         assert rc == 0 and torch.allclose(out, want, rtol=1e-4, atol=2e-4), float((out - want).abs().max())
+        if slots is not None:          # (sum, sum of squares) per MFMA fragment, filed under the right (image, 16-channel column)
+            assert torch.isfinite(slots).all()
+            v = out.view(B, 4 * Ho * Ho, Co // 16, 16).double()
+            direct = torch.stack([v.sum((1, 3)), (v * v).sum((1, 3))], -1)
+            got = slots.view(B, 4 * Ho * Ho // 16, Co // 16, 2).double().sum(1)
+            assert torch.allclose(got, direct, rtol=1e-5, atol=1e-3), float((got - direct).abs().max())
         return
     want = conv.permute(0, 2, 3, 1).reshape(M, Cout)
     ldc = Cout + 4
@@ -81,7 +90,7 @@ def test_conv_igemm_matches_conv2d(B, H, Cin, Cout, k, stride, pad, groups, tile
     if groups > 1:                                              # partial tiles only: sum the slabs + bias as k_splitk_reduce does
         ws = torch.full((groups, M, npad), float("nan"))
         rc = lib.emu_conv_igemm(ptr(xa), ptr(wp), ptr(b), ptr(out), None, ptr(ws), B, H, H, Cin, Ho, Ho, Cout, ldc, 0, k, stride, pad,
-                                groups, WM, WN, int(a_f32), 0, 0, 0, 0)
+                                groups, WM, WN, int(a_f32), 0, 0, 0, 0, None)
         assert rc == 0 and bool(torch.isnan(out).all())         # the kernel itself writes no output in this mode
         got = ws[:, :, :Cout].sum(0) + b
         assert torch.allclose(got, want + b, rtol=1e-4, atol=2e-4), float((got - want - b).abs().max())
@@ -92,7 +101,7 @@ def test_conv_igemm_matches_conv2d(B, H, Cin, Cout, k, stride, pad, groups, tile
         want = want + out[:, :Cout]
     want = want.relu() if relu == 1 else F.gelu(want) if relu == 2 else want
     rc = lib.emu_conv_igemm(ptr(xa), ptr(wp), ptr(b), ptr(out), ptr(res), None, B, H, H, Cin, Ho, Ho, Cout, ldc, 0, k, stride, pad, 1,
-                            WM, WN, int(a_f32), int(accum), 0, relu, 0)
+                            WM, WN, int(a_f32), int(accum), 0, relu, 0, None)
     assert rc == 0
     got = out[:, :Cout]
     assert torch.allclose(got, want, rtol=1e-4, atol=2e-4), float((got - want).abs().max())

@@ -59,3 +59,8 @@ def test_whole_fused_plan_against_oracle(dim):
 @pytest.mark.parametrize("name", sorted(fc.GCA_CASES))
 def test_gca_chain_on_cpu_threads(name):
     fc.run_gca_case("emu", **(fc.GCA_CASES)[name])
+
+
+@pytest.mark.parametrize("name", sorted(fc.ATTN_CASES))
+def test_attention_prologue_on_cpu_threads(name):
+    fc.run_attn_case("emu", **fc.ATTN_CASES[name])

@@ -42,5 +42,15 @@ def test_init_x_kernel_matches_conv2d(B, R, Cx, cws):
     out = torch.full((B * R * R, dim), float("nan"))
     arr = lambda v: (C.c_int * 3)(*v)
     ptr = lambda t: C.c_void_p(t.data_ptr())
-    lib.emu_init_x(ptr(x), ptr(base), ptr(tab), ptr(out), B, R, R, Cx, dim, arr(cws), arr([0, cws[0], cws[0] + cws[1]]), arr(woffs))
+    lib.emu_init_x(ptr(x), ptr(base), ptr(tab), ptr(out), B, R, R, Cx, dim, arr(cws), arr([0, cws[0], cws[0] + cws[1]]), arr(woffs), None)
     assert torch.allclose(out, want, rtol=1e-4, atol=2e-4), float((out - want).abs().max())
+    # with the statistics slots of the output (what the next GroupNorm-fused conv sums per (image, 16-channel column)): one slot
+    # per MFMA fragment = 16 pixels (two rows of an 8 x 8 tile) x 16 channels; every slot written, column sums = the tensor's
+    out2 = torch.full_like(out, float("nan"))
+    slots = torch.full((B * R * R // 16, dim // 16, 2), float("nan"))
+    lib.emu_init_x(ptr(x), ptr(base), ptr(tab), ptr(out2), B, R, R, Cx, dim, arr(cws), arr([0, cws[0], cws[0] + cws[1]]), arr(woffs), ptr(slots))
+    assert torch.equal(out2, out) and torch.isfinite(slots).all()
+    v = out.view(B, R * R, dim // 16, 16).double()
+    direct = torch.stack([v.sum((1, 3)), (v * v).sum((1, 3))], -1)                      # [B][column][2]
+    got = slots.view(B, R * R // 16, dim // 16, 2).double().sum(1)
+    assert torch.allclose(got, direct, rtol=1e-5, atol=1e-3), float((got - direct).abs().max())
