@@ -14,7 +14,10 @@ conv / linear MFMA operands of the UNet, VAE and VGG (bf16, fp32 accumulate).
 `--config 2` (BASELINE configs[2]): 6 input views, and the 256-channel view features of every novel view are NOT cached: each
 step first renders them through the Epipolar Feature Transformer (`renderer_feat(cameras=, volumetric_function=
 eft.batched_forward, n_batches=16, input_cameras=, input_rgb=)`, distillation.py:99-109: 32x32 rays x 20 depths x 6 views).
-`--config 3` = `--views-per-gpu 4` (BASELINE configs[3], 4 novel views per GPU and step).
+`--config 3` = `--views-per-gpu 4` (BASELINE configs[3], 4 novel views per GPU and step); the DEFAULT line also carries a short
+measurement of that regime (`also_measured.config3_B4`: 1 + 3 steps at 4 views on this GPU, after the headline's timed region).
+`--config 4` (BASELINE configs[4] on the GPUs given): IEEE-half MFMA operands for the UNet, the full 50-step PLMS trajectory
+(max_thres 0.999: 51 evals), and the 512 x 512 evaluation render through `render_batched` timed in `breakdown_ms`.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 N > 1 runs one rank per GPU over RCCL -- under torch.distributed.run (RANK / WORLD_SIZE in the environment), or spawned by
@@ -64,7 +67,7 @@ def huber(x, y, scaling=0.1):
 
 
 class HotPath:
-    def __init__(self, device, rank, world, max_thres, views=1, seed=0, n_input_views=2, eft_features=False):
+    def __init__(self, device, rank, world, max_thres, views=1, seed=0, n_input_views=2, eft_features=False, unet_operand=None):
         from sparsefusion_amd.nerf import NeRFNetwork, get_default_torch_ngp_opt
         from sparsefusion_amd.unet import Unet
         from sparsefusion_amd.vldm import DDPM
@@ -87,6 +90,8 @@ class HotPath:
                     cond_images_channels=256, attn_pool_text=False)
         with torch.no_grad():                                     # the reference zero-inits final_conv: use a trained-like one
             unet.final_conv.weight.normal_(0, 0.02)
+        if unet_operand:                                          # BASELINE configs[4] "fp16 UNet": IEEE-half MFMA operands, fp32 accumulate
+            unet.set_operand(unet_operand)
         self.vldm = DDPM(channels=4, unets=(unet,), conditional_encoder=None, conditional_embed_dim=None, image_sizes=(32,),
                          timesteps=500, cond_drop_prob=0.1, pred_objectives='noise', conditional=False,
                          auto_normalize_img=False, clip_output=True, dynamic_thresholding=False,
@@ -105,10 +110,9 @@ class HotPath:
         self.lambda_percep = 0.1                                  # value after start_percep_step (:176-178)
         g = torch.Generator().manual_seed(100 + rank)
         self.rays_in = pinhole_rays(128, rank % 2, 34, device)                 # one of the 2 input views
-        self.rays_novel = [pinhole_rays(128, 2 + rank * views + v, 34, device) for v in range(views)]   # this rank's novel views
         self.target_rgb = torch.rand(1, 3, 128, 128, generator=g).to(device)
         self.target_mask = (torch.rand(1, 1, 128, 128, generator=g) > 0.5).float().to(device)
-        self.features = torch.randn(views, 256, 32, 32, generator=g).to(device)  # cached EFT features of the novel views
+        self.set_views(views, g)
         self.flat_grads = None
         self.n_input_views, self.eft = n_input_views, None
         self.coll_us = {"all_gather_latents": [], "all_reduce_grads": []}     # host-timed collectives (multi-rank runs)
@@ -123,6 +127,13 @@ class HotPath:
             self.novel_cams = [self._circle_cameras([0.25 + 0.2 * (rank * views + v)], PinholeCameras).to(device) for v in range(views)]
             _, _, self.renderer_feat = init_light_field_renderer(device, 256, 256, min=1.0, max=8.0, scale_factor=8.0)   # distillation.py:86
             self.eft.encode(self.in_cams, self.in_rgb)           # once per scene (distillation.py:92-98)
+
+    def set_views(self, views, g=None):
+        """this rank's novel views of a step (cached-feature configurations): rays and the 256-channel conditioning of each"""
+        g = g or torch.Generator().manual_seed(200 + self.rank)
+        self.views = views
+        self.rays_novel = [pinhole_rays(128, 2 + self.rank * views + v, 34, self.dev) for v in range(views)]
+        self.features = torch.randn(views, 256, 32, 32, generator=g).to(self.dev)  # cached EFT features of the novel views
 
     @staticmethod
     def _circle_cameras(angles, cls):
@@ -405,13 +416,17 @@ def main():
                     help="strong scaling: this many novel views per step in total, block-sharded over the ranks (overrides --views-per-gpu)")
     ap.add_argument("--check-replicas", action="store_true", help="(default when N > 1) assert after every step that all ranks hold bit-identical NGP parameters")
     ap.add_argument("--no-check-replicas", action="store_true")
-    ap.add_argument("--config", type=int, default=1, choices=(1, 2, 3),
+    ap.add_argument("--config", type=int, default=1, choices=(1, 2, 3, 4),
                     help="BASELINE configs[k]: 1 = 2 input views, cached features (default); 2 = 6 input views, EFT feature render every step; "
-                         "3 = 4 novel views per GPU")
+                         "3 = 4 novel views per GPU; 4 = fp16-operand UNet, full 50-step PLMS trajectory (max_thres 0.999), and the 512^2 "
+                         "evaluation render through render_batched timed beside the step")
+    ap.add_argument("--no-also-measured", action="store_true", help="skip the short configs[3] (B = 4) measurement the default line carries")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.config == 3 and args.views_per_gpu == 1:
         args.views_per_gpu = 4
+    if args.config == 4:
+        args.max_thres = 0.999                                   # plms.py:60-66: the full trajectory, 50 steps = 51 UNet evals
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -446,7 +461,8 @@ def main():
             raise SystemExit("--total-views must be a multiple of the number of ranks (equal shards for the latent all-gather)")
         args.views_per_gpu = len(shard_views(args.total_views, rank, world))
     n_in = 6 if args.config == 2 else 2
-    hp = HotPath(dev, rank, world, args.max_thres, args.views_per_gpu, n_input_views=n_in, eft_features=args.config == 2)
+    hp = HotPath(dev, rank, world, args.max_thres, args.views_per_gpu, n_input_views=n_in, eft_features=args.config == 2,
+                 unet_operand="f16" if args.config == 4 else None)
     hp.check_replicas = (world > 1 or args.check_replicas) and not args.no_check_replicas
     for _ in range(args.warmup):
         hp.step()
@@ -480,15 +496,17 @@ def main():
                  "timing_note": "host wall time between device synchronisations around each collective, median over 2 extra steps after the timed region"}
 
     if rank == 0:
-        n_evals = min(int(args.max_thres * 100), 50) + 1
+        n_evals = 51 if args.max_thres >= .99 else min(int(args.max_thres * 100), 50) + 1
         res = {
             "metric": "novel views/sec, distillation steps (2 NGP renders fwd+bwd + VAE enc/dec + %d-eval PLMS + LPIPS), 256^2 / 32x32 latents, "
                       "2-view synthetic hydrant" % n_evals,
             "value": round(world * args.views_per_gpu / (ms_per_step * 1e-3), 4), "unit": "views/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "bf16 MFMA operands / f32 accumulate (UNet); f32 (NGP render)", "data": "synthetic",
+            "vs_baseline": None, "dtype": ("fp16" if args.config == 4 else "bf16") + " MFMA operands / f32 accumulate (UNet); f32 (NGP render)", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[2]: single MI355X, 6 input views, EFT feature render (32x32 rays x 20 depths x 6 views) of every novel view inside the step"
                                     if args.config == 2 else
+                                    "BASELINE configs[4] on %d GPU(s): fp16-operand UNet (libsparsefusion_hip_f16.so), full 50-step PLMS trajectory, 512^2 evaluation render timed beside the step (breakdown_ms.render_batched_512)" % world
+                                    if args.config == 4 else
                                     "BASELINE configs[1]: single MI355X" if args.views_per_gpu == 1 and world == 1 else
                                     "BASELINE configs[3]-style view sharding: %d GPU(s) x %d novel views per step" % (world, args.views_per_gpu)) +
                                    ", 256^2 hydrant-like synthetic scene, %d input views, " % n_in +
@@ -511,6 +529,16 @@ def main():
         }
         if hp.eft is not None:
             res["breakdown_ms"]["eft_feature_render_per_view"] = round(time_region(lambda: hp.render_features(), 5) / args.views_per_gpu, 3)
+        if args.config == 4:
+            # the evaluation render of configs[4]: 512 x 512 rays through render_batched in max_ray_batch chunks, no gradients
+            # (renderer_df.py:681-717, distillation.py:369-388)
+            o5, d5 = pinhole_rays(512, 5, 34, dev)
+            hp.ngp.eval()
+            kw = {k: v for k, v in vars(hp.opt).items() if k != 'max_ray_batch'}
+            with torch.no_grad():
+                res["breakdown_ms"]["render_batched_512"] = round(time_region(
+                    lambda: hp.ngp.render_batched(o5, d5, batched=True, max_ray_batch=128 * 128, perturb=False, bg_color=1, shading='albedo', **kw), 3), 3)
+            hp.ngp.train()
         if args.views_per_gpu > 1:
             Bv = args.views_per_gpu
             ctx_b = hp.unet.begin_sampling(hp.features[:Bv], torch.linspace(-3, 3, 4, device=dev))
@@ -518,6 +546,28 @@ def main():
             res["breakdown_ms"]["unet_eval_in_sampler_B%d" % Bv] = round(time_region(lambda: hp.unet.eval_prepared(ctx_b, x_b, 1), 20), 3)
         res["roofline"] = unet_roofline(hp, args.views_per_gpu)    # the batch the step ran the UNet at (configs[3]: B = 4: both rooflines)
         res["roofline_mfma"] = lds_conv_roofline(hp)
+        if world == 1 and args.config == 1 and args.views_per_gpu == 1 and not strong and not args.no_also_measured:
+            # the per-GPU regime of BASELINE configs[3] (4 novel views per GPU: the UNet at B = 4), on this GPU, in this run:
+            # 1 warm-up + 3 timed steps behind the headline's timed region (utils/load_model.py:58-69 is the same model)
+            hp.set_views(4)
+            hp._sctx = None
+            hp.step()
+            torch.cuda.synchronize()
+            t0 = time.time()
+            for _ in range(3):
+                hp.step()
+            torch.cuda.synchronize()
+            ms4 = (time.time() - t0) / 3 * 1e3
+            ctx4 = hp.unet.begin_sampling(hp.features[:4], torch.linspace(-3, 3, 4, device=dev))
+            x4 = torch.zeros(4, 4, 32, 32, device=dev)
+            ev4 = time_region(lambda: hp.unet.eval_prepared(ctx4, x4, 1), 20)
+            rf4 = unet_roofline(hp, 4)
+            res["also_measured"] = {"config3_B4": {
+                "workload": "BASELINE configs[3] per-GPU share on 1 GPU: 4 novel views per step, UNet at B = 4", "steps": 3, "warmup": 1,
+                "ms_per_step": round(ms4, 3), "value": round(4 / (ms4 * 1e-3), 3), "unit": "views/s", "unet_eval_ms": round(ev4, 4),
+                "roofline": {k: rf4[k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us", "algorithmic_bytes_per_eval")},
+                "roofline_mfma_same_kernels": rf4["mfma"]}}
+            hp.set_views(1)
         if multi is not None:
             res["multi_gpu"] = multi
         if world == 1 and not args.no_cpu_baseline:

@@ -597,21 +597,38 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
     f32x4 q[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) q[u] = *reinterpret_cast<const f32x4*>(qp + 4 * u);
-    FC_PREFETCH();
-    FC_STAMP(1);
     // key / value rows: per-head segments -> this wave stages the J rows of ITS head; shared head -> the 8 waves split the rows
+    // (all of a wave's <= 4 rows are loaded before the first LDS store, from clamped addresses: a load inside the row loop was one
+    // cold round trip per row -- the rows were written by the previous kernel on other XCDs -- 7.7 us of prologue instead of ~2)
     {
       const int j0 = at.per_head ? 0 : wave, jst = at.per_head ? 1 : NW;
       const int reg = at.per_head ? wave : 0;
-      for (int j = j0; j < J; j += jst) {
-        const int r0 = at.seg[0].rows, r1 = at.seg[1].rows;
+      const int r0 = at.seg[0].rows, r1 = at.seg[1].rows;
+      constexpr int NR = 4;                                            // per head: J <= 4; shared: ceil(24 / 8) = 3
+      float kq[NR], vq[NR];
+#pragma unroll
+      for (int u = 0; u < NR; ++u) {
+        const int j = j0 + u * jst < J ? j0 + u * jst : J - 1;
         const int si = j < r0 ? 0 : (j < r0 + r1 ? 1 : 2);
         const int r = j - (si == 0 ? 0 : (si == 1 ? r0 : r0 + r1));
-        const FAttnSeg sg = at.seg[si];
-        const long off = (long)b * sg.batch_stride + (long)r * sg.row_stride + (long)wave * (at.per_head ? sg.head_stride : 0) + lane;
-        const float kv = sg.k[off], vv = sg.k[off + sg.v_off];
-        skv[(reg * J + j) * SF_ATTN_KSTRIDE + lane] = kv;
-        skv[((nreg + reg) * J + j) * SF_ATTN_KSTRIDE + lane] = vv;
+        const float* kp = si == 0 ? at.seg[0].k : (si == 1 ? at.seg[1].k : at.seg[2].k);
+        const int voff = si == 0 ? at.seg[0].v_off : (si == 1 ? at.seg[1].v_off : at.seg[2].v_off);
+        const int rs = si == 0 ? at.seg[0].row_stride : (si == 1 ? at.seg[1].row_stride : at.seg[2].row_stride);
+        const int bs = si == 0 ? at.seg[0].batch_stride : (si == 1 ? at.seg[1].batch_stride : at.seg[2].batch_stride);
+        const int hs = si == 0 ? at.seg[0].head_stride : (si == 1 ? at.seg[1].head_stride : at.seg[2].head_stride);
+        const long off = (long)b * bs + (long)r * rs + (long)wave * (at.per_head ? hs : 0) + lane;
+        kq[u] = kp[off];
+        vq[u] = kp[off + voff];
+      }
+      FC_PREFETCH();          // the weight ring goes out BEHIND the q / k / v loads: loads return in order, and the first wait below is for k / v
+      FC_STAMP(1);
+#pragma unroll
+      for (int u = 0; u < NR; ++u) {
+        const int j = j0 + u * jst;
+        if (j < J) {
+          skv[(reg * J + j) * SF_ATTN_KSTRIDE + lane] = kq[u];
+          skv[((nreg + reg) * J + j) * SF_ATTN_KSTRIDE + lane] = vq[u];
+        }
       }
     }
     sf_sync();

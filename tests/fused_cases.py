@@ -266,7 +266,7 @@ def run_gca_case(backend, B, H, C, lazy=False, seed=0, epilogue_chunks=False):
         assert torch.allclose(h2_d.cpu(), h2, atol=1e-5)
 
 
-def run_attn_case(backend, B=2, cross=False, context=True, Cout=48, seed=0, tol=4e-3):
+def run_attn_case(backend, B=2, cross=False, context=True, Cout=48, seed=0, tol=4e-3, dbg=None, reps=1):
     """k_conv_fused<.., FNORM_ATTN>: the 16-token attention core (8 heads x 64, keys = [context tokens,] null k/v, the tokens' one
     shared k/v head -- or, cross-attention, null + 2 per-head time tokens; imagen_pytorch.py:480-566, :731-805) as the prologue of
     its output projection, against softmax(q k^T scale) v -> bf16 -> linear in torch."""
@@ -324,10 +324,15 @@ def run_attn_case(backend, B=2, cross=False, context=True, Cout=48, seed=0, tol=
     wp, bias_d, res_d = fused.pack_conv_weights(w).to(dev), bias.to(dev), res.to(dev)
     segs = segs + [(0, 0, 0, 0, 0, 0)] * (3 - len(segs))
     op = fused.mkop(OP_FCONV, 0,
-                    p=(qkv_d, None, None, None, None, None, None, wp, bias_d, out, res_d, None, None, None, None, None, None, None, None) + tuple(sg[0] for sg in segs),
+                    p=(qkv_d, None, None, None, None, None, None, wp, bias_d, out, res_d, None, None, None, None, None, dbg, None, None) + tuple(sg[0] for sg in segs),
                     i=(B, 4, 4, inner, 0, Cout, Cout, 0, 1, 0, 0, 0, ATTN, 8, 4, 1, 1, 1, 0, nq) + tuple(x for sg in segs for x in sg[2:]),
                     f=(1e-5, 1.0, 1.0) + tuple((sg[1] - sg[0]) // 4 for sg in segs) + (scale,))
     run_ops([op], backend)
+    if reps > 1:
+        import time
+        t0 = time.time()
+        run_ops([op] * reps, backend)
+        return (time.time() - t0) / reps
     e = rel(out.cpu(), want)
     assert torch.isfinite(out.cpu()).all() and e < tol, f"attention + projection mismatch rel {e}"
     return e

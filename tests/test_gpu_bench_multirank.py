@@ -55,3 +55,25 @@ def test_config2_eft_feature_render_in_the_step():
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert "configs[2]" in res["config"]["workload"] and res["breakdown_ms"]["eft_feature_render_per_view"] > 0 and res["value"] > 0
+
+
+def test_config4_fp16_unet_full_plms_and_512_render():
+    """BASELINE configs[4] as a bench workload (one GPU's share): fp16-operand UNet, the full 50-step PLMS trajectory, and the 512^2
+    evaluation render through render_batched timed beside the step."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "4", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert "configs[4]" in res["config"]["workload"] and res["dtype"].startswith("fp16") and res["config"]["unet_evals_per_step"] == 51
+    assert res["breakdown_ms"]["render_batched_512"] > 0 and res["value"] > 0
+
+
+def test_default_line_carries_the_b4_regime():
+    """The default (configs[1]) line also measures configs[3]'s per-GPU regime -- 4 novel views per step, UNet at B = 4 -- in the same run."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--max-thres", "0.06", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    b4 = res["also_measured"]["config3_B4"]
+    assert b4["ms_per_step"] > 0 and b4["value"] > 0 and b4["unet_eval_ms"] > 0 and 0 < b4["roofline"]["frac"] < 1
+    assert res["config"]["views_per_gpu"] == 1 and res["roofline"]["batch"] == 1

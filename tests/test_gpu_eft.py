@@ -130,9 +130,19 @@ def test_eft_matches_reference_golden(name):
     assert lat.shape == lat_ref.shape and rel_err(lat, lat_ref) < 2e-2
     # the chunked entry point of the pre-pass gives the same rows (distillation.py:106 uses n_batches = 16)
     rb3 = RayBundle(o[None].to(DEV), d[None].to(DEV), lengths[None].to(DEV), None)
+    # (r04: chunks are merged up to max_tokens_per_call tokens -- rays are independent, the chunking only bounds memory; both the
+    # merged single plan and four real chunks are checked)
     rgb_b, f3_b, _ = net.batched_forward(rb3, n_batches=4)
     assert rgb_b.shape == (1, o.shape[0], 3) and f3_b.shape == (1, o.shape[0], 256)
     assert rel_err(f3_b[0].cpu(), f3) < 2e-2 and float((rgb_b[0].cpu() - rgb).abs().max()) < 5e-3
+    n_fwd = [0]
+    orig = net.forward
+    net.forward = lambda *a, **k: (n_fwd.__setitem__(0, n_fwd[0] + 1), orig(*a, **k))[1]
+    net.max_tokens_per_call = 1                                        # never merge: the reference's chunking
+    rgb_c, f3_c, _ = net.batched_forward(rb3, n_batches=4)
+    assert n_fwd[0] == 4
+    assert rel_err(f3_c[0].cpu(), f3) < 2e-2 and float((rgb_c[0].cpu() - rgb).abs().max()) < 5e-3
+    assert rel_err(f3_c[0].cpu(), f3_b[0].cpu()) < 1e-3
 
 
 def test_eft_rejects_unsupported():

@@ -13,12 +13,13 @@ fc.TIMING_LIB.sf_fused_op_run.restype = C.c_int
 
 names = sys.argv[1:] or sorted(fc.CONV_CASES_FULL)
 for name in names:
-    kw = dict(fc.CONV_CASES_FULL[name])
+    attn = name.startswith("attn_")                             # attn_self / attn_cross: the attention prologue + output projection (1024 channels)
+    kw = dict(B=1, cross=name == "attn_cross", Cout=1024, seed=64) if attn else dict(fc.CONV_CASES_FULL[name])
     if kw.get("accum"):
         continue
     dbg = torch.zeros(4096 * 8, dtype=torch.int64, device="cuda:0")
     try:
-        wall = fc.run_conv_case("gpu", **kw, dbg=dbg, reps=20)
+        wall = fc.run_attn_case("gpu", **kw, dbg=dbg, reps=20) if attn else fc.run_conv_case("gpu", **kw, dbg=dbg, reps=20)
     except Exception as e:                                       # paired launches carry no stamps
         print(f"{name:28s} skipped ({e})")
         continue

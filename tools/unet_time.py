@@ -6,6 +6,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 dev = torch.device("cuda:0")
 unet = Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2), layer_attns=(False, False, False, True),
             layer_cross_attns=(False,) * 4, cond_images_channels=256, attn_pool_text=False).to(dev)
+for kv in [a for a in os.environ.get("SF_UNET_ATTRS", "").split(",") if a]:      # planner switches for A/B runs: "attn_in_out_proj=0,producer_slots=0"
+    setattr(unet, kv.split("=")[0], int(kv.split("=")[1]))
 for k, v in os.environ.items():
     if k == "SF_WAVES":
         unet.conv_waves_target = int(v)
