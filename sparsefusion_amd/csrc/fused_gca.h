@@ -271,3 +271,9 @@ SF_KERNEL(256) void k_gca_gate(GcaGateArgs a) {
     if (lane == 0) { a.slots[(long)gw * 2] = sm; a.slots[(long)gw * 2 + 1] = sq; }
   }
 }
+
+// Measured and not kept (r04): net0 + gate as ONE launch on the C <= 512 levels, every workgroup recomputing the hidden vector
+// (k_gca_ng: 64 KB of pooled partials + 64-256 KB of W0 per workgroup, then its 16 fragments).  Parity-green, 11 launches fewer,
+// and SLOWER: B = 1 eval 1.243 -> 1.336 ms (+8.5 us per block; B = 4: 1.974 -> 2.052): the redundant matvec is a chain of
+// L2-latency-bound batches on one 8-wave workgroup per CU and costs more than the 6.6 us launch it replaces -- the same outcome as
+// r02's pool + net0 merge.  The all-to-all seams of GlobalContext stay kernel boundaries.

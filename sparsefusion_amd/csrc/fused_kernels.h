@@ -43,7 +43,7 @@ enum { FNORM_NONE = 0, FNORM_GN_SELF = 1, FNORM_GN_SLOTS = 2, FNORM_LN = 3, FNOR
 // tokens, the 16 tokens' shared k/v head; external/imagen_pytorch.py:480-566, :731-805).  Key row r of segment s, head h, batch b:
 // k[b * batch_stride + r * row_stride + h * head_stride + d], value = the same address + v_off.
 #define SF_ATTN_MAX_KEYS 24
-#define SF_ATTN_PSTRIDE 28          /* floats per probability row (16-byte aligned rows of <= 24 keys) */
+#define SF_ATTN_PSTRIDE 36          /* floats per probability row: 32 key columns (two MFMA blocks) + 4, 16-byte aligned */
 #define SF_ATTN_KSTRIDE 68          /* floats per staged key / value row: 16-byte aligned, 4 consecutive rows on disjoint banks */
 #define SF_ATTN_LDS_BYTES (8 * 16 * SF_ATTN_PSTRIDE * 4 + 2 * 8 * 4 * SF_ATTN_KSTRIDE * 4)   /* >= 2 * 24 shared rows as well */
 struct FAttnSeg { const float* k; int v_off, rows, row_stride, batch_stride, head_stride; };
@@ -585,18 +585,17 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
     }
   } else if (NORM == FNORM_ATTN) {
     // ---- (b1'') the attention core: wave = head (8 waves x 64 lanes = the 512 inner channels), the tile's 16 pixels = the 16
-    // query tokens.  Scores with lane = (query i, key quarter jq): the query row sits in registers, key rows are broadcast
-    // 16-byte LDS reads; softmax over the 4 lanes of a query by shuffles; P . V with lane = output dim, values in registers and
-    // probabilities as broadcast reads; the result goes straight into the frame as the conv's bf16 A operand.
+    // query tokens.  Keys / values are staged once in LDS (fp32), scores and P . V run on the matrix cores, the softmax on the D
+    // fragments by shuffles; the result goes straight into the frame as the conv's A operand.
     const FAttn& at = a.attn;
     float* sp = reinterpret_cast<float*>(lds + a.attn_off);                 // [8 heads][16 queries][SF_ATTN_PSTRIDE]
     float* skv = sp + 8 * 16 * SF_ATTN_PSTRIDE;                             // keys [regions][J][KSTRIDE], then values
     const int J = at.J, nreg = at.per_head ? 8 : 1;
-    const int qi = lane & 15, jq = lane >> 4;
-    const float* qp = at.q + ((long)b * 16 + qi) * at.ldq + wave * 64;
-    f32x4 q[16];
+    // query A fragments straight from global memory: row (lane & 15), dims 32 ks + 8 (lane >> 4) .. + 7 of head `wave`
+    const float* qp = at.q + ((long)b * 16 + (lane & 15)) * at.ldq + wave * 64 + 8 * (lane >> 4);
+    f32x4 q[4];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) q[u] = *reinterpret_cast<const f32x4*>(qp + 4 * u);
+    for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const f32x4*>(qp + 32 * (u >> 1) + 4 * (u & 1));
     // key / value rows: per-head segments -> this wave stages the J rows of ITS head; shared head -> the 8 waves split the rows
     // (all of a wave's <= 4 rows are loaded before the first LDS store, from clamped addresses: a load inside the row loop was one
     // cold round trip per row -- the rows were written by the previous kernel on other XCDs -- 7.7 us of prologue instead of ~2)
@@ -634,48 +633,76 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
     sf_sync();
     const float* kb = skv + (at.per_head ? wave : 0) * J * SF_ATTN_KSTRIDE;
     const float* vb = skv + (nreg + (at.per_head ? wave : 0)) * J * SF_ATTN_KSTRIDE;
-    constexpr int NU = SF_ATTN_MAX_KEYS / 4;
-    float sc[NU];
-    float mx = -INFINITY;
+    // Matrix-core form (the first r04 version ran scores and P.V on the vector units out of broadcast LDS reads: 3 us of LDS time
+    // per workgroup).  fp32 operands are split into operand-type hi + lo parts and the lo x lo product is dropped (relative 2^-16):
+    // S = Q K^T as 2 key blocks x 2 k-steps x 3 MFMAs, O = P V as 4 dim blocks x 3 MFMAs.  Fragment conventions (sf_dev.h):
+    // A[m = lane & 15][k = 8 (lane >> 4) + j], B[k = 8 (lane >> 4) + j][n = lane & 15], D[m = 4 (lane >> 4) + r][n = lane & 15].
+    auto split = [](const f32x4& a, const f32x4& c, bf16x8& hi, bf16x8& lo) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const int j = jq + 4 * u;
-      const f32x4* kr = reinterpret_cast<const f32x4*>(kb + (j < J ? j : J - 1) * SF_ATTN_KSTRIDE);
-      float acc = 0.0f;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const f32x4 kk = kr[t];
-        acc = fmaf(q[t][0], kk[0], acc); acc = fmaf(q[t][1], kk[1], acc); acc = fmaf(q[t][2], kk[2], acc); acc = fmaf(q[t][3], kk[3], acc);
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = (sf_opnd)a[e]; lo[e] = (sf_opnd)(a[e] - (float)hi[e]);
+        hi[4 + e] = (sf_opnd)c[e]; lo[4 + e] = (sf_opnd)(c[e] - (float)hi[4 + e]);
       }
-      sc[u] = j < J ? acc * at.scale : -INFINITY;
-      mx = fmaxf(mx, sc[u]);
+    };
+    const int g = lane >> 4, n16 = lane & 15;
+    bf16x8 qh[2], ql[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) split(q[2 * ks], q[2 * ks + 1], qh[ks], ql[ks]);
+    f32x4 sacc[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int j = 16 * cb + n16;
+      const float* kr = kb + (j < J ? j : J - 1) * SF_ATTN_KSTRIDE + 8 * g;
+      sacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 kh, kl;
+        split(*reinterpret_cast<const f32x4*>(kr + 32 * ks), *reinterpret_cast<const f32x4*>(kr + 32 * ks + 4), kh, kl);
+        sacc[cb] = sf_mfma16(qh[ks], kh, sacc[cb]);
+        sacc[cb] = sf_mfma16(qh[ks], kl, sacc[cb]);
+        sacc[cb] = sf_mfma16(ql[ks], kh, sacc[cb]);
+      }
     }
-    mx = fmaxf(mx, sf_shfl_xor(mx, 16));
-    mx = fmaxf(mx, sf_shfl_xor(mx, 32));
-    float den = 0.0f;
+    // softmax of row i = 4 g + r over the keys: this lane holds columns n16 and 16 + n16; the other columns sit in the 16 lanes of its group
+    float* prow = sp + wave * 16 * SF_ATTN_PSTRIDE;
 #pragma unroll
-    for (int u = 0; u < NU; ++u) { sc[u] = (jq + 4 * u < J) ? expf(sc[u] - mx) : 0.0f; den += sc[u]; }
-    den += sf_shfl_xor(den, 16);
-    den += sf_shfl_xor(den, 32);
-    const float inv = 1.0f / den;
-    float* prow = sp + (wave * 16 + qi) * SF_ATTN_PSTRIDE;
-#pragma unroll
-    for (int u = 0; u < NU; ++u) prow[jq + 4 * u] = sc[u] * inv;            // zeros beyond the last key
+    for (int r = 0; r < 4; ++r) {
+      const float s0 = n16 < J ? sacc[0][r] * at.scale : -INFINITY;
+      const float s1 = 16 + n16 < J ? sacc[1][r] * at.scale : -INFINITY;
+      float mx = fmaxf(s0, s1);
+      mx = fmaxf(mx, sf_shfl_xor(mx, 1)); mx = fmaxf(mx, sf_shfl_xor(mx, 2)); mx = fmaxf(mx, sf_shfl_xor(mx, 4)); mx = fmaxf(mx, sf_shfl_xor(mx, 8));
+      const float e0 = n16 < J ? expf(s0 - mx) : 0.0f, e1 = 16 + n16 < J ? expf(s1 - mx) : 0.0f;
+      float den = e0 + e1;
+      den += sf_shfl_xor(den, 1); den += sf_shfl_xor(den, 2); den += sf_shfl_xor(den, 4); den += sf_shfl_xor(den, 8);
+      const float inv = 1.0f / den;
+      prow[(4 * g + r) * SF_ATTN_PSTRIDE + n16] = e0 * inv;               // zeros beyond the last key
+      prow[(4 * g + r) * SF_ATTN_PSTRIDE + 16 + n16] = e1 * inv;
+    }
     sf_wave_sync();
-    float vv[SF_ATTN_MAX_KEYS];
-#pragma unroll
-    for (int j = 0; j < SF_ATTN_MAX_KEYS; ++j) vv[j] = vb[(j < J ? j : J - 1) * SF_ATTN_KSTRIDE + lane];
+    bf16x8 ph, pl;
+    {
+      const float* pr = prow + n16 * SF_ATTN_PSTRIDE + 8 * g;             // A fragment: row n16, keys 8 g .. 8 g + 7
+      split(*reinterpret_cast<const f32x4*>(pr), *reinterpret_cast<const f32x4*>(pr + 4), ph, pl);
+    }
     FC_STAMP(2);
-#pragma unroll 4
-    for (int ii = 0; ii < 16; ++ii) {
-      const f32x4* pr = reinterpret_cast<const f32x4*>(sp + (wave * 16 + ii) * SF_ATTN_PSTRIDE);
-      float o = 0.0f;
 #pragma unroll
-      for (int t = 0; t < NU; ++t) {
-        const f32x4 pp = pr[t];
-        o = fmaf(pp[0], vv[4 * t], o); o = fmaf(pp[1], vv[4 * t + 1], o); o = fmaf(pp[2], vv[4 * t + 2], o); o = fmaf(pp[3], vv[4 * t + 3], o);
+    for (int db = 0; db < 4; ++db) {
+      f32x4 va, vc;                                                       // B fragment: keys 8 g + t (clamped: their P is 0), dim 16 db + n16
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j0 = 8 * g + t, j1 = 8 * g + 4 + t;
+        va[t] = vb[(j0 < J ? j0 : J - 1) * SF_ATTN_KSTRIDE + 16 * db + n16];
+        vc[t] = vb[(j1 < J ? j1 : J - 1) * SF_ATTN_KSTRIDE + 16 * db + n16];
       }
-      *reinterpret_cast<sf_opnd*>(lds + (long)ii * a.pix_stride + (wave * 64 + lane) * 2) = (sf_opnd)o;
+      bf16x8 vh, vl;
+      split(va, vc, vh, vl);
+      f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+      o = sf_mfma16(ph, vh, o);
+      o = sf_mfma16(ph, vl, o);
+      o = sf_mfma16(pl, vh, o);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<sf_opnd*>(lds + (long)(4 * g + r) * a.pix_stride + (wave * 64 + 16 * db + n16) * 2) = (sf_opnd)o[r];
     }
   } else {
     // ---- (b2) + (c): GroupNorm statistics from the producer's slots (or no normalisation), then the in-image frame rows

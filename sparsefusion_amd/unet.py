@@ -26,7 +26,7 @@ PAIR_TILES = {(1, 1, 1), (1, 1, 2), (1, 2, 2), (2, 2, 2), (4, 2, 2)}
 # (WM, WN, (TR + 2) * W / 8) for which k_conv_fused_pipe is instantiated (SF_FCONV_PIPE_VARIANTS)
 PIPE_TILES = {(1, 1, 4), (1, 2, 4), (1, 1, 6), (1, 2, 6), (2, 1, 6), (2, 2, 6), (2, 1, 8), (2, 2, 8), (2, 1, 12), (2, 2, 12), (4, 1, 16), (4, 2, 16)}
 FNORM_NONE, FNORM_GN_SELF, FNORM_GN_SLOTS, FNORM_LN, FNORM_ATTN = range(5)      # csrc/fused_kernels.h
-ATTN_LDS_BYTES = 8 * 16 * 28 * 4 + 2 * 8 * 4 * 68 * 4      # SF_ATTN_LDS_BYTES: scratch of the attention prologue (FNORM_ATTN)
+ATTN_LDS_BYTES = 8 * 16 * 36 * 4 + 2 * 8 * 4 * 68 * 4      # SF_ATTN_LDS_BYTES: scratch of the attention prologue (FNORM_ATTN)
 # Measured (WM, WN, split-K groups) of implicit-GEMM launches where the cost model of Unet.conv_tiling picks a slower tile
 # (tools/tile_sweep.py on MI355X, whole-eval time, r03: B = 1 eval 1.3246 -> 1.3004 ms): key = (m_frags, n_frags, KS, pixshuf).
 # The up-sampling 1x1 convs (PixelShuffle epilogue, no split-K) want ONE 16-row fragment per wave: a (4, 1) tile left 128
@@ -654,10 +654,10 @@ class _Plan:
         else:
             pp, pm = part_pool.ptr, part_ms.ptr
             self.op(OP_GCA, 1, p=(h2.ptr, ws, bias, lpart.ptr, pp, pm), i=(rows, cout, HW, CH, chunks, nparts, groups, npad))
-        self.op(OP_GCA, 2, p=(pp, pm, self.wptr(f"{name}.gca.net.0.weight"), self.wptr(f"{name}.gca.net.0.bias"),
-                              hid.ptr), i=(B, cout, (cout + 7) // 8 * 8, hidc, chunks))
         if want_slots:
             out.slots = self.misc.alloc(rows // 16 * (cout // 16) * 2 * 4)
+        self.op(OP_GCA, 2, p=(pp, pm, self.wptr(f"{name}.gca.net.0.weight"), self.wptr(f"{name}.gca.net.0.bias"),
+                              hid.ptr), i=(B, cout, (cout + 7) // 8 * 8, hidc, chunks))
         self.op(OP_GCA, 3, p=(h2.ptr, res.ptr, hid.ptr, self.wptr(f"{name}.gca.net.2.weight"), self.wptr(f"{name}.gca.net.2.bias"),
                               out.ptr, out.slots or 0), i=(rows, cout, HW, hidc, (hidc + 7) // 8 * 8))
 

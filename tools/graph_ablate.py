@@ -29,7 +29,7 @@ def cls(k):
         tag = {FNORM_GN_SELF: "gn_self", FNORM_GN_SLOTS: "gn_slots", FNORM_LN: "ln", FNORM_ATTN: "attn"}.get(norm, "plain")
         return f"fconv_{H}x{H}_{tag}" + ("_pipe" if o.flags & 32 else "") + ("_pool" if o.flags & 64 else "") + ("_pair" if o.flags & 16 else "")
     if o.type == OP_GCA:
-        return "gca_" + {1: "pool", 2: "net0", 3: "gate"}[o.flags] + f"_{int(round((o.i[2] if o.flags != 2 else 0) ** 0.5))}"
+        return "gca_" + {1: "pool", 2: "net0", 3: "gate"}.get(o.flags, str(o.flags)) + f"_{int(round((o.i[2] if o.flags != 2 else 0) ** 0.5))}"
     if o.type == OP_CONV:
         return f"igemm_{o.i[1]}x{o.i[2]}_k{o.i[9]}" + ("_pixshuf" if o.flags & 2 else "") + ("_deferred" if o.flags & 8 else "")
     return {OP_SLOTS: "slots", OP_LN: "layernorm", OP_ATTN: "attn16", OP_SPLITK_REDUCE: "splitk_reduce", OP_INITX: "init_x", OP_ELTWISE: "eltwise"}.get(o.type, f"op{o.type}")
