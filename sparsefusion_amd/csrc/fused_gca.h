@@ -151,9 +151,16 @@ SF_DEV void gca_net0_body(const GcaNetArgs& a, float* pooled, float* wgt) {
     }
   }
   const float* pp = a.part_pool + (long)b * a.chunks * a.C;
-  float pj0[NCK];
+  // ALL pooled partials this thread will merge are requested now (r04; the first version fetched those of its 2nd .. 4th channel
+  // inside the merge loop: up to three more dependent round trips at C = 1024): CI channels per thread x NCK chunks <= 64 loads
+  constexpr int CI = NCK <= 8 ? 4 : (NCK <= 16 ? 2 : 1);     // C <= 256 * CI is what the plans produce (host-checked; the loop below covers the rest)
+  float pj0[CI][NCK];
 #pragma unroll
-  for (int j = 0; j < NCK; ++j) pj0[j] = pp[(long)(j < a.chunks ? j : a.chunks - 1) * a.C + (tid < a.C ? tid : 0)];
+  for (int ci = 0; ci < CI; ++ci) {
+    const int cc = tid + ci * 256;
+#pragma unroll
+    for (int j = 0; j < NCK; ++j) pj0[ci][j] = pp[(long)(j < a.chunks ? j : a.chunks - 1) * a.C + (cc < a.C ? cc : 0)];
+  }
   if (wave == 0) {                                        // online-softmax merge weights of the chunks (lanes = chunks, <= 64)
     const bool on = lane < a.chunks;
     const float mj = on ? a.part_ms[((long)b * a.chunks + lane) * 2] : -INFINITY;
@@ -164,13 +171,17 @@ SF_DEV void gca_net0_body(const GcaNetArgs& a, float* pooled, float* wgt) {
     wgt[lane] = on ? wj / Z : 0.0f;                       // 0 beyond the last chunk
   }
   sf_sync();
-  for (int c = tid; c < a.C; c += 256) {
-    float pj[NCK];
 #pragma unroll
-    for (int j = 0; j < NCK; ++j) pj[j] = c == tid ? pj0[j] : pp[(long)(j < a.chunks ? j : a.chunks - 1) * a.C + c];
+  for (int ci = 0; ci < CI; ++ci) {
+    const int c = tid + ci * 256;
     float s = 0.0f;
 #pragma unroll
-    for (int j = 0; j < NCK; ++j) s = fmaf(wgt[j], pj[j], s);
+    for (int j = 0; j < NCK; ++j) s = fmaf(wgt[j], pj0[ci][j], s);
+    if (c < a.C) pooled[c] = s;
+  }
+  for (int c = tid + CI * 256; c < a.C; c += 256) {            // wider layers than the preload covers (not in the UNet's plans)
+    float s = 0.0f;
+    for (int j = 0; j < a.chunks; ++j) s = fmaf(wgt[j], pp[(long)j * a.C + c], s);
     pooled[c] = s;
   }
   sf_sync();
@@ -277,3 +288,8 @@ SF_KERNEL(256) void k_gca_gate(GcaGateArgs a) {
 // and SLOWER: B = 1 eval 1.243 -> 1.336 ms (+8.5 us per block; B = 4: 1.974 -> 2.052): the redundant matvec is a chain of
 // L2-latency-bound batches on one 8-wave workgroup per CU and costs more than the 6.6 us launch it replaces -- the same outcome as
 // r02's pool + net0 merge.  The all-to-all seams of GlobalContext stay kernel boundaries.
+// Also measured and not kept (r04, profiles/r04_graph_ablate_b1_rejected_ln_gate.log vs r04_graph_ablate_b1_first.log): k_gca_gate with the hidden
+// vector through a per-wave LDS copy and both trips' weight fragments requested up front -- +0.4 .. +1.1 us per launch (the copy is
+// one more dependent step; the scattered loads it replaced travelled with the weight loads); the LayerNorm gain / bias of
+// k_conv_fused<.., FNORM_LN> fetched with the row instead of after the statistics -- +2.4 us per launch (32 more vector loads per
+// thread in front of the row statistics).  k_gca_net0's pooled partials all requested at entry: -0.7 us per launch, kept.
