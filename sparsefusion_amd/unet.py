@@ -34,7 +34,11 @@ ATTN_LDS_BYTES = 8 * 16 * 36 * 4 + 2 * 8 * 4 * 68 * 4      # SF_ATTN_LDS_BYTES: 
 TILE_PICKS = {(4, 32, 128, False): (1, 2, 8),      # Downsample 16x16 -> 8x8, 256 -> 512, k 4 s 2
               (4, 128, 32, True): (1, 1, 1),       # Upsample 8x8 -> 16x16: 1x1 conv 1024 -> 2048 + PixelShuffle
               (16, 64, 16, True): (1, 2, 1),       # Upsample 16x16 -> 32x32: 1x1 conv 512 -> 1024 + PixelShuffle
-              (64, 1, 72, False): (1, 1, 4)}       # final 3x3 conv 256 -> 4 at 32x32
+              (64, 1, 72, False): (1, 1, 4),       # final 3x3 conv 256 -> 4 at 32x32
+              # B = 4 (BASELINE configs[3], 4 novel views per GPU; tools/tile_sweep.py 4, r04: eval 1.953 -> 1.904 ms)
+              (64, 16, 128, False): (2, 4, 4), (16, 32, 128, False): (1, 4, 4), (4, 64, 256, False): (1, 2, 4),
+              (4, 64, 288, False): (1, 4, 4), (4, 256, 32, True): (1, 2, 1), (16, 128, 32, True): (1, 4, 1),
+              (64, 64, 16, True): (1, 2, 1)}
 LDS_MAX = 163840
 SKIP_SCALE = 2 ** -0.5            # scale_skip_connection (imagen_pytorch.py:1283)
 
