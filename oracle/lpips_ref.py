@@ -53,7 +53,26 @@ def init_state(seed=0):
     return sd
 
 
-def vgg_features(sd, x):
+class _ConvRounded(torch.autograd.Function):
+    """3x3 conv whose MATRIX OPERANDS are rounded to `dt` on both passes, fp32 accumulation: forward conv(round(x), round(w)) + b,
+    backward-data conv_transpose(round(grad), round(w)) -- what an MFMA path with `dt` operands computes (no weight gradient: the
+    VGG is frozen).  Used to attribute the HIP path's gradient error to operand rounding (tests/test_gpu_lpips.py)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, dt):
+        r = lambda t: t.to(dt).float()
+        ctx.save_for_backward(w)
+        ctx.dt = dt
+        return F.conv2d(r(x), r(w), b, padding=1)
+
+    @staticmethod
+    def backward(ctx, gy):
+        (w,) = ctx.saved_tensors
+        r = lambda t: t.to(ctx.dt).float()
+        return F.conv_transpose2d(r(gy), r(w), padding=1), None, None, None
+
+
+def vgg_features(sd, x, operand_dtype=None):
     feats, cur = [], 1
     h = x
     for sl, idx, cin, cout in VGG_CONVS:
@@ -61,7 +80,8 @@ def vgg_features(sd, x):
             feats.append(h)
             h = F.max_pool2d(h, kernel_size=2, stride=2)
             cur = sl
-        h = F.relu(F.conv2d(h, sd[f"net.slice{sl}.{idx}.weight"], sd[f"net.slice{sl}.{idx}.bias"], padding=1))
+        w, b = sd[f"net.slice{sl}.{idx}.weight"], sd[f"net.slice{sl}.{idx}.bias"]
+        h = F.relu(F.conv2d(h, w, b, padding=1) if operand_dtype is None else _ConvRounded.apply(h, w, b, operand_dtype))
     feats.append(h)
     return feats
 
@@ -70,16 +90,18 @@ def _normalize(x, eps=1e-10):
     return x / (torch.sqrt(torch.sum(x ** 2, dim=1, keepdim=True)) + eps)
 
 
-def lpips(sd, in0, in1, normalize=True):
-    """in0, in1: [B, 3, H, W]; normalize=True expects [0, 1] inputs (external_utils.py:37-39). Returns [B, 1, 1, 1]."""
+def lpips(sd, in0, in1, normalize=True, operand_dtype=None, heads=range(5)):
+    """in0, in1: [B, 3, H, W]; normalize=True expects [0, 1] inputs (external_utils.py:37-39). Returns [B, 1, 1, 1].
+    `operand_dtype` (e.g. torch.bfloat16): emulate rounded conv operands (see _ConvRounded); `heads`: the feature taps summed
+    (all five in LPIPS; a subset localises an error to a VGG slice)."""
     if normalize:
         in0, in1 = 2 * in0 - 1, 2 * in1 - 1
     shift = torch.tensor(SHIFT).view(1, 3, 1, 1)
     scale = torch.tensor(SCALE).view(1, 3, 1, 1)
-    f0 = vgg_features(sd, (in0 - shift) / scale)
-    f1 = vgg_features(sd, (in1 - shift) / scale)
+    f0 = vgg_features(sd, (in0 - shift) / scale, operand_dtype)
+    f1 = vgg_features(sd, (in1 - shift) / scale, operand_dtype)
     val = 0
-    for k in range(5):
+    for k in heads:
         diff = (_normalize(f0[k]) - _normalize(f1[k])) ** 2
         val = val + F.conv2d(diff, sd[f"lin{k}.model.1.weight"]).mean([2, 3], keepdim=True)
     return val

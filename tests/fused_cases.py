@@ -405,6 +405,10 @@ CONV_CASES_FULL = {
     "unet_32x32_512": dict(B=1, H=32, W=32, C1=256, C2=256, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=14),
     "unet_32x32_res_conv": dict(B=1, H=32, W=32, C1=256, C2=256, Cout=256, k=1, norm=NONE, WM=2, WN=2, silu=False, seed=15),
     "unet_ln_ff2_2048": dict(B=1, H=4, W=4, C1=2048, C2=0, Cout=1024, k=1, norm=LN, WM=1, WN=1, silu=False, pre_gelu=True, resid=True, seed=17),
+    # the LayerNorm linears as the r04 plan runs them (plain sources): ff1 (+ GELU epilogue), ff2, the merged q | k | v projection
+    "unet_ln_ff1_1024": dict(B=1, H=4, W=4, C1=1024, C2=0, Cout=2048, k=1, norm=LN, WM=1, WN=1, silu=False, out_gelu=True, seed=65),
+    "unet_ln_ff2_2048_plain": dict(B=1, H=4, W=4, C1=2048, C2=0, Cout=1024, k=1, norm=LN, WM=1, WN=1, silu=False, resid=True, seed=66),
+    "unet_ln_qkv_1024": dict(B=1, H=4, W=4, C1=1024, C2=0, Cout=640, k=1, norm=LN, WM=1, WN=1, silu=False, seed=67),
     "unet_ln_qkv_lazy": dict(B=1, H=4, W=4, C1=1024, C2=0, Cout=640, k=1, norm=LN, WM=1, WN=1, silu=False, lazy=1, seed=18),
     "unet_pair_8x8_1536": dict(B=1, H=8, W=8, C1=1024, C2=512, Cout=1024, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=24, pair=True),
     "unet_pair_4x4_2048_lazy": dict(B=1, H=4, W=4, C1=1024, C2=1024, Cout=1024, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=1, seed=25, pair=True),

@@ -90,8 +90,39 @@ def make_plms_canonical():
     torch.save(out, os.path.join(HERE, "plms_sample_canonical.pt"))
 
 
+def make_medium():
+    """The dim-128 configuration (oracle/unet_ref.MEDIUM: every block on the fused kernels of the canonical plan): one forward of the
+    reference Unet and one reference PLMSSampler.sample at max_thres = 0.5 (51 evals, B = 2) -> unet_medium.pt, unet_keys_medium.json."""
+    cfg = unet_ref.MEDIUM
+    net = _reference_unet(cfg).eval()
+    spec = [(k, list(v.shape)) for k, v in net.state_dict().items()]
+    json.dump(spec, open(os.path.join(HERE, "unet_keys_medium.json"), "w"))
+    sd = unet_ref.init_state([(k, tuple(s)) for k, s in spec], seed=0)
+    net.load_state_dict(sd, strict=True)
+    x, ls, cond = inputs(cfg, 2, seed=5)
+    with torch.no_grad():
+        y = net.forward_with_cond_scale(x, ls, cond_images=cond, cond_scale=1.)
+    out = {"forward": dict(B=2, input_seed=5, state_seed=0, y=y.clone())}
+    vldm = ref_loader.reference_vldm(dict(cfg, layer_cross_attns=(False,) * 4, attn_pool_text=False)).eval()
+    unet = vldm.unets[0]
+    unet.load_state_dict(sd, strict=True)
+    sampler = ref_loader.reference_plms(vldm, 50)
+    g = torch.Generator().manual_seed(17)
+    lat = 0.5 * torch.randn(2, 4, 32, 32, generator=g)
+    cond = torch.randn(2, cfg["cond_images_channels"], 32, 32, generator=g)
+    torch.manual_seed(81)
+    with torch.no_grad():
+        img, x_noisy, noise, acp = sampler.sample(lat.clone(), cond_images=cond, use_tqdm=False, return_noise=True, max_thres=0.5)
+    out["plms"] = dict(B=2, input_seed=17, noise_seed=81, max_thres=0.5, img=img.clone(), x_noisy=x_noisy.clone(), noise=noise.clone(),
+                       alpha_cumprod=acp.clone())
+    print("medium params %.2fM" % (sum(v.numel() for v in sd.values()) / 1e6), "out std %.4f" % y.std().item(), "plms std", img.std().item())
+    torch.save(out, os.path.join(HERE, "unet_medium.pt"))
+
+
 if __name__ == "__main__":
-    if "--canonical-plms" in sys.argv:
+    if "--medium" in sys.argv:
+        make_medium()
+    elif "--canonical-plms" in sys.argv:
         make_plms_canonical()
     else:
         make_unet()

@@ -36,6 +36,47 @@ def test_unet_forward_matches_reference_golden(name):
     assert rel_err(y0, y[:1]) < TOL_REL and rel_err(y0, g["y"][:1]) < TOL_REL
 
 
+def test_unet_medium_config_runs_the_canonical_kernels_and_matches_reference():
+    """dim 128: every block of this configuration plans onto the fused kernels the 400 M-parameter model runs (slot statistics,
+    fixed-order 4x4 sums, pooled fragments, attention prologue: no atomics anywhere, unlike dim 64) -- a model-level parity case
+    that runs the SAME reductions as the benchmarked plan: forward golden, 51-eval PLMS trajectory golden (B = 2), bitwise
+    reproducibility."""
+    from sparsefusion_amd.unet import OP_GN_ACT, OP_GCA_POOL, OP_ATTN
+    from sparsefusion_amd.vldm import DDPM
+    from sparsefusion_amd.plms import PLMSSampler
+    name = "medium"
+    G = torch.load(f"{GOLD}/unet_medium.pt")
+    g = G["forward"]
+    net = _unet(name)
+    x, ls, cond = inputs(CONFIGS[name], g["B"], g["input_seed"])
+    y = net.forward_with_cond_scale(x.to(DEV), ls.to(DEV), cond_images=cond.to(DEV), cond_scale=1.).cpu()
+    plan = net._plan(g["B"], torch.device(DEV))
+    assert plan.zero.off == 0 and not any(o.type in (OP_GN_ACT, OP_GCA_POOL, OP_ATTN) for o in plan.ops)     # fully fused, nothing accumulates with atomics
+    r, c = rel_err(y, g["y"]), cosine(y, g["y"])
+    print(f"unet[medium] rel L2 err {r:.3e}  cosine {c:.6f}")
+    assert r < TOL_REL and c > TOL_COS
+    y2 = net.forward_with_cond_scale(x.to(DEV), ls.to(DEV), cond_images=cond.to(DEV), cond_scale=1.).cpu()
+    assert torch.equal(y, y2)
+    rr = G["plms"]
+    vldm = DDPM(channels=4, unets=(net,), conditional_encoder=None, conditional_embed_dim=None, image_sizes=(32,),
+                timesteps=500, cond_drop_prob=0.1, pred_objectives='noise', conditional=False, auto_normalize_img=False,
+                clip_output=True, dynamic_thresholding=False, dynamic_thresholding_percentile=.68, clip_value=10).to(DEV)
+    gg = torch.Generator().manual_seed(rr["input_seed"])
+    lat = 0.5 * torch.randn(2, 4, 32, 32, generator=gg)
+    cond = torch.randn(2, CONFIGS[name]["cond_images_channels"], 32, 32, generator=gg)
+    torch.manual_seed(rr["noise_seed"])
+    noises = [torch.randn(2, 4, 32, 32).to(DEV) for _ in range(unet_ref.plms_noise_count(rr["max_thres"]))]
+    imgs = []
+    for _ in range(2):
+        img, xn, nz, acp = PLMSSampler(vldm, 50).sample(lat.to(DEV), cond_images=cond.to(DEV), use_tqdm=False, return_noise=True,
+                                                        max_thres=rr["max_thres"], noises=noises)
+        imgs.append(img.cpu())
+    e, cc = rel_err(imgs[0], rr["img"]), cosine(imgs[0], rr["img"])
+    print(f"plms medium (51 evals, B=2) rel {e:.3e} cos {cc:.6f}")
+    assert torch.equal(nz.cpu(), rr["noise"]) and e < 3e-2 and cc > 0.9995
+    assert torch.equal(imgs[0], imgs[1])                          # a seeded trajectory is reproducible bit for bit
+
+
 def test_unet_fp16_operands_match_reference_golden():
     """BASELINE configs[4] "fp16 UNet": the same plan on the IEEE-half operand build of the library (csrc/sf_operand.h,
     libsparsefusion_hip_f16.so: v_mfma_f32_16x16x32_f16, fp32 accumulate) against the fp32 reference golden -- selected per module

@@ -18,6 +18,28 @@ def test_unet_restatement_matches_reference(name):
     assert torch.allclose(y, g["y"], rtol=1e-4, atol=2e-5), (y - g["y"]).abs().max()
 
 
+def test_unet_and_plms_restatement_match_reference_medium():
+    """dim 128 (oracle/unet_ref.MEDIUM: the smallest configuration the HIP planner runs entirely on the canonical plan's fused kernels):
+    the reference's forward and its 51-eval PLMS trajectory (tests/golden/make_golden_unet.py --medium)."""
+    G = torch.load(f"{GOLD}/unet_medium.pt")
+    g = G["forward"]
+    sd = state("medium", g["state_seed"])
+    x, ls, cond = inputs(CONFIGS["medium"], g["B"], g["input_seed"])
+    with torch.no_grad():
+        y = unet_ref.unet_forward(sd, x, ls, cond)
+    assert y.abs().max() > 0.5 and torch.allclose(y, g["y"], rtol=1e-4, atol=2e-5), (y - g["y"]).abs().max()
+    r = G["plms"]
+    gg = torch.Generator().manual_seed(r["input_seed"])
+    lat = 0.5 * torch.randn(2, 4, 32, 32, generator=gg)
+    cond = torch.randn(2, CONFIGS["medium"]["cond_images_channels"], 32, 32, generator=gg)
+    torch.manual_seed(r["noise_seed"])
+    noises = [torch.randn(2, 4, 32, 32) for _ in range(unet_ref.plms_noise_count(r["max_thres"]))]
+    with torch.no_grad():
+        img, xn, nz, acp, ev = unet_ref.plms_sample(lambda a, b: unet_ref.unet_forward(sd, a, b, cond), lat, r["max_thres"], noises)
+    assert ev == 51 and torch.equal(nz, r["noise"]) and torch.allclose(xn, r["x_noisy"], atol=1e-6)
+    assert torch.allclose(img, r["img"], rtol=1e-3, atol=2e-4), (img - r["img"]).abs().max()
+
+
 def test_param_spec_matches_reference_keys():
     from sparsefusion_amd.unet import unet_param_spec
     for name, cfg in CONFIGS.items():

@@ -7,7 +7,7 @@ import torch
 from oracle import unet_ref
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CONFIGS = {"canonical": unet_ref.CANONICAL, "small": unet_ref.SMALL}
+CONFIGS = {"canonical": unet_ref.CANONICAL, "small": unet_ref.SMALL, "medium": unet_ref.MEDIUM}
 
 
 def spec(name):
