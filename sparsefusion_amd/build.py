@@ -71,7 +71,8 @@ def build_variant(tag, defines, verbose=True, timing=False, sources=("unet_fused
     os.makedirs(OBJ_DIR, exist_ok=True)
     dflags = ["-D" + d for d in defines]
     if timing:
-        out = os.path.join(HERE, f"libsf_fused_timing_{tag}.so")
+        os.makedirs(os.path.join(ROOT, "tools", "_build"), exist_ok=True)
+        out = os.path.join(ROOT, "tools", "_build", f"libsf_fused_timing_{tag}.so")
         srcs = [os.path.join(CSRC, f) for f in ("unet_fused.hip", "core.hip")]
         cmd = [HIPCC] + FLAGS + dflags + ["-DSF_FCONV_TIMING", "-shared", "-o", out] + srcs
     else:
@@ -121,7 +122,8 @@ def build_f16(verbose=True, force=False):
 def build_timing(verbose=True):
     """libsf_fused_timing.so: unet_fused.hip with in-kernel phase timestamps (-DSF_FCONV_TIMING), a measurement aid for
     tools/fconv_phases.py -- never loaded by the package."""
-    out = os.path.join(HERE, "libsf_fused_timing.so")
+    os.makedirs(os.path.join(ROOT, "tools", "_build"), exist_ok=True)
+    out = os.path.join(ROOT, "tools", "_build", "libsf_fused_timing.so")      # a measurement aid: not next to the product library
     srcs = [os.path.join(CSRC, f) for f in ("unet_fused.hip", "core.hip")]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):

@@ -29,21 +29,15 @@
 // k_conv3_halo (conv_halo.h) and this kernel keeps the 1x1 / stride-2 layers.
 #pragma once
 #include "conv_lds.h"
-#ifndef SF_GLDS_EXPERIMENT
-#define SF_GLDS_EXPERIMENT 0
-#endif
 
 // ---- epilogue of the 8-wave tiles (k_conv_glds, k_conv3_halo): the 128 x 16*BNF tile goes through LDS once so that every global
 // access is a full float4 of one row (the fragment layout gives a lane one column of four rows: 64-byte pieces per store
 // instruction, 64 stores per lane; measured 42 -> 33 us on the 128x128 256->256 layer).  All 8 waves write: thread t owns the
 // float4 column c4 = t % (COLS / 4) of rows t / (COLS / 4) + k * (512 / (COLS / 4)).  pix(row) = the row's pixel index in the
-// output tensor or -1.  Host-checked: Cout, ldc, co_off are multiples of 4.  SF_GLDS_EXPERIMENT 9: no epilogue (measurement).
+// output tensor or -1.  Host-checked: Cout, ldc, co_off are multiples of 4.
 template <int BNF, int LDS_BYTES, bool GN, class Pix>
 SF_DEV void conv_tile_epilogue(const ConvArgs& a, char* lds, const f32x4 (&acc)[4][BNF / 2], const bool loader, const int wm, const int wn,
                                const int lane, const int nt, const int mt, double* __restrict__ gn_part, const int gn_cg, Pix pix) {
-#if SF_GLDS_EXPERIMENT == 9
-  return;
-#endif
   constexpr int WNF = BNF / 2;
   constexpr int COLS = 16 * BNF, F4 = COLS / 4, RPP = 512 / F4, PITCH = COLS + 4;      // pitch = 4 mod 8 floats: the four row groups of a
   static_assert(128 * PITCH * 4 <= LDS_BYTES, "the output tile fits the staging buffers");   // fragment store land on disjoint banks
@@ -179,39 +173,19 @@ SF_DEV void conv_glds_body(const ConvArgs& a, double* __restrict__ gn_part, cons
     int i_ks = 0, i_cc = 0, i_ky = 0, i_kx = 0, i_buf = 0;
     auto issue_next = [&]() {
       char* sb = lds + i_buf * STAGE;
-#if SF_GLDS_EXPERIMENT == 2                     // (measurement builds, tools/conv_time.py) 2: no loads at all
-      if (++i_buf == NST) i_buf = 0;
-      return;
-#endif
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-#if SF_GLDS_EXPERIMENT == 3 || SF_GLDS_EXPERIMENT == 6   // 3: every stage re-reads stage 0 (A and B cache-hot); 6: A only
-        const int iy = py[q], ix = px[q];
-#else
         const int iy = py[q] + i_ky, ix = px[q] + i_kx;
-#endif
         const bool ok = pv[q] & (iy >= 0) & (iy < a.H) & (ix >= 0) & (ix < a.W);          // no short circuit: one select, no branch
         const int cy = min(max(iy, 0), a.H - 1) >> a.ups, cx = min(max(ix, 0), a.W - 1) >> a.ups;
-#if SF_GLDS_EXPERIMENT == 3 || SF_GLDS_EXPERIMENT == 6
-        const sf_opnd* p = in + ((pbase[q] + (long)cy * Ws + cx) * a.Cin + coff[q & 1]);
-#else
         const sf_opnd* p = in + ((pbase[q] + (long)cy * Ws + cx) * a.Cin + i_cc * 64 + coff[q & 1]);
-#endif
-#if SF_GLDS_EXPERIMENT == 4                     // 4: no A traffic (every lane reads the zero line)
-        const void* src = (ok && i_ks < 0) ? static_cast<const void*>(p) : static_cast<const void*>(sf_zero128 + (lane & 7) * 4);
-#else
         const void* src = ok ? static_cast<const void*>(p) : static_cast<const void*>(sf_zero128 + (lane & 7) * 4);
-#endif
         sf_glds16(sb + (2 * lw) * 2048 + q * 1024, src);
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-#if SF_GLDS_EXPERIMENT == 3 || SF_GLDS_EXPERIMENT == 5   // 5: B re-reads its first k-steps (cache-hot), A normal
-        for (int j = 0; j < BLD; ++j) sf_glds16(sb + A_BYTES + ((BLD * lw + j) * 2 + u) * 1024, wbase[j] + (long)u * 64);
-#else
         for (int j = 0; j < BLD; ++j) sf_glds16(sb + A_BYTES + ((BLD * lw + j) * 2 + u) * 1024, wbase[j] + (long)(i_ks + u) * 64);
-#endif
       i_ks += 2;
       if (++i_cc == cpairs) {
         i_cc = 0;
@@ -239,9 +213,6 @@ SF_DEV void conv_glds_body(const ConvArgs& a, double* __restrict__ gn_part, cons
     SF_LGKM0();                                     // no scalar load pending into the loop: its LDS waits can then be counted ones
     for (int s = 0; s < S; ++s) {
       sf_lds_barrier();                             // (waits for this wave's reads of stage s - 1, then meets the loaders)
-#if SF_GLDS_EXPERIMENT == 1                     // 1: the matrix waves only keep the barriers (what do the loads alone cost?)
-      continue;
-#endif
       const char* sb = lds + r_buf * STAGE;
       // fragment reads in the order the MFMAs need them (A0, all B, then the other A rows), k-step 1 behind k-step 0
       bf16x8 fa[2][4], fb[2][WNF];

@@ -210,11 +210,10 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   // rows: each weight byte crosses the fabric once, the activation map is fetched by all 8 L2s) is the measured best on every
   // layer: sharing rows instead (R = 2 / 4, each XCD then pulls 1 / R of the activations and R x the weights) was slower even
   // on the 32x32 layers whose activations outweigh their weights (r03: eval 1.311 / 1.335 / 1.402 ms for R = 1 / 2 / 4;
-  // choosing R per layer by fabric bytes: 1.314).  SF_XCD_R forces another R for A/B.
+  // choosing R per layer by fabric bytes: 1.314; the SF_XCD_R switch of that A/B was retired in r04, fconv_tile_of keeps the general map).
   a.xcd_map = 0;
   if (MT > 1 && a.S == 1) {
-    static const int force_r = getenv("SF_XCD_R") ? atoi(getenv("SF_XCD_R")) : 1;
-    const int R = (force_r == 2 || force_r == 4 || force_r == 8) ? force_r : 1;
+    const int R = 1;
     if (MT % R == 0 && a.n_tiles % (8 / R) == 0) a.xcd_map = R;
     else if (a.n_tiles % 8 == 0) a.xcd_map = 1;
   }

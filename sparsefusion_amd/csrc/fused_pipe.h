@@ -12,7 +12,7 @@
 // weights or feeds the matrix pipe: the launch costs ~max(staging, main) instead of their sum.  Statistics, affine table,
 // epilogue, slots and context logits are those of k_conv_fused.
 //
-// What bounds the chunk loop (r03, measurement builds -DSF_STAGE_EXPERIMENT=1..4 of tools/fconv_phases.py,
+// What bounds the chunk loop (r03, measurement builds of this source -- their #if branches were removed in r04 --,
 // profiles/r03_stage_experiment.log): the CU's vector-memory path, 64 B / clk shared by all 8 waves.  A chunk moves 48 KB of
 // fp32 activations (3 haloed rows x 128 channels) and 72 KB of weights (36 k-steps x WN KiB) through it = 0.8 us of its 1.3-1.9 us;
 // without the SiLU arithmetic the 512-channel 32x32 layer's loop falls 7.4 -> 5.3 us, without ANY arithmetic 5.2, without the
@@ -108,13 +108,8 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
     const bool first = cg < a.s1.C;
     const float* srcp = first ? a.s1.p + cg : a.s2.p + (cg - a.s1.C);
     const int srcld = first ? a.s1.C : a.s2.C;
-#if defined(SF_STAGE_EXPERIMENT) && SF_STAGE_EXPERIMENT == 4           // 4: every element re-reads ONE pixel (L1 hits: no activation traffic)
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) pool[vo + e] = *reinterpret_cast<const f32x4*>(srcp + mxo[0] * srcld);
-#else
 #pragma unroll
     for (int e = 0; e < EPT; ++e) pool[vo + e] = *reinterpret_cast<const f32x4*>(srcp + mxo[e] * srcld);
-#endif
   };
   auto consume = [&](int c, const int vo) {
     const int cg = c * CC + tcx * 4;
@@ -125,8 +120,7 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
       f32x4 y = pool[vo + e] * A + Bv;
-#if !defined(SF_STAGE_EXPERIMENT) || SF_STAGE_EXPERIMENT == 0          // 1: no SiLU, 2: no arithmetic at all (measurement builds of
-      const f32x4 t = y * -1.4426950408889634f;                         // tools/fconv_phases.py only: where does the staging time go?)
+      const f32x4 t = y * -1.4426950408889634f;
       f32x4 ex;
 #pragma unroll
       for (int j = 0; j < 4; ++j) ex[j] = sf_exp2(t[j]);
@@ -134,9 +128,6 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) ex[j] = sf_rcp(ex[j]);
       y = y * ex;
-#elif SF_STAGE_EXPERIMENT >= 2
-      y = pool[vo + e];
-#endif
       bf16x4 o;
       o[0] = (sf_opnd)y[0]; o[1] = (sf_opnd)y[1]; o[2] = (sf_opnd)y[2]; o[3] = (sf_opnd)y[3];
       *reinterpret_cast<bf16x4*>(buf + (long)fpx[e] * pstr) = o;
@@ -304,10 +295,8 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
         for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
           for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = sf_mfma16(fa[mi], __builtin_bit_cast(bf16x8, pool[i * WN + ni]), acc[mi][ni]);
-#if !defined(SF_STAGE_EXPERIMENT) || SF_STAGE_EXPERIMENT != 3        // 3: no weight stream after the first ring fill (measurement build)
 #pragma unroll
         for (int ni = 0; ni < WN; ++ni) pool[i * WN + ni] = __builtin_bit_cast(f32x4, wload(cn, i, ni));
-#endif
         if (POOL) {                                        // one more MFMA per m-fragment, BEHIND the ring refill (the weight stream
           bf16x8 wl = *reinterpret_cast<const bf16x8*>(weffL + (woff[i] + c * (CC / 32) * 64));   // is what this loop waits on);
           if (!col0) wl = sf_zero8();                                                               // woff = k-step * 64 bytes as well

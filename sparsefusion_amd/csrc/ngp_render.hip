@@ -23,7 +23,6 @@
 #include "ngp_field_lds.h"
 #include "ngp_bwd_mfma.h"
 #include "ngp_composite_wave.h"
-#include "ngp_fwd_mfma.h"
 #include <stdlib.h>
 #include <mutex>
 
@@ -329,47 +328,15 @@ extern "C" int sf_ngp_render_forward(const sf_ngp_field* f, const float* rays_o,
   float* feat_c = field_cache;
   float* feat_f = field_cache ? field_cache + NT * NGP_FEAT : nullptr;
   uint32_t* perm = field_cache ? reinterpret_cast<uint32_t*>(field_cache + 2 * NT * NGP_FEAT) : nullptr;
-  // EXPERIMENTAL (SF_NGP_FWD_MFMA=1): hidden layers of the field on the matrix cores (ngp_fwd_mfma.h); parity-green, measured
-  // slower in its first shape (render forward 1.34 vs 1.12 ms) -- the default stays the VALU kernel.
-  static const bool fwd_mfma = getenv("SF_NGP_FWD_MFMA") && atoi(getenv("SF_NGP_FWD_MFMA")) != 0;
-  if (fwd_mfma && field_cache) SF_FAIL(SF_ERR_INVALID, "ngp_render: the experimental MFMA forward does not fill the field cache (pass NULL)");
-  FFArgs fa;
-  uint32_t grid_ff = 0;
-  const size_t lds_ff = (size_t)FF_LDS_FLOATS * sizeof(float);
-  if (fwd_mfma) {
-    int dev_id = 0;
-    (void)hipGetDevice(&dev_id);
-    static unsigned attr_ff_mask = 0;
-    if (dev_id >= 32 || !(attr_ff_mask & (1u << dev_id))) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_field_fwd_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds_ff) != hipSuccess)
-        SF_FAIL(SF_ERR_LAUNCH, "ngp_field_fwd_mfma: cannot raise dynamic LDS limit to %zu", lds_ff);
-      if (dev_id < 32) attr_ff_mask |= 1u << dev_id;
-    }
-    fa.table = f->embeddings; fa.w0 = f->w0; fa.b0 = f->b0; fa.w1 = f->w1; fa.b1 = f->b1; fa.w2 = f->w2; fa.b2 = f->b2;
-    fa.bound = f->bound; fa.lv = lv;
-    fa.rays_o = rays_o; fa.rays_d = rays_d; fa.aabb = aabb; fa.nears = nears; fa.fars = fars;
-    fa.P = P; fa.T = T;
-    const uint32_t trips = sf_div_up(P, FB_PTS);
-    grid_ff = trips < 1024 ? sf_div_up(trips, 4) : 256;       // one resident workgroup per CU (LDS-bound), 4 waves each
-    fa.lin = lin; fa.u = u_coarse; fa.z_in = nullptr; fa.mode = 0; fa.z_out = z_c; fa.sigma = sig_c; fa.rgb = rgb_c;
-    k_ngp_field_fwd_mfma<<<grid_ff, 256, lds_ff, st>>>(fa);
-  } else {
-    k_ngp_field<0><<<gridp, 256, 0, st>>>(fp, lv, rays_o, rays_d, aabb, nears, fars, lin, u_coarse, nullptr, nullptr, P, T,
-                                          z_c, sig_c, rgb_c, feat_c);
-  }
+  k_ngp_field<0><<<gridp, 256, 0, st>>>(fp, lv, rays_o, rays_d, aabb, nears, fars, lin, u_coarse, nullptr, nullptr, P, T,
+                                        z_c, sig_c, rgb_c, feat_c);
   SF_CHECK_LAUNCH("ngp_field_coarse");
   const uint32_t gridr = sf_div_up(N, 64);
   k_ngp_sample_fine<<<gridr, 64, 2 * T * 64 * sizeof(float), st>>>(z_c, sig_c, u_fine, u_fine_row_stride, nears, fars,
                                                                   N, T, z_f);
   SF_CHECK_LAUNCH("ngp_sample_fine");
-  if (fwd_mfma) {
-    fa.lin = nullptr; fa.u = nullptr; fa.z_in = z_f; fa.mode = 1; fa.z_out = nullptr; fa.sigma = sig_f; fa.rgb = rgb_f;
-    k_ngp_field_fwd_mfma<<<grid_ff, 256, lds_ff, st>>>(fa);
-  } else {
-    k_ngp_field<1><<<gridp, 256, 0, st>>>(fp, lv, rays_o, rays_d, aabb, nears, fars, nullptr, nullptr, z_f, nullptr, P, T,
-                                          nullptr, sig_f, rgb_f, feat_f);
-  }
+  k_ngp_field<1><<<gridp, 256, 0, st>>>(fp, lv, rays_o, rays_d, aabb, nears, fars, nullptr, nullptr, z_f, nullptr, P, T,
+                                        nullptr, sig_f, rgb_f, feat_f);
   SF_CHECK_LAUNCH("ngp_field_fine");
   // one WAVE per ray: rank sort of cat([coarse, fine]) by readlane keys + scans (ngp_composite_wave.h)
   k_ngp_composite_wave<<<sf_div_up(N, 4), 256, 4 * 5 * 2 * T * sizeof(float), st>>>(
@@ -407,34 +374,31 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
   static unsigned attr_mask = 0;
   if (dev_id >= 32 || !(attr_mask & (1u << dev_id))) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_field_bwd_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_scatter<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_scatter<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_scatter<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc) != hipSuccess)
       SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: cannot raise the dynamic LDS limits");
     if (dev_id < 32) attr_mask |= 1u << dev_id;
   }
-  // tuning knobs (A/B on the GPU box): threads per cached-level workgroup, scale cutoff of the LDS cache, fine levels in
-  // their own high-occupancy launch
-  static const int sc_threads = getenv("SF_SC_THREADS") ? atoi(getenv("SF_SC_THREADS")) : 1024;
-  static const float sc_cutoff = getenv("SF_SC_CUTOFF") ? (float)atof(getenv("SF_SC_CUTOFF")) : 640.0f;
-  static const bool sc_split = getenv("SF_SC_SPLIT") ? atoi(getenv("SF_SC_SPLIT")) != 0 : true;
-  static const uint32_t sc_run = getenv("SF_SC_RUN") && atoi(getenv("SF_SC_RUN")) > 0 ? (uint32_t)atoi(getenv("SF_SC_RUN")) : 32u;   // measured 4 / 8 / 16 / 32: 6.95 / 6.85 / 6.81 / 6.76 ms render fwd+bwd
+  // scatter shape, measured on MI355X in r02 (the A/B environment switches were retired in r04): 1024 threads per cached-level
+  // workgroup (256 / 512 / 1024: 8.55 / - / 7.84 ms render fwd+bwd), LDS cache up to scale 640 (160 / 320 / 640 / all levels: 7.82 /
+  // 7.63 / 7.51 / 8.27 ms), the finer levels in their own high-occupancy launch, 32 sorted samples merged per thread before the cache
+  // (4 / 8 / 16 / 32: 6.95 / 6.85 / 6.81 / 6.76 ms)
+  constexpr float sc_cutoff = 640.0f;
+  constexpr uint32_t sc_run = 32u;
   // levels up to scale ~640 profit from the LDS cache (measured r02: cut-off 160 / 320 / 640 / none = 7.82 / 7.63 / 7.51 / 8.27 ms render fwd+bwd)
   uint32_t cached = 0;
   while (cached < lv.L && lv.scale[cached] <= sc_cutoff) ++cached;
-  const uint32_t last = (dfeat && sc_split) ? cached : lv.L;     // levels [0, last): k_ngp_scatter, [last, L): k_ngp_scatter_fine
+  const uint32_t last = dfeat ? cached : lv.L;     // levels [0, last): k_ngp_scatter, [last, L): k_ngp_scatter_fine
 
   // ---- the pipeline (r03).  Three kernels with three different bottlenecks: the field backward (fp32 MFMA + 113 KB of LDS,
   // one workgroup per CU), the fine-level scatter (memory-side atomic unit, no LDS, VALU idle) and the cached-level scatter
   // (LDS atomics, 96 KB).  The rays are cut into chunks; the fine-level scatter of chunk c runs on a side stream while the
   // field backward of chunk c + 1 occupies the CUs, and the last one runs beside the cached-level scatter (one launch over
   // all rays, its LDS cache wants every ray of an 8x8 patch).  dfeat keeps the level-major layout of the whole ray set.
-  // SF_NGP_OVERLAP=0: everything on the caller's stream in one chunk (A/B).
-  static const bool overlap = !(getenv("SF_NGP_OVERLAP") && atoi(getenv("SF_NGP_OVERLAP")) == 0);
-  static const uint32_t want_chunks = getenv("SF_NGP_CHUNKS") && atoi(getenv("SF_NGP_CHUNKS")) > 0 ? (uint32_t)atoi(getenv("SF_NGP_CHUNKS")) : 4u;
+  // (r03 A/B: 1 / 2 / 4 / 8 chunks 5.96 / 5.65 / 5.64 / 6.00 ms, no overlap 6.33 ms; the switches were retired in r04.)
+  constexpr uint32_t want_chunks = 4u;
   struct Side { hipStream_t s; hipEvent_t fork, join; };
   static Side side[32] = {};
-  const bool fork = overlap && dfeat && last < lv.L && dev_id < 32;
+  const bool fork = dfeat && last < lv.L && dev_id < 32;
   uint32_t n_chunks = 1;
   if (fork) {
     n_chunks = want_chunks;
@@ -495,12 +459,7 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
   }
   if (dfeat && last > 0) {
     const uint32_t grid_sc = sf_div_up(N, SC_RAYS);
-    if (sc_threads == 256)
-      k_ngp_scatter<256><<<grid_sc, 256, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, T2, rays_per_row, cached, last, sc_run);
-    else if (sc_threads == 512)
-      k_ngp_scatter<512><<<grid_sc, 512, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, T2, rays_per_row, cached, last, sc_run);
-    else
-      k_ngp_scatter<1024><<<grid_sc, 1024, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, T2, rays_per_row, cached, last, sc_run);
+    k_ngp_scatter<1024><<<grid_sc, 1024, lds_sc, st>>>(lv, f->bound, g->g_embeddings, rays_o, rays_d, aabb, z_sorted, dfeat, N, T2, rays_per_row, cached, last, sc_run);
     SF_CHECK_LAUNCH("ngp_scatter");
   }
   if (side_join.join()) SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: join failed");

@@ -505,11 +505,8 @@ static void launch_conv(const ConvArgs& a, bool a_fp32, int blocks, hipStream_t 
 }
 
 // k_conv_glds (conv_glds.h): the LDS-tiled conv for operand-type activations, staged by LDS-DMA through a ring of NST buffers.
-// SF_CONV_GLDS = 0 keeps those layers on k_conv_lds (A/B), 3 / 4 picks the ring depth (default 4).
-static int conv_glds_depth() {
-  static const int v = [] { const char* e = getenv("SF_CONV_GLDS"); const int d = e ? atoi(e) : 4; return (d == 3 || d == 4) ? d : 0; }();
-  return v;
-}
+// Ring depth 4 by default (3 measures the same: the ring is not latency bound; a tile code selects either explicitly, as the tests do).
+static int conv_glds_depth() { return 4; }
 template <int BNF, int NST, bool GN>
 static int launch_conv_glds(const ConvArgs& a, int nblk, double* part, int cg, hipStream_t st) {
   static unsigned mask = 0;
@@ -526,11 +523,8 @@ static int launch_conv_glds(const ConvArgs& a, int nblk, double* part, int cg, h
   return SF_OK;
 }
 // k_conv3_halo (conv_halo.h): 3x3 / stride 1 / pad 1 layers with the pixel tile's halo staged once per 64-channel chunk.
-// SF_CONV_HALO = 0 keeps them on k_conv_glds (A/B).
-static bool conv_halo_enabled() {
-  static const bool v = [] { const char* e = getenv("SF_CONV_HALO"); return !e || atoi(e) != 0; }();
-  return v;
-}
+// (the default kernel of those layers; tile-code selectors 3 / 4 pick k_conv_glds, 1 k_conv_lds: tests compare all three)
+static bool conv_halo_enabled() { return true; }
 template <int BNF, int NST, bool GN>
 static int launch_conv_halo(const ConvArgs& a, int nblk, double* part, int cg, hipStream_t st) {
   static unsigned mask = 0;

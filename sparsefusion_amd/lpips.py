@@ -167,7 +167,7 @@ class LPIPS(nn.Module):
         self.lazy_consumers = 0
         self.ss_total = 0
         self.lds_conv_min_blocks = 96
-        self.conv_twin = os.environ.get("SF_LPIPS_TWIN", "1") != "0"     # conv -> conv links of a VGG slice in operand type (r03); 0 = fp32 reads, A/B
+        self.conv_twin = True             # conv -> conv links of a VGG slice in operand type (r03); False = fp32 reads
         self._pack_cache, self._plans, self._serial = None, {}, 0
         # the `lpips` package ships pretrained VGG16 + learned lin heads; this module starts from a seeded random init and has
         # no network access: until load_state_dict() brings real weights the distance is NOT the LPIPS metric

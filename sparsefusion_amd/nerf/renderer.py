@@ -75,7 +75,7 @@ class _FieldHandle:
         return f
 
 
-_FEAT_CACHE = os.environ.get("SF_NGP_FEAT_CACHE", "1") != "0" and not (os.environ.get("SF_NGP_FWD_MFMA", "0") not in ("", "0"))
+_FEAT_CACHE = True        # False: the backward re-gathers the features (the C ABI's field_cache = NULL path; tests flip this module attribute)
 
 
 class _RenderFn(torch.autograd.Function):
@@ -96,7 +96,7 @@ class _RenderFn(torch.autograd.Function):
         f = handle.struct(params)
         # field cache (r03): when a backward will follow, the forward keeps the hash-grid features of every sample and the sort
         # permutation, so the backward reads 128 bytes per sample instead of re-gathering 16 levels x 8 corners (0.73 ms of a
-        # 4.5 ms backward at 128^2 rays x 128 samples; 268 MB per render held until then).  SF_NGP_FEAT_CACHE=0: recompute (A/B).
+        # 4.5 ms backward at 128^2 rays x 128 samples; 268 MB per render held until then).  `_FEAT_CACHE = False`: recompute.
         cache = None
         # `grad_mode` = torch.is_grad_enabled() at the call site: needs_input_grad mirrors requires_grad even under no_grad(), and
         # grad mode is always off in here -- an eval render of a trainable field must not allocate / write the 268 MB cache

@@ -403,8 +403,8 @@ class _Plan:
 
     def gemv(self, x_ptr, M, ldx, wname, bname, y_ptr, ldy, N, K, in_silu=False, out_act=0):
         Kp = (K + 7) // 8 * 8
-        # > 8 rows (a sampler's time table): k_gemm_rows, up to 64 rows per launch (SF_GEMM_ROWS=0: the 8-row kernel, A/B switch)
-        step = 8 if (M <= 8 or os.environ.get("SF_GEMM_ROWS", "1") == "0") else 64
+        # > 8 rows (a sampler's time table): k_gemm_rows, up to 64 rows per launch 
+        step = 8 if M <= 8 else 64
         for m0 in range(0, M, step):
             mm = min(step, M - m0)
             self.op(OP_GEMV, (1 if in_silu else 0) | (out_act << 1),
@@ -1095,15 +1095,17 @@ class Unet(nn.Module):
         self.tb_stride = (off + 63) // 64 * 64
         self.conv_waves_target = 1024       # waves wanted per conv launch (4 per CU) before split-K stops
         self.lds_conv_min_blocks = 96       # use k_conv_lds when a layer has at least this many 128 x 128 output tiles
-        self.unfused_min_rows = int(os.environ.get("SF_UNFUSED_ROWS", "8192"))     # ResnetBlocks with B*H*W >= this at the 32x32 / 16x16 levels leave the fused kernels (_Plan.resnet; measured r03: B = 8 eval 3.33 -> 2.96 ms, B = 32 11.5 -> 7.8 ms, B = 4 unchanged)
+        self.unfused_min_rows = 8192     # ResnetBlocks with B*H*W >= this at the 32x32 / 16x16 levels leave the fused kernels (_Plan.resnet; measured r03: B = 8 eval 3.33 -> 2.96 ms, B = 32 11.5 -> 7.8 ms, B = 4 unchanged)
         self.lazy_consumers = 3             # bit 0: split-K reductions, bit 1: gated residuals are materialised by their first consumer
-        # GroupNorm inside the conv launches (k_conv_fused) wherever the layer fits; SF_UNET_FUSED=0 = the first-round plan (A/B runs)
-        self.fused = os.environ.get("SF_UNET_FUSED", "1") != "0"
-        self.pair_res_conv = os.environ.get("SF_PAIR", "1") != "0"      # conv1 || res_conv of a ResnetBlock in one launch
-        self.initx_direct = os.environ.get("SF_INITX", "1") != "0"      # latent half of the init conv as one direct-convolution launch
-        self.big_tile_min_batch = int(os.environ.get("SF_BIG_TILE_B", "2"))   # batch from which the 8x8 / 16x16 / 32x32 maps use 32- / 32- / 64-pixel tiles (r03: B = 2 eval 1.70 -> 1.50 ms, B = 4 2.62 -> 2.02, B = 32 16.4 -> 11.5; at B = 1 they would leave half the CUs idle; 999 = never)
-        self.gca_epilogue_pool = os.environ.get("SF_GCA_EPI_POOL", "1") != "0"   # GlobalContext pooling in conv2's epilogue (0 = k_gca_pool launch, A/B)
-        self.fconv_pipe = os.environ.get("SF_PIPE", "1") != "0"         # slot-GroupNorm 3x3 convs on k_conv_fused_pipe (staging || matrix work)
+        # Planner attributes (plain Python attributes since r04 -- the SF_* environment switches of the r01-r03 A/B runs are retired;
+        # tools/unet_time.py sets them through SF_UNET_ATTRS, tests/test_gpu_unet.py::test_plan_switches_match_oracle covers them).
+        # GroupNorm inside the conv launches (k_conv_fused) wherever the layer fits; False = the first-round plan
+        self.fused = True
+        self.pair_res_conv = True           # conv1 || res_conv of a ResnetBlock in one launch
+        self.initx_direct = True            # latent half of the init conv as one direct-convolution launch
+        self.big_tile_min_batch = 2         # batch from which the 8x8 / 16x16 / 32x32 maps use 32- / 32- / 64-pixel tiles (r03: B = 2 eval 1.70 -> 1.50 ms, B = 4 2.62 -> 2.02, B = 32 16.4 -> 11.5; at B = 1 they would leave half the CUs idle; 999 = never)
+        self.gca_epilogue_pool = True       # GlobalContext pooling in conv2's epilogue (False = k_gca_pool launch)
+        self.fconv_pipe = True              # slot-GroupNorm 3x3 convs on k_conv_fused_pipe (staging || matrix work)
         self.producer_slots = True          # r04: k_init_x / the Upsample epilogue leave their consumers' statistics slots, the final conv's split-K reduction writes NCHW (False: the r03 k_slots / k_unpack_out launches; parity tests)
         self.attn_in_out_proj = True        # the 16-token attention core in the prologue of its output projection (False: k_attn16 launch; parity tests)
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches

@@ -284,8 +284,8 @@ class AutoencoderKL(nn.Module):
         self.lds_conv_min_blocks = 96
         # EXPERIMENTAL, not yet measured: GroupNorm statistics from the producing conv's epilogue (csrc/conv_lds.h) instead of a pass
         # over the tensor; parity-checked on CPU threads (tests/test_hostemu_conv_lds.py)
-        self.conv_twin = os.environ.get("SF_VAE_TWIN", "1") != "0"       # Upsample convs read an operand-type twin of the block output (r03) instead of the fp32 tensor; 0 = A/B
-        self.gn_epilogue = os.environ.get("SF_VAE_GN_EPI", "1") != "0"   # GroupNorm statistics out of the producing conv's epilogue (r03: encode 1.80 -> 1.72 ms, decode 2.94 -> 2.76 ms); 0 = the statistics pass, A/B
+        self.conv_twin = True             # Upsample convs read an operand-type twin of the block output (r03) instead of the fp32 tensor
+        self.gn_epilogue = True           # GroupNorm statistics out of the producing conv's epilogue (r03: encode 1.80 -> 1.72 ms, decode 2.94 -> 2.76 ms); False = the statistics pass
         self._pack_cache, self._plans = None, {}
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys)

@@ -1,79 +1,60 @@
-"""Opt-in GPU checks of the EXPERIMENTAL kernels that are built and parity-checked on CPU threads but not (fully) run on the GPU
-yet: each variant is evaluated in a child process with its A/B switch set (the switches are read once
-per process) and compared with the default path evaluated the same way.  Skipped unless SF_TEST_EXPERIMENTAL=1, so the regular
-`pytest -m gpu` run is not affected:
-
-    SF_TEST_EXPERIMENTAL=1 python -m pytest tests/test_gpu_experimental.py -q -m gpu
-"""
-import os
-import subprocess
-import sys
-import tempfile
-
+"""GPU parity of the planner switches of the SD-VAE and LPIPS plans that the default suite would otherwise never run (r04: they
+are plain module attributes -- the SF_* environment switches of the r01-r03 A/B runs are retired -- and every one of them has a
+parity case here, in the regular `pytest -m gpu` run; the UNet's are in tests/test_gpu_unet.py::test_plan_switches_match_oracle,
+the NGP field cache in tests/test_gpu_ngp.py::test_field_cache_equals_regather)."""
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("SF_TEST_EXPERIMENTAL") != "1", reason="set SF_TEST_EXPERIMENTAL=1 to run")]
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-VAE_SNIPPET = """
-import sys, torch
-sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + '/tests')
-from vae_common import CONFIGS, ddconfig, inputs, state
-from sparsefusion_amd.vae import AutoencoderKL
-cfg = CONFIGS['canonical']
-net = AutoencoderKL(ddconfig=ddconfig(cfg), embed_dim=cfg['embed_dim'])
-net.load_state_dict(state('canonical'))
-net = net.cuda()
-img, z = inputs(cfg, 1, 5)
-torch.save({{'lat': net.encode(img.cuda()).mode().cpu(), 'dec': net.decode(z.cuda()).cpu()}}, {out!r})
-"""
-
-NGP_SNIPPET = """
-import sys, torch
-sys.path.insert(0, {root!r})
-from oracle import ngp_ref
-from sparsefusion_amd.nerf import NeRFNetwork, get_default_torch_ngp_opt
-p = ngp_ref.init_params(bound=4, seed=1, table_std=0.5, sigma_bias=-3.0)
-net = NeRFNetwork(get_default_torch_ngp_opt())
-net.load_state_dict({{k: p[k] for k in net.state_dict().keys()}})
-net = net.cuda().train()
-o, d = ngp_ref.circle_rays(48, view=7)
-torch.manual_seed(3)
-r = net.render(o[None].cuda(), d[None].cuda(), staged=False, perturb=True, bg_color=0, shading='albedo', **vars(net.opt))
-g = torch.Generator().manual_seed(9)
-gi, gw = torch.randn(1, 48 * 48, 3, generator=g).cuda(), torch.randn(48 * 48, generator=g).cuda()
-((r['image'] * gi).sum() + (r['weights_sum'] * gw).sum()).backward()
-torch.save({{'image': r['image'].detach().cpu(), 'ws': r['weights_sum'].detach().cpu(),
-            'g_table': net.encoder.embeddings.grad.cpu(), 'g_w1': net.sigma_net.net[1].weight.grad.cpu()}}, {out!r})
-"""
-
-
-def _run(snippet, env):
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "o.pt")
-        subprocess.check_call([sys.executable, "-c", snippet.format(root=ROOT, out=out)], env=dict(os.environ, **env), cwd=ROOT)
-        return torch.load(out)
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
 
 
 def _rel(a, b):
     return float((a - b).norm() / b.norm())
 
 
-def test_vae_gn_statistics_from_the_conv_epilogue():
-    """SF_VAE_GN_EPI=1 (k_conv_lds_gn + k_gn_finalize) gives the same encode / decode as the statistics pass up to the bf16
-    decorrelation of the path (a last-ulp difference in a GroupNorm statistic re-rounds the bf16 operands downstream: measured
-    4.8e-3 on the first GPU run, r3a; the path itself sits 7e-3 from the fp32 reference, tests/test_gpu_vae.py)."""
-    ref, got = _run(VAE_SNIPPET, {"SF_VAE_GN_EPI": "0"}), _run(VAE_SNIPPET, {"SF_VAE_GN_EPI": "1"})    # 1 is the default since r03
-    for k in ("lat", "dec"):
-        assert torch.isfinite(got[k]).all() and _rel(got[k], ref[k]) < 1e-2, (k, _rel(got[k], ref[k]))
+@pytest.mark.parametrize("attr", ["gn_epilogue", "conv_twin"])
+def test_vae_plan_switches_match_the_default_plan_and_the_oracle(attr):
+    """`gn_epilogue = False`: GroupNorm statistics from a pass over the tensor (k_gn_stats_px) instead of the producing conv's epilogue
+    sums (k_conv_lds_gn / halo + k_gn_finalize); `conv_twin = False`: Upsample / Downsample / nin_shortcut convs read the fp32 block
+    output instead of the operand-type twin.  Same results up to the bf16 decorrelation of the path (a last-ulp difference in a
+    statistic re-rounds operands downstream: measured 4.8e-3), and both within the reference tolerance."""
+    from oracle import vae_ref
+    from vae_common import CONFIGS, ddconfig, inputs, state
+    from sparsefusion_amd.vae import AutoencoderKL
+    cfg = CONFIGS["canonical"]
+    sd = state("canonical")
+    img, z = inputs(cfg, 1, 5)
+    outs = {}
+    for on in (True, False):
+        net = AutoencoderKL(ddconfig=ddconfig(cfg), embed_dim=cfg["embed_dim"])
+        net.load_state_dict(sd)
+        setattr(net, attr, on)
+        net = net.to(DEV)
+        outs[on] = (net.encode(img.to(DEV)).mode().cpu(), net.decode(z.to(DEV)).cpu())
+    with torch.no_grad():
+        lat_ref, dec_ref = vae_ref.encode_mode(sd, cfg, img), vae_ref.decode(sd, cfg, z)
+    for k, ref in ((0, lat_ref), (1, dec_ref)):
+        assert torch.isfinite(outs[False][k]).all() and _rel(outs[False][k], outs[True][k]) < 1e-2
+        assert _rel(outs[False][k], ref) < 2e-2 and _rel(outs[True][k], ref) < 2e-2
 
 
-@pytest.mark.parametrize("knob", ["SF_NGP_OVERLAP", "SF_NGP_FWD_MFMA"])      # overlap: 1 is the default (chunked backward + side stream)
-def test_ngp_render_variants_match_default(knob):
-    ref, got = _run(NGP_SNIPPET, {knob: "0"}), _run(NGP_SNIPPET, {knob: "1"})
-    assert torch.allclose(got["image"], ref["image"], atol=2e-6) and torch.allclose(got["ws"], ref["ws"], atol=2e-6)
-    assert _rel(got["g_w1"], ref["g_w1"]) < 1e-4
-    lvl = lambda t: t.abs().sum()
-    assert abs(float(lvl(got["g_table"]) / lvl(ref["g_table"])) - 1.0) < 1e-3
+def test_lpips_fp32_links_match_the_operand_type_twins():
+    """`conv_twin = False`: the conv -> conv links inside a VGG slice read the fp32 ReLU output instead of its operand-type twin
+    (both are rounded to the operand type before the MFMA: same value, other kernels)."""
+    from oracle import lpips_ref
+    from sparsefusion_amd.lpips import LPIPS
+    sd = lpips_ref.init_state(seed=0)
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.rand(1, 3, 64, 64, generator=g), torch.rand(1, 3, 64, 64, generator=g)
+    res = {}
+    for on in (True, False):
+        net = LPIPS(net='vgg')
+        net.load_state_dict(sd, strict=True)
+        net.conv_twin = on
+        net = net.to(DEV)
+        p = a.to(DEV).requires_grad_(True)
+        d = net(p, b.to(DEV), normalize=True)
+        d.sum().backward()
+        res[on] = (d.detach().cpu(), p.grad.cpu())
+    assert _rel(res[False][0], res[True][0]) < 2e-3 and _rel(res[False][1], res[True][1]) < 3e-2

@@ -188,6 +188,32 @@ def test_plan_switches_match_oracle(switch):
     assert torch.isfinite(y).all() and r < TOL_REL and c > TOL_COS and rel_err(y, y_def) < TOL_REL
 
 
+def test_r04_fusions_match_the_r03_plan():
+    """The launch fusions of round 4 -- attention core in the prologue of its output projection, statistics slots from k_init_x and
+    the Upsample epilogue, NCHW output from the final split-K reduction -- against the plan without them (k_attn16, k_slots,
+    k_unpack_out launches) and, with the GlobalContext pooling back in its own launch, against the oracle: same values to the bf16
+    tolerance, fewer ops."""
+    name = "canonical"
+    sd = state(name)
+    net = _unet(name, sd)
+    g = torch.Generator().manual_seed(57)
+    x, cond = torch.randn(1, 4, 32, 32, generator=g), torch.randn(1, 256, 32, 32, generator=g)
+    ls = unet_ref.log_snr(torch.tensor([0.45]))
+    with torch.no_grad():
+        y_ref = unet_ref.unet_forward(sd, x, ls, cond)
+    ctx = net.begin_sampling(cond.to(DEV), ls.to(DEV))
+    y_new = net.eval_prepared(ctx, x.to(DEV), 0).clone().cpu()
+    n_new = ctx["plan"].n_body_ops
+    net.attn_in_out_proj, net.producer_slots, net.gca_epilogue_pool = False, False, False
+    net.drop_plans()
+    ctx = net.begin_sampling(cond.to(DEV), ls.to(DEV))
+    y_old = net.eval_prepared(ctx, x.to(DEV), 0).clone().cpu()
+    n_old = ctx["plan"].n_body_ops
+    print(f"body ops {n_old} -> {n_new}; r04 vs r03 plan {rel_err(y_new, y_old):.3e}; vs oracle {rel_err(y_new, y_ref):.3e} / {rel_err(y_old, y_ref):.3e}")
+    assert n_new <= n_old - 20
+    assert rel_err(y_new, y_old) < TOL_REL and rel_err(y_new, y_ref) < TOL_REL and rel_err(y_old, y_ref) < TOL_REL
+
+
 def test_sampler_fast_path_equals_forward():
     """Unet.begin_sampling / eval_prepared (time table once per trajectory + plan body per eval) is the same computation as
     Unet.forward: same kernels on the same operands.  Not bit-identical: the GroupNorm statistics of the 4x4 level meet

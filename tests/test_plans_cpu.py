@@ -143,9 +143,9 @@ def test_unet_plan_invariants():
     assert lazy_ops < len(_Plan(net, 1, CPU).build().ops)
 
 
-def test_time_table_plan_uses_one_launch_per_linear(monkeypatch):
+def test_time_table_plan_uses_one_launch_per_linear():
     """A sampler's time table (Unet.time_table, 51 log-snr rows): every Linear of the time path is ONE OP_GEMV with all rows
-    (k_gemm_rows: <= 64 rows on the MFMA M side), not one per 8 rows; SF_GEMM_ROWS=0 restores the 8-row launches."""
+    (k_gemm_rows: <= 64 rows on the MFMA M side), not one per 8 rows."""
     from sparsefusion_amd import unet as unet_mod
     from sparsefusion_amd.unet import Unet, _TimePlan
     net = Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2), layer_attns=(False, False, False, True),
@@ -156,9 +156,6 @@ def test_time_table_plan_uses_one_launch_per_linear(monkeypatch):
     assert max(o.i[1] for o in gemvs) == net.ss_total                 # the 27 time_mlp Linears batched into one matrix
     big = _TimePlan(net, 100, CPU).build()                            # more rows than one launch takes: chunks of 64
     assert sorted({o.i[0] for o in big.ops if o.type == unet_mod.OP_GEMV}) == [36, 64]
-    monkeypatch.setenv("SF_GEMM_ROWS", "0")
-    old = [o for o in _TimePlan(net, 51, CPU).build().ops if o.type == unet_mod.OP_GEMV]
-    assert len(old) == 7 * len(gemvs) and max(o.i[0] for o in old) == 8
 
 
 def test_vae_lpips_eft_plan_invariants():
@@ -185,13 +182,13 @@ def test_vae_lpips_eft_plan_invariants():
 def test_vae_gn_epilogue_plan(monkeypatch):
     """Every GroupNorm whose input was last written by a whole-tensor k_conv_lds launch takes its statistics from that conv's
     epilogue (flag 128 + partials buffer + group width on the conv, OP_GN_FINALIZE, flag 2 on the GroupNorm); the others keep
-    the statistics pass.  Default since r03 (measured on the GPU); SF_VAE_GN_EPI=0 restores the statistics pass everywhere."""
+    the statistics pass.  Default since r03 (measured on the GPU); `vae.gn_epilogue = False` restores the statistics pass everywhere."""
     from sparsefusion_amd import unet as unet_mod
     from sparsefusion_amd.vae import AutoencoderKL, _VaePlan
-    monkeypatch.setenv("SF_VAE_GN_EPI", "0")
-    base = _VaePlan(AutoencoderKL(), "dec", 1, CPU).build()
+    off = AutoencoderKL()
+    off.gn_epilogue = False
+    base = _VaePlan(off, "dec", 1, CPU).build()
     assert not any(o.type == unet_mod.OP_GN_FINALIZE or (o.type == unet_mod.OP_CONV and o.flags & 128) for o in base.ops)
-    monkeypatch.delenv("SF_VAE_GN_EPI")
     vae = AutoencoderKL()
     for kind, B in (("enc", 1), ("dec", 2)):
         s = _VaePlan(vae, kind, B, CPU).build()
@@ -225,10 +222,10 @@ def test_lds_conv_selection_rule():
     assert big and all(o.i[14] >= 256 or o.i[6] < 64 for o in big)                 # every wide 128^2 / 256^2 conv is LDS-tiled
 
 
-def test_vae_upsample_reads_the_operand_twin(monkeypatch):
+def test_vae_upsample_reads_the_operand_twin():
     """r03: the decoder's three Upsample convs read an operand-type twin of the block output that the producing conv2 (an LDS-tiled
     kernel from 64 tiles on when k_conv3_halo can take the layer, csrc/conv_halo.h) writes in its epilogue -- bf16 A operand, the
-    nearest-x2 view folded into the halo addressing -- instead of the fp32 tensor; SF_VAE_TWIN=0 restores the fp32 read."""
+    nearest-x2 view folded into the halo addressing -- instead of the fp32 tensor; `vae.conv_twin = False` restores the fp32 read."""
     from sparsefusion_amd.unet import OP_CONV
     from sparsefusion_amd.vae import AutoencoderKL, _VaePlan
     ops = _VaePlan(AutoencoderKL(), "dec", 1, CPU).build().ops
@@ -249,7 +246,8 @@ def test_vae_upsample_reads_the_operand_twin(monkeypatch):
     assert len(down) == 3 and all(not (o.flags & 1) for o in down)                              # Downsample convs read the block's twin
     assert all(any(q.type == OP_CONV and q.p[5] == o.p[0] for q in enc) for o in down)
     assert all(q.i[14] >= 256 for q in ops if q.type == OP_CONV and q.i[9] == 3 and q.i[4] == 32 and q.i[3] == 512 and q.i[6] == 512)   # 32x32 layers: 64 tiles
-    monkeypatch.setenv("SF_VAE_TWIN", "0")
-    ops0 = _VaePlan(AutoencoderKL(), "dec", 1, CPU).build().ops
+    plain = AutoencoderKL()
+    plain.conv_twin = False
+    ops0 = _VaePlan(plain, "dec", 1, CPU).build().ops
     assert all(o.flags & 1 for o in ops0 if o.type == OP_CONV and o.flags & 16)
     assert not any(q.p[5] for q in ops0 if q.type == OP_CONV and q.i[14] >= 256)

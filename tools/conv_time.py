@@ -1,5 +1,5 @@
 """Event-timed single conv layers on the LDS-tiled kernels: python tools/conv_time.py [sel ...]  (sel 1 = k_conv_lds, 3 / 4 = k_conv_glds
-ring depth, 6 / 7 = k_conv3_halo; SF_HIP_LIB selects a measurement build of csrc/conv_glds.h, see SF_GLDS_EXPERIMENT there)."""
+ring depth, 6 / 7 = k_conv3_halo)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sparsefusion_amd import _lib
