@@ -2,7 +2,8 @@
 The `lpips` package and the pretrained VGG16 are not available (parity unpinned, see the oracle header): both sides use
 the same seeded synthetic weights.  bf16 MFMA operands / fp32 accumulate: distance within 1e-2 relative (measured
 3e-4), gradient w.r.t. the rendered image within 8e-2 relative L2 and cosine > 0.997 (measured 5e-2 / 0.9988: 13 conv
-layers forward and 13 backward in bf16, plus ReLU masks that flip for pre-activations within bf16 rounding of zero)."""
+layers forward and 13 backward in bf16, plus ReLU masks that flip for pre-activations within bf16 rounding of zero; r04: the
+error is localised per feature tap and attributed to operand rounding by the last test of this file)."""
 import pytest
 import torch
 
@@ -87,9 +88,22 @@ def test_lpips_gradient_error_is_operand_rounding_and_where_it_comes_from():
               f"bf16-operand oracle vs fp32 oracle {per_head[-1][2]:.2e}")
     gh, g32, gbf = grads(sd, range(5))
     print(f"all taps:   HIP vs fp32 oracle {rel(gh, g32):.2e}   HIP vs bf16-operand oracle {rel(gh, gbf):.2e}   bf16-operand oracle vs fp32 {rel(gbf, g32):.2e}")
+    # measured on MI355X (r04):        HIP vs fp32    HIP vs bf16-operand oracle    bf16-operand oracle vs fp32
+    #   tap relu1_2                      2.4e-2           4.7e-5                          2.4e-2
+    #   tap relu2_2                      7.6e-2           1.2e-3                          7.6e-2
+    #   tap relu3_3                      1.6e-1           1.8e-2                          1.6e-1
+    #   tap relu4_3                      2.2e-1           6.6e-2                          2.2e-1
+    #   tap relu5_3                      2.9e-1           1.8e-1                          3.1e-1
+    #   all five (LPIPS)                 5.0e-2           1.7e-2                          5.1e-2
+    # i.e. at every tap the HIP gradient is exactly as far from fp32 as ANY bf16-operand evaluation of the same network is, the
+    # distance grows with the number of bf16 conv layers (and ReLU masks) the gradient crosses, and the two bf16 evaluations agree
+    # to 5e-5 on the first slice (same roundings) and decorrelate through mask flips deeper down.  The sum is dominated by the
+    # shallow taps (largest gradients), hence 5e-2 overall.
     assert rel(gh, g32) < 8e-2 and rel(gh, gbf) < 3e-2
-    assert all(e32 < 1.2e-1 and ebf < 5e-2 for e32, ebf, _ in per_head)
-    assert per_head[0][0] < per_head[4][0]                   # the shallow tap is the accurate one: depth owns the error
+    for (e32, ebf, eref) in per_head:
+        assert e32 < 1.15 * eref + 1e-3                      # never worse than operand rounding alone explains
+    assert per_head[0][1] < 1e-3 and per_head[1][1] < 1e-2   # shallow slices: the two bf16 evaluations round the same values
+    assert all(per_head[k][0] < per_head[k + 1][0] for k in range(4))      # depth owns the error
 
 
 def test_perceptual_loss_wrapper_and_errors():
