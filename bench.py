@@ -304,7 +304,7 @@ def unet_roofline(hp, B=1):
     return {"bound": "hbm", "kernel": "k_conv_fused / k_conv_fused_pipe / _pair (GroupNorm | LayerNorm + conv in one launch)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
-            "traffic_note": "HBM counters need separate rocprofv3 --pmc passes; not collected inside bench.py (see profiles/r03_*_pmc.json)",
+            "traffic_note": "not collected in this run (--no-traffic, B > 1 or a multi-rank run): see profiles/r04_unet_eval_b1_pmc.json",
             "batch": B, "launches": n_launch, "ops": len(idx), "avg_launch_us": round(fconv_ms / n_launch * 1e3, 2),
             "algorithmic_bytes_per_launch": fconv_bytes // n_launch, "algorithmic_bytes_per_eval": fconv_bytes,
             "fused_conv_ms_per_eval": round(fconv_ms, 4),
@@ -314,6 +314,43 @@ def unet_roofline(hp, B=1):
             "whole_eval": {"ms": round(eval_ms, 4), "ops": plan.n_body_ops, "weight_bytes": all_conv_bytes,
                            "GBs": round(all_conv_bytes / (eval_ms * 1e-3) / 1e9, 1),
                            "frac": round(all_conv_bytes / (eval_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+
+
+def measure_fconv_traffic(timeout_s=240):
+    """HBM bytes fetched per fused-conv launch, from the PMC counters, for `roofline.traffic`: a child process replays three B = 1 evals
+    (tools/unet_eval_loop.py, plain launches) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` -- its own counter pass with the kernel
+    trace only, as MI355X_MICROARCH.md prescribes -- and the mean over all k_conv_fused* dispatches is corrected x2 (FETCH_SIZE reports
+    half of a wide coalesced streaming read on gfx950; KiB units).  Returns (bytes or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="sf_pmc_", dir="/tmp")
+    try:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        subprocess.run([exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", out, "--", sys.executable,
+                        os.path.join(ROOT, "tools", "unet_eval_loop.py"), "1", "3"], cwd="/tmp", env=env, timeout=timeout_s,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        tot, n = 0.0, 0
+        for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if "k_conv_fused" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+                    tot += float(r["Counter_Value"])
+                    n += 1
+        if not n:
+            return None, "the counter pass recorded no k_conv_fused dispatch"
+        return int(tot / n * 1024 * 2), ("mean FETCH_SIZE over %d k_conv_fused* dispatches of a child process (3 evals, B = 1) under rocprofv3 --kernel-trace "
+                                         "--pmc FETCH_SIZE, KiB x 1024 x 2 (gfx950: the counter reports half of a wide coalesced read)" % n)
+    except Exception as e:                                            # noqa: BLE001 -- a bench line without counters is still a bench line
+        return None, "counter pass failed: %r" % (e,)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
 def lds_conv_roofline(hp):
@@ -422,6 +459,7 @@ def main():
                          "evaluation render through render_batched timed beside the step")
     ap.add_argument("--no-also-measured", action="store_true", help="skip the short configs[3] (B = 4) measurement the default line carries")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 counter pass (child process) that fills roofline.traffic")
     args = ap.parse_args()
     if args.config == 3 and args.views_per_gpu == 1:
         args.views_per_gpu = 4
@@ -545,6 +583,10 @@ def main():
             x_b = torch.zeros(Bv, 4, 32, 32, device=dev)
             res["breakdown_ms"]["unet_eval_in_sampler_B%d" % Bv] = round(time_region(lambda: hp.unet.eval_prepared(ctx_b, x_b, 1), 20), 3)
         res["roofline"] = unet_roofline(hp, args.views_per_gpu)    # the batch the step ran the UNet at (configs[3]: B = 4: both rooflines)
+        if world == 1 and args.views_per_gpu == 1 and not args.no_traffic:
+            res["roofline"]["traffic"], res["roofline"]["traffic_note"] = measure_fconv_traffic()
+            if res["roofline"]["traffic"]:
+                res["roofline"]["traffic_over_algorithmic"] = round(res["roofline"]["traffic"] / res["roofline"]["algorithmic_bytes_per_launch"], 3)
         res["roofline_mfma"] = lds_conv_roofline(hp)
         if world == 1 and args.config == 1 and args.views_per_gpu == 1 and not strong and not args.no_also_measured:
             # the per-GPU regime of BASELINE configs[3] (4 novel views per GPU: the UNet at B = 4), on this GPU, in this run:

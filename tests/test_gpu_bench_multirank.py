@@ -50,7 +50,7 @@ def test_bench_spawns_its_own_ranks():
 def test_config2_eft_feature_render_in_the_step():
     """BASELINE configs[2] as a bench workload: 6 input views, the EFT feature render of the novel view inside every step."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "2", "--steps", "1", "--warmup", "1", "--max-thres", "0.06",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--no-traffic"]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -60,7 +60,7 @@ def test_config2_eft_feature_render_in_the_step():
 def test_config4_fp16_unet_full_plms_and_512_render():
     """BASELINE configs[4] as a bench workload (one GPU's share): fp16-operand UNet, the full 50-step PLMS trajectory, and the 512^2
     evaluation render through render_batched timed beside the step."""
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "4", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", "4", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-traffic"]
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
@@ -77,3 +77,5 @@ def test_default_line_carries_the_b4_regime():
     b4 = res["also_measured"]["config3_B4"]
     assert b4["ms_per_step"] > 0 and b4["value"] > 0 and b4["unet_eval_ms"] > 0 and 0 < b4["roofline"]["frac"] < 1
     assert res["config"]["views_per_gpu"] == 1 and res["roofline"]["batch"] == 1
+    rf = res["roofline"]                # the counter pass of the default line: measured HBM fetch per fused-conv launch, or null with a reason
+    assert (rf["traffic"] is None and rf["traffic_note"]) or (rf["traffic"] > 1e6 and 0.5 < rf["traffic_over_algorithmic"] < 10)
