@@ -46,6 +46,34 @@ SF_KERNEL(256) void k_layernorm(const float* __restrict__ in, const float* __res
   }
 }
 
+// Many short rows (the EFT transformers: 122 880 rows of 256 channels): one WAVE per row, four channels per lane, no block barrier --
+// the block-per-row kernel above spends its time in two barriers and one element per thread (91 us for 252 MB moved, r04 trace); this one
+// is one load, two shuffle reductions and one store per lane.  Same arithmetic (two-pass variance, fp32).  C == 256 only.
+SF_KERNEL(256) void k_layernorm_w256(const float* __restrict__ in, const float* __restrict__ gain, const float* __restrict__ bias,
+                                     void* __restrict__ out, const float* __restrict__ resid, int R, float eps, int pre_gelu, int out_f32) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  f32x4 v = *reinterpret_cast<const f32x4*>(in + row * 256 + lane * 4);
+  const f32x4 g = *reinterpret_cast<const f32x4*>(gain + lane * 4);
+  const f32x4 bq = bias ? *reinterpret_cast<const f32x4*>(bias + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 rq = (resid && out_f32) ? *reinterpret_cast<const f32x4*>(resid + row * 256 + lane * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  if (pre_gelu) { v[0] = sf_gelu(v[0]); v[1] = sf_gelu(v[1]); v[2] = sf_gelu(v[2]); v[3] = sf_gelu(v[3]); }
+  const float mean = sf_wave_sum((v[0] + v[1]) + (v[2] + v[3])) / 256.0f;
+  const f32x4 d = v - mean;
+  const float rstd = sf_rsqrt(sf_wave_sum(fmaf(d[0], d[0], fmaf(d[1], d[1], fmaf(d[2], d[2], d[3] * d[3])))) / 256.0f + eps);
+  f32x4 y;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) y[j] = d[j] * rstd * g[j] + bq[j];
+  if (out_f32) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + row * 256 + lane * 4) = y + rq;
+  } else {
+    bf16x4 o;
+    o[0] = (sf_opnd)y[0]; o[1] = (sf_opnd)y[1]; o[2] = (sf_opnd)y[2]; o[3] = (sf_opnd)y[3];
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<sf_opnd*>(out) + row * 256 + lane * 4) = o;
+  }
+}
+
 struct AttnSeg { const float* k; const float* v; int rows, row_stride, batch_stride, head_stride; };
 SF_KERNEL(256) void k_attn16(const float* __restrict__ q, void* __restrict__ out, AttnSeg s0, AttnSeg s1,
                                                 AttnSeg s2, int heads, int ldq, float scale, int out_f32) {

@@ -702,6 +702,12 @@ static int run_gn(const sf_op& op, hipStream_t st) {
 static int run_ln(const sf_op& op, hipStream_t st) {
   const int R = op.i[0], C = op.i[1];
   if (C % 64 || C > 2048) SF_FAIL(SF_ERR_INVALID, "layernorm: C must be a multiple of 64 and <= 2048");
+  if (C == 256 && R >= 1024) {                               // many short rows (EFT): one wave per row
+    k_layernorm_w256<<<sf_div_up(R, 4), 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3],
+                                                      (const float*)op.p[4], R, op.f[0], op.flags & 1, (op.flags & 2) ? 1 : 0);
+    SF_CHECK_LAUNCH("layernorm_w256");
+    return SF_OK;
+  }
   k_layernorm<<<R, 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3],
                                               (const float*)op.p[4], R, C, op.f[0], op.flags & 1, (op.flags & 2) ? 1 : 0);
   SF_CHECK_LAUNCH("layernorm");

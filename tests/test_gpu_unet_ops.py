@@ -333,7 +333,8 @@ def test_gn_act(B, H, C1, C2, with_ss):
 
 @pytest.mark.parametrize("R,C,gelu,bias,f32,res", [(16, 1024, False, False, False, False), (32, 2048, True, False, False, False),
                                                      (4, 256, False, True, True, False), (48, 1024, False, False, True, True),
-                                                     (7, 64, False, False, True, False)])
+                                                     (7, 64, False, False, True, False),
+                                                     (4099, 256, False, True, True, True), (2048, 256, True, False, False, False)])      # k_layernorm_w256 (EFT: many 256-channel rows)
 def test_layernorm(R, C, gelu, bias, f32, res):
     g = torch.Generator().manual_seed(R + C)
     x = torch.randn(R, C, generator=g) * 3 + 1

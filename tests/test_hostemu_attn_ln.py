@@ -28,7 +28,8 @@ def _lib():
 
 
 @pytest.mark.parametrize("R,Cc,gelu,bias,resid,out_f32", [(16, 1024, False, True, True, True), (5, 192, True, False, False, False),
-                                                         (3, 2048, False, True, False, False)])
+                                                         (3, 2048, False, True, False, False),
+                                                         (10, 256, False, True, True, True), (7, 256, True, False, False, False)])      # k_layernorm_w256
 def test_layernorm_kernel(R, Cc, gelu, bias, resid, out_f32):
     lib = _lib()
     g = torch.Generator().manual_seed(R + Cc)
