@@ -50,7 +50,8 @@ SF_KERNEL(256) void k_layernorm(const float* __restrict__ in, const float* __res
 // the block-per-row kernel above spends its time in two barriers and one element per thread (91 us for 252 MB moved, r04 trace); this one
 // is one load, two shuffle reductions and one store per lane.  Same arithmetic (two-pass variance, fp32).  C == 256 only.
 SF_KERNEL(256) void k_layernorm_w256(const float* __restrict__ in, const float* __restrict__ gain, const float* __restrict__ bias,
-                                     void* __restrict__ out, const float* __restrict__ resid, int R, float eps, int pre_gelu, int out_f32) {
+                                     void* __restrict__ out, const float* __restrict__ resid, int R, float eps, int pre_gelu, int out_f32,
+                                     sf_opnd* __restrict__ twin) {      // twin: also an operand-type copy of the fp32 output (the next linear's A operand)
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= R) return;
@@ -66,7 +67,13 @@ SF_KERNEL(256) void k_layernorm_w256(const float* __restrict__ in, const float* 
 #pragma unroll
   for (int j = 0; j < 4; ++j) y[j] = d[j] * rstd * g[j] + bq[j];
   if (out_f32) {
-    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + row * 256 + lane * 4) = y + rq;
+    y = y + rq;
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + row * 256 + lane * 4) = y;
+    if (twin) {
+      bf16x4 o;
+      o[0] = (sf_opnd)y[0]; o[1] = (sf_opnd)y[1]; o[2] = (sf_opnd)y[2]; o[3] = (sf_opnd)y[3];
+      *reinterpret_cast<bf16x4*>(twin + row * 256 + lane * 4) = o;
+    }
   } else {
     bf16x4 o;
     o[0] = (sf_opnd)y[0]; o[1] = (sf_opnd)y[1]; o[2] = (sf_opnd)y[2]; o[3] = (sf_opnd)y[3];

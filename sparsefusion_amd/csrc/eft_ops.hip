@@ -156,8 +156,9 @@ __global__ __launch_bounds__(256) void k_harmonic(const float* __restrict__ src,
 // qkv [M, 768] (q | k | v, E = 256).  Group g holds S rows: row(g, s) = g * gmul + s * stride.  out [M, 256].
 #define EFT_E 256
 #define EFT_SMAX 24
-__global__ __launch_bounds__(256) void k_attn_small(const float* __restrict__ qkv, float* __restrict__ out, int S, long stride,
-                                                    long gmul, float scale) {
+// out16 (r04): the result in MFMA operand type instead of fp32 -- its only consumer is the output projection, which rounds it anyway.
+__global__ __launch_bounds__(256) void k_attn_small(const float* __restrict__ qkv, float* __restrict__ out, sf_opnd* __restrict__ out16, int S,
+                                                    long stride, long gmul, float scale) {
   __shared__ float sq[EFT_SMAX][EFT_E], sk[EFT_SMAX][EFT_E];
   __shared__ float sp[EFT_SMAX][EFT_SMAX + 1];
   const long g = blockIdx.x;
@@ -197,7 +198,10 @@ __global__ __launch_bounds__(256) void k_attn_small(const float* __restrict__ qk
   }
 #pragma unroll
   for (int s = 0; s < EFT_SMAX; ++s)
-    if (s < S) out[(g * gmul + s * stride) * EFT_E + threadIdx.x] = acc[s];
+    if (s < S) {
+      if (out16) out16[(g * gmul + s * stride) * EFT_E + threadIdx.x] = (sf_opnd)acc[s];
+      else out[(g * gmul + s * stride) * EFT_E + threadIdx.x] = acc[s];
+    }
 }
 
 // ---- softmax pooling over the sequence (+ optional colour head) --------------------------------------------------
@@ -272,9 +276,9 @@ int sf_plan_eft_op(const sf_op* opp, void* stream) {
     }
     case 3: {                                                    // ATTN: i = groups(2), S, stride(2), gmul(2) ; f[0] = scale
       const long G = i64(op, 0);
-      if (op.i[2] < 1 || op.i[2] > EFT_SMAX || !op.p[0] || !op.p[3]) SF_FAIL(SF_ERR_INVALID, "attn_small: sequence length 1..%d", EFT_SMAX);
+      if (op.i[2] < 1 || op.i[2] > EFT_SMAX || !op.p[0] || (!op.p[3] && !op.p[4])) SF_FAIL(SF_ERR_INVALID, "attn_small: sequence length 1..%d", EFT_SMAX);
       if (G > 0x7fffffffL) SF_FAIL(SF_ERR_INVALID, "attn_small: too many groups");
-      k_attn_small<<<(uint32_t)G, 256, 0, st>>>((const float*)op.p[0], (float*)op.p[3], op.i[2], i64(op, 3), i64(op, 5), op.f[0]);
+      k_attn_small<<<(uint32_t)G, 256, 0, st>>>((const float*)op.p[0], (float*)op.p[3], (sf_opnd*)op.p[4], op.i[2], i64(op, 3), i64(op, 5), op.f[0]);      // p[4]: operand-type output instead of p[3]
       break;
     }
     case 4: {                                                    // POOL: i = groups(2), S, stride(2), gmul(2)

@@ -704,10 +704,11 @@ static int run_ln(const sf_op& op, hipStream_t st) {
   if (C % 64 || C > 2048) SF_FAIL(SF_ERR_INVALID, "layernorm: C must be a multiple of 64 and <= 2048");
   if (C == 256 && R >= 1024) {                               // many short rows (EFT): one wave per row
     k_layernorm_w256<<<sf_div_up(R, 4), 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3],
-                                                      (const float*)op.p[4], R, op.f[0], op.flags & 1, (op.flags & 2) ? 1 : 0);
+                                                      (const float*)op.p[4], R, op.f[0], op.flags & 1, (op.flags & 2) ? 1 : 0, (sf_opnd*)op.p[5]);
     SF_CHECK_LAUNCH("layernorm_w256");
     return SF_OK;
   }
+  if (op.p[5]) SF_FAIL(SF_ERR_INVALID, "layernorm: the operand-type twin output exists for >= 1024 rows of 256 channels only");
   k_layernorm<<<R, 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3],
                                               (const float*)op.p[4], R, C, op.f[0], op.flags & 1, (op.flags & 2) ? 1 : 0);
   SF_CHECK_LAUNCH("layernorm");

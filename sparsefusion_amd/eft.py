@@ -122,29 +122,41 @@ class _EftPlan(_Plan):
         return self
 
     # ---- transformer pieces (eft.py:19-52; nn.TransformerEncoderLayer(256, 1, 256), post-norm, ReLU)
-    def linear(self, x, M, wname, bname, out, cout, resid=None, act=0):
-        self.conv(x, True, 1, M, wname, bname, out, cout, 0, cout, 1, batch=1, resid=resid, relu=(act == 1), gelu=(act == 2))
+    def linear(self, x, M, wname, bname, out, cout, resid=None, act=0, twin=None):
+        """r04: where the producer left an operand-type twin of x (a LayerNorm, a ReLU linear, the attention core), the linear reads
+        that -- half the A bytes, and the LDS-DMA kernel (k_conv_glds) instead of the register-staged k_conv_lds: the 48 K = 256
+        linears of the three transformers were 7.5 ms of a 13.8 ms feature render.  Same operand values (the fp32 path rounds on load)."""
+        tw = x.twin if getattr(self.u, "linear_twin", True) else None
+        self.conv(tw if tw is not None else x, tw is None, 1, M, wname, bname, out, cout, 0, cout, 1, batch=1, resid=resid, relu=(act == 1),
+                  gelu=(act == 2), twin=twin)
 
     def encoder_layer(self, p, x, M, S, stride, gmul):
+        tw_ok = getattr(self.u, "linear_twin", True) and M >= 1024
         qkv = self.zf32(M, 768)
         self.linear(x, M, p + ".self_attn.in_proj_weight", p + ".self_attn.in_proj_bias", qkv, 768)
-        att = self.f32(M, 256)
-        self.eft_op(3, (qkv.ptr, 0, 0, att.ptr), _i64(M // S) + (S,) + _i64(stride) + _i64(gmul), (1.0 / math.sqrt(256.0),))
+        if tw_ok:                                                 # the attention core writes the operand type directly (no fp32 copy)
+            att = _T(0, M, 256)
+            att.twin = self.bf16(M, 256)
+            self.eft_op(3, (qkv.ptr, 0, 0, 0, att.twin.ptr), _i64(M // S) + (S,) + _i64(stride) + _i64(gmul), (1.0 / math.sqrt(256.0),))
+        else:
+            att = self.f32(M, 256)
+            self.eft_op(3, (qkv.ptr, 0, 0, att.ptr), _i64(M // S) + (S,) + _i64(stride) + _i64(gmul), (1.0 / math.sqrt(256.0),))
         y = self.zf32(M, 256)
         self.linear(att, M, p + ".self_attn.out_proj.weight", p + ".self_attn.out_proj.bias", y, 256, resid=x)
         x1 = self.f32(M, 256)
-        self.ln(y, p + ".norm1.weight", p + ".norm1.bias", x1, 256, M, out_f32=True)
+        self.ln(y, p + ".norm1.weight", p + ".norm1.bias", x1, 256, M, out_f32=True, twin=self.bf16(M, 256) if tw_ok else None)
         h = self.zf32(M, 256)
-        self.linear(x1, M, p + ".linear1.weight", p + ".linear1.bias", h, 256, act=1)
+        self.linear(x1, M, p + ".linear1.weight", p + ".linear1.bias", h, 256, act=1, twin=self.bf16(M, 256) if tw_ok else None)
         y2 = self.zf32(M, 256)
         self.linear(h, M, p + ".linear2.weight", p + ".linear2.bias", y2, 256, resid=x1)
         x2 = self.f32(M, 256)
-        self.ln(y2, p + ".norm2.weight", p + ".norm2.bias", x2, 256, M, out_f32=True)
+        self.ln(y2, p + ".norm2.weight", p + ".norm2.bias", x2, 256, M, out_f32=True, twin=self.bf16(M, 256) if tw_ok else None)
         return x2
 
     def transformer(self, t, w_in, K, M, S, stride, gmul):
         x = self.zf32(M, 256)
-        self.linear(_T(w_in.ptr, M, K), M, t + ".pre.0.weight", t + ".pre.0.bias", x, 256, act=2)
+        self.linear(_T(w_in.ptr, M, K), M, t + ".pre.0.weight", t + ".pre.0.bias", x, 256, act=2,
+                    twin=self.bf16(M, 256) if (getattr(self.u, "linear_twin", True) and M >= 1024) else None)
         for i in range(4):
             x = self.encoder_layer(f"{t}.encoder.layers.{i}", x, M, S, stride, gmul)
         return x
@@ -210,6 +222,7 @@ class EpipolarFeatureTransformer(nn.Module):
             self._add(name, shape, g)
         self.input_bbox = self.input_cameras = self.input_images = self.encoder_latent = None
         self.conv_waves_target, self.lazy_consumers, self.ss_total, self.lds_conv_min_blocks = 1024, 0, 0, 96
+        self.linear_twin = True             # r04: transformer linears read operand-type twins their producers leave (False: fp32 reads; tests compare)
         self._pack_cache, self._plans, self._enc = None, {}, None
 
     conv_tiling = Unet.conv_tiling
@@ -237,6 +250,7 @@ class EpipolarFeatureTransformer(nn.Module):
         return {'model': 'patch_nerf', 'conv_dims': self.conv_dims, 'encoder': self.encoder}
 
     def invalidate(self):
+        self.linear_twin = True             # r04: transformer linears read operand-type twins their producers leave (False: fp32 reads; tests compare)
         self._pack_cache, self._plans, self._enc = None, {}, None
 
     def load_state_dict(self, *a, **k):

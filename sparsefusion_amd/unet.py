@@ -394,12 +394,16 @@ class _Plan:
                    raw.ptr if raw else 0, stats) + lp,
                 i=(self.B, x.HW, C1, C2, getattr(self.u, "tb_stride", 0)) + li + (groups,), f=(eps, SKIP_SCALE))
 
-    def ln(self, x, gname, bname, out, C, rows, eps=1e-5, gelu=False, out_f32=False, resid=None):
+    def ln(self, x, gname, bname, out, C, rows, eps=1e-5, gelu=False, out_f32=False, resid=None, twin=None):
+        """`twin`: an operand-type [rows][C] buffer that also receives the (fp32-output) result -- the A operand of the next linear
+        (k_layernorm_w256: C = 256, rows >= 1024 only)."""
         self.need(x)
         self.need(resid)
+        assert twin is None or (out_f32 and C == 256 and rows >= 1024)
         self.op(OP_LN, (1 if gelu else 0) | (2 if out_f32 else 0),
-                p=(x.ptr, self.wptr(gname), self.wptr(bname) if bname else 0, out.ptr, resid.ptr if resid else 0),
+                p=(x.ptr, self.wptr(gname), self.wptr(bname) if bname else 0, out.ptr, resid.ptr if resid else 0, twin.ptr if twin else 0),
                 i=(rows, C), f=(eps,))
+        out.twin = twin
 
     def gemv(self, x_ptr, M, ldx, wname, bname, y_ptr, ldy, N, K, in_silu=False, out_act=0):
         Kp = (K + 7) // 8 * 8

@@ -9,7 +9,7 @@
 extern "C" void emu_layernorm(const float* in, const float* gain, const float* bias, void* out, const float* resid, int R, int C, float eps,
                               int pre_gelu, int out_f32) {
   if (C == 256 && R >= 6) {                     // (the launcher takes this kernel from 1024 rows on; the test drives it with fewer)
-    hipemu::launch((unsigned)((R + 3) / 4), 256, 0, [&] { k_layernorm_w256(in, gain, bias, out, resid, R, eps, pre_gelu, out_f32); });
+    hipemu::launch((unsigned)((R + 3) / 4), 256, 0, [&] { k_layernorm_w256(in, gain, bias, out, resid, R, eps, pre_gelu, out_f32, nullptr); });
     return;
   }
   hipemu::launch((unsigned)R, 256, 0, [&] { k_layernorm(in, gain, bias, out, resid, R, C, eps, pre_gelu, out_f32); });

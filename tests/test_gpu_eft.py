@@ -145,6 +145,27 @@ def test_eft_matches_reference_golden(name):
     assert rel_err(f3_c[0].cpu(), f3_b[0].cpu()) < 1e-2          # other M -> other conv kernels / tiles: bf16-path noise (measured 3.9e-3)
 
 
+def test_eft_transformer_linears_on_operand_twins_match_fp32_reads():
+    """r04: the K = 256 linears of the three transformers read operand-type twins that their producers (LayerNorm, ReLU linear, the
+    attention core) leave, through the LDS-DMA conv kernel; `linear_twin = False` plans the fp32 reads of r03.  Same operand values
+    (the fp32 path rounds on load), other kernels: equal to accumulation order.  Needs >= 1024 tokens per transformer."""
+    import collections
+    RayBundle = collections.namedtuple("RayBundle", ["origins", "directions", "lengths", "xys"])
+    cams, images, o, d, lengths = scene(NC=3, R=64, N=96, D=20, seed=7)
+    outs = {}
+    for on in (True, False):
+        net = _module()
+        net.linear_twin = on
+        rb = RayBundle(o.to(DEV), d.to(DEV), lengths.to(DEV), None)
+        rgb, f3, _ = net(rb, input_cameras=cams.to(DEV), input_rgb=images.to(DEV))
+        outs[on] = (rgb.cpu(), f3.cpu())
+        plan = [v for k, v in net._plans.items() if k[0] == "fwd"][0]
+        from sparsefusion_amd.unet import OP_CONV
+        n16 = sum(1 for op in plan.ops if op.type == OP_CONV and not (op.flags & 1))
+        assert (n16 >= 24) if on else (n16 == 0), n16          # (the third transformer runs on N * NC = 288 tokens here: below the twin threshold)
+    assert rel_err(outs[True][1], outs[False][1]) < 5e-3 and float((outs[True][0] - outs[False][0]).abs().max()) < 5e-3
+
+
 def test_eft_rejects_unsupported():
     from sparsefusion_amd.eft import EpipolarFeatureTransformer
     with pytest.raises(NotImplementedError):
