@@ -92,7 +92,8 @@ class PLMSSampler():
         if fast:
             eval_times = list(dict.fromkeys(tl[:-1] + [tl[1]]))     # every step's t, plus t_next of the first (improved Euler)
             row_of = {t: k for k, t in enumerate(eval_times)}
-            ctx = unet.begin_sampling(cond_images, torch.stack([alpha_cosine_log_snr(_f(t)) for t in eval_times]).to(dev))
+            ctx = unet.begin_sampling(cond_images, torch.stack([alpha_cosine_log_snr(_f(t)) for t in eval_times]).to(dev),
+                                      table_key=tuple(eval_times))        # same schedule as the last call: the cached time table
             x_slot = ctx["plan"].x_view.view(shape)                 # the plan's input buffer: latents live there between steps
 
         row_ready = [None]          # the table row the last sf_plms_step already copied into the plan (one launch less per eval)

@@ -214,6 +214,23 @@ def test_r04_fusions_match_the_r03_plan():
     assert rel_err(y_new, y_old) < TOL_REL and rel_err(y_new, y_ref) < TOL_REL and rel_err(y_old, y_ref) < TOL_REL
 
 
+def test_time_table_is_cached_per_schedule_until_the_weights_change():
+    """Unet.time_table(log_snrs, key=): the time path is a function of the weights and the schedule only, so a sampler that passes a
+    key (PLMSSampler: the tuple of its times) gets the same read-only table on every trajectory; load_state_dict / .to() drop it."""
+    name = "small"
+    net = _unet(name)
+    x, ls, cond = inputs(CONFIGS[name], 2, 3)
+    c1 = net.begin_sampling(cond.to(DEV), ls.to(DEV), table_key=("k", 2))
+    c2 = net.begin_sampling(cond.to(DEV), ls.to(DEV), table_key=("k", 2))
+    fresh = net.begin_sampling(cond.to(DEV), ls.to(DEV))["table"]
+    assert c1["table"] is c2["table"] and fresh is not c1["table"] and torch.equal(fresh, c1["table"])
+    y = net.eval_prepared(c2, x.to(DEV), 1).clone()
+    net.load_state_dict(state(name, seed=1), strict=True)              # other weights: the cached table must not survive
+    c3 = net.begin_sampling(cond.to(DEV), ls.to(DEV), table_key=("k", 2))
+    assert c3["table"] is not c1["table"] and not torch.equal(c3["table"], c1["table"])
+    assert not torch.equal(net.eval_prepared(c3, x.to(DEV), 1), y)
+
+
 def test_sampler_fast_path_equals_forward():
     """Unet.begin_sampling / eval_prepared (time table once per trajectory + plan body per eval) is the same computation as
     Unet.forward: same kernels on the same operands.  Not bit-identical: the GroupNorm statistics of the 4x4 level meet
