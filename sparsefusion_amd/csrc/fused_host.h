@@ -100,6 +100,7 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   a.wk = (const float*)op.p[17]; a.logit_part = (float*)op.p[18];
   a.weff = nullptr; a.pool_part = nullptr; a.weff_off = 0;
   a.attn = FAttn{}; a.attn_off = 0;
+  a.rc_w = nullptr; a.rc_bias = nullptr; a.rc_out = nullptr; a.rc_off = 0; a.rc_buf_bytes = 0;
   if (op.flags & 64) {                 // epilogue pooling (k_conv_fused_pipe<.., POOL>): p 17 = w_eff bf16 [KS * 32], p 18 = pooled fragments
     a.weff = (const sf_opnd*)op.p[17]; a.pool_part = (float*)op.p[18];
     a.wk = nullptr; a.logit_part = nullptr;
@@ -242,6 +243,42 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
 }
 
 static inline int fconv_pipe_ept(const FConvArgs& a) { return (a.TR + 2) * a.W / 8; }
+
+// (WM, WN, EPT) of k_conv_fused_pipe_rc: the pipelined tiles with registers to spare for the res_conv's accumulators and ring slot
+#define SF_FCONV_PIPE_RC_VARIANTS(X) \
+  X(1, 1, 4) \
+  X(1, 2, 4) \
+  X(1, 1, 6) \
+  X(1, 2, 6) \
+  X(2, 1, 6) \
+  X(2, 2, 6) \
+  X(2, 1, 8) \
+  X(2, 2, 8) \
+  X(2, 1, 12) \
+  X(2, 2, 12)
+
+// A pipelined pair whose res_conv can ride in conv1's workgroups (k_conv_fused_pipe_rc): fills a.rc_* / the LDS layout and returns true.
+// `a` = conv1 as set up by fconv_setup, `b` = the res_conv, WM / WN the common tile, lds_bytes conv1's.
+// Measured (profiles/r04_pipe_rc_merge_ab.log): B = 1 eval 1.233 -> 1.190 ms, B = 2 1.417 -> 1.401, B = 4 1.908 -> 1.876 (its 32x32 pairs
+// run the WM = 4 tile, which keeps the two-kernel launch); a pair launch 22-23 -> 17-18 us.
+static inline bool fconv_pipe_rc_merge(FConvArgs& a, const FConvArgs& b, int WM, int WN, uint32_t& lds_bytes) {
+  if (WM > 2 || a.weff || a.logit_part || b.k != 1 || b.norm != FNORM_NONE || b.S != 1 || b.Cout != a.Cout || b.ldc != b.Cout || b.co_off ||
+      b.resid || b.accum || b.slots_out || b.out_gelu || b.silu || b.logit_part || !b.out || b.s1.mode || a.s1.mode ||
+      b.s1.p != a.s1.p || b.s2.p != a.s2.p || b.s1.C != a.s1.C || b.s2.C != a.s2.C || b.s1.scale != a.s1.scale || b.s2.scale != a.s2.scale)
+    return false;
+  const uint32_t raw = (((uint32_t)(16 * WM + 1) * a.pix_stride) + 15) & ~15u;
+  // LDS: [frames][red: + WM * WN fragments per matrix wave][table][misc][raw operand x 2]
+  const int red_old = 1024 * (SF_FCONV_WAVES / 2) * (WM * WN), red_new = 1024 * (SF_FCONV_WAVES / 2) * (2 * WM * WN);
+  const uint32_t total = lds_bytes + (uint32_t)(red_new - red_old) + 2 * raw;
+  if (total > SF_LDS_MAX) return false;
+  a.tab_off += red_new - red_old;
+  a.misc_off += red_new - red_old;
+  a.rc_off = (int)((lds_bytes + (uint32_t)(red_new - red_old) + 15) & ~15u);
+  a.rc_buf_bytes = (int)raw;
+  lds_bytes = (uint32_t)a.rc_off + 2 * raw;
+  a.rc_w = b.w; a.rc_bias = b.bias; a.rc_out = b.out;
+  return lds_bytes <= SF_LDS_MAX;
+}
 
 // Pair = op1 (flags & 16) + the op after it: same tile shape, op2 un-normalised, same lazy mode (op2 with s1.p == null when lazy).
 static inline int fconv_pair_setup(const sf_op& op1, const sf_op& op2, FConvPairArgs& p, int& WM, int& WN, uint32_t& grid, uint32_t& lds_bytes,

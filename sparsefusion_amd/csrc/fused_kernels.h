@@ -97,6 +97,12 @@ struct FConvArgs {
   float* pool_part;                  // [M / 16][Cout] un-normalised pooled fragments sum_p exp(l_p - max_frag) * out[p, n];
                                      // directly behind it [M / 16][2] = (max_frag, sum_p exp(l_p - max_frag)): one chunk = 16 pixels
   int weff_off;                      // LDS byte offset of the w_eff table
+  // k_conv_fused_pipe<.., RC = true> (r04): the block's res_conv (1x1 conv of the RAW concat, imagen_pytorch.py:700-729) rides in the
+  // SAME workgroups as conv1 -- one more k-step per matrix wave and chunk on a raw operand copy of the tile's own pixels
+  const bf16x8* rc_w;                // packed 1x1 weights [Cout / 16][C / 32][lane][8], or null
+  const float* rc_bias;
+  float* rc_out;                     // [M][Cout]
+  int rc_off, rc_buf_bytes;          // LDS: two raw-operand buffers of (16 * WM + 1) pixels x 128 channels
   FAttn attn;                        // FNORM_ATTN only
   int attn_off;                      //   LDS byte offset of its scratch (SF_ATTN_LDS_BYTES)
 };

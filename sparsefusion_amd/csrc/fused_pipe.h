@@ -27,7 +27,7 @@
 // behind the weight ring): 1.231 -> 1.245 ms at B = 1, 1.415 -> 1.421 at B = 2 (profiles/r04_pipe_all_waves_stage_chunk0_ab.log):
 // +28 VGPRs and eight more loads in front of the matrix waves' weight ring cost more than the shorter first phase saves.
 
-template <int WM, int WN, int EPT, int NW, bool POOL = false>
+template <int WM, int WN, int EPT, int NW, bool POOL = false, bool RC = false>
 SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
   constexpr int NT = NW * 64, NWM = NW / 2;             // NWM matrix waves, NT - 64 * NWM staging threads
   constexpr int CC = 128;                               // input channels per pipeline chunk (4 k-steps per tap)
@@ -86,7 +86,8 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
   // ONE register pool for both roles (the ring of the matrix waves, the two staging batches of the others): declared as
   // separate arrays the compiler keeps both alive across the role-independent code and allocates their SUM
   constexpr int NB = EPT <= 4 ? 4 : (EPT <= 6 ? 3 : 2);       // staging batches (chunks) in registers: ~16-24 float4 loads in flight per thread
-  constexpr int NP = (KPW * WN > NB * EPT) ? KPW * WN : NB * EPT;
+  constexpr int KR = KPW + (RC ? 1 : 0);                      // ring steps per matrix wave and chunk: RC = one more, on the raw operand
+  constexpr int NP = (KR * WN > NB * EPT) ? KR * WN : NB * EPT;
   f32x4 pool[NP];
 
   // ---- staging threads: a fixed float4 channel chunk (tcx) of every chunk, pixel lanes tp, tp + 8, ...
@@ -134,6 +135,14 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
       bf16x4 o;
       o[0] = (sf_opnd)y[0]; o[1] = (sf_opnd)y[1]; o[2] = (sf_opnd)y[2]; o[3] = (sf_opnd)y[3];
       *reinterpret_cast<bf16x4*>(buf + (long)fpx[e] * pstr) = o;
+      if (RC) {                                            // the res_conv's A operand: the tile's OWN pixels (frame rows 1 .. TR), raw x scale
+        const int pi = tp + e * 8, fr = pi >> a.logW;
+        const bool own = fpx[e] != FR * FW && fr >= 1 && fr <= a.TR;
+        const f32x4 rw = pool[vo + e] * scale;
+        bf16x4 q;
+        q[0] = (sf_opnd)rw[0]; q[1] = (sf_opnd)rw[1]; q[2] = (sf_opnd)rw[2]; q[3] = (sf_opnd)rw[3];
+        *reinterpret_cast<bf16x4*>(lds + a.rc_off + (c & 1) * a.rc_buf_bytes + tcx * 8 + (long)(own ? pi - a.W : 16 * WM) * pstr) = q;
+      }
     }
   };
 
@@ -161,11 +170,30 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
   };
   if (wave < ngs) slot_loads(wave, lane);
   // ---- first loads of every role go out before anything waits
+  // RC: matrix wave w multiplies the raw operand's 32-channel sub-chunk w of every chunk with the res_conv's weights
+  const bf16x8* rcw[WN];
+#pragma unroll
+  for (int ni = 0; ni < WN; ++ni) {
+    int nf = nt * WN + ni;
+    if (nf > a.n_frags - 1) nf = a.n_frags - 1;
+    rcw[ni] = RC ? a.rc_w + ((long)nf * a.cchunks + (mx_role ? wave : 0)) * 64 + lane : nullptr;
+  }
+  auto rcload = [&](int c, int ni) -> bf16x8 {
+#if SF_NT_W
+    return __builtin_nontemporal_load(&rcw[ni][(long)c * (CC / 32) * 64]);
+#else
+    return rcw[ni][(long)c * (CC / 32) * 64];
+#endif
+  };
   if (mx_role) {
 #pragma unroll
     for (int i = 0; i < KPW; ++i)
 #pragma unroll
       for (int ni = 0; ni < WN; ++ni) pool[i * WN + ni] = __builtin_bit_cast(f32x4, wload(0, i, ni));
+    if (RC) {
+#pragma unroll
+      for (int ni = 0; ni < WN; ++ni) pool[KPW * WN + ni] = __builtin_bit_cast(f32x4, rcload(0, ni));
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < NB - 1; ++j) issue(j < NCH ? j : NCH - 1, j * EPT);
@@ -266,6 +294,11 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
   for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
     for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc2[RC ? WM : 1][RC ? WN : 1];                   // RC: the res_conv's accumulators
+#pragma unroll
+  for (int mi = 0; mi < (RC ? WM : 1); ++mi)
+#pragma unroll
+    for (int ni = 0; ni < (RC ? WN : 1); ++ni) acc2[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 accl[POOL ? WM : 1];                            // POOL: context-logit fragment of every m-fragment (column 0 = the logit)
 #pragma unroll
   for (int mi = 0; mi < (POOL ? WM : 1); ++mi) accl[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -307,6 +340,18 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
           for (int mi = 0; mi < WM; ++mi) accl[mi] = sf_mfma16(fa[mi], wl, accl[mi]);
         }
       }
+      if (RC) {                                            // k-step 10 of this wave: raw operand, sub-chunk `wave`, res_conv weights
+        const char* rb = lds + a.rc_off + (c & 1) * a.rc_buf_bytes + wave * 64 + (lane >> 4) * 16;
+        bf16x8 fr_[WM];
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) fr_[mi] = *reinterpret_cast<const bf16x8*>(rb + (mi * 16 + (lane & 15)) * pstr);
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < WN; ++ni) acc2[mi][ni] = sf_mfma16(fr_[mi], __builtin_bit_cast(bf16x8, pool[KPW * WN + ni]), acc2[mi][ni]);
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) pool[KPW * WN + ni] = __builtin_bit_cast(f32x4, rcload(cn, ni));
+      }
       sf_sync();
     }
   } else {
@@ -329,7 +374,7 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
   FP_STAMP(4);
 
   // ---- epilogue: the NWM K-slices meet in LDS; wave f < F finalises fragment f
-  constexpr int FT = POOL ? F + WM : F;                           // POOL: + one context-logit fragment per m-fragment
+  constexpr int FT = F + (POOL ? WM : 0) + (RC ? F : 0);          // POOL: + one context-logit fragment per m-fragment; RC: + the res_conv's tile
   float* red = reinterpret_cast<float*>(lds + a.red_off);         // [matrix wave][frag][r][lane]
   if (mx_role) {
 #pragma unroll
@@ -344,7 +389,16 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[((wave * FT + F + mi) * 4 + r) * 64 + lane] = accl[mi][r];
     }
+    if (RC) {
+#pragma unroll
+      for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[((wave * FT + F + (POOL ? WM : 0) + mi * WN + ni) * 4 + r) * 64 + lane] = acc2[mi][ni][r];
+    }
   }
+  const float rcb = (RC && fin && n < a.Cout && a.rc_bias) ? a.rc_bias[n] : 0.0f;
   sf_sync();
   if (fin) {
     const int f = wave;
@@ -363,6 +417,16 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
         float lp = v[r] * wkv;
         lp += sf_shfl_xor(lp, 1); lp += sf_shfl_xor(lp, 2); lp += sf_shfl_xor(lp, 4); lp += sf_shfl_xor(lp, 8);
         if ((lane & 15) == 0) a.logit_part[(long)my_nf * a.M + mrow + r] = lp;
+      }
+    }
+    if (RC && n < a.Cout) {                              // res_conv output of this fragment: plain rows [M][Cout]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = ((F + (POOL ? WM : 0) + f) * 4 + r) * 64 + lane;
+        float sacc = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NWM; ++w) sacc += red[idx + w * FT * 256];
+        a.rc_out[(mrow + r) * a.Cout + n] = sacc + rcb;
       }
     }
     float sm = 0.0f, sq = 0.0f;
@@ -429,6 +493,14 @@ template <int WM, int WN, int EPT, int NW, bool POOL = false>
 SF_KERNEL(NW * 64) void k_conv_fused_pipe(FConvArgs a) {
   sf_touch_kernarg<(int)sizeof(FConvArgs)>();
   conv_fused_pipe_body<WM, WN, EPT, NW, POOL>(a, (int)blockIdx.x);
+}
+
+// conv1 + res_conv of one ResnetBlock in the SAME workgroups (r04): see FConvArgs.rc_w.  Replaces k_conv_fused_pipe_pair -- two
+// sets of workgroups, i.e. two rounds on the chip at one workgroup per CU -- where the tile has the registers for it (WM <= 2).
+template <int WM, int WN, int EPT, int NW>
+SF_KERNEL(NW * 64) void k_conv_fused_pipe_rc(FConvArgs a) {
+  sf_touch_kernarg<(int)sizeof(FConvArgs)>();
+  conv_fused_pipe_body<WM, WN, EPT, NW, false, true>(a, (int)blockIdx.x);
 }
 
 // conv1 (pipelined) || res_conv (plain 1x1, k_conv_fused body) of one ResnetBlock in one launch: see k_conv_fused_pair.

@@ -71,6 +71,15 @@ static int launch_fconv_pipe_pair(const FConvPairArgs& p, uint32_t grid, uint32_
   return SF_OK;
 }
 
+template <int WM, int WN, int EPT>
+static int launch_fconv_pipe_rc(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStream_t st) {
+  static unsigned mask = 0;
+  if (int rc = allow_big_lds(k_conv_fused_pipe_rc<WM, WN, EPT, SF_FCONV_WAVES>, lds, mask)) return rc;
+  k_conv_fused_pipe_rc<WM, WN, EPT, SF_FCONV_WAVES><<<grid, SF_FCONV_WAVES * 64, lds, st>>>(a);
+  SF_CHECK_LAUNCH("conv_fused_pipe_rc");
+  return SF_OK;
+}
+
 int sf_plan_fused_pair(const sf_op* op1, const sf_op* op2, void* stream) {
   FConvPairArgs p;
   int WM, WN;
@@ -78,6 +87,16 @@ int sf_plan_fused_pair(const sf_op* op1, const sf_op* op2, void* stream) {
   if (fconv_pair_setup(*op1, *op2, p, WM, WN, grid, lds, sf_err_buf, sizeof(sf_err_buf))) return SF_ERR_INVALID;
   if (op1->flags & 32) {
     const int EPT = fconv_pipe_ept(p.a);
+    {                                                     // r04: the res_conv inside conv1's workgroups where the tile allows it
+      FConvArgs a1;
+      int wm1, wn1;
+      uint32_t g1, l1;
+      if (!fconv_setup(*op1, a1, wm1, wn1, g1, l1, sf_err_buf, sizeof(sf_err_buf)) && fconv_pipe_rc_merge(a1, p.b, WM, WN, l1)) {
+#define SF_TRYR(wm, wn, ept) if (WM == wm && WN == wn && EPT == ept) return launch_fconv_pipe_rc<wm, wn, ept>(a1, g1, l1, (hipStream_t)stream);
+        SF_FCONV_PIPE_RC_VARIANTS(SF_TRYR)
+#undef SF_TRYR
+      }
+    }
 #define SF_TRYP(wm, wn, ept) if (WM == wm && WN == wn && EPT == ept) return launch_fconv_pipe_pair<wm, wn, ept>(p, grid, lds, (hipStream_t)stream);
     SF_FCONV_PIPE_VARIANTS(SF_TRYP)
 #undef SF_TRYP

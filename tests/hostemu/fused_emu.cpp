@@ -19,6 +19,9 @@ static void emu_fconv_pair(const FConvPairArgs& p, uint32_t grid, uint32_t lds) 
   hipemu::launch(grid, SF_FCONV_WAVES * 64, lds, [&] { k_conv_fused_pair<WM, WN, D, NORM, LAZY, SF_FCONV_WAVES>(p); });
 }
 
+static int g_rc_launches = 0;
+extern "C" int emu_rc_launches() { return g_rc_launches; }      // how many pairs ran as k_conv_fused_pipe_rc (tests assert the path was taken)
+
 static int emu_run_pair(const sf_op* op1, const sf_op* op2, char* err, int errn) {
   FConvPairArgs p;
   int WM, WN;
@@ -26,6 +29,21 @@ static int emu_run_pair(const sf_op* op1, const sf_op* op2, char* err, int errn)
   if (fconv_pair_setup(*op1, *op2, p, WM, WN, grid, lds, err, (size_t)errn)) return 1;
   if (op1->flags & 32) {
     const int EPT = fconv_pipe_ept(p.a);
+    {
+      FConvArgs a1;
+      int wm1, wn1;
+      uint32_t g1, l1;
+      if (!fconv_setup(*op1, a1, wm1, wn1, g1, l1, err, (size_t)errn) && fconv_pipe_rc_merge(a1, p.b, WM, WN, l1)) {
+#define SF_TRYR(wm, wn, ept) \
+        if (WM == wm && WN == wn && EPT == ept) { \
+          hipemu::launch(g1, SF_FCONV_WAVES * 64, l1, [&] { k_conv_fused_pipe_rc<wm, wn, ept, SF_FCONV_WAVES>(a1); }); \
+          ++g_rc_launches; \
+          return 0; \
+        }
+        SF_FCONV_PIPE_RC_VARIANTS(SF_TRYR)
+#undef SF_TRYR
+      }
+    }
 #define SF_TRYP(wm, wn, ept) \
     if (WM == wm && WN == wn && EPT == ept) { \
       hipemu::launch(grid, SF_FCONV_WAVES * 64, lds, [&] { k_conv_fused_pipe_pair<wm, wn, ept, SF_FCONV_WAVES>(p); }); \

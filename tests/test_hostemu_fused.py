@@ -64,3 +64,13 @@ def test_gca_chain_on_cpu_threads(name):
 @pytest.mark.parametrize("name", sorted(fc.ATTN_CASES))
 def test_attention_prologue_on_cpu_threads(name):
     fc.run_attn_case("emu", **fc.ATTN_CASES[name])
+
+
+def test_pipelined_pairs_run_the_merged_res_conv_kernel():
+    """conv1 || res_conv of the pipelined tiles with WM <= 2 run as ONE set of workgroups (k_conv_fused_pipe_rc, r04): the pair case
+    above must actually have taken that kernel; the 64-pixel tile (WM = 4) keeps the two-kernel launch."""
+    n0 = fused.lib().emu_rc_launches()
+    fc.run_conv_case("emu", **fc.CONV_CASES["pipe_pair_gn_slots_concat_8x8"])
+    n1 = fused.lib().emu_rc_launches()
+    fc.run_conv_case("emu", **fc.CONV_CASES["pipe_pair_gn_slots_wide_rows_wm4"])
+    assert n1 == n0 + 1 and fused.lib().emu_rc_launches() == n1
