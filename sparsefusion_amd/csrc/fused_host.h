@@ -57,7 +57,9 @@
 // (2, *, 8), (2, *, 6) and (4, *, 16): the 32-pixel tiles of the 16x16 (TR = 2) and 8x8 (TR = 4) maps and the 64-pixel tile of the
 // 32x32 map (TR = 2) that the planner picks
 // from B = 4 on -- 32 pixels per workgroup re-read each weight byte half as often as 16 (the chunk loop is bound by the CU's
-// vector-memory path, fused_pipe.h), and there are still >= 256 workgroups.
+// vector-memory path, fused_pipe.h), and there are still >= 256 workgroups.  Measured and not kept (r04,
+// profiles/r04_huge_tiles_b4_ab.log): 64-pixel tiles at 16x16 (TR = 4) / 8x8 (TR = 8) for B = 4 -- one round of 256 workgroups
+// instead of two rounds of 512 -- 1.862 vs 1.860 ms: what the single round saves, the lost conv1 + res_conv merge (WM <= 2) costs.
 #define SF_FCONV_PIPE_VARIANTS(X) \
   X(1, 1, 4) \
   X(1, 2, 4) \
