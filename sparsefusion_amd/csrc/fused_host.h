@@ -51,7 +51,8 @@
   X(1, 1, 12, FNORM_LN, 0) \
   X(1, 1, 12, FNORM_LN, 1) \
   X(1, 2, 8, FNORM_LN, 0) \
-  X(1, 1, 12, FNORM_ATTN, 0)
+  X(1, 1, 12, FNORM_ATTN, 0) \
+  X(1, 2, 8, FNORM_ATTN, 0)
 
 // Pipelined slot-GroupNorm 3x3 convs (k_conv_fused_pipe, op flag 32): (WM, WN, EPT = (TR + 2) * W / 8 staging elements per thread and chunk)
 // (2, *, 8), (2, *, 6) and (4, *, 16): the 32-pixel tiles of the 16x16 (TR = 2) and 8x8 (TR = 4) maps and the 64-pixel tile of the

@@ -220,9 +220,9 @@ def test_time_table_is_cached_per_schedule_until_the_weights_change():
     name = "small"
     net = _unet(name)
     x, ls, cond = inputs(CONFIGS[name], 2, 3)
-    c1 = net.begin_sampling(cond.to(DEV), ls.to(DEV), table_key=("k", 2))
-    c2 = net.begin_sampling(cond.to(DEV), ls.to(DEV), table_key=("k", 2))
     fresh = net.begin_sampling(cond.to(DEV), ls.to(DEV))["table"]
+    c1 = net.begin_sampling(cond.to(DEV), ls.to(DEV), table_key=("k", 2))
+    c2 = net.begin_sampling(cond.to(DEV), ls.to(DEV), table_key=("k", 2))         # (c1 is stale now: one trajectory per plan)
     assert c1["table"] is c2["table"] and fresh is not c1["table"] and torch.equal(fresh, c1["table"])
     y = net.eval_prepared(c2, x.to(DEV), 1).clone()
     net.load_state_dict(state(name, seed=1), strict=True)              # other weights: the cached table must not survive

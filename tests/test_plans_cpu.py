@@ -251,3 +251,37 @@ def test_vae_upsample_reads_the_operand_twin():
     ops0 = _VaePlan(plain, "dec", 1, CPU).build().ops
     assert all(o.flags & 1 for o in ops0 if o.type == OP_CONV and o.flags & 16)
     assert not any(q.p[5] for q in ops0 if q.type == OP_CONV and q.i[14] >= 256)
+
+
+def test_every_planned_fused_conv_has_a_kernel_variant():
+    """The planner (unet.py) and the instantiation lists (csrc/fused_host.h SF_FCONV_*_VARIANTS) are two tables: every OP_FCONV of
+    the canonical plans at B = 1 .. 32 -- including the batch sizes no GPU test runs -- must name an instantiated
+    (WM, WN, norm, lazy) / (WM, WN, EPT) combination (r04: the attention output projection at B >= 8 planned WN = 2, which had none)."""
+    from sparsefusion_amd import unet as U
+    txt = open(os.path.join(ROOT, "sparsefusion_amd", "csrc", "fused_host.h")).read()
+    norms = {"FNORM_NONE": 0, "FNORM_GN_SELF": 1, "FNORM_GN_SLOTS": 2, "FNORM_LN": 3, "FNORM_ATTN": 4}
+
+    def table(macro):
+        body = re.search(r"#define " + macro + r"\(X\)((?:\s*\\\n\s*X\([^)]*\))+)", txt).group(1)
+        return [tuple(t.strip() for t in m.split(",")) for m in re.findall(r"X\(([^)]*)\)", body)]
+
+    plain = {(int(a), int(b), norms[n], int(lz)) for a, b, _, n, lz in table("SF_FCONV_VARIANTS")}
+    pairs = {(int(a), int(b), norms[n], int(lz)) for a, b, _, n, lz in table("SF_FCONV_PAIR_VARIANTS")}
+    pipes = {(int(a), int(b), int(e)) for a, b, e in table("SF_FCONV_PIPE_VARIANTS")}
+    net = U.Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2), layer_attns=(False, False, False, True),
+                 layer_cross_attns=(False,) * 4, cond_images_channels=256, attn_pool_text=False)
+    for B in (1, 2, 3, 4, 8, 16, 32):
+        ops = U._Plan(net, B, CPU).build().ops
+        for k, o in enumerate(ops):
+            if o.type != U.OP_FCONV:
+                continue
+            WM, WN, norm, lazy, TR, W = o.i[15], o.i[16], o.i[12], o.i[9], o.i[14], o.i[2]
+            second = k > 0 and ops[k - 1].type == U.OP_FCONV and (ops[k - 1].flags & 16)
+            if o.flags & 32:
+                assert (WM, WN, (TR + 2) * W // 8) in pipes, (B, k, WM, WN, TR, W)
+            elif o.flags & 16:
+                assert (WM, WN, norm, lazy) in pairs, (B, k, WM, WN, norm, lazy)
+            elif second:
+                assert norm == 0                                  # the res_conv half runs inside its partner's instantiation
+            else:
+                assert (WM, WN, norm, lazy) in plain, (B, k, WM, WN, norm, lazy)
