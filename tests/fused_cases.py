@@ -266,7 +266,7 @@ def run_gca_case(backend, B, H, C, lazy=False, seed=0, epilogue_chunks=False):
         assert torch.allclose(h2_d.cpu(), h2, atol=1e-5)
 
 
-def run_attn_case(backend, B=2, cross=False, context=True, Cout=48, seed=0, tol=4e-3, dbg=None, reps=1):
+def run_attn_case(backend, B=2, cross=False, context=True, Cout=48, seed=0, tol=4e-3, dbg=None, reps=1, WN=1):
     """k_conv_fused<.., FNORM_ATTN>: the 16-token attention core (8 heads x 64, keys = [context tokens,] null k/v, the tokens' one
     shared k/v head -- or, cross-attention, null + 2 per-head time tokens; imagen_pytorch.py:480-566, :731-805) as the prologue of
     its output projection, against softmax(q k^T scale) v -> bf16 -> linear in torch."""
@@ -325,7 +325,7 @@ def run_attn_case(backend, B=2, cross=False, context=True, Cout=48, seed=0, tol=
     segs = segs + [(0, 0, 0, 0, 0, 0)] * (3 - len(segs))
     op = fused.mkop(OP_FCONV, 0,
                     p=(qkv_d, None, None, None, None, None, None, wp, bias_d, out, res_d, None, None, None, None, None, dbg, None, None) + tuple(sg[0] for sg in segs),
-                    i=(B, 4, 4, inner, 0, Cout, Cout, 0, 1, 0, 0, 0, ATTN, 8, 4, 1, 1, 1, 0, nq) + tuple(x for sg in segs for x in sg[2:]),
+                    i=(B, 4, 4, inner, 0, Cout, Cout, 0, 1, 0, 0, 0, ATTN, 8, 4, 1, WN, 1, 0, nq) + tuple(x for sg in segs for x in sg[2:]),
                     f=(1e-5, 1.0, 1.0) + tuple((sg[1] - sg[0]) // 4 for sg in segs) + (scale,))
     run_ops([op], backend)
     if reps > 1:
@@ -339,7 +339,8 @@ def run_attn_case(backend, B=2, cross=False, context=True, Cout=48, seed=0, tol=
 
 
 ATTN_CASES = {"self_context": dict(B=2, cross=False, context=True, seed=61), "self_plain": dict(B=1, cross=False, context=False, seed=62),
-              "cross_time_tokens": dict(B=2, cross=True, seed=63, Cout=64)}
+              "cross_time_tokens": dict(B=2, cross=True, seed=63, Cout=64),
+              "self_context_wn2": dict(B=2, cross=False, context=True, seed=68, Cout=64, WN=2)}      # the B >= 8 tile of the output projection
 
 GCA_CASES = {"4x4_lazy": dict(B=2, H=4, C=128, lazy=True), "8x8": dict(B=1, H=8, C=64, seed=1), "16x16": dict(B=1, H=16, C=64, seed=2),
              "8x8_c192_b2": dict(B=2, H=8, C=192, seed=8),

@@ -24,9 +24,10 @@ def test_gca_chain_on_gpu(name):
     fc.run_gca_case("gpu", **({**fc.GCA_CASES, **fc.GCA_CASES_FULL})[name])
 
 
-@pytest.mark.parametrize("name", sorted(fc.ATTN_CASES) + ["unet_self_1024", "unet_cross_1024"])
+@pytest.mark.parametrize("name", sorted(fc.ATTN_CASES) + ["unet_self_1024", "unet_cross_1024", "unet_b8_self_1024_wn2"])
 def test_attention_prologue_on_gpu(name):
     """k_conv_fused<.., FNORM_ATTN>: the 16-token attention core in the prologue of its output projection (r04; was k_attn16 + conv)."""
-    kw = fc.ATTN_CASES.get(name) or dict(B=1, cross=name == "unet_cross_1024", Cout=1024, seed=64)
+    kw = fc.ATTN_CASES.get(name) or (dict(B=8, cross=False, Cout=1024, seed=69, WN=2) if name.endswith("wn2") else
+                                     dict(B=1, cross=name == "unet_cross_1024", Cout=1024, seed=64))
     e = fc.run_attn_case("gpu", **kw)
     print(f"{name}: rel {e:.2e}")
