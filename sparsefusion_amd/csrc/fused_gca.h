@@ -24,13 +24,12 @@ struct GcaPoolArgs {
 // grid = B * chunks * (C / 64); 256 threads = 16 channel float4 lanes x 16 pixel lanes.
 // Every phase issues its loads as one independent batch: a dependent load per loop trip costs an L2 / fabric round trip
 // (~0.5 us), and the first version of this kernel spent 30 us summing 256 logit parts one after the other.
-SF_KERNEL(256) void k_gca_pool(GcaPoolArgs a) {
-  sf_touch_kernarg<(int)sizeof(GcaPoolArgs)>();
+SF_DEV void gca_pool_body(const GcaPoolArgs& a, const int bid) {
   SF_SHARED float e[128];
   SF_SHARED float red[16][132];
   const int tid = threadIdx.x, lane = tid & 63;
   const int cslabs = a.C >> 6;
-  const int cs = blockIdx.x % cslabs, bc = blockIdx.x / cslabs;      // bc = image * chunks + chunk
+  const int cs = bid % cslabs, bc = bid / cslabs;      // bc = image * chunks + chunk
   const int b = bc / a.chunks, ch = bc - b * a.chunks;
   const long m0 = (long)b * a.HW + (long)ch * a.CH;
   // the first trip of phase (3)'s operand loads goes out NOW: they do not depend on the logits, and issued after the softmax
@@ -119,6 +118,11 @@ SF_KERNEL(256) void k_gca_pool(GcaPoolArgs a) {
     for (int k = 0; k < 16; ++k) s += red[k][tid];
     a.part_pool[(long)bc * a.C + cs * 64 + tid] = s;
   }
+}
+
+SF_KERNEL(256) void k_gca_pool(GcaPoolArgs a) {
+  sf_touch_kernarg<(int)sizeof(GcaPoolArgs)>();
+  gca_pool_body(a, (int)blockIdx.x);
 }
 
 struct GcaNetArgs {

@@ -510,3 +510,16 @@ SF_KERNEL(NW * 64) void k_conv_fused_pipe_pair(FConvPairArgs p) {
   if ((int)blockIdx.x < p.grid_b) conv_fused_body<WM, WN, (WM * WN == 1 ? 12 : 8), FNORM_NONE, 0, NW>(p.b, (int)blockIdx.x);
   else conv_fused_pipe_body<WM, WN, EPT, NW>(p.a, (int)blockIdx.x - p.grid_b);
 }
+
+// A ResnetBlock's res_conv beside the (16-workgroup) GlobalContext pooling launch of the same block (r04, the 4x4 level): in the
+// conv1 || res_conv pair of that level the 64 res_conv workgroups were a second round behind conv1's 256 AND evaluated the whole
+// lazy split-K source (six loads per element, 458 KB per workgroup): 24 us per pair against 11.6 for conv1 alone.  The result is
+// only needed by the gate launch, so the res_conv runs here, on the source conv1 has materialised meanwhile, on CUs the pooling
+// leaves idle.  512-thread workgroups; a pooling workgroup retires its upper half at once (ended waves leave the barrier count).
+#include "fused_gca.h"
+template <int WM, int WN, int D, int NW>
+SF_KERNEL(NW * 64) void k_gca_pool_rc(GcaPoolArgs pa, FConvArgs b, int grid_b) {
+  sf_touch_kernarg<(int)(sizeof(GcaPoolArgs) + sizeof(FConvArgs))>();
+  if ((int)blockIdx.x < grid_b) conv_fused_body<WM, WN, D, FNORM_NONE, 0, NW>(b, (int)blockIdx.x);
+  else if (threadIdx.x < 256) gca_pool_body(pa, (int)blockIdx.x - grid_b);
+}

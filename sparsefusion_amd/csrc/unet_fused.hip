@@ -80,7 +80,27 @@ static int launch_fconv_pipe_rc(const FConvArgs& a, uint32_t grid, uint32_t lds,
   return SF_OK;
 }
 
+// op1 = an un-normalised fconv (a res_conv, flags & 16), op2 = the GlobalContext pooling op of the same block: one launch
+static int run_pool_rc_pair(const sf_op& op1, const sf_op& op2, hipStream_t st) {
+  FConvArgs b;
+  int WM, WN;
+  uint32_t gb, lds, gp;
+  GcaPoolArgs pa;
+  GcaNetArgs na;
+  GcaGateArgs ga;
+  if (fconv_setup(op1, b, WM, WN, gb, lds, sf_err_buf, sizeof(sf_err_buf)) || gca_setup(op2, pa, na, ga, gp, sf_err_buf, sizeof(sf_err_buf)))
+    return SF_ERR_INVALID;
+  if (op2.flags != 1 || b.norm != FNORM_NONE || b.s1.mode || WM != 1 || WN != 1 || (op1.flags & 32) || b.dbg)
+    SF_FAIL(SF_ERR_INVALID, "pool || res_conv pair: a plain 16-pixel x 16-channel res_conv tile next to a pooling op required");
+  static unsigned mask = 0;
+  if (int rc = allow_big_lds(k_gca_pool_rc<1, 1, 12, SF_FCONV_WAVES>, lds, mask)) return rc;
+  k_gca_pool_rc<1, 1, 12, SF_FCONV_WAVES><<<gb + gp, SF_FCONV_WAVES * 64, lds, st>>>(pa, b, (int)gb);
+  SF_CHECK_LAUNCH("gca_pool_rc");
+  return SF_OK;
+}
+
 int sf_plan_fused_pair(const sf_op* op1, const sf_op* op2, void* stream) {
+  if (op2->type == SF_OP_GCA) return run_pool_rc_pair(*op1, *op2, (hipStream_t)stream);
   FConvPairArgs p;
   int WM, WN;
   uint32_t grid, lds;

@@ -603,13 +603,21 @@ class _Plan:
         # conv1 and res_conv read the same input and are independent: one launch (k_conv_fused_pair) when their tiles match
         pair = (cin != cout and getattr(self.u, "pair_res_conv", True) and g1[1:3] == gr[1:3] and gr[3] == 1
                 and (g1[1], g1[2], norm) in PAIR_TILES)
+        # r04, 4x4 level: a gca block's res_conv is only needed by the gate, so it runs beside the 16-workgroup pooling launch
+        # (k_gca_pool_rc) on the materialised input instead of as a second round of workgroups re-reducing conv1's lazy source
+        late_rc = (cin != cout and gca and H == 4 and getattr(self.u, "res_conv_beside_pool", True) and gr[1:4] == (1, 1, 1)
+                   and cout % 64 == 0 and cout <= 2048)
+        pair = pair and not late_rc
         lz = self.fconv(x, skip, H, f"{name}.block1.project.weight", f"{name}.block1.project.bias", h, cout, 3, norm, g1,
                         gname=f"{name}.block1.groupnorm", want_slots=slots, pair_first=pair)
         rc = None
+        emit_rc = None
         if cin != cout:                                             # res_conv reads the raw concat (x is materialised by conv1)
             rc = self.zf32(rows, cout, HW)
-            self.fconv(x, skip, H, f"{name}.res_conv.weight", f"{name}.res_conv.bias", rc, cout, 1, FNORM_NONE, gr, silu=False,
-                       pair_lazy=lz if pair else None)
+            emit_rc = lambda first=False: self.fconv(x, skip, H, f"{name}.res_conv.weight", f"{name}.res_conv.bias", rc, cout, 1,
+                                                     FNORM_NONE, gr, silu=False, pair_lazy=lz if pair else None, pair_first=first)
+            if not late_rc:
+                emit_rc()
         if cross:
             h = self.cross_attention(f"{name}.cross_attn.fn", h)
         ss_ptr = self.ss.ptr + self.u.ss_offset[name] * 4
@@ -635,14 +643,16 @@ class _Plan:
             lpart = self.f32(nparts, rows)
             self.fconv(h, None, H, w2, b2, h2, cout, 3, norm, g2, gname=gn2, ss_ptr=ss_ptr,
                        logit=(self.wptr(f"{name}.gca.to_k.weight"), lpart.ptr))
-            self.gca_fused(name, h2, cout, res, out, lpart, nparts, slots)
+            self.gca_fused(name, h2, cout, res, out, lpart, nparts, slots, before_pool=emit_rc if late_rc else None)
             return out
+        if late_rc:
+            emit_rc()
         self.fconv(h, None, H, w2, b2, h2, cout, 3, norm, g2, gname=gn2, ss_ptr=ss_ptr)
         gate = self.gca_gate(name, h2, cout)
         out.lazy = ("gate", h2.ptr, gate.ptr, res.ptr)
         return out
 
-    def gca_fused(self, name, h2, cout, res, out, lpart, nparts, want_slots, pooled=None):
+    def gca_fused(self, name, h2, cout, res, out, lpart, nparts, want_slots, pooled=None, before_pool=None):
         """GlobalContext + gated residual in three launches (csrc/fused_gca.h): out = h2 * gca(h2) + res, materialised, with
         its statistics slots when the consumer is a slot-GroupNorm conv."""
         B, HW, rows = self.B, h2.HW, h2.rows
@@ -656,11 +666,14 @@ class _Plan:
             _, ws, bias, _, groups, npad, wi = h2.lazy
             h2.lazy = None
             self.ws_owners[wi] = None
-        self.need(res)
+        if before_pool is None:
+            self.need(res)
         if pooled is not None:                                  # the producing conv's epilogue already pooled 16-pixel fragments
             pp, pm, chunks = pooled
         else:
             pp, pm = part_pool.ptr, part_ms.ptr
+            if before_pool is not None:                         # the block's res_conv shares this launch (flag 16 on the fconv)
+                before_pool(True)
             self.op(OP_GCA, 1, p=(h2.ptr, ws, bias, lpart.ptr, pp, pm), i=(rows, cout, HW, CH, chunks, nparts, groups, npad))
         if want_slots:
             out.slots = self.misc.alloc(rows // 16 * (cout // 16) * 2 * 4)
@@ -1106,6 +1119,7 @@ class Unet(nn.Module):
         # GroupNorm inside the conv launches (k_conv_fused) wherever the layer fits; False = the first-round plan
         self.fused = True
         self.pair_res_conv = True           # conv1 || res_conv of a ResnetBlock in one launch
+        self.res_conv_beside_pool = True    # 4x4 gca blocks: the res_conv shares the GlobalContext pooling launch instead
         self.initx_direct = True            # latent half of the init conv as one direct-convolution launch
         self.big_tile_min_batch = 2         # batch from which the 8x8 / 16x16 / 32x32 maps use 32- / 32- / 64-pixel tiles (r03: B = 2 eval 1.70 -> 1.50 ms, B = 4 2.62 -> 2.02, B = 32 16.4 -> 11.5; at B = 1 they would leave half the CUs idle; 999 = never)
         self.gca_epilogue_pool = True       # GlobalContext pooling in conv2's epilogue (False = k_gca_pool launch)

@@ -23,6 +23,18 @@ static int g_rc_launches = 0;
 extern "C" int emu_rc_launches() { return g_rc_launches; }      // how many pairs ran as k_conv_fused_pipe_rc (tests assert the path was taken)
 
 static int emu_run_pair(const sf_op* op1, const sf_op* op2, char* err, int errn) {
+  if (op2->type == SF_OP_GCA) {                    // res_conv || GlobalContext pooling (k_gca_pool_rc)
+    FConvArgs b;
+    int WM, WN;
+    uint32_t gb, lds, gp;
+    GcaPoolArgs pa;
+    GcaNetArgs na;
+    GcaGateArgs ga;
+    if (fconv_setup(*op1, b, WM, WN, gb, lds, err, (size_t)errn) || gca_setup(*op2, pa, na, ga, gp, err, (size_t)errn)) return 1;
+    if (op2->flags != 1 || b.norm != FNORM_NONE || b.s1.mode || WM != 1 || WN != 1) { snprintf(err, errn, "pool || res_conv pair: bad operands"); return 1; }
+    hipemu::launch(gb + gp, SF_FCONV_WAVES * 64, lds, [&] { k_gca_pool_rc<1, 1, 12, SF_FCONV_WAVES>(pa, b, (int)gb); });
+    return 0;
+  }
   FConvPairArgs p;
   int WM, WN;
   uint32_t grid, lds;

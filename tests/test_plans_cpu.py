@@ -63,7 +63,11 @@ def _audit(ops, name, sized=False):
             second_of_pair = kk > 0 and ops[kk - 1].type == unet.OP_FCONV and (ops[kk - 1].flags & 16)
             # the res_conv half of a pair reads a lazy source without materialising it (p[0] null): only there
             assert (o.p[0] or (second_of_pair and lmode)) and o.p[7] and (o.p[9] or S > 1), where
-            if o.flags & 16:
+            if (o.flags & 16) and ops[kk + 1].type == unet.OP_GCA:     # res_conv beside the pooling launch (k_gca_pool_rc)
+                nx = ops[kk + 1]
+                assert nx.flags == 1 and norm == unet.FNORM_NONE and k == 1 and [WM, WN, S] == [1, 1, 1] and not lmode, where + ": pool pair"
+                assert nx.i[0] == B * H * W and nx.i[1] == Cout, where + ": pool pair halves belong to one block"
+            elif o.flags & 16:
                 nx = ops[kk + 1]
                 assert nx.type == unet.OP_FCONV and nx.i[12] == unet.FNORM_NONE and list(nx.i)[15:18] == [WM, WN, 1] and nx.i[9] == lmode, where + ": pair"
                 assert (WM, WN, norm) in unet.PAIR_TILES and not (nx.flags & 16), where + ": pair variant"
@@ -279,6 +283,8 @@ def test_every_planned_fused_conv_has_a_kernel_variant():
             second = k > 0 and ops[k - 1].type == U.OP_FCONV and (ops[k - 1].flags & 16)
             if o.flags & 32:
                 assert (WM, WN, (TR + 2) * W // 8) in pipes, (B, k, WM, WN, TR, W)
+            elif (o.flags & 16) and ops[k + 1].type == U.OP_GCA:
+                assert (WM, WN, norm, lazy) == (1, 1, 0, 0), (B, k)  # k_gca_pool_rc<1, 1, 12> (unet_fused.hip::run_pool_rc_pair)
             elif o.flags & 16:
                 assert (WM, WN, norm, lazy) in pairs, (B, k, WM, WN, norm, lazy)
             elif second:
