@@ -23,6 +23,7 @@
 #include "ngp_field_lds.h"
 #include "ngp_bwd_mfma.h"
 #include "ngp_composite_wave.h"
+#include "ngp_scatter_bin.h"
 #include <stdlib.h>
 #include <mutex>
 
@@ -108,9 +109,9 @@ __global__ __launch_bounds__(64) void k_ngp_sample_fine(
 //   * fine levels: direct global atomics, z-corner pairs merged on z-dropped levels (ngp_scatter rule).
 // ---------------------------------------------------------------------------
 #define SC_RAYS 64
-#define SC_SLOTS 8192
+#define SC_SLOTS 4096
 #define SC_EMPTY 0xffffffffu
-// NT threads share one 96 KB LDS cache (one workgroup per CU): NT = 1024 puts 4 waves on every SIMD -- the loop body is a
+// NT threads share one 80 KB LDS cache (r04: 4096 slots of doubles; r02: 8192 of floats) (one workgroup per CU): NT = 1024 puts 4 waves on every SIMD -- the loop body is a
 // chain of dependent global loads, hash arithmetic and LDS atomics, and with the first version's 256 threads (ONE wave per
 // SIMD) every one of those latencies was exposed.  `last_level`: levels [0, last_level) are walked by this kernel.
 template <int NT>
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(NT) void k_ngp_scatter(
     uint32_t last_level, uint32_t sc_run) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   uint32_t* tags = reinterpret_cast<uint32_t*>(smem);            // [SC_SLOTS]
-  float* vals = smem + SC_SLOTS;                                 // [SC_SLOTS][2]
+  double* vals = reinterpret_cast<double*>(smem + SC_SLOTS);     // [SC_SLOTS][2], doubles: ds_add_f64 is 7x the rate of ds_add_f32 (sf_dev.h)
   const uint32_t P = N * T2;
   float box[6];
 #pragma unroll
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(NT) void k_ngp_scatter(
   for (uint32_t l = 0; l < last_level; ++l) {
     const bool cached = l < cached_levels;
     if (cached) {
-      for (uint32_t s = threadIdx.x; s < SC_SLOTS; s += NT) { tags[s] = SC_EMPTY; vals[2 * s] = 0.f; vals[2 * s + 1] = 0.f; }
+      for (uint32_t s = threadIdx.x; s < SC_SLOTS; s += NT) { tags[s] = SC_EMPTY; vals[2 * s] = 0.0; vals[2 * s + 1] = 0.0; }
       __syncthreads();
     }
     float* tab = gtable + (size_t)lv.offset[l] * 2;
@@ -150,10 +151,10 @@ __global__ __launch_bounds__(NT) void k_ngp_scatter(
     const uint32_t runs = (T2 + sc_run - 1) / sc_run;
     auto flush = [&](uint32_t row, float v, uint32_t ch) {
       if (cached) {
-        const uint32_t slot = (row * 2654435761u) >> 19;         // 13 bits -> SC_SLOTS
+        const uint32_t slot = (row * 2654435761u) >> 20;         // 12 bits -> SC_SLOTS
         const uint32_t prev = atomicCAS(&tags[slot], SC_EMPTY, row);
         if (prev == SC_EMPTY || prev == row) {
-          atomicAdd(&vals[2 * slot + ch], v);
+          sf_lds_add_f64(&vals[2 * slot + ch], (double)v);
           return;
         }
       }
@@ -205,8 +206,8 @@ __global__ __launch_bounds__(NT) void k_ngp_scatter(
       for (uint32_t s = threadIdx.x; s < SC_SLOTS; s += NT) {
         const uint32_t row = tags[s];
         if (row != SC_EMPTY) {
-          SF_ATOMIC_ADD(tab + (size_t)row * 2, vals[2 * s]);
-          SF_ATOMIC_ADD(tab + (size_t)row * 2 + 1, vals[2 * s + 1]);
+          SF_ATOMIC_ADD(tab + (size_t)row * 2, (float)vals[2 * s]);
+          SF_ATOMIC_ADD(tab + (size_t)row * 2 + 1, (float)vals[2 * s + 1]);
         }
       }
       __syncthreads();
@@ -294,9 +295,20 @@ extern "C" int sf_ngp_density(const sf_ngp_field* f, const float* xyz, uint32_t 
 }
 
 // workspace (floats): forward z_c, sig_c [N*T]; rgb_c [3NT]; z_f, sig_f [N*T]; rgb_f [3NT]  -> 10*N*T
-// backward: dsig [2NT] + drgb [6NT] + d(features) level-major [16][2NT][2] = 72*N*T.
+// backward: dsig [2NT] + drgb [6NT] + d(features) level-major [16][2NT][2] = 72*N*T, then the binned scatter's cursors and entries.
+// the backward cuts the rays into chunks (pipeline below): as many as keep a chunk a multiple of 256 rays and >= 2048 rays
+static uint32_t ngp_bwd_chunks(uint32_t N) {
+  uint32_t n = 4u;
+  while (n > 1 && (N % n || (N / n) % 256 || N / n < 2048)) --n;
+  return n;
+}
+// binned scatter (ngp_scatter_bin.h): cursors + 20-byte entries of ONE chunk: 4 corner pairs x every level + slack per bucket
+#define SB_CURSOR_WORDS (NGP_MAX_LEVELS * SB_MAX_BUCKETS)
+static uint64_t ngp_bin_entries(uint32_t N, uint32_t T) {
+  return (uint64_t)(N / ngp_bwd_chunks(N)) * 2 * T * 4 * NGP_MAX_LEVELS + (uint64_t)SB_CURSOR_WORDS * 64;
+}
 extern "C" uint64_t sf_ngp_render_workspace_bytes(uint32_t N, uint32_t T) {
-  return (uint64_t)(8 + 4 * NGP_MAX_LEVELS) * N * T * sizeof(float);
+  return (uint64_t)(8 + 4 * NGP_MAX_LEVELS) * N * T * sizeof(float) + (uint64_t)SB_CURSOR_WORDS * 4 + ngp_bin_entries(N, T) * 20;
 }
 
 extern "C" uint64_t sf_ngp_render_cache_bytes(uint32_t N, uint32_t T) {
@@ -370,7 +382,7 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
   if (hipGetDevice(&dev_id) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "hipGetDevice failed");
   float* dfeat = g->g_embeddings ? drgb + 3 * M : nullptr;        // NULL table gradient = table frozen
   const size_t lds2 = (size_t)FB_LDS_FLOATS * sizeof(float);
-  const size_t lds_sc = (size_t)SC_SLOTS * 3 * sizeof(float);
+  const size_t lds_sc = (size_t)SC_SLOTS * (sizeof(uint32_t) + 2 * sizeof(double));
   static unsigned attr_mask = 0;
   if (dev_id >= 32 || !(attr_mask & (1u << dev_id))) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngp_field_bwd_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess ||
@@ -387,7 +399,35 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
   // levels up to scale ~640 profit from the LDS cache (measured r02: cut-off 160 / 320 / 640 / none = 7.82 / 7.63 / 7.51 / 8.27 ms render fwd+bwd)
   uint32_t cached = 0;
   while (cached < lv.L && lv.scale[cached] <= sc_cutoff) ++cached;
-  const uint32_t last = dfeat ? cached : lv.L;     // levels [0, last): k_ngp_scatter, [last, L): k_ngp_scatter_fine
+  // r04: the levels whose cell is smaller than a ray patch's footprint (no merging in the LDS cache) are BINNED by table slice and
+  // reduced in LDS instead of sending one device atomic per corner (ngp_scatter_bin.h); tables beyond 2^22 rows keep the atomics
+  static const bool use_bin = !getenv("SF_NGP_BIN") || atoi(getenv("SF_NGP_BIN"));
+  static const float bin_cutoff = getenv("SF_NGP_BIN_CUTOFF") ? (float)atof(getenv("SF_NGP_BIN_CUTOFF")) : 60.0f;
+  uint32_t first_bin = lv.L;
+  uint32_t bucket0[NGP_MAX_LEVELS + 1] = {};
+  if (dfeat && use_bin) {
+    first_bin = 0;
+    while (first_bin < lv.L && lv.scale[first_bin] <= bin_cutoff) ++first_bin;
+    uint32_t tb = 0;
+    for (uint32_t l = 0; l <= NGP_MAX_LEVELS; ++l) {
+      bucket0[l] = tb;
+      if (l >= first_bin && l < lv.L) {
+        const uint32_t nb = (lv.hsize[l] + SB_ROWS - 1) >> SB_ROWS_LOG;
+        if (nb > SB_MAX_BUCKETS) { first_bin = lv.L; break; }
+        tb += nb;
+      }
+    }
+  }
+  const bool binned = first_bin < lv.L;
+  if (binned && cached > first_bin) cached = first_bin;
+  const uint32_t last = !dfeat ? lv.L : binned ? first_bin : cached;     // levels [0, last): k_ngp_scatter, [last, L): binned / k_ngp_scatter_fine
+  const uint32_t total_buckets = bucket0[NGP_MAX_LEVELS];
+  uint32_t* bin_cursor = reinterpret_cast<uint32_t*>(workspace + (size_t)(8 + 4 * NGP_MAX_LEVELS) * N * T);
+  uint32_t* bin_rows = bin_cursor + SB_CURSOR_WORDS;
+  const uint64_t bin_entries = ngp_bin_entries(N, T) & ~(uint64_t)3;       // (keeps the value rows 16-byte aligned)
+  f32x4* bin_vals = reinterpret_cast<f32x4*>(bin_rows + bin_entries);
+  const uint32_t bin_cap = binned ? (uint32_t)(bin_entries / total_buckets) : 0;
+  if (binned && hipMemsetAsync(bin_cursor, 0, (size_t)total_buckets * 4, st) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: memset failed");
 
   // ---- the pipeline (r03).  Three kernels with three different bottlenecks: the field backward (fp32 MFMA + 113 KB of LDS,
   // one workgroup per CU), the fine-level scatter (memory-side atomic unit, no LDS, VALU idle) and the cached-level scatter
@@ -395,15 +435,10 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
   // field backward of chunk c + 1 occupies the CUs, and the last one runs beside the cached-level scatter (one launch over
   // all rays, its LDS cache wants every ray of an 8x8 patch).  dfeat keeps the level-major layout of the whole ray set.
   // (r03 A/B: 1 / 2 / 4 / 8 chunks 5.96 / 5.65 / 5.64 / 6.00 ms, no overlap 6.33 ms; the switches were retired in r04.)
-  constexpr uint32_t want_chunks = 4u;
   struct Side { hipStream_t s; hipEvent_t fork, join; };
   static Side side[32] = {};
   const bool fork = dfeat && last < lv.L && dev_id < 32;
-  uint32_t n_chunks = 1;
-  if (fork) {
-    n_chunks = want_chunks;
-    while (n_chunks > 1 && (N % n_chunks || (N / n_chunks) % 256 || N / n_chunks < 2048)) --n_chunks;
-  }
+  const uint32_t n_chunks = (dfeat && last < lv.L) ? ngp_bwd_chunks(N) : 1;      // (the entries buffer is sized for this chunking)
   // The side stream and its fork / join events are ONE set per device: two host threads (or two caller streams) rendering on the
   // same device would re-record each other's events, so the whole fork .. join section runs under the lock (host-side enqueue only:
   // microseconds).  The guard below joins the side stream into the caller's stream on EVERY exit path, error returns included.
@@ -450,11 +485,26 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
         sf = sd.s;
         side_join.forked = true;
       }
-      const uint64_t items = (uint64_t)4 * Pc * (lv.L - last);
-      const uint32_t grid_f = (uint32_t)(items / 256 < 16384 ? (items + 255) / 256 : 16384);
-      k_ngp_scatter_fine<<<grid_f, 256, 0, sf>>>(lv, f->bound, g->g_embeddings, a.rays_o, a.rays_d, aabb, a.z_s, dfeat, Nc, T2, last,
-                                                 (uint32_t)M, c * Pc);
-      SF_CHECK_LAUNCH("ngp_scatter_fine");
+      if (binned) {
+        SBArgs b{};
+        b.lv = lv; b.bound = f->bound; b.rays_o = a.rays_o; b.rays_d = a.rays_d; b.aabb = aabb; b.z_s = a.z_s; b.dfeat = dfeat;
+        b.gtable = g->g_embeddings; b.cursor = bin_cursor; b.rows = bin_rows; b.vals = bin_vals;
+        b.P = Pc; b.T2 = T2; b.first_level = first_bin; b.P_stride = (uint32_t)M; b.p_off = c * Pc; b.cap = bin_cap;
+        SBRArgs r{};
+        r.lv = lv; r.gtable = g->g_embeddings; r.cursor = bin_cursor; r.rows = bin_rows; r.vals = bin_vals; r.first_level = first_bin; r.cap = bin_cap;
+        for (uint32_t l = 0; l <= NGP_MAX_LEVELS; ++l) { b.bucket0[l] = bucket0[l]; r.bucket0[l] = bucket0[l]; }
+        const uint32_t tiles = sf_div_up(Pc, SB_THREADS);
+        k_ngp_bin<<<tiles < 1024 ? tiles : 1024, SB_THREADS, 0, sf>>>(b);
+        SF_CHECK_LAUNCH("ngp_bin");
+        k_ngp_bin_reduce<<<total_buckets, SBR_THREADS, 0, sf>>>(r);           // leaves the cursors at zero for the next chunk
+        SF_CHECK_LAUNCH("ngp_bin_reduce");
+      } else {
+        const uint64_t items = (uint64_t)4 * Pc * (lv.L - last);
+        const uint32_t grid_f = (uint32_t)(items / 256 < 16384 ? (items + 255) / 256 : 16384);
+        k_ngp_scatter_fine<<<grid_f, 256, 0, sf>>>(lv, f->bound, g->g_embeddings, a.rays_o, a.rays_d, aabb, a.z_s, dfeat, Nc, T2, last,
+                                                   (uint32_t)M, c * Pc);
+        SF_CHECK_LAUNCH("ngp_scatter_fine");
+      }
     }
   }
   if (dfeat && last > 0) {

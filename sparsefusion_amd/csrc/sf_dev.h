@@ -39,6 +39,16 @@ static inline void sf_lds_add(float* p, float v) {
     memcpy(&neu, &f, 4);
   } while (!__atomic_compare_exchange_n(u, &old, neu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
 }
+static inline void sf_lds_add_f64(double* p, double v) {
+  uint64_t* u = reinterpret_cast<uint64_t*>(p);
+  uint64_t old = __atomic_load_n(u, __ATOMIC_RELAXED), neu;
+  do {
+    double f;
+    memcpy(&f, &old, 8);
+    f += v;
+    memcpy(&neu, &f, 8);
+  } while (!__atomic_compare_exchange_n(u, &old, neu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+}
 static inline float sf_rsqrt(float v) { return 1.0f / sqrtf(v); }
 static inline void sf_wave_sync() { hipemu::t_wave->bar.wait(); }
 static inline void sf_global_add(float* p, float v) { sf_lds_add(p, v); }
@@ -126,6 +136,9 @@ SF_DEV uint32_t sf_readlane(uint32_t v, uint32_t src) { return __builtin_amdgcn_
 SF_DEV float sf_exp(float v) { return __expf(v); }
 SF_DEV float sf_exp2(float v) { return __builtin_amdgcn_exp2f(v); }      // raw v_exp_f32 (no denormal fix-up: the result feeds 1 + e)
 SF_DEV void sf_lds_add(float* p, float v) { atomicAdd(p, v); }
+// gfx950: ds_add_f32 retires 0.33 lane-operations per clock and CU, ds_add_f64 2.3, ds_add_u32 5.5 (random addresses in a 32 KB
+// slice, tools/exp/lds_atomic_rate.hip, profiles/r04_lds_atomic_rate.log) -- LDS accumulators that take many atomics are doubles
+SF_DEV void sf_lds_add_f64(double* p, double v) { atomicAdd(p, v); }
 SF_DEV float sf_rsqrt(float v) { return rsqrtf(v); }
 // same-wave LDS hand-off: DS operations of one wave execute in order; this only keeps the compiler from reordering them
 SF_DEV void sf_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }

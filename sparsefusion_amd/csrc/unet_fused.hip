@@ -6,11 +6,11 @@
 
 // Dynamic LDS above 64 KiB must be enabled per kernel AND per device (a process may drive several GPUs).
 template <class K>
-static int allow_big_lds(K kernel, uint32_t bytes, unsigned& device_mask) {
+static int allow_big_lds(K kernel, uint32_t bytes, unsigned& device_mask, int limit = SF_LDS_MAX) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "hipGetDevice failed");
   if (dev < 32 && (device_mask & (1u << dev))) return SF_OK;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_MAX) != hipSuccess)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, limit) != hipSuccess)
     SF_FAIL(SF_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
   if (dev < 32) device_mask |= 1u << dev;
   return SF_OK;
@@ -93,7 +93,9 @@ static int run_pool_rc_pair(const sf_op& op1, const sf_op& op2, hipStream_t st) 
   if (op2.flags != 1 || b.norm != FNORM_NONE || b.s1.mode || WM != 1 || WN != 1 || (op1.flags & 32) || b.dbg)
     SF_FAIL(SF_ERR_INVALID, "pool || res_conv pair: a plain 16-pixel x 16-channel res_conv tile next to a pooling op required");
   static unsigned mask = 0;
-  if (int rc = allow_big_lds(k_gca_pool_rc<1, 1, 12, SF_FCONV_WAVES>, lds, mask)) return rc;
+  constexpr int dyn_max = SF_LDS_MAX - 16384;                    // the pooling body keeps 9 KB of static LDS in the same kernel
+  if ((int)lds > dyn_max) SF_FAIL(SF_ERR_INVALID, "pool || res_conv pair: %u bytes of LDS", lds);
+  if (int rc = allow_big_lds(k_gca_pool_rc<1, 1, 12, SF_FCONV_WAVES>, lds, mask, dyn_max)) return rc;
   k_gca_pool_rc<1, 1, 12, SF_FCONV_WAVES><<<gb + gp, SF_FCONV_WAVES * 64, lds, st>>>(pa, b, (int)gb);
   SF_CHECK_LAUNCH("gca_pool_rc");
   return SF_OK;

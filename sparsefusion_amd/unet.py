@@ -606,7 +606,7 @@ class _Plan:
         # r04, 4x4 level: a gca block's res_conv is only needed by the gate, so it runs beside the 16-workgroup pooling launch
         # (k_gca_pool_rc) on the materialised input instead of as a second round of workgroups re-reducing conv1's lazy source
         late_rc = (cin != cout and gca and H == 4 and getattr(self.u, "res_conv_beside_pool", True) and gr[1:4] == (1, 1, 1)
-                   and cout % 64 == 0 and cout <= 2048)
+                   and cout % 64 == 0 and cout <= 2048 and cin <= 4096)    # (LDS: 16 pixels x cin operands beside the pooling's 9 KB)
         pair = pair and not late_rc
         lz = self.fconv(x, skip, H, f"{name}.block1.project.weight", f"{name}.block1.project.bias", h, cout, 3, norm, g1,
                         gname=f"{name}.block1.groupnorm", want_slots=slots, pair_first=pair)

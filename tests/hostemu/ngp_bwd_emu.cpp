@@ -87,3 +87,51 @@ extern "C" void emu_field_bwd(const float* table, const int32_t* h_offsets, uint
     }
   }
 }
+
+// ---- binned table-gradient scatter (sparsefusion_amd/csrc/ngp_scatter_bin.h) against ngp_scatter (ngp_device.h), levels
+// [first_level, L); `chunks` rounds of bin + reduce over consecutive ray ranges share the entries buffer (cursor reset by the reducer)
+#include "../../sparsefusion_amd/csrc/ngp_scatter_bin.h"
+extern "C" int emu_bin_scatter(const int32_t* h_offsets, uint32_t L, float S, uint32_t H, uint32_t gridtype, float bound,
+                               const float* rays_o, const float* rays_d, const float* aabb, const float* z_s, const float* dfeat,
+                               uint32_t N, uint32_t T2, uint32_t first_level, uint32_t cap, uint32_t chunks, uint32_t grid, int use_ref,
+                               float* gtable) {
+  NgpLevels lv;
+  fill_levels(&lv, h_offsets, L, S, H, gridtype);
+  const uint32_t P = N * T2;
+  if (use_ref) {
+    for (uint32_t p = 0; p < P; ++p) {
+      const uint32_t n = p / T2;
+      float x[3], x01[3], df[NGP_FEAT] = {0};
+      ngp_point(rays_o + n * 3, rays_d + n * 3, z_s[p], aabb, x);
+      const bool inside = ngp_unit(x, bound, x01);
+      for (uint32_t l = first_level; l < L; ++l) { df[2 * l] = dfeat[((size_t)l * P + p) * 2]; df[2 * l + 1] = dfeat[((size_t)l * P + p) * 2 + 1]; }
+      ngp_scatter(lv, gtable, x01, inside, df);
+    }
+    return 0;
+  }
+  SBArgs b{};
+  SBRArgs r{};
+  uint32_t tb = 0;
+  for (uint32_t l = 0; l <= NGP_MAX_LEVELS; ++l) {
+    b.bucket0[l] = r.bucket0[l] = tb;
+    if (l >= first_level && l < L) {
+      const uint32_t nb = (lv.hsize[l] + SB_ROWS - 1) >> SB_ROWS_LOG;
+      if (nb > SB_MAX_BUCKETS) return 1;
+      tb += nb;
+    }
+  }
+  std::vector<uint32_t> cursor(tb, 0), rows((size_t)tb * cap);
+  std::vector<f32x4> vals((size_t)tb * cap);
+  b.lv = lv; b.bound = bound; b.aabb = aabb; b.dfeat = dfeat; b.gtable = gtable; b.cursor = cursor.data(); b.rows = rows.data(); b.vals = vals.data();
+  b.T2 = T2; b.first_level = first_level; b.P_stride = P; b.cap = cap;
+  r.lv = lv; r.gtable = gtable; r.cursor = cursor.data(); r.rows = rows.data(); r.vals = vals.data(); r.first_level = first_level; r.cap = cap;
+  const uint32_t Nc = (N + chunks - 1) / chunks;
+  for (uint32_t c = 0; c * Nc < N; ++c) {
+    const uint32_t n0 = c * Nc, nn = n0 + Nc <= N ? Nc : N - n0;
+    b.rays_o = rays_o + (size_t)n0 * 3; b.rays_d = rays_d + (size_t)n0 * 3; b.z_s = z_s + (size_t)n0 * T2; b.P = nn * T2; b.p_off = n0 * T2;
+    hipemu::launch(grid, SB_THREADS, 0, [&] { k_ngp_bin(b); });
+    hipemu::launch(tb, SBR_THREADS, 0, [&] { k_ngp_bin_reduce(r); });
+    for (uint32_t k = 0; k < tb; ++k) if (cursor[k]) return 2;          // the reducer leaves every cursor at zero
+  }
+  return 0;
+}

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.skipif(not fused.available(), reason="host clang not fo
 
 def _lib():
     srcs = [os.path.join(HERE, "ngp_bwd_emu.cpp"), os.path.join(HERE, "hip_emu.h")] + \
-           [os.path.join(HERE, "..", "..", "sparsefusion_amd", "csrc", f) for f in ("ngp_bwd_mfma.h", "ngp_device.h", "sf_dev.h")]
+           [os.path.join(HERE, "..", "..", "sparsefusion_amd", "csrc", f) for f in ("ngp_bwd_mfma.h", "ngp_scatter_bin.h", "ngp_device.h", "sf_dev.h")]
     if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(s) for s in srcs):
         os.makedirs(os.path.dirname(SO), exist_ok=True)
         subprocess.check_call([fused.CLANG, "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + HERE, "-Wall", "-Wno-unused-function",
@@ -66,3 +66,42 @@ def test_field_backward_mfma_matches_per_point_math():
     for name, a, b in zip(("g_w0", "g_b0", "g_w1", "g_b1", "g_w2", "g_b2", "dfeat"), got, ref):
         err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-20)
         assert err < 2e-5, ("cache", name, err)
+
+
+@pytest.mark.parametrize("case", ["roomy", "overflow", "tiled"])
+def test_binned_scatter_matches_per_corner_adds(case):
+    """k_ngp_bin + k_ngp_bin_reduce (csrc/ngp_scatter_bin.h, r04: the hashed levels' table gradient without per-corner device
+    atomics) against ngp_scatter of ngp_device.h on the same feature gradients: roomy buckets, buckets so small that most
+    contributions take the overflow path (direct adds), and a `tiled` grid (z-dropped levels, skewed buckets); two chunks share the
+    entries buffer, several tiles per workgroup, a ragged last tile."""
+    lib = _lib()
+    g = torch.Generator().manual_seed(1)
+    N, T2 = 150, 22                                           # P = 3300: tiles of 1024 samples, the last one ragged
+    P = N * T2
+    o, d = ngp_ref.circle_rays(13, view=1)
+    o, d = o[:N].contiguous(), d[:N].contiguous()
+    z = (torch.rand(N, T2, generator=g) * 9.0 + 1.0).sort(1).values.contiguous()
+    L, S = 16, float(np.log2(ngp_ref.per_level_scale(4)))
+    sizes = [min(1 << 14, (int(np.ceil(16 * 2.0 ** (l * S))) + 1) ** 3) for l in range(L)]      # a 2^14-row hash map: 8 buckets per level
+    offs = torch.tensor(np.concatenate([[0], np.cumsum([(n + 7) // 8 * 8 for n in sizes])]), dtype=torch.int32)
+    dfeat = torch.randn(L, P, 2, generator=g)
+    dfeat[:, ::7] = 0.0                                       # dead samples
+    aabb = torch.tensor([-4.0] * 3 + [4.0] * 3)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    first, cap, gridtype = {"roomy": (1, 8192, 0), "overflow": (1, 8, 0), "tiled": (5, 512, 1)}[case]
+
+    def run(use_ref, chunks=1, grid=1):
+        tab = torch.zeros(int(offs[-1]), 2)
+        rc = lib.emu_bin_scatter(ptr(offs), C.c_uint32(L), C.c_float(S), C.c_uint32(16), C.c_uint32(gridtype), C.c_float(4.0), ptr(o), ptr(d),
+                                 ptr(aabb), ptr(z), ptr(dfeat), C.c_uint32(N), C.c_uint32(T2), C.c_uint32(first), C.c_uint32(cap),
+                                 C.c_uint32(chunks), C.c_uint32(grid), C.c_int(use_ref), ptr(tab))
+        assert rc == 0, rc
+        return tab
+
+    ref = run(1)
+    lo = int(offs[first])
+    assert float(ref[lo:].abs().max()) > 0 and float(ref[:lo].abs().max()) == 0
+    for chunks, grid in ((1, 1), (2, 3)) if case == "roomy" else ((2, 2),):
+        got = run(0, chunks, grid)
+        err = float((got - ref).abs().max()) / float(ref.abs().max())
+        assert err < 1e-5, (case, chunks, grid, err)
