@@ -291,17 +291,19 @@ def unet_roofline(hp, B=1):
     unet.eval_prepared(ctx, torch.zeros(B, 4, 32, 32, device=hp.dev), 0)
     plan = ctx["plan"]
     ops = [plan.body_array[k] for k in range(plan.n_body_ops)]
-    idx = [k for k, o in enumerate(ops) if o.type == OP_FCONV]
-    sub = (_lib.SfOp * len(idx))(*[ops[k] for k in idx])            # pairs stay adjacent: both halves are FCONV ops
-    n_launch = len(idx) - sum(1 for k in idx if ops[k].flags & 16)
+    # pairs stay adjacent: both halves are FCONV ops -- or (r04, the 4x4 gca blocks) a res_conv and the GlobalContext pooling op that
+    # shares its launch (k_gca_pool_rc): that op belongs to the launch and comes along
+    idx = [k for k, o in enumerate(ops) if o.type == OP_FCONV or (k and ops[k - 1].type == OP_FCONV and ops[k - 1].flags & 16)]
+    sub = (_lib.SfOp * len(idx))(*[ops[k] for k in idx])
+    n_launch = len(idx) - sum(1 for k in idx if ops[k].type == OP_FCONV and ops[k].flags & 16)
     fconv_bytes = int(sum(_op_weight_bytes(ops[k]) for k in idx))
-    fconv_flops = float(sum(_fconv_flops(ops[k]) for k in idx))
+    fconv_flops = float(sum(_fconv_flops(ops[k]) for k in idx if ops[k].type == OP_FCONV))
     fconv_ms = _graph_time_ms(sub, len(idx))
     eval_ms = _graph_time_ms(plan.body_array, plan.n_body_ops)
     all_conv_bytes = int(sum(_op_weight_bytes(o) for o in ops if o.type in (OP_CONV, OP_FCONV)))
     achieved = fconv_bytes / (fconv_ms * 1e-3) / 1e9
     tflops = fconv_flops / (fconv_ms * 1e-3) / 1e12
-    return {"bound": "hbm", "kernel": "k_conv_fused / k_conv_fused_pipe / _pair (GroupNorm | LayerNorm + conv in one launch)",
+    return {"bound": "hbm", "kernel": "k_conv_fused / k_conv_fused_pipe / _pair / k_gca_pool_rc (GroupNorm | LayerNorm + conv in one launch)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
             "traffic_note": "not collected in this run (--no-traffic, B > 1 or a multi-rank run): see profiles/r04_unet_eval_b1_pmc.json",
@@ -340,7 +342,7 @@ def measure_fconv_traffic(timeout_s=240):
         tot, n = 0.0, 0
         for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
-                if "k_conv_fused" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE":
+                if ("k_conv_fused" in r["Kernel_Name"] or "k_gca_pool_rc" in r["Kernel_Name"]) and r["Counter_Name"] == "FETCH_SIZE":
                     tot += float(r["Counter_Value"])
                     n += 1
         if not n:

@@ -177,7 +177,7 @@ int sf_ngp_density(const sf_ngp_field* f, const float* xyz, uint32_t P,
  * ([N,T] with stride T for training, or one [T] row linspace(.5/T,1-.5/T,T) with
  * stride 0 for det=True).  Saved for backward: z_sorted [N,2T], sigma_s [N,2T],
  * rgb_s [N,2T,3], nears/fars [N].  Outputs image [N,3], depth [N], weights_sum [N].
- * bg_color: scalar background.  workspace: sf_ngp_render_workspace_bytes(N,T). */
+ * bg_color: scalar background.  workspace: sf_ngp_render_forward_workspace_bytes(N,T) (the backward's is larger and also fits). */
 int sf_ngp_render_forward(const sf_ngp_field* f, const float* rays_o,
                           const float* rays_d, const float* aabb, uint32_t N,
                           uint32_t T, float min_near, const float* lin,
@@ -204,7 +204,11 @@ int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_grad* g,
                            float* workspace, uint64_t workspace_bytes,
                            void* stream);
 
+/* workspace of the backward (also enough for the forward): composite / field gradients per sample plus, since r04, the bins of the
+ * table-gradient scatter (csrc/ngp_scatter_bin.h: 20-byte entries of one ray chunk, ~0.7 GB at 128 x 128 rays x 64 + 64 samples). */
 uint64_t sf_ngp_render_workspace_bytes(uint32_t N, uint32_t T);
+/* workspace of the forward alone (10 * N * T floats): what an evaluation render needs */
+uint64_t sf_ngp_render_forward_workspace_bytes(uint32_t N, uint32_t T);
 
 /* field_cache (both calls; NULL = none): sf_ngp_render_cache_bytes(N, T) bytes the forward fills with the hash-grid features of
  * every sample ([N*T][32] coarse, [N*T][32] fine) and the sort permutation ([N][2T] u32); the backward then reads a sample's

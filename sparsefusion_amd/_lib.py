@@ -97,6 +97,7 @@ SIGNATURES = {
                                          c_f32p, u32, u32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                          C.c_float, c_f32p, c_f32p, u32, c_f32p, c_f32p, u64, C.c_void_p]),
     "sf_ngp_render_workspace_bytes": (u64, [u32, u32]),
+    "sf_ngp_render_forward_workspace_bytes": (u64, [u32, u32]),
     "sf_ngp_render_cache_bytes": (u64, [u32, u32]),
     "sf_ngp_render_occ_eval": (C.c_int, [C.POINTER(SfNgpField), c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_float, u32, u32, u32,
                                          c_f32p, C.c_float, u32, c_f32p, c_f32p, c_f32p, C.c_void_p]),

@@ -297,19 +297,27 @@ extern "C" int sf_ngp_density(const sf_ngp_field* f, const float* xyz, uint32_t 
 // workspace (floats): forward z_c, sig_c [N*T]; rgb_c [3NT]; z_f, sig_f [N*T]; rgb_f [3NT]  -> 10*N*T
 // backward: dsig [2NT] + drgb [6NT] + d(features) level-major [16][2NT][2] = 72*N*T, then the binned scatter's cursors and entries.
 // the backward cuts the rays into chunks (pipeline below): as many as keep a chunk a multiple of 256 rays and >= 2048 rays
+#ifndef NGP_BWD_CHUNKS
+#define NGP_BWD_CHUNKS 4u
+#endif
 static uint32_t ngp_bwd_chunks(uint32_t N) {
-  uint32_t n = 4u;
+  uint32_t n = NGP_BWD_CHUNKS;
   while (n > 1 && (N % n || (N / n) % 256 || N / n < 2048)) --n;
   return n;
 }
 // binned scatter (ngp_scatter_bin.h): cursors + 20-byte entries of ONE chunk: 4 corner pairs x every level + slack per bucket
 #define SB_CURSOR_WORDS (NGP_MAX_LEVELS * SB_MAX_BUCKETS)
+#ifndef SB_LEVELS_BUDGET
+#define SB_LEVELS_BUDGET (2 * NGP_MAX_LEVELS)     // entries for twice as many levels as exist: a bucket holds ~2.7 x its uniform share
+#endif                                            // (max / mean of the bucket loads on the reference scene: <= 1.9; 4.17 -> 3.86 ms with the room)
 static uint64_t ngp_bin_entries(uint32_t N, uint32_t T) {
-  return (uint64_t)(N / ngp_bwd_chunks(N)) * 2 * T * 4 * NGP_MAX_LEVELS + (uint64_t)SB_CURSOR_WORDS * 64;
+  return (uint64_t)(N / ngp_bwd_chunks(N)) * 2 * T * 4 * SB_LEVELS_BUDGET + (uint64_t)SB_CURSOR_WORDS * 64;
 }
 extern "C" uint64_t sf_ngp_render_workspace_bytes(uint32_t N, uint32_t T) {
   return (uint64_t)(8 + 4 * NGP_MAX_LEVELS) * N * T * sizeof(float) + (uint64_t)SB_CURSOR_WORDS * 4 + ngp_bin_entries(N, T) * 20;
 }
+
+extern "C" uint64_t sf_ngp_render_forward_workspace_bytes(uint32_t N, uint32_t T) { return (uint64_t)10 * N * T * sizeof(float); }
 
 extern "C" uint64_t sf_ngp_render_cache_bytes(uint32_t N, uint32_t T) {
   return ((uint64_t)2 * N * T * NGP_FEAT + (uint64_t)N * 2 * T) * sizeof(float);
@@ -325,7 +333,7 @@ extern "C" int sf_ngp_render_forward(const sf_ngp_field* f, const float* rays_o,
   hipStream_t st = (hipStream_t)stream;
   if (N == 0) return SF_OK;
   if (T < 4 || T > 64) SF_FAIL(SF_ERR_INVALID, "ngp_render: T must be in [4,64]");
-  if (workspace_bytes < sf_ngp_render_workspace_bytes(N, T)) SF_FAIL(SF_ERR_INVALID, "ngp_render: workspace too small");
+  if (workspace_bytes < sf_ngp_render_forward_workspace_bytes(N, T)) SF_FAIL(SF_ERR_INVALID, "ngp_render: workspace too small");
   if (!lin || !u_fine) SF_FAIL(SF_ERR_INVALID, "ngp_render: lin and u_fine tables are required");
   NgpLevels lv;
   if (int rc = sf_ngp_make_levels(f, &lv, st)) return rc;
@@ -395,17 +403,22 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
   // 7.63 / 7.51 / 8.27 ms), the finer levels in their own high-occupancy launch, 32 sorted samples merged per thread before the cache
   // (4 / 8 / 16 / 32: 6.95 / 6.85 / 6.81 / 6.76 ms)
   constexpr float sc_cutoff = 640.0f;
-  constexpr uint32_t sc_run = 32u;
+#ifndef SC_RUN
+#define SC_RUN 32u
+#endif
+  constexpr uint32_t sc_run = SC_RUN;
   // levels up to scale ~640 profit from the LDS cache (measured r02: cut-off 160 / 320 / 640 / none = 7.82 / 7.63 / 7.51 / 8.27 ms render fwd+bwd)
   uint32_t cached = 0;
   while (cached < lv.L && lv.scale[cached] <= sc_cutoff) ++cached;
   // r04: the levels whose cell is smaller than a ray patch's footprint (no merging in the LDS cache) are BINNED by table slice and
   // reduced in LDS instead of sending one device atomic per corner (ngp_scatter_bin.h); tables beyond 2^22 rows keep the atomics
-  static const bool use_bin = !getenv("SF_NGP_BIN") || atoi(getenv("SF_NGP_BIN"));
-  static const float bin_cutoff = getenv("SF_NGP_BIN_CUTOFF") ? (float)atof(getenv("SF_NGP_BIN_CUTOFF")) : 60.0f;
+  // (measured r04, render fwd + bwd: atomics 5.02 ms; binned from scale > 45 / 60 / 80 / 112 / 160: 4.97 / 4.45 / 4.50 / 4.43 / 4.58 ms with
+  // one entry per corner, 60 / 112: 4.20 / 4.21 ms with pair entries, profiles/r04_ngp_binned_scatter_ab.log; the A/B switches are
+  // retired: the dense levels keep the LDS cache, the hashed ones are binned)
+  constexpr float bin_cutoff = 60.0f;
   uint32_t first_bin = lv.L;
   uint32_t bucket0[NGP_MAX_LEVELS + 1] = {};
-  if (dfeat && use_bin) {
+  if (dfeat) {
     first_bin = 0;
     while (first_bin < lv.L && lv.scale[first_bin] <= bin_cutoff) ++first_bin;
     uint32_t tb = 0;

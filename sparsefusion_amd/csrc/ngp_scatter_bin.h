@@ -1,32 +1,34 @@
-// Table-gradient scatter of the hashed levels WITHOUT per-sample device atomics (r04): bin, then reduce in LDS.
+// Table-gradient scatter of the wrapped (hashed / tiled) levels WITHOUT per-sample device atomics (r04): bin, then reduce in LDS.
 //
 // Why.  Device-memory fp32 atomics execute at the memory side on MI355X (~20 G 16-byte granules per second, measured r02), and
-// a 128 x 128 x 128 render puts 16.8 M corner contributions into each 2^19-row level: on the levels whose cell is smaller than
-// the footprint of an 8 x 8 ray patch (scale > ~110) the LDS cache of k_ngp_scatter finds nothing to merge, and the backward was
-// bound by ~90 M atomic granules (k_ngp_scatter_fine 1.67 ms + the upper levels of k_ngp_scatter ~1.3 ms, alone).  Globally,
-// though, every table row is hit ~32 times per render.  So:
+// a 128 x 128 x 128 render puts 16.8 M corner contributions into every level (the reference field, network_grid.py:63: 16 levels,
+// 2^16 rows each from level 3 on, `tiled`): on the levels whose cell is smaller than the footprint of an 8 x 8 ray patch the LDS
+// cache of k_ngp_scatter finds nothing to merge, and the backward was bound by the number of atomic granules (k_ngp_scatter_fine
+// 1.67 ms + the upper levels of k_ngp_scatter ~1.3 ms, alone).  Globally, though, every table row is hit ~256 times per render.  So:
 //   k_ngp_bin         one workgroup = a tile of 1024 samples, four levels at a time: the contributions of an x-corner PAIR (two table
-//                     rows, 2 x 2 values; both rows lie in one BUCKET of 2048 consecutive rows but for ~1 pair in 2048) are ranked
+//                     rows, 2 x 2 values; both rows lie in one BUCKET of 1024 consecutive rows but for ~1 pair in 1024) are ranked
 //                     inside the bucket by a returning LDS atomic, the workgroup reserves a contiguous run per touched bucket with
 //                     ONE returning device atomic on the bucket's cursor, and the 20-byte entries are stored there (plain stores:
 //                     the runs of a tile are assembled in its XCD's L2; the kernel is bound by the number of store instructions,
 //                     all of them divergent -- pairs halve it);
-//   k_ngp_bin_reduce  one workgroup per bucket: its entries stream in coalesced, accumulate in a 32 KB LDS slice of DOUBLES (ds_add_f64:
+//   k_ngp_bin_reduce  one workgroup per bucket: its entries stream in coalesced, accumulate in a 16 KB LDS slice of DOUBLES (ds_add_f64:
 //                     fp32 LDS atomics retire 0.33 lane-operations per clock and CU on gfx950, fp64 ones 2.3 -- sf_dev.h),
 //                     and the slice is added to the gradient table with plain vector read-modify-writes -- the workgroup is the
 //                     only writer of those rows while it runs (stream order; the cached-level kernel owns other levels).
-// Device atomics per level: one per (tile, touched bucket) ~ 0.5 M instead of 8.4 M granules.  A bucket that overflows its
-// capacity (a skewed `tiled` level, adversarial input) falls back to direct atomics for the overflow: always correct.
-// 47 KB of LDS at most: both kernels run beside k_ngp_field_bwd_mfma's 113 KB on the same CU.
+// Device atomics per level: one per (tile, touched bucket), <= 64 per 4096 pairs, instead of one granule per pair.  A bucket that
+// overflows its capacity (a skewed `tiled` level, adversarial input) falls back to direct atomics for the overflow: always correct.
+// 16 KB of LDS each: both kernels run beside k_ngp_field_bwd_mfma's 113 KB on the same CU.
 // Reference semantics: external/gridencoder/src/gridencoder.cu:203-262 (kernel_grid_backward: atomicAdd per corner and channel);
 // values equal ngp_scatter (ngp_device.h) up to fp32 summation order, which atomics never fixed either.
 #pragma once
 #include "sf_dev.h"
 #include "ngp_device.h"
 
-#define SB_ROWS_LOG 11
+#ifndef SB_ROWS_LOG
+#define SB_ROWS_LOG 10          // measured on the reference field (2^16-row `tiled` levels), render fwd + bwd: 2048 / 1024 / 512 rows = 4.27 / 3.90 / 4.13 ms
+#endif
 #define SB_ROWS (1u << SB_ROWS_LOG)   // table rows per bucket
-#define SB_MAX_BUCKETS 256            // per level: hsize <= 2^19, the reference's log2_hashmap_size (larger tables keep k_ngp_scatter_fine)
+#define SB_MAX_BUCKETS (1u << (19 - SB_ROWS_LOG))            // per level: hsize <= 2^19, the reference's log2_hashmap_size (larger tables keep k_ngp_scatter_fine)
 #define SB_THREADS 1024
 
 #ifdef SF_HOST_EMU
@@ -44,7 +46,7 @@ struct SBArgs {
   const float* dfeat;          // level-major [L][P_stride][2], this launch's points at p_off
   float* gtable;
   uint32_t* cursor;            // [buckets]: entries reserved so far (zero before the first k_ngp_bin of a reduce round)
-  uint32_t* rows;              // [buckets][cap]  row of the pair's first corner | (row1 - row0 + 2048) << 20
+  uint32_t* rows;              // [buckets][cap]  row of the pair's first corner | (row1 - row0 + 2048) << 20 (|row1 - row0| < rows per bucket)
   f32x4* vals;                 // [buckets][cap]  (w0 dF0, w0 dF1, w1 dF0, w1 dF1)
   uint32_t P, T2, first_level, P_stride, p_off, cap;
   uint32_t bucket0[NGP_MAX_LEVELS + 1];      // first bucket of level l (levels below first_level hold none)
@@ -133,7 +135,7 @@ SF_KERNEL(SB_THREADS) void k_ngp_bin(SBArgs a) {
               f32x4 v = {SF_MUL(c.w[2 * j], d[g][0]), SF_MUL(c.w[2 * j], d[g][1]), SF_MUL(c.w[2 * j + 1], d[g][0]), SF_MUL(c.w[2 * j + 1], d[g][1])};
               const bool full = pos >= a.cap;                            // bucket full: the pair goes straight to the table
               uint32_t word = r0 | ((r1 - r0 + 2048u) << 20);
-              if (full || (r1 >> SB_ROWS_LOG) != b) {                    // second row in another bucket (~1 pair in 2048): direct adds
+              if (full || (r1 >> SB_ROWS_LOG) != b) {                    // second row in another bucket (~1 pair in 1024): direct adds
                 sf_global_add(tab + (size_t)r1 * 2, v[2]);
                 sf_global_add(tab + (size_t)r1 * 2 + 1, v[3]);
                 v[2] = 0.0f; v[3] = 0.0f;
@@ -167,7 +169,7 @@ struct SBRArgs {
 // one workgroup per bucket; leaves the bucket's cursor at zero for the next round.  Every global access is issued in batches of
 // SBR_U per thread before its first use: with one load in flight per thread (the first version) the entries of a bucket were
 // 115 dependent round trips per thread -- 1.37 ms per launch for 400 MB.
-#define SBR_THREADS 1024
+#define SBR_THREADS (SB_ROWS < 1024u ? (int)SB_ROWS : 1024)
 #define SBR_U 4
 SF_KERNEL(SBR_THREADS) void k_ngp_bin_reduce(SBRArgs a) {
   SF_SHARED double acc[SB_ROWS * 2];

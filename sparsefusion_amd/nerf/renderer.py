@@ -91,7 +91,7 @@ class _RenderFn(torch.autograd.Function):
         rgb_s = torch.empty(N, 2 * T, 3, **f32)
         image, depth, ws = torch.empty(N, 3, **f32), torch.empty(N, **f32), torch.empty(N, **f32)
         lib = _lib.lib()
-        wbytes = lib.sf_ngp_render_workspace_bytes(N, T)
+        wbytes = lib.sf_ngp_render_forward_workspace_bytes(N, T)
         work = torch.empty(max(1, wbytes // 4), **f32)
         f = handle.struct(params)
         # field cache (r03): when a backward will follow, the forward keeps the hash-grid features of every sample and the sort

@@ -82,13 +82,13 @@ def test_binned_scatter_matches_per_corner_adds(case):
     o, d = o[:N].contiguous(), d[:N].contiguous()
     z = (torch.rand(N, T2, generator=g) * 9.0 + 1.0).sort(1).values.contiguous()
     L, S = 16, float(np.log2(ngp_ref.per_level_scale(4)))
-    sizes = [min(1 << 14, (int(np.ceil(16 * 2.0 ** (l * S))) + 1) ** 3) for l in range(L)]      # a 2^14-row hash map: 8 buckets per level
+    sizes = [min(1 << 12, (int(np.ceil(16 * 2.0 ** (l * S))) + 1) ** 3) for l in range(L)]      # a 2^12-row hash map: 4 buckets per level
     offs = torch.tensor(np.concatenate([[0], np.cumsum([(n + 7) // 8 * 8 for n in sizes])]), dtype=torch.int32)
     dfeat = torch.randn(L, P, 2, generator=g)
     dfeat[:, ::7] = 0.0                                       # dead samples
     aabb = torch.tensor([-4.0] * 3 + [4.0] * 3)
     ptr = lambda t: C.c_void_p(t.data_ptr())
-    first, cap, gridtype = {"roomy": (1, 8192, 0), "overflow": (1, 8, 0), "tiled": (5, 512, 1)}[case]
+    first, cap, gridtype = {"roomy": (6, 16384, 0), "overflow": (10, 8, 0), "tiled": (9, 1024, 1)}[case]
 
     def run(use_ref, chunks=1, grid=1):
         tab = torch.zeros(int(offs[-1]), 2)
