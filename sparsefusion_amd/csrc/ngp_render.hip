@@ -298,23 +298,23 @@ extern "C" int sf_ngp_density(const sf_ngp_field* f, const float* xyz, uint32_t 
 // backward: dsig [2NT] + drgb [6NT] + d(features) level-major [16][2NT][2] = 72*N*T, then the binned scatter's cursors and entries.
 // the backward cuts the rays into chunks (pipeline below): as many as keep a chunk a multiple of 256 rays and >= 2048 rays
 #ifndef NGP_BWD_CHUNKS
-#define NGP_BWD_CHUNKS 4u
+#define NGP_BWD_CHUNKS 2u       // r03 (atomic scatters): 1 / 2 / 4 / 8 chunks = 5.96 / 5.65 / 5.64 / 6.00 ms; r04 (binned): 1 / 2 / 4 / 8 = 3.71 / 3.55 / 3.68 / 4.11 ms
 #endif
 static uint32_t ngp_bwd_chunks(uint32_t N) {
   uint32_t n = NGP_BWD_CHUNKS;
   while (n > 1 && (N % n || (N / n) % 256 || N / n < 2048)) --n;
   return n;
 }
-// binned scatter (ngp_scatter_bin.h): cursors + 20-byte entries of ONE chunk: 4 corner pairs x every level + slack per bucket
+// binned scatter (ngp_scatter_bin.h): cursors + 16-byte entries of ONE chunk: 4 corner pairs x every level + slack per bucket
 #define SB_CURSOR_WORDS (NGP_MAX_LEVELS * SB_MAX_BUCKETS)
 #ifndef SB_LEVELS_BUDGET
-#define SB_LEVELS_BUDGET (2 * NGP_MAX_LEVELS)     // entries for twice as many levels as exist: a bucket holds ~2.7 x its uniform share
-#endif                                            // (max / mean of the bucket loads on the reference scene: <= 1.9; 4.17 -> 3.86 ms with the room)
+#define SB_LEVELS_BUDGET 24                       // entries for 24 level-slots per sample (12 levels are binned): a bucket holds 2 x its uniform
+#endif                                            // share (max / mean of the bucket loads on the reference scene: <= 1.9; 16 / 24 / 32 slots: 3.61 / 3.55 / 3.58 ms)
 static uint64_t ngp_bin_entries(uint32_t N, uint32_t T) {
   return (uint64_t)(N / ngp_bwd_chunks(N)) * 2 * T * 4 * SB_LEVELS_BUDGET + (uint64_t)SB_CURSOR_WORDS * 64;
 }
 extern "C" uint64_t sf_ngp_render_workspace_bytes(uint32_t N, uint32_t T) {
-  return (uint64_t)(8 + 4 * NGP_MAX_LEVELS) * N * T * sizeof(float) + (uint64_t)SB_CURSOR_WORDS * 4 + ngp_bin_entries(N, T) * 20;
+  return (uint64_t)(8 + 4 * NGP_MAX_LEVELS) * N * T * sizeof(float) + (uint64_t)SB_CURSOR_WORDS * 4 + ngp_bin_entries(N, T) * 16;
 }
 
 extern "C" uint64_t sf_ngp_render_forward_workspace_bytes(uint32_t N, uint32_t T) { return (uint64_t)10 * N * T * sizeof(float); }
@@ -436,9 +436,8 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
   const uint32_t last = !dfeat ? lv.L : binned ? first_bin : cached;     // levels [0, last): k_ngp_scatter, [last, L): binned / k_ngp_scatter_fine
   const uint32_t total_buckets = bucket0[NGP_MAX_LEVELS];
   uint32_t* bin_cursor = reinterpret_cast<uint32_t*>(workspace + (size_t)(8 + 4 * NGP_MAX_LEVELS) * N * T);
-  uint32_t* bin_rows = bin_cursor + SB_CURSOR_WORDS;
-  const uint64_t bin_entries = ngp_bin_entries(N, T) & ~(uint64_t)3;       // (keeps the value rows 16-byte aligned)
-  f32x4* bin_vals = reinterpret_cast<f32x4*>(bin_rows + bin_entries);
+  f32x4* bin_ent = reinterpret_cast<f32x4*>(bin_cursor + SB_CURSOR_WORDS);      // (16-byte aligned: 72 N T floats + 2^13 words)
+  const uint64_t bin_entries = ngp_bin_entries(N, T);
   const uint32_t bin_cap = binned ? (uint32_t)(bin_entries / total_buckets) : 0;
   if (binned && hipMemsetAsync(bin_cursor, 0, (size_t)total_buckets * 4, st) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: memset failed");
 
@@ -501,10 +500,10 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
       if (binned) {
         SBArgs b{};
         b.lv = lv; b.bound = f->bound; b.rays_o = a.rays_o; b.rays_d = a.rays_d; b.aabb = aabb; b.z_s = a.z_s; b.dfeat = dfeat;
-        b.gtable = g->g_embeddings; b.cursor = bin_cursor; b.rows = bin_rows; b.vals = bin_vals;
+        b.gtable = g->g_embeddings; b.cursor = bin_cursor; b.ent = bin_ent;
         b.P = Pc; b.T2 = T2; b.first_level = first_bin; b.P_stride = (uint32_t)M; b.p_off = c * Pc; b.cap = bin_cap;
         SBRArgs r{};
-        r.lv = lv; r.gtable = g->g_embeddings; r.cursor = bin_cursor; r.rows = bin_rows; r.vals = bin_vals; r.first_level = first_bin; r.cap = bin_cap;
+        r.lv = lv; r.gtable = g->g_embeddings; r.cursor = bin_cursor; r.ent = bin_ent; r.first_level = first_bin; r.cap = bin_cap;
         for (uint32_t l = 0; l <= NGP_MAX_LEVELS; ++l) { b.bucket0[l] = bucket0[l]; r.bucket0[l] = bucket0[l]; }
         const uint32_t tiles = sf_div_up(Pc, SB_THREADS);
         k_ngp_bin<<<tiles < 1024 ? tiles : 1024, SB_THREADS, 0, sf>>>(b);

@@ -8,7 +8,7 @@
 //   k_ngp_bin         one workgroup = a tile of 1024 samples, four levels at a time: the contributions of an x-corner PAIR (two table
 //                     rows, 2 x 2 values; both rows lie in one BUCKET of 1024 consecutive rows but for ~1 pair in 1024) are ranked
 //                     inside the bucket by a returning LDS atomic, the workgroup reserves a contiguous run per touched bucket with
-//                     ONE returning device atomic on the bucket's cursor, and the 20-byte entries are stored there (plain stores:
+//                     ONE returning device atomic on the bucket's cursor, and the 16-byte entries are stored there (plain stores:
 //                     the runs of a tile are assembled in its XCD's L2; the kernel is bound by the number of store instructions,
 //                     all of them divergent -- pairs halve it);
 //   k_ngp_bin_reduce  one workgroup per bucket: its entries stream in coalesced, accumulate in a 16 KB LDS slice of DOUBLES (ds_add_f64:
@@ -28,6 +28,7 @@
 #define SB_ROWS_LOG 10          // measured on the reference field (2^16-row `tiled` levels), render fwd + bwd: 2048 / 1024 / 512 rows = 4.27 / 3.90 / 4.13 ms
 #endif
 #define SB_ROWS (1u << SB_ROWS_LOG)   // table rows per bucket
+static_assert(SB_ROWS_LOG <= 10, "the entry word keeps row1 - row0 + 1024 in 11 bits");
 #define SB_MAX_BUCKETS (1u << (19 - SB_ROWS_LOG))            // per level: hsize <= 2^19, the reference's log2_hashmap_size (larger tables keep k_ngp_scatter_fine)
 #define SB_THREADS 1024
 
@@ -46,11 +47,26 @@ struct SBArgs {
   const float* dfeat;          // level-major [L][P_stride][2], this launch's points at p_off
   float* gtable;
   uint32_t* cursor;            // [buckets]: entries reserved so far (zero before the first k_ngp_bin of a reduce round)
-  uint32_t* rows;              // [buckets][cap]  row of the pair's first corner | (row1 - row0 + 2048) << 20 (|row1 - row0| < rows per bucket)
-  f32x4* vals;                 // [buckets][cap]  (w0 dF0, w0 dF1, w1 dF0, w1 dF1)
+  f32x4* ent;                  // [buckets][cap] 16-byte entries {word, a, b, ratio} (sb_pack below)
   uint32_t P, T2, first_level, P_stride, p_off, cap;
   uint32_t bucket0[NGP_MAX_LEVELS + 1];      // first bucket of level l (levels below first_level hold none)
 };
+
+// One 16-byte entry per x-corner pair.  The four contributions of a pair are the outer product (w0, w1) x (dF0, dF1): the entry keeps
+// the products of the corner with the LARGER weight (a, b) and the weight ratio <= 1; the reducer rebuilds the other corner's as a * ratio,
+// b * ratio (two roundings instead of one: <= 2 ulp on the smaller contribution).  word = row0 | (row1 - row0 + 1024) << 20 | swap << 31
+// (swap: (a, b) belong to row1); |row1 - row0| < SB_ROWS because both rows lie in the entry's bucket.
+SF_DEV f32x4 sb_pack(uint32_t r0, uint32_t r1, float w0, float w1, float d0, float d1) {
+  const bool swap = w1 > w0;
+  const float wh = swap ? w1 : w0, wl = swap ? w0 : w1;
+  const uint32_t word = r0 | ((r1 - r0 + 1024u) << 20) | (swap ? 0x80000000u : 0u);
+  f32x4 e;
+  e[0] = __builtin_bit_cast(float, word);
+  e[1] = SF_MUL(wh, d0);
+  e[2] = SF_MUL(wh, d1);
+  e[3] = wh > 0.0f ? SF_DIV(wl, wh) : 0.0f;
+  return e;
+}
 
 // Levels are taken SB_G at a time: the device atomics of a group go out together (one per thread), and a group's feature-gradient
 // rows are one batch of loads.  The ranks of a group wait in registers (16 bits each); the cells are computed again for the stores.
@@ -132,22 +148,18 @@ SF_KERNEL(SB_THREADS) void k_ngp_bin(SBArgs a) {
             if (j < np) {
               const uint32_t r0 = c.row[2 * j], r1 = c.row[2 * j + 1], b = r0 >> SB_ROWS_LOG;
               const uint32_t pos = base[g][b] + ((rk[g][j >> 1] >> (16 * (j & 1))) & 0xffffu);
-              f32x4 v = {SF_MUL(c.w[2 * j], d[g][0]), SF_MUL(c.w[2 * j], d[g][1]), SF_MUL(c.w[2 * j + 1], d[g][0]), SF_MUL(c.w[2 * j + 1], d[g][1])};
+              const float w0 = c.w[2 * j], w1 = c.w[2 * j + 1];
               const bool full = pos >= a.cap;                            // bucket full: the pair goes straight to the table
-              uint32_t word = r0 | ((r1 - r0 + 2048u) << 20);
-              if (full || (r1 >> SB_ROWS_LOG) != b) {                    // second row in another bucket (~1 pair in 1024): direct adds
-                sf_global_add(tab + (size_t)r1 * 2, v[2]);
-                sf_global_add(tab + (size_t)r1 * 2 + 1, v[3]);
-                v[2] = 0.0f; v[3] = 0.0f;
-                word = r0 | (2048u << 20);
+              const bool split = (r1 >> SB_ROWS_LOG) != b;               // second row in another bucket (~1 pair in 1024): direct adds
+              if (full || split) {
+                sf_global_add(tab + (size_t)r1 * 2, SF_MUL(w1, d[g][0]));
+                sf_global_add(tab + (size_t)r1 * 2 + 1, SF_MUL(w1, d[g][1]));
               }
               if (full) {
-                sf_global_add(tab + (size_t)r0 * 2, v[0]);
-                sf_global_add(tab + (size_t)r0 * 2 + 1, v[1]);
+                sf_global_add(tab + (size_t)r0 * 2, SF_MUL(w0, d[g][0]));
+                sf_global_add(tab + (size_t)r0 * 2 + 1, SF_MUL(w0, d[g][1]));
               } else {
-                const size_t e = (size_t)(b0 + b) * a.cap + pos;
-                a.rows[e] = word;
-                a.vals[e] = v;
+                a.ent[(size_t)(b0 + b) * a.cap + pos] = split ? sb_pack(r0, r0, w0, 0.0f, d[g][0], d[g][1]) : sb_pack(r0, r1, w0, w1, d[g][0], d[g][1]);
               }
             }
           }
@@ -161,7 +173,7 @@ SF_KERNEL(SB_THREADS) void k_ngp_bin(SBArgs a) {
 struct SBRArgs {
   NgpLevels lv;
   float* gtable;
-  uint32_t* cursor; const uint32_t* rows; const f32x4* vals;
+  uint32_t* cursor; const f32x4* ent;
   uint32_t first_level, cap;
   uint32_t bucket0[NGP_MAX_LEVELS + 1];
 };
@@ -179,17 +191,14 @@ SF_KERNEL(SBR_THREADS) void k_ngp_bin_reduce(SBRArgs a) {
   if (n > a.cap) n = a.cap;
   uint32_t l = a.first_level;
   while (l + 1 < a.lv.L && gb >= a.bucket0[l + 1]) ++l;
-  const uint32_t* rows = a.rows + (size_t)gb * a.cap;
-  const f32x4* vals = a.vals + (size_t)gb * a.cap;
-  uint32_t r[SBR_U];
+  const f32x4* ent = a.ent + (size_t)gb * a.cap;
   f32x4 v[SBR_U];
   auto fetch = [&](uint32_t i0) {
 #pragma unroll
     for (int u = 0; u < SBR_U; ++u) {
       uint32_t i = i0 + u * SBR_THREADS + tid;
       if (i > n - 1) i = n - 1;                                          // unconditional loads (clamped): one straight-line block
-      r[u] = rows[i];
-      v[u] = vals[i];
+      v[u] = ent[i];
     }
   };
   fetch(0);                                                              // the first batch is in flight while the slice is zeroed
@@ -197,20 +206,21 @@ SF_KERNEL(SBR_THREADS) void k_ngp_bin_reduce(SBRArgs a) {
   sf_sync();
   if (tid == 0) a.cursor[gb] = 0;
   for (uint32_t i0 = 0; i0 < n; i0 += SBR_U * SBR_THREADS) {
-    uint32_t rc[SBR_U];
     f32x4 vc[SBR_U];
 #pragma unroll
-    for (int u = 0; u < SBR_U; ++u) { rc[u] = r[u]; vc[u] = v[u]; }
+    for (int u = 0; u < SBR_U; ++u) vc[u] = v[u];
     if (i0 + SBR_U * SBR_THREADS < n) fetch(i0 + SBR_U * SBR_THREADS);   // next batch under this batch's LDS atomics
 #pragma unroll
     for (int u = 0; u < SBR_U; ++u) {
       if (i0 + u * SBR_THREADS + tid < n) {
-        const uint32_t q = rc[u] & (SB_ROWS - 1), q1 = q + (rc[u] >> 20) - 2048u;      // both rows of the pair lie in this bucket
-        sf_lds_add_f64(&acc[2 * q], (double)vc[u][0]);
-        sf_lds_add_f64(&acc[2 * q + 1], (double)vc[u][1]);
-        if (vc[u][2] != 0.0f || vc[u][3] != 0.0f) {
-          sf_lds_add_f64(&acc[2 * q1], (double)vc[u][2]);
-          sf_lds_add_f64(&acc[2 * q1 + 1], (double)vc[u][3]);
+        const uint32_t word = __builtin_bit_cast(uint32_t, vc[u][0]);
+        const uint32_t q0 = word & (SB_ROWS - 1), q1 = q0 + ((word >> 20) & 2047u) - 1024u;      // both rows of the pair lie in this bucket
+        const uint32_t qh = (word >> 31) ? q1 : q0, ql = (word >> 31) ? q0 : q1;
+        sf_lds_add_f64(&acc[2 * qh], (double)vc[u][1]);
+        sf_lds_add_f64(&acc[2 * qh + 1], (double)vc[u][2]);
+        if (vc[u][3] != 0.0f) {
+          sf_lds_add_f64(&acc[2 * ql], (double)(vc[u][1] * vc[u][3]));
+          sf_lds_add_f64(&acc[2 * ql + 1], (double)(vc[u][2] * vc[u][3]));
         }
       }
     }

@@ -120,11 +120,11 @@ extern "C" int emu_bin_scatter(const int32_t* h_offsets, uint32_t L, float S, ui
       tb += nb;
     }
   }
-  std::vector<uint32_t> cursor(tb, 0), rows((size_t)tb * cap);
-  std::vector<f32x4> vals((size_t)tb * cap);
-  b.lv = lv; b.bound = bound; b.aabb = aabb; b.dfeat = dfeat; b.gtable = gtable; b.cursor = cursor.data(); b.rows = rows.data(); b.vals = vals.data();
+  std::vector<uint32_t> cursor(tb, 0);
+  std::vector<f32x4> ent((size_t)tb * cap);
+  b.lv = lv; b.bound = bound; b.aabb = aabb; b.dfeat = dfeat; b.gtable = gtable; b.cursor = cursor.data(); b.ent = ent.data();
   b.T2 = T2; b.first_level = first_level; b.P_stride = P; b.cap = cap;
-  r.lv = lv; r.gtable = gtable; r.cursor = cursor.data(); r.rows = rows.data(); r.vals = vals.data(); r.first_level = first_level; r.cap = cap;
+  r.lv = lv; r.gtable = gtable; r.cursor = cursor.data(); r.ent = ent.data(); r.first_level = first_level; r.cap = cap;
   const uint32_t Nc = (N + chunks - 1) / chunks;
   for (uint32_t c = 0; c * Nc < N; ++c) {
     const uint32_t n0 = c * Nc, nn = n0 + Nc <= N ? Nc : N - n0;

@@ -265,7 +265,7 @@ def test_render_full_size_properties(golden):
 
 def test_binned_table_gradient_equals_per_corner_atomics_at_full_size(golden):
     """r04: the table gradient of the fused backward (csrc/ngp_scatter_bin.h: wrapped levels binned by table slice and reduced in
-    LDS doubles, four ray chunks sharing the bins; dense levels through the LDS cache) at the BASELINE size, against an independent
+    LDS doubles, two ray chunks sharing the bins; dense levels through the LDS cache) at the BASELINE size, against an independent
     scatter of the SAME per-level feature gradients: the reference-ABI grid-encoder backward (csrc/gridencoder.hip, one device atomic
     per corner and channel = external/gridencoder/src/gridencoder.cu:203-262).  Equal up to fp32 summation order."""
     from sparsefusion_amd import _lib

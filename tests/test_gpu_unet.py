@@ -190,8 +190,8 @@ def test_plan_switches_match_oracle(switch):
 
 def test_r04_fusions_match_the_r03_plan():
     """The launch fusions of round 4 -- attention core in the prologue of its output projection, statistics slots from k_init_x and
-    the Upsample epilogue, NCHW output from the final split-K reduction -- against the plan without them (k_attn16, k_slots,
-    k_unpack_out launches) and, with the GlobalContext pooling back in its own launch, against the oracle: same values to the bf16
+    the Upsample epilogue, NCHW output from the final split-K reduction, the 4x4 res_conv beside the GlobalContext pooling launch --
+    against the plan without them (k_attn16, k_slots, k_unpack_out launches, conv1 || res_conv pairs) and, with the GlobalContext pooling back in its own launch, against the oracle: same values to the bf16
     tolerance, fewer ops."""
     name = "canonical"
     sd = state(name)
@@ -204,7 +204,7 @@ def test_r04_fusions_match_the_r03_plan():
     ctx = net.begin_sampling(cond.to(DEV), ls.to(DEV))
     y_new = net.eval_prepared(ctx, x.to(DEV), 0).clone().cpu()
     n_new = ctx["plan"].n_body_ops
-    net.attn_in_out_proj, net.producer_slots, net.gca_epilogue_pool = False, False, False
+    net.attn_in_out_proj, net.producer_slots, net.gca_epilogue_pool, net.res_conv_beside_pool = False, False, False, False
     net.drop_plans()
     ctx = net.begin_sampling(cond.to(DEV), ls.to(DEV))
     y_old = net.eval_prepared(ctx, x.to(DEV), 0).clone().cpu()
