@@ -301,8 +301,12 @@ extern "C" int sf_ngp_density(const sf_ngp_field* f, const float* xyz, uint32_t 
 #define NGP_BWD_CHUNKS 2u       // r03 (atomic scatters): 1 / 2 / 4 / 8 chunks = 5.96 / 5.65 / 5.64 / 6.00 ms; r04 (binned): 1 / 2 / 4 / 8 = 3.71 / 3.55 / 3.68 / 4.11 ms
 #endif
 static uint32_t ngp_bwd_chunks(uint32_t N) {
+  auto ok = [&](uint32_t n) { return n >= 1 && N % n == 0 && (N / n) % 256 == 0 && N / n >= 2048; };
+  // large ray sets: chunks of at most 8192 rays, so that the bins of one chunk (the workspace) stay at 1.6 GB
+  for (uint32_t n = (N + 8191) / 8192; n > NGP_BWD_CHUNKS && n <= 64; ++n)
+    if (ok(n)) return n;
   uint32_t n = NGP_BWD_CHUNKS;
-  while (n > 1 && (N % n || (N / n) % 256 || N / n < 2048)) --n;
+  while (n > 1 && !ok(n)) --n;
   return n;
 }
 // binned scatter (ngp_scatter_bin.h): cursors + 16-byte entries of ONE chunk: 4 corner pairs x every level + slack per bucket
