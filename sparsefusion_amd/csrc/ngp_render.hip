@@ -300,14 +300,23 @@ extern "C" int sf_ngp_density(const sf_ngp_field* f, const float* xyz, uint32_t 
 #ifndef NGP_BWD_CHUNKS
 #define NGP_BWD_CHUNKS 2u       // r03 (atomic scatters): 1 / 2 / 4 / 8 chunks = 5.96 / 5.65 / 5.64 / 6.00 ms; r04 (binned): 1 / 2 / 4 / 8 = 3.71 / 3.55 / 3.68 / 4.11 ms
 #endif
-static uint32_t ngp_bwd_chunks(uint32_t N) {
-  auto ok = [&](uint32_t n) { return n >= 1 && N % n == 0 && (N / n) % 256 == 0 && N / n >= 2048; };
+struct NgpChunks { uint32_t n, max_rays, start[66]; };      // chunk c = rays [start[c], start[c + 1])
+static NgpChunks ngp_bwd_plan(uint32_t N) {
+  NgpChunks c{};
+  auto equal = [&](uint32_t k) {
+    c.n = k; c.max_rays = N / k;
+    for (uint32_t i = 0; i <= k; ++i) c.start[i] = i * (N / k);
+  };
+  auto ok = [&](uint32_t rays, uint32_t k) { return k >= 1 && rays % k == 0 && (rays / k) % 256 == 0 && rays / k >= 2048; };
+  // (a small first chunk, so that the side stream starts early, measured slower: first chunk 1/4, 1/8, 1/16 of the rays = 3.63 / 3.63 /
+  // 3.66 ms against 3.54 for two equal chunks, profiles/r04_ngp_binned_tuning.log -- co-running kernels cost their sum, not their maximum)
   // large ray sets: chunks of at most 8192 rays, so that the bins of one chunk (the workspace) stay at 1.6 GB
-  for (uint32_t n = (N + 8191) / 8192; n > NGP_BWD_CHUNKS && n <= 64; ++n)
-    if (ok(n)) return n;
-  uint32_t n = NGP_BWD_CHUNKS;
-  while (n > 1 && !ok(n)) --n;
-  return n;
+  for (uint32_t k = (N + 8191) / 8192; k > NGP_BWD_CHUNKS && k <= 64; ++k)
+    if (ok(N, k)) { equal(k); return c; }
+  uint32_t k = NGP_BWD_CHUNKS;
+  while (k > 1 && !ok(N, k)) --k;
+  equal(k);
+  return c;
 }
 // binned scatter (ngp_scatter_bin.h): cursors + 16-byte entries of ONE chunk: 4 corner pairs x every level + slack per bucket
 #define SB_CURSOR_WORDS (NGP_MAX_LEVELS * SB_MAX_BUCKETS)
@@ -315,7 +324,7 @@ static uint32_t ngp_bwd_chunks(uint32_t N) {
 #define SB_LEVELS_BUDGET 24                       // entries for 24 level-slots per sample (12 levels are binned): a bucket holds 2 x its uniform
 #endif                                            // share (max / mean of the bucket loads on the reference scene: <= 1.9; 16 / 24 / 32 slots: 3.61 / 3.55 / 3.58 ms)
 static uint64_t ngp_bin_entries(uint32_t N, uint32_t T) {
-  return (uint64_t)(N / ngp_bwd_chunks(N)) * 2 * T * 4 * SB_LEVELS_BUDGET + (uint64_t)SB_CURSOR_WORDS * 64;
+  return (uint64_t)ngp_bwd_plan(N).max_rays * 2 * T * 4 * SB_LEVELS_BUDGET + (uint64_t)SB_CURSOR_WORDS * 64;
 }
 extern "C" uint64_t sf_ngp_render_workspace_bytes(uint32_t N, uint32_t T) {
   return (uint64_t)(8 + 4 * NGP_MAX_LEVELS) * N * T * sizeof(float) + (uint64_t)SB_CURSOR_WORDS * 4 + ngp_bin_entries(N, T) * 16;
@@ -454,7 +463,9 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
   struct Side { hipStream_t s; hipEvent_t fork, join; };
   static Side side[32] = {};
   const bool fork = dfeat && last < lv.L && dev_id < 32;
-  const uint32_t n_chunks = (dfeat && last < lv.L) ? ngp_bwd_chunks(N) : 1;      // (the entries buffer is sized for this chunking)
+  NgpChunks plan = ngp_bwd_plan(N);                                            // (the entries buffer is sized for this chunking)
+  if (!(dfeat && last < lv.L)) { plan.n = 1; plan.start[0] = 0; plan.start[1] = N; }
+  const uint32_t n_chunks = plan.n;
   // The side stream and its fork / join events are ONE set per device: two host threads (or two caller streams) rendering on the
   // same device would re-record each other's events, so the whole fork .. join section runs under the lock (host-side enqueue only:
   // microseconds).  The guard below joins the side stream into the caller's stream on EVERY exit path, error returns included.
@@ -474,17 +485,18 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
       SF_FAIL(SF_ERR_LAUNCH, "ngp_render_backward: cannot create the side stream");
     side_join.sd = &sd; side_join.st = st;
   }
-  const uint32_t Nc = N / n_chunks, T2 = 2 * T;
-  const uint32_t Pc = Nc * T2;
+  const uint32_t T2 = 2 * T;
   for (uint32_t c = 0; c < n_chunks; ++c) {
+    const uint32_t n0 = plan.start[c], Nc = plan.start[c + 1] - n0;
+    const uint32_t Pc = Nc * T2, P0 = n0 * T2;
     // matrix-core field backward of chunk c: one wave per 32 points and trip, six fp32 GEMMs on v_mfma_f32_16x16x4_f32 (ngp_bwd_mfma.h)
     FBArgs a{};
     a.table = f->embeddings; a.w0 = f->w0; a.b0 = f->b0; a.w1 = f->w1; a.b1 = f->b1; a.w2 = f->w2; a.b2 = f->b2; a.bound = f->bound;
     a.g_w0 = g->g_w0; a.g_b0 = g->g_b0; a.g_w1 = g->g_w1; a.g_b1 = g->g_b1; a.g_w2 = g->g_w2; a.g_b2 = g->g_b2;
     a.lv = lv;
-    a.rays_o = rays_o + (size_t)c * Nc * 3; a.rays_d = rays_d + (size_t)c * Nc * 3; a.aabb = aabb;
-    a.z_s = z_sorted + (size_t)c * Pc; a.dsig = dsig + (size_t)c * Pc; a.drgb = drgb + (size_t)c * Pc * 3; a.dfeat_out = dfeat;
-    a.P = Pc; a.T2 = T2; a.dfeat_P = (uint32_t)M; a.p_off = c * Pc;
+    a.rays_o = rays_o + (size_t)n0 * 3; a.rays_d = rays_d + (size_t)n0 * 3; a.aabb = aabb;
+    a.z_s = z_sorted + (size_t)P0; a.dsig = dsig + (size_t)P0; a.drgb = drgb + (size_t)P0 * 3; a.dfeat_out = dfeat;
+    a.P = Pc; a.T2 = T2; a.dfeat_P = (uint32_t)M; a.p_off = P0;
     a.feat_c = field_cache;                           // (or all three null: the kernel re-gathers the features)
     a.feat_f = field_cache ? field_cache + (size_t)N * T * NGP_FEAT : nullptr;
     a.perm = field_cache ? reinterpret_cast<const uint32_t*>(field_cache + 2 * (size_t)N * T * NGP_FEAT) : nullptr;
@@ -505,7 +517,7 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
         SBArgs b{};
         b.lv = lv; b.bound = f->bound; b.rays_o = a.rays_o; b.rays_d = a.rays_d; b.aabb = aabb; b.z_s = a.z_s; b.dfeat = dfeat;
         b.gtable = g->g_embeddings; b.cursor = bin_cursor; b.ent = bin_ent;
-        b.P = Pc; b.T2 = T2; b.first_level = first_bin; b.P_stride = (uint32_t)M; b.p_off = c * Pc; b.cap = bin_cap;
+        b.P = Pc; b.T2 = T2; b.first_level = first_bin; b.P_stride = (uint32_t)M; b.p_off = P0; b.cap = bin_cap;
         SBRArgs r{};
         r.lv = lv; r.gtable = g->g_embeddings; r.cursor = bin_cursor; r.ent = bin_ent; r.first_level = first_bin; r.cap = bin_cap;
         for (uint32_t l = 0; l <= NGP_MAX_LEVELS; ++l) { b.bucket0[l] = bucket0[l]; r.bucket0[l] = bucket0[l]; }
@@ -518,7 +530,7 @@ extern "C" int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_
         const uint64_t items = (uint64_t)4 * Pc * (lv.L - last);
         const uint32_t grid_f = (uint32_t)(items / 256 < 16384 ? (items + 255) / 256 : 16384);
         k_ngp_scatter_fine<<<grid_f, 256, 0, sf>>>(lv, f->bound, g->g_embeddings, a.rays_o, a.rays_d, aabb, a.z_s, dfeat, Nc, T2, last,
-                                                   (uint32_t)M, c * Pc);
+                                                   (uint32_t)M, P0);
         SF_CHECK_LAUNCH("ngp_scatter_fine");
       }
     }

@@ -210,14 +210,24 @@ def run_slots_case(backend):
     assert torch.allclose(sl2.cpu(), slots_of(x, M, C), rtol=1e-5, atol=1e-4)
 
 
-def run_gca_case(backend, B, H, C, lazy=False, seed=0, epilogue_chunks=False):
-    """k_gca_pool -> k_gca_net0 -> k_gca_gate against GlobalContext + gated residual (imagen_pytorch.py:916-941, :727-729)."""
+def run_gca_case(backend, B, H, C, lazy=False, seed=0, epilogue_chunks=False, rc=None):
+    """k_gca_pool -> k_gca_net0 -> k_gca_gate against GlobalContext + gated residual (imagen_pytorch.py:916-941, :727-729).
+    rc = (C1, C2): the residual is the block's res_conv -- a 1x1 conv of the raw concat(x, skip * 2^-1/2) -- computed by an
+    un-normalised fconv op that shares the pooling launch (k_gca_pool_rc, r04: flag 16 on the fconv, the pooling op right behind it)."""
     dev = "cpu" if backend == "emu" else "cuda:0"
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g)
     HW, M, HID = H * H, B * H * H, max(3, C // 2)
     h2, res, wk = rn(M, C), rn(M, C), rn(C) * 0.3
     W0, b0, W2, b2 = rn(HID, C) / C ** 0.5, rn(HID) * 0.1, rn(C, HID) / HID ** 0.5, rn(C) * 0.1
+    rc_op = None
+    if rc is not None:
+        assert not epilogue_chunks and H == 4
+        C1, C2 = rc
+        xa, xb = rn(M, C1) * 1.5 + 0.3, (rn(M, C2) if C2 else None)
+        xc = torch.cat([xa, xb * 2 ** -0.5], 1) if C2 else xa
+        w_rc, b_rc = rn(C, C1 + C2, 1, 1) / (C1 + C2) ** 0.5, rn(C)
+        res = to_rows(F.conv2d(bf(nhwc(xc, B, H, H)), bf(w_rc), None)) + b_rc
     sm = torch.softmax((h2 @ wk).view(B, HW), 1)
     pooled = (sm[:, :, None] * h2.view(B, HW, C)).sum(1)
     hid = F.silu(pooled @ bf(W0).t() + b0)
@@ -239,13 +249,21 @@ def run_gca_case(backend, B, H, C, lazy=False, seed=0, epilogue_chunks=False):
         groups = npad = 0
         h2_d, ws_d, bias_d = dv(h2), None, None
     lp_d, res_d = dv(lpart), dv(res)
+    if rc is not None:
+        res_d = dv(torch.full((M, C), float("nan")))          # written by the res_conv half of the shared launch
+        xa_d, xb_d, wrc_d, brc_d = dv(xa), (dv(xb) if C2 else None), dv(fused.pack_conv_weights(w_rc)), dv(b_rc)      # (kept alive: ops hold raw pointers)
+        rc_op = fused.mkop(OP_FCONV, 16,
+                           p=(xa_d, None, None, None, None, xb_d, None, wrc_d, brc_d, res_d,
+                              None, None, None, None, None, None, None, None, None),
+                           i=(B, H, H, C1, C2, C, C, 0, 1, 0, 0, 0, NONE, 8, 4, 1, 1, 1, 0), f=(1e-5, 1.0, 2 ** -0.5))
     part_pool, part_ms = torch.zeros(B * chunks, C, device=dev), torch.zeros(B * chunks, 2, device=dev)
     W0p = dv(F.pad(W0, (0, Kp - C)).to(torch.bfloat16).contiguous())
     W2p = dv(F.pad(W2, (0, Kp2 - HID)).to(torch.bfloat16).contiguous())
     b0_d, b2_d = dv(b0), dv(b2)
     hid_d, out = torch.zeros(B, HID, device=dev), torch.zeros(M, C, device=dev)
     slots = torch.zeros(M // 16, C // 16, 2, device=dev)
-    head = [fused.mkop(OP_GCA, 1, p=(h2_d, ws_d, bias_d, lp_d, part_pool, part_ms), i=(M, C, HW, CH, chunks, nparts, groups, npad)),
+    head = ([rc_op] if rc_op is not None else []) + [
+         fused.mkop(OP_GCA, 1, p=(h2_d, ws_d, bias_d, lp_d, part_pool, part_ms), i=(M, C, HW, CH, chunks, nparts, groups, npad)),
          fused.mkop(OP_GCA, 2, p=(part_pool, part_ms, W0p, b0_d, hid_d), i=(B, C, Kp, HID, chunks))]
     if epilogue_chunks:            # the pooled 16-pixel fragments as the producing conv's epilogue leaves them (fused_pipe.h POOL):
         assert not lazy            # HW / 16 chunks per image, net0 merges up to 64 of them
@@ -260,6 +278,9 @@ def run_gca_case(backend, B, H, C, lazy=False, seed=0, epilogue_chunks=False):
            fused.mkop(OP_GCA, 3, p=(h2_d, res_d, hid_d, W2p, b2_d, out, slots), i=(M, C, HW, HID, Kp2))]
     run_ops(ops, backend)
     assert torch.allclose(hid_d.cpu(), hid, rtol=2e-4, atol=2e-5), "hidden vector wrong"
+    if rc is not None:
+        assert rel(res_d.cpu(), res) < 4e-3, "res_conv beside the pooling launch wrong"
+        want = h2 * gate.repeat_interleave(HW, 0) + res_d.cpu()
     assert torch.allclose(out.cpu(), want, rtol=2e-4, atol=2e-4), "gated residual wrong"
     assert torch.allclose(slots.cpu(), slots_of(want, M, C), rtol=1e-4, atol=2e-3)
     if lazy:
@@ -342,14 +363,18 @@ ATTN_CASES = {"self_context": dict(B=2, cross=False, context=True, seed=61), "se
               "cross_time_tokens": dict(B=2, cross=True, seed=63, Cout=64),
               "self_context_wn2": dict(B=2, cross=False, context=True, seed=68, Cout=64, WN=2)}      # the B >= 8 tile of the output projection
 
-GCA_CASES = {"4x4_lazy": dict(B=2, H=4, C=128, lazy=True), "8x8": dict(B=1, H=8, C=64, seed=1), "16x16": dict(B=1, H=16, C=64, seed=2),
+GCA_CASES = {"4x4_lazy": dict(B=2, H=4, C=128, lazy=True),
+             "4x4_lazy_res_conv_beside_pool": dict(B=2, H=4, C=128, lazy=True, seed=21, rc=(96, 64)),
+             "4x4_res_conv_beside_pool_no_skip": dict(B=1, H=4, C=64, seed=22, rc=(128, 0)), "8x8": dict(B=1, H=8, C=64, seed=1), "16x16": dict(B=1, H=16, C=64, seed=2),
              "8x8_c192_b2": dict(B=2, H=8, C=192, seed=8),
              "32x32_epilogue_chunks": dict(B=2, H=32, C=64, seed=11, epilogue_chunks=True),
              "16x16_epilogue_chunks": dict(B=1, H=16, C=320, seed=12, epilogue_chunks=True),
              "8x8_epilogue_chunks": dict(B=2, H=8, C=128, seed=13, epilogue_chunks=True)}
 GCA_CASES_FULL = {"unet_32x32_epilogue_chunks": dict(B=1, H=32, C=256, seed=14, epilogue_chunks=True),
                   "unet_b4_16x16_epilogue_chunks": dict(B=4, H=16, C=512, seed=15, epilogue_chunks=True),
-                  "unet_4x4": dict(B=1, H=4, C=1024, lazy=True, seed=3), "unet_8x8": dict(B=1, H=8, C=1024, seed=4),
+                  "unet_4x4": dict(B=1, H=4, C=1024, lazy=True, seed=3),
+                  "unet_4x4_res_conv_beside_pool": dict(B=1, H=4, C=1024, lazy=True, seed=23, rc=(1024, 1024)),
+                  "unet_b4_4x4_res_conv_beside_pool": dict(B=4, H=4, C=1024, lazy=True, seed=24, rc=(1024, 1024)), "unet_8x8": dict(B=1, H=8, C=1024, seed=4),
                   "unet_32x32": dict(B=1, H=32, C=256, seed=5), "unet_b4_16x16": dict(B=4, H=16, C=512, seed=6)}
 
 
