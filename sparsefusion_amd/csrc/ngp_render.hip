@@ -170,6 +170,9 @@ __global__ __launch_bounds__(NT) void k_ngp_scatter(
       uint32_t prow[4] = {SC_EMPTY, SC_EMPTY, SC_EMPTY, SC_EMPTY};
       float pacc[4] = {0.f, 0.f, 0.f, 0.f};
       const uint32_t k1 = k0 + sc_run < T2 ? k0 + sc_run : T2;
+      // (r04: the run walked in batches of 4 / 8 / 16 samples with their gradient and depth loads issued together measured SLOWER,
+      // 3.76 / 3.76 / 3.86 against 3.55 ms render fwd + bwd, profiles/r04_ngp_binned_tuning.log: 128 VGPRs at 1024 threads, and the
+      // kernel runs beside the last chunk's bin + reduce, whose memory traffic it then competes with)
       for (uint32_t k = k0; k < k1; ++k) {
         const uint32_t p = n * T2 + k;
         const float dfc = dfeat[((size_t)l * P + p) * 2 + ch];
