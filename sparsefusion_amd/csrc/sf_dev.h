@@ -1,6 +1,6 @@
 // Device-side vocabulary of the fused UNet kernels (gfx950): vector types, the MFMA tile op, wave reductions.
 // Built two ways: by hipcc for gfx950 (the product), and by the host clang with -DSF_HOST_EMU for the kernel-logic
-// tests of tests/hostemu (one OS thread per lane; test infrastructure, never shipped or timed).
+// tests of tests/hostemu (every lane a fiber on the CPU, deterministic schedule; test infrastructure, never shipped or timed).
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -102,23 +102,25 @@ static inline f32x4 sf_mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 // the hardware may land it: a read that does not sit behind the right counted wait + barrier sees stale data and the test fails);
 // HIPEMU_GLDS_IMMEDIATE=1 lands it at issue instead (the earliest moment: a buffer restaged while another wave still reads it shows).
 struct SfGldsPending { char* dst; const char* src; };
-static thread_local SfGldsPending sf_glds_q[64];
-static thread_local int sf_glds_head = 0, sf_glds_n = 0;
+struct SfGldsLane { SfGldsPending q[64]; int head = 0, n = 0; };
+static SfGldsLane sf_glds_lane[1024];                     // one queue per lane of the workgroup (the lanes are fibers on one OS thread, hip_emu.h)
 static inline bool sf_glds_immediate() { static const bool v = getenv("HIPEMU_GLDS_IMMEDIATE") && atoi(getenv("HIPEMU_GLDS_IMMEDIATE")); return v; }
 static inline void sf_glds16(char* lds_wave_base, const void* gsrc) {
   char* dst = lds_wave_base + hipemu::t_lane * 16;
   if (sf_glds_immediate()) { memcpy(dst, gsrc, 16); return; }
-  if (sf_glds_n == 64) { fprintf(stderr, "sf_glds16: more than 64 LDS-DMA loads in flight (vmcnt is 6 bits)\n"); abort(); }
-  sf_glds_q[(sf_glds_head + sf_glds_n++) & 63] = SfGldsPending{dst, (const char*)gsrc};
+  SfGldsLane& g = sf_glds_lane[threadIdx.x];
+  if (g.n == 64) { fprintf(stderr, "sf_glds16: more than 64 LDS-DMA loads in flight (vmcnt is 6 bits)\n"); abort(); }
+  g.q[(g.head + g.n++) & 63] = SfGldsPending{dst, (const char*)gsrc};
 }
 template <int N>
 static inline void sf_vmcnt() {
-  while (sf_glds_n > N) { memcpy(sf_glds_q[sf_glds_head].dst, sf_glds_q[sf_glds_head].src, 16); sf_glds_head = (sf_glds_head + 1) & 63; --sf_glds_n; }
+  SfGldsLane& g = sf_glds_lane[threadIdx.x];
+  while (g.n > N) { memcpy(g.q[g.head].dst, g.q[g.head].src, 16); g.head = (g.head + 1) & 63; --g.n; }
 }
 static inline void sf_lds_barrier() { hipemu::syncthreads(); }
 #define SF_SCHED_GROUP(mask, n) do { } while (0)
 #define SF_LGKM0() do { } while (0)
-static inline void sf_glds_done() { if (sf_glds_n) { fprintf(stderr, "LDS-DMA loads still in flight at kernel end\n"); abort(); } }
+static inline void sf_glds_done() { if (sf_glds_lane[threadIdx.x].n) { fprintf(stderr, "LDS-DMA loads still in flight at kernel end\n"); abort(); } }
 static const uint32_t sf_zero128[32] __attribute__((aligned(128))) = {0};
 #else
 #include <hip/hip_runtime.h>

@@ -1,5 +1,5 @@
 // CPU harness for the fused UNet kernels (sparsefusion_amd/csrc/fused_kernels.h): the SAME kernel source, compiled
-// by the host clang with one OS thread per lane (hip_emu.h), driven by the SAME op decoding as the gfx950 launchers
+// by the host clang with one fiber per lane (hip_emu.h), driven by the SAME op decoding as the gfx950 launchers
 // (fused_host.h).  Test infrastructure only -- checks kernel logic (indexing, LDS layout, fragment order, lazy
 // sources, statistics) on a GPU-less machine; the product path is unet_fused.hip on the GPU.
 #ifndef SF_HOST_EMU
