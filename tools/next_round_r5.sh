@@ -11,7 +11,7 @@ hipcc --offload-arch=gfx950 -O3 tools/exp/store_patterns.hip -o /tmp/store_patte
 cd /tmp
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rpn -- python $GRAFT_REPO_ROOT/tools/ngp_microbench.py > $O/rpn.log 2>&1
 cp $(find /tmp/rpn -name "*kernel_stats.csv" | head -1) $O/r05_ngp_microbench_kernel_stats.csv; grep render $O/rpn.log
-# 3. LDS counters of the fused UNet convs (never taken: the r04 counter passes had no SQ_LDS_* columns), one pass, kernel trace only
+# 3. LDS counters of the fused UNet convs again (r04: LDS active 5-8 % of a launch, profiles/r04_unet_lds_pmc_by_kernel.log), one pass, kernel trace only
 timeout 150 rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/u4 -- python $GRAFT_REPO_ROOT/tools/unet_eval_loop.py 1 6 > $O/u4.log 2>&1
 python $GRAFT_REPO_ROOT/tools/pmc_collect.py /tmp/u4 k_conv_fused > $O/r05_unet_fconv_lds_pmc.json; head -c 600 $O/r05_unet_fconv_lds_pmc.json
 # 4. the in-graph cost table the round starts from
