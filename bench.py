@@ -67,12 +67,18 @@ def huber(x, y, scaling=0.1):
 
 
 class HotPath:
-    def __init__(self, device, rank, world, max_thres, views=1, seed=0, n_input_views=2, eft_features=False, unet_operand=None):
+    def __init__(self, device, rank, world, max_thres, views=1, seed=0, n_input_views=2, eft_features=False, unet_operand=None,
+                 thres_range=None):
         from sparsefusion_amd.nerf import NeRFNetwork, get_default_torch_ngp_opt
         from sparsefusion_amd.unet import Unet
         from sparsefusion_amd.vldm import DDPM
         from sparsefusion_amd.plms import PLMSSampler
         self.dev, self.rank, self.world, self.max_thres, self.views = device, rank, world, max_thres, views
+        # r05: the reference draws max_thres anew on EVERY step (distillation.py:303 torch.rand(1).clamp(0, .99)), so the
+        # sampler's schedule -- and the UNet time table built from it -- changes every step.  `thres_range` = (lo, hi): this step's
+        # max_thres is drawn uniformly from it on a seeded HOST generator (identical on every rank); None = the fixed `max_thres`.
+        self.thres_range, self.thres_gen = thres_range, torch.Generator().manual_seed(seed + 4242)
+        self.evals_run = 0                                        # UNet evals of the steps so far (counted on the host from the schedule)
         torch.manual_seed(seed)                                   # identical replicas on every rank
         self.opt = get_default_torch_ngp_opt()
         ngp = NeRFNetwork(self.opt)
@@ -182,11 +188,19 @@ class HotPath:
             torch.cuda.synchronize()
             self.coll_us["all_reduce_grads"].append((time.perf_counter() - t0) * 1e6)
 
-    def after_step(self):
+    def verify_replicas(self):
+        """all ranks hold bit-identical NGP parameters?  Two small collectives and a host sync: called ONCE, after the timed region
+        (r04 ran it inside every timed step)."""
         if self.check_replicas and self.world > 1:
             from sparsefusion_amd.distributed import replicas_identical
             self.replicas_ok = replicas_identical(self.ngp)
             assert self.replicas_ok, "NGP replicas diverged"
+
+    def draw_max_thres(self):
+        if self.thres_range is None:
+            return self.max_thres
+        lo, hi = self.thres_range
+        return lo + (hi - lo) * float(torch.rand(1, generator=self.thres_gen))
 
     def step(self):
         # A: input view
@@ -214,15 +228,17 @@ class HotPath:
             if self.world > 1 and self.time_collectives:
                 torch.cuda.synchronize()
                 self.coll_us["all_gather_latents"].append((time.perf_counter() - t0) * 1e6)
+            mt = self.draw_max_thres()
+            n_steps = 50 if mt >= .99 else min(int(mt * 100), 50)
+            self.evals_run += n_steps + 1 if n_steps else 0
             pred_x0, x_noisy, noise, acp = self.plms.sample(latents, cond_images=self.features, use_tqdm=False,
-                                                            return_noise=True, max_thres=self.max_thres)
+                                                            return_noise=True, max_thres=mt)
             pred_img = ((self.vae.decode(pred_x0 / self.z_scale) + 1) * 0.5).clip(0.0, 1.0)   # distillation.py:309
         loss = fusion_loss(img256, sil256, pred_img, 1 - acp, 1e-3, 1e-3)       # (1 - a_bar) * L1 + opacity + entropy (:310-343)
         loss = loss + self.percep(img256, pred_img, normalize=True).mean() * self.lambda_percep          # :312-314
         loss.backward()
         self.sync_grads()
         self.optim.step()
-        self.after_step()
 
 
 def time_region(fn, iters):
@@ -449,7 +465,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--max-thres", type=float, default=0.5)
+    ap.add_argument("--max-thres", type=float, default=None,
+                    help="fixed max_thres of every step's PLMS call (the r01-r04 lines: 0.5).  Default (r05): drawn anew on every step, uniformly "
+                         "in [0.5, 0.99) -- always the full 50 steps = 51 UNet evals, the upper end of what the reference's own draw "
+                         "(distillation.py:303, U[0, .99)) produces, and a fresh schedule / UNet time table per step as in the reference")
     ap.add_argument("--views-per-gpu", type=int, default=1, help="novel views distilled per GPU and step (BASELINE config 4: 4)")
     ap.add_argument("--total-views", type=int, default=0,
                     help="strong scaling: this many novel views per step in total, block-sharded over the ranks (overrides --views-per-gpu)")
@@ -467,6 +486,9 @@ def main():
         args.views_per_gpu = 4
     if args.config == 4:
         args.max_thres = 0.999                                   # plms.py:60-66: the full trajectory, 50 steps = 51 UNet evals
+    thres_range = (0.5, 0.99) if args.max_thres is None else None
+    if args.max_thres is None:
+        args.max_thres = 0.5                                     # (the value the eval count below is derived from; every draw gives 50 steps)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -502,7 +524,7 @@ def main():
         args.views_per_gpu = len(shard_views(args.total_views, rank, world))
     n_in = 6 if args.config == 2 else 2
     hp = HotPath(dev, rank, world, args.max_thres, args.views_per_gpu, n_input_views=n_in, eft_features=args.config == 2,
-                 unet_operand="f16" if args.config == 4 else None)
+                 unet_operand="f16" if args.config == 4 else None, thres_range=thres_range)
     hp.check_replicas = (world > 1 or args.check_replicas) and not args.no_check_replicas
     for _ in range(args.warmup):
         hp.step()
@@ -521,6 +543,31 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
     ms_per_step = float(dt) / args.steps * 1e3
+    hp.verify_replicas()                                            # once, OUTSIDE the timed region
+    total32 = None
+    if args.config == 1 and args.views_per_gpu == 1 and not strong and not args.no_also_measured and 32 % world == 0:
+        # BASELINE configs[3] as the strong-scaling experiment it names ("32 novel views per step sharded 4/GPU ... >= 3.5x at 8 GPUs"):
+        # 32 novel views per step in total, block-sharded over the ranks (demo.py:59 is the replica split this replaces), at EVERY N --
+        # the N = 1 line carries 32 views on one GPU, so value(N) / value(1) of this object is the strong-scaling ratio from driver
+        # records alone.  1 warm-up + 2 timed steps behind the headline's timed region, barrier + max over ranks like the headline.
+        hp.set_views(32 // world)
+        hp._sctx = None
+        hp.step()
+        barrier()
+        t0 = time.time()
+        for _ in range(2):
+            hp.step()
+        barrier()
+        dt32 = torch.tensor([time.time() - t0], device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(dt32, op=torch.distributed.ReduceOp.MAX)
+        ms32 = float(dt32) / 2 * 1e3
+        total32 = {"workload": "BASELINE configs[3]: 32 novel views per step in total, block-sharded %d per GPU over %d GPU(s) (UNet at B = %d), "
+                               "latents all-gathered, NGP gradients all-reduced" % (32 // world, world, 32 // world),
+                   "scaling": "strong", "total_views": 32, "views_per_gpu": 32 // world, "n_gpus": world, "steps": 2, "warmup": 1,
+                   "ms_per_step": round(ms32, 3), "value": round(32 / (ms32 * 1e-3), 3), "unit": "views/s"}
+        hp.set_views(1)
+        hp._sctx = None
     multi = None
     if world > 1:                                                   # after the timed region: what the collectives cost, on every rank
         import torch.distributed as dist
@@ -533,6 +580,7 @@ def main():
                  "all_gather_latents_us": med(hp.coll_us["all_gather_latents"]), "all_reduce_grads_us": med(hp.coll_us["all_reduce_grads"]),
                  "all_reduce_bytes": int(hp.grads.flat.numel() * hp.grads.flat.element_size()), "collectives_per_step": {"all_gather": 1, "all_reduce": 2},
                  "replicas_identical": bool(getattr(hp, "replicas_ok", None)) if hp.check_replicas else None,
+                 "replicas_check": "once after the timed region (r04: inside every timed step)",
                  "timing_note": "host wall time between device synchronisations around each collective, median over 2 extra steps after the timed region"}
 
     if rank == 0:
@@ -552,7 +600,9 @@ def main():
                                    ", 256^2 hydrant-like synthetic scene, %d input views, " % n_in +
                                    "32x32 latent UNet (400.68M params, B=%d per GPU) + NGP render 128x128 rays x (64+64) samples; "
                                    "SD-VAE encode 256^2 -> 32x32x4 and decode back (83.65M params) and LPIPS-VGG16 fwd+bwd at 256^2 every step; "
-                                   "max_thres=%.2f" % (args.views_per_gpu, args.max_thres),
+                                   "%s" % (args.views_per_gpu, "max_thres drawn per step in [0.50, 0.99) (50 PLMS steps every step; a new schedule and "
+                                                                "UNet time table per step, as distillation.py:303 causes)" if thres_range
+                                           else "max_thres=%.2f fixed" % args.max_thres),
                        "views_per_gpu": args.views_per_gpu, "unet_evals_per_step": n_evals, "rays_per_render": 16384,
                        "parallelism": "view-sharded replicas x%d, RCCL all-gather(latents) + all-reduce(NGP grads)" % world},
         }
@@ -589,6 +639,16 @@ def main():
             res["roofline"]["traffic"], res["roofline"]["traffic_note"] = measure_fconv_traffic()
             if res["roofline"]["traffic"]:
                 res["roofline"]["traffic_over_algorithmic"] = round(res["roofline"]["traffic"] / res["roofline"]["algorithmic_bytes_per_launch"], 3)
+        we = res["roofline"]["whole_eval"]
+        # the eval as the sampler pays it, at top level (r04 review): against the conv / linear weights the replayed body streams
+        # (the time-MLP / time-token weights are hoisted into Unet.time_table once per schedule) and
+        # against SURVEY 8(d)'s own figure, 400.68 M parameters x 2 B
+        res["roofline"]["frac_whole_eval"] = we["frac"]
+        res["roofline"]["frac_whole_eval_survey_8d_bytes"] = round(801.4e6 / (we["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        res["roofline"]["whole_eval_note"] = ("whole_eval.ms = one hipGraph replay of the %d-op eval body (what each of the sampler's evals costs); "
+                                              "frac_whole_eval = whole_eval.weight_bytes (%.1f MB streamed by the body; the time-path weights are read once per "
+                                              "schedule by Unet.time_table, not per eval) / ms / 8 TB/s; frac_whole_eval_survey_8d_bytes uses SURVEY 8(d)'s "
+                                              "801.4 MB (all 400.68 M parameters)" % (we["ops"], we["weight_bytes"] / 1e6))
         res["roofline_mfma"] = lds_conv_roofline(hp)
         if world == 1 and args.config == 1 and args.views_per_gpu == 1 and not strong and not args.no_also_measured:
             # the per-GPU regime of BASELINE configs[3] (4 novel views per GPU: the UNet at B = 4), on this GPU, in this run:
@@ -612,6 +672,24 @@ def main():
                 "roofline": {k: rf4[k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us", "algorithmic_bytes_per_eval")},
                 "roofline_mfma_same_kernels": rf4["mfma"]}}
             hp.set_views(1)
+            hp._sctx = None
+            # the reference's own draw (distillation.py:303: max_thres ~ U[0, .99) -> min(int(100 max_thres), 50) PLMS steps, 37.6 on
+            # average): 8 steps on the same seeded generator
+            keep_range, e0 = hp.thres_range, hp.evals_run
+            hp.thres_range = (0.0, 0.99)
+            hp.step()
+            torch.cuda.synchronize()
+            e0, t0 = hp.evals_run, time.time()
+            for _ in range(8):
+                hp.step()
+            torch.cuda.synchronize()
+            msr = (time.time() - t0) / 8 * 1e3
+            res["also_measured"]["reference_max_thres_draw"] = {
+                "workload": "configs[1] with the reference's per-step draw max_thres ~ U[0, .99) (distillation.py:303)", "steps": 8, "warmup": 1,
+                "ms_per_step": round(msr, 3), "value": round(1 / (msr * 1e-3), 3), "unit": "views/s", "unet_evals_per_step_mean": round((hp.evals_run - e0) / 8, 2)}
+            hp.thres_range = keep_range
+        if total32 is not None:
+            res.setdefault("also_measured", {})["config3_total32"] = total32
         if multi is not None:
             res["multi_gpu"] = multi
         if world == 1 and not args.no_cpu_baseline:

@@ -204,8 +204,10 @@ int sf_ngp_render_backward(const sf_ngp_field* f, const sf_ngp_field_grad* g,
                            float* workspace, uint64_t workspace_bytes,
                            void* stream);
 
-/* workspace of the backward (also enough for the forward): composite / field gradients per sample plus, since r04, the bins of the
- * table-gradient scatter (csrc/ngp_scatter_bin.h: 20-byte entries of one ray chunk, ~0.7 GB at 128 x 128 rays x 64 + 64 samples). */
+/* workspace of the backward (also enough for the forward): composite / field gradients per sample (72 N T floats) plus, since r04,
+ * the bins of the table-gradient scatter (csrc/ngp_scatter_bin.h): 16-byte entries, 96 per sample of ONE ray chunk -- chunks hold at
+ * most 8192 rays for any N (r05: unequal chunks where N has no equal split), i.e. <= 1.6 GB of bins at T = 64 whatever N is
+ * (128 x 128 rays x 64 + 64 samples: 1.6 GB of bins + 0.3 GB of per-sample gradients). */
 uint64_t sf_ngp_render_workspace_bytes(uint32_t N, uint32_t T);
 /* workspace of the forward alone (10 * N * T floats): what an evaluation render needs */
 uint64_t sf_ngp_render_forward_workspace_bytes(uint32_t N, uint32_t T);

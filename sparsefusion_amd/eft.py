@@ -250,7 +250,8 @@ class EpipolarFeatureTransformer(nn.Module):
         return {'model': 'patch_nerf', 'conv_dims': self.conv_dims, 'encoder': self.encoder}
 
     def invalidate(self):
-        self.linear_twin = True             # r04: transformer linears read operand-type twins their producers leave (False: fp32 reads; tests compare)
+        """drop everything derived from the parameters (packed weights, plans, the encoded input views); configuration switches
+        such as `linear_twin` are NOT touched (r04 reset it here: an A/B that set it before .to() / load_state_dict compared twin with twin)"""
         self._pack_cache, self._plans, self._enc = None, {}, None
 
     def load_state_dict(self, *a, **k):

@@ -633,6 +633,8 @@ class _Plan:
                 and self.pipe_lds_bytes(H, cout, g2[0], g2[1], g2[2], pool=True) <= LDS_MAX):      # else: the k_gca_pool plan below
             # r03: the softmax pooling of the GlobalContext rides in conv2's epilogue (k_conv_fused_pipe<.., POOL>: context logits
             # from the conv's own staged input through w_eff, one pooled fragment per 16 pixels) -> net0 -> gate: 2 launches
+            if late_rc:                                           # (unreachable today: late_rc needs H == 4 = GN_SELF, pipe_ok needs GN_SLOTS;
+                emit_rc()                                         #  a planner change must not leave `res = rc` unwritten)
             pbuf = self.f32(rows // 16, cout + 2)                 # [M/16][cout] pooled fragments, then [M/16][2] (max, sum of exp)
             self.fconv(h, None, H, w2, b2, h2, cout, 3, norm, g2, gname=gn2, ss_ptr=ss_ptr, pool=(self.wptr(f"{name}.__weff__"), pbuf.ptr))
             self.gca_fused(name, h2, cout, res, out, None, 0, slots, pooled=(pbuf.ptr, pbuf.ptr + rows // 16 * cout * 4, HW // 16))
@@ -796,7 +798,9 @@ class _Plan:
             kp = qkv.ptr + inner * 4                           # one shared k/v head right of the 8 query heads
             segs += [(nk, nk + dh * 4, 1, 0, 0, 0), (kp, kp + dh * 4, 16, nq, 16 * nq, 0)]
         o = self.zf32(rows, d, 16)
-        if getattr(self.u, "attn_in_out_proj", True) and heads == 8 and dh == 64 and all(sg[2] <= (4 if sg[5] else 24) for sg in segs):
+        # (the guard mirrors fused_host.h: the TOTAL number of keys, <= 4 if any segment keeps its own k / v per head, else <= 24)
+        nkeys, per_head = sum(sg[2] for sg in segs), any(sg[5] for sg in segs if sg[2])
+        if getattr(self.u, "attn_in_out_proj", True) and heads == 8 and dh == 64 and len(segs) <= 3 and 1 <= nkeys <= (4 if per_head else 24):
             # r04: the attention core runs in the prologue of its output projection (k_conv_fused<.., FNORM_ATTN>: wave = head, the 64
             # workgroups each redo the 16-token core -- 0.3 MFLOP -- instead of one more dependent launch)
             qv = _T(qkv.ptr, rows, inner, 16)
@@ -998,12 +1002,16 @@ class _Plan:
                 x = y
         x = self.resnet("final_res_block", x, None, u.dim, H, gca=True)
         self.out = self.f32(B, u.channels * HW)
-        o = _T(self.out.ptr, B * HW, u.channels, HW)
-        self.conv(x, True, R, R, "final_conv.weight", "final_conv.bias", o, u.channels, 0, u.channels, 3, 1, 1,
-                  nchw=getattr(u, "producer_slots", True))
-        if not self.last_conv_nchw:                                  # the conv was not split-K (or the switch is off): rows, then unpack
+        # the split-K reduction of the final conv writes the NCHW output itself when the conv IS split-K; decided BEFORE emitting (r04
+        # emitted, looked at the result and popped the op again, which left the first attempt's workspace reservation, `written`
+        # entry and a possible reduce op of the workspace's previous owner in the plan)
+        _, _, fgroups = u.conv_tiling((B * HW + 15) // 16, (u.channels + 15) // 16, 9 * (x.C // 32), False)
+        if getattr(u, "producer_slots", True) and fgroups > 1 and (u.channels + 15) // 16 < 4:      # (n_frags < 4: never the LDS-tiled kernel)
+            o = _T(self.out.ptr, B * HW, u.channels, HW)
+            self.conv(x, True, R, R, "final_conv.weight", "final_conv.bias", o, u.channels, 0, u.channels, 3, 1, 1, nchw=True)
+            assert self.last_conv_nchw, "final conv: the split-K reduction was expected to write NCHW"
+        else:                                                        # rows, then unpack
             o = self.zf32(B * HW, u.channels, HW)
-            self.ops.pop()
             self.conv(x, True, R, R, "final_conv.weight", "final_conv.bias", o, u.channels, 0, u.channels, 3, 1, 1)
             self.op(OP_ELTWISE, 3, p=(o.ptr, 0, 0, self.out.ptr), i=(B, HW, u.channels, u.channels))
         # r04: the sampler's init conv (k_init_x) leaves the statistics slots of x0 itself.  The full plan's k_slots pass over x0 --
@@ -1401,14 +1409,20 @@ class Unet(nn.Module):
         time tokens of every attention that sees them (external/imagen_pytorch.py:1514-1604) -- everything that depends on
         the time alone.  One call per sampler trajectory replaces ~14 launches and a 72 MB weight read in each eval.
         `key` (hashable, e.g. the tuple of the trajectory's times): the table is a function of the weights and the times only, so a
-        sampler that runs the same schedule again (every distillation step does) gets the SAME tensor back -- read-only by contract --
-        until the parameters change (invalidate(): load_state_dict / .to() / .half()); r04: -0.35 ms per distillation step."""
+        caller that runs the SAME schedule again gets the same tensor back -- read-only by contract -- until the parameters change
+        (invalidate(): load_state_dict / .to() / .half()).  Who profits: samplers driven with a fixed `max_thres` (evaluation
+        sweeps, the r01-r04 bench lines: -0.35 ms per call).  The reference's distillation loop does NOT: it draws `max_thres`
+        anew on every step (sparsefusion/distillation.py:303) and the times are linspace(max_thres, 0, n + 1), so its key differs
+        on essentially every step and every table is built (r05: bench.py draws per step for that reason).  The cache therefore
+        holds the TWO most recent schedules only (T x tb_stride floats each), not eight dead tables."""
         _lib.require_cuda(log_snrs)
         ck = None
         if key is not None:
             ck = (key, str(log_snrs.device), self.operand)
             hit = self.__dict__.get("_table_cache", {}).get(ck)
             if hit is not None:
+                cache = self.__dict__["_table_cache"]
+                cache[ck] = cache.pop(ck)                                   # most recently used last
                 return hit
         T = log_snrs.numel()
         plan = self._time_plan(T, log_snrs.device)
@@ -1417,7 +1431,7 @@ class Unet(nn.Module):
         table = plan.table_view.clone()
         if ck is not None:
             cache = self.__dict__.setdefault("_table_cache", {})
-            if len(cache) >= 8:
+            while len(cache) >= 2:
                 cache.pop(next(iter(cache)))
             cache[ck] = table
         return table

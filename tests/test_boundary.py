@@ -84,3 +84,18 @@ def test_ngp_state_dict_keys():
     assert set(net.state_dict().keys()) == want
     groups = net.get_params(5e-4)
     assert groups[0]["lr"] == pytest.approx(5e-3) and groups[1]["lr"] == pytest.approx(5e-4)
+
+
+def test_render_backward_workspace_is_bounded_for_any_ray_count():
+    """r05: the bins of the table-gradient scatter are sized by the largest ray chunk of the backward, and a ray count
+    without an equal split (200^2 = 40 000, 65 535) used to make ONE chunk of all rays (7.9 GB / 13 GB of bins).  Chunks now hold at
+    most 8192 rays for any N (host-side arithmetic of the C ABI: no GPU needed)."""
+    from sparsefusion_amd import _lib
+    lib = _lib.lib()
+    T = 64
+    per_sample = 72 * T * 4                                            # composite / field gradients: 72 N T floats
+    bins_8192 = 8192 * 2 * T * 4 * 24 * 16                             # 96 sixteen-byte entries per sample of one 8192-ray chunk
+    for N in (16384, 40000, 65535, 10000, 8192 * 3 + 1):
+        wb = lib.sf_ngp_render_workspace_bytes(N, T)
+        assert wb <= N * per_sample + bins_8192 + (1 << 21), (N, wb)
+    assert lib.sf_ngp_render_workspace_bytes(256, T) < 256 * per_sample + 256 * 2 * T * 4 * 24 * 16 + (1 << 21)

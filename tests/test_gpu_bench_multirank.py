@@ -45,6 +45,12 @@ def test_bench_spawns_its_own_ranks():
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["n_gpus"] == 2 and res["scaling"] == "weak" and res["multi_gpu"]["world_size_seen"] == 2
     assert res["multi_gpu"]["replicas_identical"] is True and res["value"] > 0
+    # r05: the N > 1 line also carries BASELINE configs[3] as the strong-scaling experiment it names -- 32 novel views per step in
+    # total, block-sharded over the ranks (16 per rank here) -- next to the weak-scaling headline
+    t32 = res["also_measured"]["config3_total32"]
+    assert t32["scaling"] == "strong" and t32["total_views"] == 32 and t32["views_per_gpu"] == 16 and t32["n_gpus"] == 2
+    assert t32["value"] > 0 and abs(t32["value"] - 32 / (t32["ms_per_step"] * 1e-3)) < 1e-2 * t32["value"]
+    assert "once after the timed region" in res["multi_gpu"]["replicas_check"]
 
 
 def test_config2_eft_feature_render_in_the_step():
@@ -79,3 +85,20 @@ def test_default_line_carries_the_b4_regime():
     assert res["config"]["views_per_gpu"] == 1 and res["roofline"]["batch"] == 1
     rf = res["roofline"]                # the counter pass of the default line: measured HBM fetch per fused-conv launch, or null with a reason
     assert (rf["traffic"] is None and rf["traffic_note"]) or (rf["traffic"] > 1e6 and 0.5 < rf["traffic_over_algorithmic"] < 10)
+    # r05: the whole-eval fraction at top level (against the streamed bytes and against SURVEY 8(d)'s 801.4 MB), the 32-views-on-one-GPU
+    # baseline of the strong-scaling experiment, and a run with the reference's own max_thres draw
+    assert 0 < rf["frac_whole_eval"] < rf["frac_whole_eval_survey_8d_bytes"] < 1 and rf["whole_eval"]["ms"] > 0
+    t32 = res["also_measured"]["config3_total32"]
+    assert t32["n_gpus"] == 1 and t32["views_per_gpu"] == 32 and t32["value"] > 0
+    rd = res["also_measured"]["reference_max_thres_draw"]
+    assert rd["ms_per_step"] > 0 and 20 <= rd["unet_evals_per_step_mean"] <= 51
+
+
+def test_default_max_thres_is_drawn_per_step():
+    """r05: without --max-thres every step draws its own max_thres in [0.5, 0.99) (a new schedule and UNet time table
+    per step, as distillation.py:303 causes; always 50 PLMS steps = 51 evals)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-traffic", "--no-also-measured"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert "drawn per step" in res["config"]["workload"] and res["config"]["unet_evals_per_step"] == 51 and res["value"] > 0

@@ -224,10 +224,17 @@ def test_time_table_is_cached_per_schedule_until_the_weights_change():
     c1 = net.begin_sampling(cond.to(DEV), ls.to(DEV), table_key=("k", 2))
     c2 = net.begin_sampling(cond.to(DEV), ls.to(DEV), table_key=("k", 2))         # (c1 is stale now: one trajectory per plan)
     assert c1["table"] is c2["table"] and fresh is not c1["table"] and torch.equal(fresh, c1["table"])
+    # r05: a loop that draws a new schedule every step (the reference's distillation loop, distillation.py:303) never hits: the
+    # cache keeps the two most recent schedules only
+    for j in range(5):
+        net.begin_sampling(cond.to(DEV), ls.to(DEV), table_key=("other", j))
+    assert len(net._table_cache) == 2 and all(k[0][0] == "other" for k in net._table_cache)
+    c2 = net.begin_sampling(cond.to(DEV), ls.to(DEV), table_key=("k", 2))
+    assert torch.equal(c2["table"], fresh)
     y = net.eval_prepared(c2, x.to(DEV), 1).clone()
     net.load_state_dict(state(name, seed=1), strict=True)              # other weights: the cached table must not survive
     c3 = net.begin_sampling(cond.to(DEV), ls.to(DEV), table_key=("k", 2))
-    assert c3["table"] is not c1["table"] and not torch.equal(c3["table"], c1["table"])
+    assert c3["table"] is not c2["table"] and not torch.equal(c3["table"], fresh)
     assert not torch.equal(net.eval_prepared(c3, x.to(DEV), 1), y)
 
 
