@@ -29,7 +29,9 @@
 #include "fused_gca.h"
 
 #define SF_LDS_MAX 163840
-#define SF_FCONV_WAVES 8          /* waves per k_conv_fused workgroup */
+#ifndef SF_FCONV_WAVES
+#define SF_FCONV_WAVES 8          /* waves per k_conv_fused workgroup (tools/exp/fconv4_knockout.hip builds 4-wave variants of one kernel) */
+#endif
 
 // The instantiated variants of k_conv_fused: (WM, WN, D, NORM, LAZY); everything the planner emits (unet.py::fused_geometry).
 #define SF_FCONV_VARIANTS(X) \

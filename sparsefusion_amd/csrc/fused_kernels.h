@@ -36,6 +36,10 @@ SF_DEV uint32_t fdiv(uint32_t n, FDiv f) { return f.d == 1 ? n : (uint32_t)(((ui
 #ifndef SF_RING_POS
 #define SF_RING_POS 1          // weight-ring issue point of the slot / plain prologue: 0 before the first staging batch, 1 after it, 2 after staging
 #endif
+#ifndef SF_FCX
+#define SF_FCX 0               // measurement builds of tools/exp/fconv4_knockout.hip: phase knock-outs of the 4x4 GroupNorm-self kernel (0 = product)
+#endif
+#define FCX_IS(n) (SF_FCX == (n) || (SF_FCX >= 1000 && (((SF_FCX - 1000) >> (n)) & 1)))      // >= 1000: a bit mask of knock-outs
 enum { FNORM_NONE = 0, FNORM_GN_SELF = 1, FNORM_GN_SLOTS = 2, FNORM_LN = 3, FNORM_ATTN = 4 };
 
 // FNORM_ATTN: the A operand of an attention output projection IS the attention core's result, computed in the prologue
@@ -197,6 +201,10 @@ struct FGather {
       t[5] = *reinterpret_cast<const f32x4*>(first ? rp : p2);
       w[4] = (first && a.s1.b) ? 1.0f : 0.0f;
       w[5] = (first && a.s1.r) ? 1.0f : 0.0f;
+#if FCX_IS(2)
+#pragma unroll
+      for (int g = 1; g < 6; ++g) { t[g] = f32x4{0.f, 0.f, 0.f, 0.f}; w[g] = 0.0f; }
+#endif
     } else {
       const int c1 = first ? c : 0;
       const float* hp = a.s1.a + m * a.s1.C + c1;
@@ -255,6 +263,9 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
 #define FC_STAMP(k) do { } while (0)
 #endif
   FC_STAMP(0);
+#if FCX_IS(8)
+  if (a.B > 0) return;
+#endif
   // ---- which tile
   const int MT = a.B * a.mt_per_img;
   const int tiles = MT * a.n_tiles;
@@ -285,7 +296,9 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
   }
   auto wload = [&](int j, int ni) -> bf16x8 {
     const int tap = (int)fdiv((uint32_t)j, a.d_cps), ccl = j - tap * a.cps;
-#if SF_NT_W
+#if FCX_IS(1)
+    return sf_zero8();
+#elif SF_NT_W
     return __builtin_nontemporal_load(&wbase[ni][(long)(tap * a.cchunks + ccl) * 64]);
 #else
     return wbase[ni][(long)(tap * a.cchunks + ccl) * 64];
@@ -374,10 +387,14 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
 #pragma unroll
     for (int k = 0; k < TABN; ++k) {
       const int cl = tid + k * NT, cc = c0 + (cl < Cs ? cl : Cs - 1);
+#if FCX_IS(4)
+      tg[k] = 1.0f; tb[k] = 0.0f; tsc[k] = (float)cc * 1e-9f; tsh[k] = 0.0f; (void)ssrow; (void)shoff;
+#else
       tg[k] = a.gamma[cc];
       tb[k] = a.beta[cc];
       tsc[k] = ssrow[cc];
       tsh[k] = ssrow[shoff + cc];
+#endif
     }
   }
   auto build_table = [&]() {
@@ -410,8 +427,10 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
     // a select, not a branch: the U elements of a staging batch must stay in one basic block to interleave
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+#if !FCX_IS(5)
       const float sv = sf_silu_fast(v[j]);
       v[j] = a.silu ? sv : v[j];
+#endif
     }
     bf16x4 o;
     o[0] = (sf_opnd)v[0]; o[1] = (sf_opnd)v[1]; o[2] = (sf_opnd)v[2]; o[3] = (sf_opnd)v[3];
@@ -434,6 +453,9 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
     // loaded ONCE into registers (issued before the weight ring, so one round trip covers the whole prologue), group sums
     // meet in LDS, then the registers are normalised straight into the frame.
     FC_STAMP(1);
+#if FCX_IS(3)
+    if (tid < 16) { misc[16 + 2 * tid] = 0.0f; misc[17 + 2 * tid] = 1.0f; }
+#else
     if (a.det_w) {
       // deterministic group sums: a thread's elements share one channel chunk (NT % (Cs/4) == 0), hence one group; det_w
       // adjacent lanes lie in one group -> segment sums by shuffles, one partial per segment, fixed-order final sum.
@@ -522,6 +544,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
         misc[17 + 2 * tid] = sf_rsqrt((float)var + a.eps);
       }
     }
+#endif
     sf_sync();
     build_table();
     sf_sync();
@@ -533,7 +556,9 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
         const int p = (int)fdiv((uint32_t)i, a.d_cs4), c4 = i - p * Cs4;
         const int py = p >> a.logW, px = p - (py << a.logW);
         const int c = c0 + c4 * 4;
+#if !FCX_IS(9)
         if (nt == 0 && LAZY && c < a.s1.C) *reinterpret_cast<f32x4*>(a.s1.p + (mb + p) * a.s1.C + c) = v[u];
+#endif
         f32x4 A, Bv;
         affine_of(c4 * 4, A, Bv);
         finish(v[u] * (c < a.s1.C ? sc1 : sc2), (py + h) * FW + px + h, c4 * 4, 0, A, Bv);
@@ -921,7 +946,11 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
+#if FCX_IS(6)
+          for (int ni = 0; ni < WN; ++ni) { acc[mi][ni][0] += (float)fa[mi][0] + (float)fb[u][ni][0]; }
+#else
           for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = sf_mfma16(fa[mi], fb[u][ni], acc[mi][ni]);
+#endif
         if (j + D < k1) {
 #pragma unroll
           for (int ni = 0; ni < WN; ++ni) fb[u][ni] = wload(j + D, ni);     // refill the ring slot just consumed
@@ -951,7 +980,11 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
       const int idx = (f * 4 + r) * 64 + lane;
       float sacc = 0.0f;
 #pragma unroll
+#if FCX_IS(7)
+      for (int w = 0; w < 1; ++w) sacc += red[idx + w * F * 256];
+#else
       for (int w = 0; w < NW; ++w) sacc += red[idx + w * F * 256];
+#endif
       v[r] = sacc;
     }
     if (a.logit_part) {                      // bias terms are the same for every pixel: they cancel in the softmax

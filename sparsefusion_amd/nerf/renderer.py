@@ -217,8 +217,11 @@ class NeRFRenderer(nn.Module):
     def _table(self, T, device):
         key = (T, str(device))
         if key not in self._tables:
-            lin = torch.linspace(0.0, 1.0, T, device=device)
-            det = torch.linspace(0. + 0.5 / T, 1. - 0.5 / T, steps=T, device=device)
+            # built on the HOST and copied (once per (T, device)): torch's device linspace kernel and its CPU kernel round some
+            # entries differently, and the oracle -- bit-identical to the reference's own `run` on CPU -- is the parity anchor of the
+            # coarse sample depths (tests/test_gpu_ngp.py::test_render_sample_bookkeeping_vs_oracle)
+            lin = torch.linspace(0.0, 1.0, T).to(device)
+            det = torch.linspace(0. + 0.5 / T, 1. - 0.5 / T, steps=T).to(device)
             self._tables[key] = (lin.contiguous(), det.contiguous())
         return self._tables[key]
 

@@ -419,7 +419,8 @@ def _forward_with_bookkeeping(net, p, o, d, uc, uf):
     lib = _lib.lib()
     f32 = dict(dtype=torch.float32, device=DEV)
     od, dd, aabb = o.to(DEV).contiguous(), d.to(DEV).contiguous(), p["aabb_train"].to(DEV).contiguous()
-    lin = torch.linspace(0.0, 1.0, T, **f32)
+    lin = net._table(T, torch.device(DEV))[0]                      # the table the renderer itself passes (host linspace, copied)
+    assert torch.equal(lin.cpu(), torch.linspace(0.0, 1.0, T))
     ucd, ufd = uc.to(DEV).contiguous(), uf.to(DEV).contiguous()
     nears, fars = torch.empty(N, **f32), torch.empty(N, **f32)
     z_s, sig_s, rgb_s = torch.empty(N, 2 * T, **f32), torch.empty(N, 2 * T, **f32), torch.empty(N, 2 * T, 3, **f32)
@@ -458,11 +459,15 @@ def test_render_sample_bookkeeping_vs_oracle(golden, case):
       * the sort: z_sorted is bit-exactly the ascending order of the HIP path's own cat([coarse, fine]) and the permutation the field
         cache keeps is the stable argsort of it (coarse before fine on ties = torch.sort of the concatenation where values are
         distinct); on every ray whose fine depths are bit-equal to the oracle's the permutation EQUALS the oracle's z_index;
-      * the T fine depths are NOT bit-exact and cannot be: they are an inverse-CDF draw whose cdf is a float sum of 62 weights, and
-        torch's CPU reduction order (vectorised cascade, ISA dependent) differs from the reference's CUDA order and from ours
-        (sequential in double); a last-place difference in the cdf is amplified by 1 / (cdf_hi - cdf_lo) (>= 1e-5).  Stated bound:
-        |dz| <= 2e-3 * (far - near) on every sample, >= 90 % of the fine depths bit-equal, and the number of samples that land in a
-        different cell of the FINEST grid level is reported and bounded (< 2 % of the fine samples)."""
+      * the T fine depths are NOT bit-exact and cannot be: they are an inverse-CDF draw whose pdf is weights / torch.sum(weights), and
+        torch's CPU float reduction order (a vectorised cascade, ISA dependent) differs from the reference's CUDA order and from ours
+        (sequential, in double, rounded once); a last-place difference of the total moves every cdf entry, and the interpolation
+        divides by cdf_hi - cdf_lo (>= 1e-5).  Measured on MI355X (r05): 21-24 % of the fine depths bit-equal, the rest a few units in
+        the last place away: max |dz| = 1.5e-6 / 7.6e-6 of (far - near) at 256 / 16 384 rays; 0.15 % / 0.13 % of the fine samples
+        land in a different cell of the FINEST grid level (24 of 16 320 / 1 318 of 1 048 576).  Stated bounds: |dz| <= 5e-5 * (far - near)
+        on every sample, fewer than 0.5 % finest-level cell changes.
+    (r05 found the coarse depths 1 ulp off on 19 % of the samples -- hipcc had fused the multiply-adds of the position arithmetic,
+    csrc/ngp_device.h SF_MUL / SF_ADD -- and the renderer's linspace table built by the device kernel; both fixed with this test.)"""
     g = golden["teacher"]
     p = params_from_cfg(g["cfg"])
     net = _net(p).train()
@@ -480,7 +485,9 @@ def test_render_sample_bookkeeping_vs_oracle(golden, case):
     # (1) per-ray bookkeeping and the coarse samples: bit-exact
     assert torch.equal(got["nears"], ref["nears"]) and torch.equal(got["fars"], ref["fars"])
     assert torch.equal(got["nears"] < got["fars"], live)
-    assert torch.equal(got["z_coarse"][live], ref["z_coarse"][live]), "coarse sample depths must be bit-exact"
+    zc_bad = got["z_coarse"][live] != ref["z_coarse"][live]
+    assert not bool(zc_bad.any()), ("coarse sample depths must be bit-exact", int(zc_bad.sum()),
+                                    float((got["z_coarse"][live] - ref["z_coarse"][live]).abs().max()))
     # (2) the sort of the HIP path's own samples: exact, stable
     cat = torch.cat([got["z_coarse"], got["z_fine"]], dim=1)
     want_sorted, want_perm = torch.sort(cat, dim=1, stable=True)
@@ -499,9 +506,9 @@ def test_render_sample_bookkeeping_vs_oracle(golden, case):
     flip_frac = flips.float().mean().item()
     print(f"\n[bookkeeping {case}] rays {N} live {int(live.sum())}: fine z bit-equal {100 * frac_equal:.2f} %, max |dz| / (far - near) "
           f"{worst:.2e}, finest-level cell flips {int(flips.sum())} of {flips.numel()} fine samples ({100 * flip_frac:.3f} %)")
-    assert frac_equal >= 0.90
-    assert worst <= 2e-3
-    assert flip_frac < 0.02
+    assert frac_equal >= 0.05            # (informational: a collapse to ~0 would mean a systematic difference, not rounding)
+    assert worst <= 5e-5
+    assert flip_frac < 0.005
     # (4) rays whose fine depths are all bit-equal: the permutation IS the oracle's z_index (torch.sort of the concatenation),
     # checked where the oracle's sorted depths are distinct (torch.sort is not stable by default)
     ray_same = same.all(dim=1)
@@ -511,6 +518,21 @@ def test_render_sample_bookkeeping_vs_oracle(golden, case):
     distinct[:, 1:] &= ref_sorted[live][:, 1:] != ref_sorted[live][:, :-1]
     distinct[:, :-1] &= ref_sorted[live][:, 1:] != ref_sorted[live][:, :-1]
     sel = ray_same[:, None] & distinct
-    assert int(ray_same.sum()) >= 0.3 * int(live.sum()), "too few rays with bit-equal fine depths to check the permutation on"
+    # (few rays qualify -- all 64 fine depths bit-equal --; the comparison is exact on those, and (2) above pins the sort itself on all)
+    print(f"[bookkeeping {case}] rays with all fine depths bit-equal: {int(ray_same.sum())}")
     assert torch.equal(got["perm"][live][sel], ref_index[live][sel])
     assert torch.equal(got["z_sorted"][live][ray_same], ref["z_sorted"][live][ray_same])
+    # every ray: the permutation restricted to the COARSE samples is the oracle's (their depths are bit-equal and ascending), and the
+    # rank of a fine sample among all samples differs from the oracle's only where two depths are closer than the fine-depth bound
+    rank_hip = torch.argsort(got["perm"][live], dim=1)           # rank_hip[n, j] = sorted position of sample j of cat([coarse, fine])
+    rank_ref = torch.argsort(ref_index[live], dim=1)
+    moved = rank_hip != rank_ref
+    zcat_ref = torch.cat([ref["z_coarse"], ref["z_fine"]], dim=1)[live]
+    gap = torch.full_like(zcat_ref, float("inf"))
+    srt = ref_sorted[live]
+    d = srt[:, 1:] - srt[:, :-1]
+    near_gap = torch.minimum(torch.cat([d, torch.full_like(d[:, :1], float("inf"))], 1), torch.cat([torch.full_like(d[:, :1], float("inf")), d], 1))
+    gap.scatter_(1, ref_index[live], near_gap)                   # distance of every sample to its nearest neighbour in depth (oracle)
+    print(f"[bookkeeping {case}] samples whose sorted position differs from the oracle's: {int(moved.sum())} of {moved.numel()}")
+    assert bool((gap[moved] <= 2 * 5e-5 * span.expand_as(gap)[moved]).all()), "a sample changed its sorted position without a near-tie in depth"
+    assert moved.float().mean().item() < 0.005
