@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
+#include <string>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -140,13 +141,24 @@ static double run(const char* tag, int nbuf, int pf_shift, bool prefetch, bool u
   return us;
 }
 
-int main() {
+// argv[1] (optional): run only this variant of the 72 KiB chain, once ("none" | "hot" | "noweights" | "same" | "shifted") -- the target of a
+// rocprofv3 --pmc FETCH_SIZE pass that calibrates the counter on this access pattern (known bytes: 256 x 72 KiB of nt dwordx4 weight loads).
+int main(int argc, char** argv) {
   const int NBUF = 16;                                           // 16 x 37.7 MB = 604 MB of distinct weights: beyond L2 + Infinity Cache
   const size_t wbytes = (size_t)NBUF * 256 * 144 * 1024;
   char* wbuf; float *x0, *x1;
   CK(hipMalloc(&wbuf, wbytes)); CK(hipMalloc(&x0, 4 * 16 * 1024 * 4)); CK(hipMalloc(&x1, 4 * 16 * 1024 * 4));
   CK(hipMemset(wbuf, 0, wbytes)); CK(hipMemset(x0, 0, 4 * 16 * 1024 * 4)); CK(hipMemset(x1, 0, 4 * 16 * 1024 * 4));
   hipStream_t st; CK(hipStreamCreate(&st));
+  if (argc > 1) {
+    const std::string v = argv[1];
+    if (v == "none") run<72>("none", NBUF, 0, false, true, wbuf, x0, x1, st);
+    else if (v == "hot") run<72>("hot", 1, 0, false, true, wbuf, x0, x1, st);
+    else if (v == "noweights") run<72>("noweights", NBUF, 0, false, false, wbuf, x0, x1, st);
+    else if (v == "same") run<72>("same", NBUF, 0, true, true, wbuf, x0, x1, st);
+    else if (v == "shifted") run<72>("shifted", NBUF, 1, true, true, wbuf, x0, x1, st);
+    return 0;
+  }
   for (int pass = 0; pass < 2; ++pass) {
     run<72>("none", NBUF, 0, false, true, wbuf, x0, x1, st);
     run<72>("same", NBUF, 0, true, true, wbuf, x0, x1, st);

@@ -29,10 +29,10 @@ sel = [k for k, o in enumerate(ops) if o.type == OP_FCONV and o.i[1] == 4 and o.
 print(f"B={B}: {len(ops)} body ops, {len(sel)} 4x4 GroupNorm-self launches (lazy {sum(1 for k in sel if ops[k].i[9] == 1)})", flush=True)
 
 
-def build(v, waves):
-    out = f"/tmp/fcx_{v}_{waves}.so"
+def build(v, waves, defs=()):
+    out = f"/tmp/fcx_{v}_{waves}_{abs(hash(tuple(defs))) % 100000}.so"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", f"-DSF_FCX={v}",
-                           f"-DSF_FCONV_WAVES={waves}",
+                           f"-DSF_FCONV_WAVES={waves}", *["-D" + d for d in defs],
                            "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "exp", "fconv4_knockout.hip"), "-o", out],
                           stderr=subprocess.DEVNULL)
     l = C.CDLL(out)
@@ -90,15 +90,23 @@ def run_alone(vlib):
             assert vlib.fcx_run(C.addressof(one[k]), st) == 0
 
 
+if os.environ.get("SF_FCX_PLAIN"):        # SF_FCX_PLAIN=<variant>: N plain (un-captured) evals with that variant, for a rocprofv3 counter pass
+    vs, *defs = os.environ["SF_FCX_PLAIN"].split(":")
+    vl = build(int(vs), 8, defs) if vs != "product" else None
+    for _ in range(int(os.environ.get("SF_FCX_EVALS", "3"))):
+        run_eval(vl)
+    torch.cuda.synchronize()
+    sys.exit(0)
 base_eval = time_graph(lambda: run_eval(None))
 base_alone = time_graph(lambda: run_alone(None))
 print(f"product library: eval {base_eval:8.1f} us   the {len(sel)} launches alone {base_alone:7.1f} us ({base_alone / len(sel):5.2f} each)", flush=True)
 names = {0: "product kernel (this TU)", 1: "no weight loads", 2: "one load per lazy element (not six)", 3: "no statistics", 4: "no gamma/beta/scale-shift loads",
          5: "no SiLU", 6: "no MFMA", 7: "no cross-wave sum", 8: "empty body", 9: "no lazy materialisation"}
 for vs in variants:
+    vs, *defs = vs.split(":")                                   # "<n>[w<waves>][:MACRO=value ...]"
     v, waves = (int(vs.split("w")[0]), int(vs.split("w")[1])) if "w" in vs else (int(vs), 8)
-    vl = build(v, waves)
+    vl = build(v, waves, defs)
     te, ta = time_graph(lambda: run_eval(vl)), time_graph(lambda: run_alone(vl))
     nm = names.get(v, "mask " + ",".join(str(b) for b in range(16) if (v - 1000) >> b & 1) if v >= 1000 else str(v))
-    nm += "" if waves == 8 else f" [{waves} waves]"
-    print(f"variant {v:5d} {nm:40s} eval {te:8.1f} us ({(te - base_eval) / len(sel):+6.2f} per launch)   alone {ta:7.1f} us ({ta / len(sel):5.2f} each)", flush=True)
+    nm += ("" if waves == 8 else f" [{waves} waves]") + (" " + " ".join(defs) if defs else "")
+    print(f"variant {v:5d} {nm:64s} eval {te:8.1f} us ({(te - base_eval) / len(sel):+6.2f} per launch)   alone {ta:7.1f} us ({ta / len(sel):5.2f} each)", flush=True)
