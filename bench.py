@@ -4,7 +4,8 @@
 One "step" = one pass of the north-star hot path for one novel view per GPU, synthetic 2-view scene:
   A  input-view NGP render (128x128 rays, 64+64 samples) fwd + bwd + Adam           distillation.py:185-247
   B  novel-view NGP render fwd -> x2 bilinear -> SD-VAE encode(.).mode() * z_scale -> PLMSSampler.sample(
-     max_thres=0.5: 50 steps = 51 UNet evals at 32x32 latents, 256-ch view features) -> SD-VAE decode ->
+     max_thres drawn per step in [0.5, 0.99) (r05; `--max-thres 0.5` = the fixed schedule of the r01-r04 lines): 50 steps = 51 UNet evals
+     at 32x32 latents, 256-ch view features) -> SD-VAE decode ->
      (1-alpha_bar)*L1 + 1e-3*opacity + 1e-3*entropy -> bwd + Adam                    distillation.py:262-352
      + 0.1 * LPIPS-VGG(render, decoded)  (lambda_percep of itr > 1000, distillation.py:176-178,312-314)
 Everything runs on this repo's HIP path: NGP render, UNet/PLMS, the SD-VAE and the LPIPS
@@ -22,8 +23,11 @@ measurement of that regime (`also_measured.config3_B4`: 1 + 3 steps at 4 views o
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
 N > 1 runs one rank per GPU over RCCL -- under torch.distributed.run (RANK / WORLD_SIZE in the environment), or spawned by
 bench.py itself when it is started plainly (it re-execs under torch.distributed.run): every rank distils its own novel
-view (weak scaling); the ranks all-gather the rendered latents and all-reduce (mean) the NGP gradients
-before each optimiser step so the replicas stay identical."""
+view (weak scaling: the headline); the ranks all-gather the rendered latents and all-reduce (mean) the NGP gradients
+before each optimiser step so the replicas stay identical; that they are is checked once, after the timed region.
+Every line (N = 1 included) also carries `also_measured.config3_total32`: BASELINE configs[3] as the strong-scaling experiment it
+names -- 32 novel views per step in total, block-sharded over the ranks (4 per GPU at N = 8) -- so that value(N) / value(1) of
+that object is the ">= 3.5x at 8 GPUs" figure."""
 import argparse
 import json
 import os

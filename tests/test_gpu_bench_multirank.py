@@ -1,6 +1,6 @@
 """Dry run of the multi-rank path of bench.py on ONE GPU: two ranks share cuda:0, the collectives go through gloo
 (SF_BENCH_BACKEND=gloo) -- exercises view sharding (--total-views, strong scaling), the latent all-gather, the in-place
-all-reduce of the flat NGP gradient buffer, the per-step replica check and the max-over-ranks timing / JSON line.
+all-reduce of the flat NGP gradient buffer, the replica check (once, after the timed region) and the max-over-ranks timing / JSON line.
 RCCL itself only runs on the driver's multi-GPU node."""
 import json
 import os
