@@ -1,0 +1,171 @@
+// k_conv4_gn: the GroupNorm-self 3x3 conv of the UNet's 4x4 level (external/imagen_pytorch.py:641-662 at 16 pixels), the same op,
+// operands and LDS layout as k_conv_fused<1, 1, 12, FNORM_GN_SELF, LAZY, 8> (fused_kernels.h) for the one geometry every such layer
+// of the plans has: H = W = 4, k = 3, a 16-pixel x 16-channel tile, S > 1 input-channel slices of TWO whole groups each
+// (Cs = 256 | 512), split-K slabs out.  r05.
+//
+// Why a second kernel for one geometry.  A graph chain that imitates this launch -- 64 KB lazy slice, statistics, SiLU, LDS frame, 72 KB
+// weight slab requested at entry, LDS reduction -- costs 6.9 us per launch on MI355X (tools/exp/weight_prefetch_chain.hip: boundary
+// 2.05 + issue 0.5 + weight flight at 6.5 TB/s 2.9 + tail 1.5); the general kernel costs 11.3, and no reordering INSIDE it moved that by
+// more than 0.5 us (profiles/r05_fconv4_order_lean_ab.log): its prologue is one source for every norm / lazy / tile / slice shape, with
+// run-time selected paths -- and where two paths define the destination registers of loads in flight hipcc drains vmcnt(0) at the merge
+// (seen in the ISA).  Here everything that shapes the instruction stream is a template parameter:
+//   * every load of the launch is requested in the first ~100 instructions, in the order it is needed: the thread's 2 | 4 lazy elements
+//     (its channel chunk is fixed: c4 = tid % CS4), the four float4 of ITS affine operands (gamma, beta, scale, shift: no LDS table),
+//     then its whole share of the weight slice (9 | 18 k-steps: no ring refill);
+//   * ONE barrier between the gather and the frame: segment sums by half-wave / wave shuffles, one partial per segment, and every
+//     thread adds the 8 | 4 partials of its own group in segment order, in double (fixed order: run-to-run identical);
+//   * main loop = 9 | 18 MFMAs per wave on LDS fragments, the 8 K-slices meet in LDS, wave 0 stores the slab tile (and the partial
+//     context logits of a GlobalContext block's conv2).
+// Values: the arithmetic of k_conv_fused up to the summation order of the group statistics (double either way).
+#pragma once
+#include "fused_kernels.h"
+
+// CS4 = float4 chunks per slice (64: Cs = 256, 128: Cs = 512); LAZY = mode of source 1 (FSrc)
+template <int CS4, int LAZY>
+SF_DEV void conv4_gn_body(const FConvArgs& a, const int bid) {
+  constexpr int NT = 512, NE = CS4 / 32;              // 16 pixels x CS4 chunks over 512 threads: 2 | 4 elements per thread
+  constexpr int CPS = CS4 / 8;                        // 32-channel k-chunks per slice: 8 | 16
+  constexpr int KW = 9 * CPS / 8;                     // k-steps per wave: 9 | 18
+  constexpr int W = CS4 / 2;                          // lanes per statistics segment = float4 chunks per group: 32 | 64
+  constexpr int NSEG = NT / W;                        // 16 | 8 segments, segment sl belongs to group sl & 1
+  constexpr int FW = 6;                               // frame: 6 x 6 pixels
+  SF_DYN_LDS(lds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles = a.B * a.n_tiles;
+  const int s = bid / tiles, t = bid - s * tiles;
+  const int nt = t % a.n_tiles, b = t / a.n_tiles;
+  const int c0 = s * (CS4 * 4);
+  const long mb = (long)b * 16;
+  const float sc1 = a.s1.scale, sc2 = a.s2.scale;
+  const int c4 = tid & (CS4 - 1), c = c0 + c4 * 4;
+  const int px0 = tid / CS4;                          // element u is pixel px0 + u * (NT / CS4)
+
+  // ---- (1) every load of the launch, in the order of need
+  FGather<LAZY> gq[NE];
+#pragma unroll
+  for (int u = 0; u < NE; ++u) gq[u].issue(a, mb + px0 + u * (NT / CS4), c);
+  const float* ssrow = a.ss ? a.ss + (long)b * a.ss_stride : a.gamma;      // any valid address when there is no scale / shift
+  const int shoff = a.ss ? a.C : 0;
+  f32x4 qg = *reinterpret_cast<const f32x4*>(a.gamma + c);
+  f32x4 qb = *reinterpret_cast<const f32x4*>(a.beta + c);
+  const f32x4 qsc = *reinterpret_cast<const f32x4*>(ssrow + c);
+  const f32x4 qsh = *reinterpret_cast<const f32x4*>(ssrow + shoff + c);
+  const int nf = nt < a.n_frags ? nt : a.n_frags - 1;
+  const int n = nf * 16 + (lane & 15);
+  // context-logit weight of this output channel (wave 0 uses it): an UNCONDITIONAL load from a selected address, ahead of the weight
+  // slice -- a load under `if (a.wk)` behind it would make the compiler drain the whole slice at the merge
+  const float wkq = (a.wk ? a.wk : a.gamma)[a.wk && n < a.Cout ? n : 0];
+  const float wkv = a.wk ? wkq : 0.0f;
+  const bf16x8* wbase = a.w + ((long)nf * a.KS + s * CPS) * 64 + lane;
+  bf16x8 fb[KW];
+#pragma unroll
+  for (int i = 0; i < KW; ++i) {
+    const int j = wave * KW + i, tap = j / CPS, ccl = j - tap * CPS;
+#if SF_NT_W
+    fb[i] = __builtin_nontemporal_load(&wbase[(long)(tap * a.cchunks + ccl) * 64]);
+#else
+    fb[i] = wbase[(long)(tap * a.cchunks + ccl) * 64];
+#endif
+  }
+
+  // ---- (2) zero padding of the frame: the 20 border pixels, 8 threads per pixel
+  for (int q = tid >> 3; q < FW * FW; q += NT / 8) {
+    const int fr = q / FW, fx = q - fr * FW;
+    if (fr == 0 || fr == FW - 1 || fx == 0 || fx == FW - 1) {
+      char* dst = lds + (long)q * a.pix_stride;
+      for (int c8 = (tid & 7); c8 < CS4 / 2; c8 += 8) *reinterpret_cast<bf16x8*>(dst + c8 * 16) = sf_zero8();
+    }
+  }
+
+  // ---- (3) element values, segment sums (this thread's elements lie in ONE group: c4 is fixed)
+  const bool first = c < a.s1.C;
+  const float scl = first ? sc1 : sc2;
+  f32x4 v[NE];
+  float sm = 0.0f, sq = 0.0f;
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    v[u] = gq[u].combine();
+    const f32x4 w = v[u] * scl;
+    sm += (w[0] + w[1]) + (w[2] + w[3]);
+    sq = fmaf(w[0], w[0], sq); sq = fmaf(w[1], w[1], sq); sq = fmaf(w[2], w[2], sq); sq = fmaf(w[3], w[3], sq);
+  }
+  sm = sf_group_sum(sm, W);
+  sq = sf_group_sum(sq, W);
+  float* misc = reinterpret_cast<float*>(lds + a.misc_off);
+  float* part = misc + 160;                              // [NSEG][2]
+  if ((lane & (W - 1)) == 0) { part[2 * (tid / W)] = sm; part[2 * (tid / W) + 1] = sq; }
+  sf_sync();
+  // ---- (4) (mean, rstd) of this thread's group: its NSEG / 2 partials in segment order (uniform addresses per half-wave: broadcasts)
+  const int gi = c4 / W;                                 // 0 | 1
+  double S = 0.0, Q = 0.0;
+#pragma unroll
+  for (int k = 0; k < NSEG / 2; ++k) {
+    S += (double)part[2 * (2 * k + gi)];
+    Q += (double)part[2 * (2 * k + gi) + 1];
+  }
+  const double mean_d = S * a.inv_n;
+  double var = Q * a.inv_n - mean_d * mean_d;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)mean_d, rstd = sf_rsqrt((float)var + a.eps);
+  // y = x * A + B  ==  ((x - mean) * rstd * gamma + beta) * (scale + 1) + shift   (x = the scaled source value)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float A = rstd * qg[j], scj = a.ss ? qsc[j] + 1.0f : 1.0f, shj = a.ss ? qsh[j] : 0.0f;
+    qg[j] = A * scj;
+    qb[j] = (qb[j] - mean * A) * scj + shj;
+  }
+  // ---- (5) normalise, activate, bf16 into the frame; the workgroups of n-tile 0 materialise a lazy first source
+#pragma unroll
+  for (int u = 0; u < NE; ++u) {
+    const int p = px0 + u * (NT / CS4), py = p >> 2, pxx = p & 3;
+    if (LAZY && nt == 0 && first && a.s1.p) *reinterpret_cast<f32x4*>(a.s1.p + (mb + p) * a.s1.C + c) = v[u];
+    f32x4 y = (v[u] * scl) * qg + qb;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sv = sf_silu_fast(y[j]);
+      y[j] = a.silu ? sv : y[j];
+    }
+    bf16x4 o;
+    o[0] = (sf_opnd)y[0]; o[1] = (sf_opnd)y[1]; o[2] = (sf_opnd)y[2]; o[3] = (sf_opnd)y[3];
+    *reinterpret_cast<bf16x4*>(lds + (long)((py + 1) * FW + pxx + 1) * a.pix_stride + c4 * 8) = o;
+  }
+  sf_sync();
+
+  // ---- (6) main loop: this wave's k-steps (tap-major, then 32-channel chunk) on the frame
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int pA = lane & 15;
+  const char* abase = lds + (long)((pA >> 2) * FW + (pA & 3)) * a.pix_stride + (lane >> 4) * 16;
+#pragma unroll
+  for (int i = 0; i < KW; ++i) {
+    const int j = wave * KW + i, tap = j / CPS, ccl = j - tap * CPS;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const bf16x8 fa = *reinterpret_cast<const bf16x8*>(abase + (long)(ky * FW + kx) * a.pix_stride + ccl * 64);
+    acc = sf_mfma16(fa, fb[i], acc);
+  }
+  // ---- (7) the 8 K-slices of the workgroup meet in LDS; wave 0 stores the slab tile
+  float* red = reinterpret_cast<float*>(lds + a.red_off);         // [wave][r][lane]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[(wave * 4 + r) * 64 + lane] = acc[r];
+  sf_sync();
+  if (wave == 0 && nt < a.n_frags) {
+    const long mrow = mb + (lane >> 4) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float sacc = 0.0f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) sacc += red[(w * 4 + r) * 64 + lane];
+      if (a.logit_part) {                    // bias terms are the same for every pixel: they cancel in the softmax
+        float lp = sacc * wkv;
+        lp += sf_shfl_xor(lp, 1); lp += sf_shfl_xor(lp, 2); lp += sf_shfl_xor(lp, 4); lp += sf_shfl_xor(lp, 8);
+        if ((lane & 15) == 0) a.logit_part[((long)s * a.n_frags + nt) * a.M + mrow + r] = lp;
+      }
+      a.ws[((long)s * a.M + mrow + r) * a.npad + n] = sacc;
+    }
+  }
+}
+
+template <int CS4, int LAZY>
+SF_KERNEL(512) void k_conv4_gn(FConvArgs a) {
+  sf_touch_kernarg<(int)sizeof(FConvArgs)>();
+  conv4_gn_body<CS4, LAZY>(a, (int)blockIdx.x);
+}

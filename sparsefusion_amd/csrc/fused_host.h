@@ -11,6 +11,7 @@
 //   flags: 1 SiLU after the norm, 2 GELU before the LayerNorm, 4 accumulate into out, 8 GELU on the final output,
 //          32 pipelined kernel (k_conv_fused_pipe: slot GroupNorm, k = 3, plain source, C % 128 == 0),
 //          16 pair: the NEXT op (an un-normalised fconv of the same tile shape) runs in the same launch (k_conv_fused_pair)
+//          64 GlobalContext pooling in the epilogue (k_conv_fused_pipe<.., POOL>), 128 keep the general kernel where k_conv4_gn would take the op
 //   f: 0 eps  1 s1.scale  2 s2.scale
 //   norm == FNORM_ATTN (the attention core as the prologue of its output projection; k = 1, 4x4 map, C1 = 512 = 8 heads x 64):
 //      p: 0 q rows [B * 16][ldq] (instead of a source tensor)  19..21 key pointers of the <= 3 key / value segments
@@ -27,6 +28,7 @@
 #include "fused_kernels.h"
 #include "fused_pipe.h"
 #include "fused_gca.h"
+#include "fused_conv4.h"
 
 #define SF_LDS_MAX 163840
 #ifndef SF_FCONV_WAVES
@@ -248,6 +250,18 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
 }
 
 static inline int fconv_pipe_ept(const FConvArgs& a) { return (a.TR + 2) * a.W / 8; }
+
+// k_conv4_gn (fused_conv4.h, r05) takes the op when it is the 4x4 level's GroupNorm-self 3x3 conv in the geometry the kernel is written
+// for; returns CS4 (64 | 128) or 0 = the general kernel.  Op flag 128 (planner attribute Unet.conv4 = False) keeps the general kernel.
+static inline int conv4_cs4(const sf_op& op, const FConvArgs& a, int WM, int WN) {
+  if (op.flags & (16 | 32 | 64 | 128)) return 0;
+  if (a.norm != FNORM_GN_SELF || a.H != 4 || a.W != 4 || a.k != 3 || a.TR != 4 || WM != 1 || WN != 1) return 0;
+  if (a.S < 2 || !a.ws || a.dbg || a.G != 8 || (a.cps != 8 && a.cps != 16)) return 0;
+  if (((a.C / a.G) / 4) * 2 != a.cps * 8) return 0;                        // a slice = two whole groups
+  if (a.s1.mode == 1 && a.s1.groups > 4) return 0;
+  if (((uintptr_t)a.gamma | (uintptr_t)a.beta | (uintptr_t)a.ss) & 15 || (a.ss && a.ss_stride % 4)) return 0;      // float4 affine operands
+  return a.cps * 8;
+}
 
 // (WM, WN, EPT) of k_conv_fused_pipe_rc: the pipelined tiles with registers to spare for the res_conv's accumulators and ring slot
 #define SF_FCONV_PIPE_RC_VARIANTS(X) \

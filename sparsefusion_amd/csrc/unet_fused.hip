@@ -25,6 +25,15 @@ static int launch_fconv(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStre
   return SF_OK;
 }
 
+template <int CS4, int LAZY>
+static int launch_conv4(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStream_t st) {
+  static unsigned mask = 0;
+  if (int rc = allow_big_lds(k_conv4_gn<CS4, LAZY>, lds, mask)) return rc;
+  k_conv4_gn<CS4, LAZY><<<grid, 512, lds, st>>>(a);
+  SF_CHECK_LAUNCH("conv4_gn");
+  return SF_OK;
+}
+
 template <int WM, int WN, int EPT, bool POOL>
 static int launch_fconv_pipe(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStream_t st) {
   static unsigned mask = 0;
@@ -45,6 +54,11 @@ static int run_fconv(const sf_op& op, hipStream_t st) {
     SF_FCONV_PIPE_VARIANTS(SF_TRYP)
 #undef SF_TRYP
     SF_FAIL(SF_ERR_INVALID, "fconv pipe: no kernel variant for tile %dx%d, %d staging elements", WM, WN, EPT);
+  }
+  if (const int cs4 = conv4_cs4(op, a, WM, WN)) {       // r05: the 4x4 level's GroupNorm-self conv on its own kernel (fused_conv4.h)
+#define SF_TRY4(c4_, lz_) if (cs4 == c4_ && a.s1.mode == lz_) return launch_conv4<c4_, lz_>(a, grid, lds, st);
+    SF_TRY4(64, 0) SF_TRY4(64, 1) SF_TRY4(64, 2) SF_TRY4(128, 0) SF_TRY4(128, 1) SF_TRY4(128, 2)
+#undef SF_TRY4
   }
 #define SF_TRY(wm, wn, d, nm_, lz_) \
   if (WM == wm && WN == wn && a.norm == nm_ && a.s1.mode == lz_) return launch_fconv<wm, wn, d, nm_, lz_>(a, grid, lds, st);

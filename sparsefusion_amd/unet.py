@@ -568,7 +568,7 @@ class _Plan:
             ai = (ldq,) + tuple(v for _, _, rows, rs, bs, hs in segs for v in (rows, rs, bs, hs))
             af = tuple((sv - sk) // 4 for sk, sv, *_ in segs) + (scale,)
         self.op(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0) | (8 if out_gelu else 0) | (16 if pair_first else 0)
-                | (32 if pipe else 0) | (64 if pool is not None else 0),
+                | (32 if pipe else 0) | (64 if pool is not None else 0) | (0 if getattr(self.u, "conv4", True) else 128),
                 p=(x_ptr, lp[0], lp[1], lp[2], x.slots or 0, skip.ptr if skip else 0, (skip.slots or 0) if skip else 0,
                    self.wptr(wname), 0 if S > 1 else bias, out.ptr, 0 if S > 1 else res, ws, slots_out, gam, bet, ss_ptr, 0,
                    logit[0] if logit else 0, logit[1] if logit else 0) + ap,
@@ -1134,6 +1134,7 @@ class Unet(nn.Module):
         self.fconv_pipe = True              # slot-GroupNorm 3x3 convs on k_conv_fused_pipe (staging || matrix work)
         self.producer_slots = True          # r04: k_init_x / the Upsample epilogue leave their consumers' statistics slots, the final conv's split-K reduction writes NCHW (False: the r03 k_slots / k_unpack_out launches; parity tests)
         self.attn_in_out_proj = True        # the 16-token attention core in the prologue of its output projection (False: k_attn16 launch; parity tests)
+        self.conv4 = True                   # r05: the 4x4 level's GroupNorm-self 3x3 convs on k_conv4_gn (csrc/fused_conv4.h); False: op flag 128 = k_conv_fused (parity tests)
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches
         self._pack_cache = None
         self._plans = {}

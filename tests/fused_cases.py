@@ -53,7 +53,7 @@ def run_ops(ops, backend):
 
 def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, silu=True, ss=True, accum=False, resid=False,
                   slots=True, pre_gelu=False, ln_bias=False, seed=0, G=8, scale2=2 ** -0.5, tol=4e-3, dbg=None, reps=1, logits=False,
-                  out_gelu=False, pair=False, pipe=False, pool=False):
+                  out_gelu=False, pair=False, pipe=False, pool=False, general=False):
     dev = "cpu" if backend == "emu" else "cuda:0"
     d = lambda t: None if t is None else t.to(dev)
     g = torch.Generator().manual_seed(seed)
@@ -117,7 +117,7 @@ def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, 
         wk_d = d(weff)
         lpart = d(torch.full((M // 16 * Cout + M // 16 * 2,), float("nan")))
     op = fused.mkop(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0) | (8 if out_gelu else 0) | (32 if pipe else 0)
-                    | (64 if pool else 0),
+                    | (64 if pool else 0) | (128 if general else 0),     # 128: keep the general kernel (r05: k_conv4_gn takes the 4x4 geometry otherwise)
                     p=(s1["p"], s1["a"], s1["b"], s1["r"], sl1, x2_d, sl2, wp, bias_d, out, res_d, wsl, slots_out, gamma_d, beta_d, ssv_d, dbg, wk_d, lpart),
                     i=(B, H, W, C1, C2, Cout, ldc, co_off, k, s1["mode"], s1["groups"], s1["npad"], norm, G, TR, WM, WN, S, 2 * C),
                     f=(1e-5, 1.0, scale2))
@@ -386,6 +386,13 @@ CONV_CASES = {
     # of the GN_SELF statistics (r02: LDS float atomics, order dependent)
     "gn_self_odd_groups_fallback_4x4": dict(B=2, H=4, W=4, C1=96, C2=0, Cout=32, k=3, norm=GN_SELF, WM=1, WN=1, seed=41),
     "gn_self_concat_gate_lazy_4x4": dict(B=1, H=4, W=4, C1=64, C2=64, Cout=32, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=2, seed=1),
+    # r05: the geometry k_conv4_gn is written for (csrc/fused_conv4.h: 4 slices of two whole groups each, Cs = 256 | 512), every lazy
+    # mode, with and without scale / shift and SiLU, partial context logits, two images; `general=True` = the same op on k_conv_fused
+    "conv4_gn_lazy_splitk_1024": dict(B=1, H=4, W=4, C1=1024, C2=0, Cout=32, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=1, seed=71, logits=True),
+    "conv4_gn_concat_gate_2048": dict(B=1, H=4, W=4, C1=1024, C2=1024, Cout=16, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=2, seed=72),
+    "conv4_gn_plain_1024_b2": dict(B=2, H=4, W=4, C1=1024, C2=0, Cout=16, k=3, norm=GN_SELF, WM=1, WN=1, S=4, ss=False, silu=False, seed=73),
+    "conv4_gn_concat_lazy_2048": dict(B=1, H=4, W=4, C1=1024, C2=1024, Cout=16, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=1, seed=74, logits=True),
+    "conv4_geometry_on_the_general_kernel": dict(B=1, H=4, W=4, C1=1024, C2=0, Cout=16, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=1, seed=71, general=True),
     # 8x8 level: 2-row tiles with halo rows from neighbouring tiles, statistics from producer slots, final epilogue + slots
     "gn_slots_concat_8x8": dict(B=1, H=8, W=8, C1=128, C2=128, Cout=32, k=3, norm=GN_SLOTS, WM=1, WN=1, resid=True, seed=2),
     # 32-pixel rows (WM = 2), 2 n-fragments per tile, accumulate mode

@@ -19,6 +19,8 @@ static void emu_fconv_pair(const FConvPairArgs& p, uint32_t grid, uint32_t lds) 
   hipemu::launch(grid, SF_FCONV_WAVES * 64, lds, [&] { k_conv_fused_pair<WM, WN, D, NORM, LAZY, SF_FCONV_WAVES>(p); });
 }
 
+static int g_conv4_launches = 0;
+extern "C" int emu_conv4_launches() { return g_conv4_launches; }  // how many ops ran on k_conv4_gn (tests assert the path was taken)
 static int g_rc_launches = 0;
 extern "C" int emu_rc_launches() { return g_rc_launches; }      // how many pairs ran as k_conv_fused_pipe_rc (tests assert the path was taken)
 
@@ -93,6 +95,12 @@ extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
 #undef SF_TRYP
       snprintf(err, errn, "fconv pipe: no kernel variant for tile %dx%d, %d staging elements", WM, WN, EPT);
       return 1;
+    }
+    if (const int cs4 = conv4_cs4(*op, a, WM, WN)) {        // the same dispatch as unet_fused.hip::run_fconv (r05: k_conv4_gn)
+#define SF_TRY4(c4_, lz_) \
+      if (cs4 == c4_ && a.s1.mode == lz_) { hipemu::launch(grid, 512, lds, [&] { k_conv4_gn<c4_, lz_>(a); }); ++g_conv4_launches; return 0; }
+      SF_TRY4(64, 0) SF_TRY4(64, 1) SF_TRY4(64, 2) SF_TRY4(128, 0) SF_TRY4(128, 1) SF_TRY4(128, 2)
+#undef SF_TRY4
     }
 #define SF_TRY(wm, wn, d, nm_, lz_) \
     if (WM == wm && WN == wn && a.norm == nm_ && a.s1.mode == lz_) { emu_fconv<wm, wn, d, nm_, lz_>(a, grid, lds); return 0; }

@@ -74,3 +74,14 @@ def test_pipelined_pairs_run_the_merged_res_conv_kernel():
     n1 = fused.lib().emu_rc_launches()
     fc.run_conv_case("emu", **fc.CONV_CASES["pipe_pair_gn_slots_wide_rows_wm4"])
     assert n1 == n0 + 1 and fused.lib().emu_rc_launches() == n1
+
+
+def test_the_4x4_geometry_runs_on_k_conv4_gn():
+    """r05: an op of the geometry csrc/fused_conv4.h is written for must take that kernel (fused_host.h::conv4_cs4, the dispatch
+    unet_fused.hip::run_fconv shares with this harness); op flag 128 and every other 4x4 shape keep k_conv_fused."""
+    n0 = fused.lib().emu_conv4_launches()
+    fc.run_conv_case("emu", **fc.CONV_CASES["conv4_gn_lazy_splitk_1024"])
+    n1 = fused.lib().emu_conv4_launches()
+    fc.run_conv_case("emu", **fc.CONV_CASES["conv4_geometry_on_the_general_kernel"])
+    fc.run_conv_case("emu", **fc.CONV_CASES["gn_self_sliced_lazy_splitk_4x4"])
+    assert n1 == n0 + 1 and fused.lib().emu_conv4_launches() == n1
