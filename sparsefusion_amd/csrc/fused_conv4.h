@@ -169,3 +169,151 @@ SF_KERNEL(512) void k_conv4_gn(FConvArgs a) {
   sf_touch_kernarg<(int)sizeof(FConvArgs)>();
   conv4_gn_body<CS4, LAZY>(a, (int)blockIdx.x);
 }
+
+// k_lin4_ln: LayerNorm -> Linear on the 16-token map (the transformer blocks of the 4x4 level: merged q | k | v projection, ff1 with its
+// GELU epilogue, ff2 with its residual; external/imagen_pytorch.py:480-566, :944-1010) -- the same op, operands and LDS layout as
+// k_conv_fused<1, WN, ., FNORM_LN, 0, 8> for a plain source of C = 1024 | 2048 channels, built like k_conv4_gn: the row (8 | 16 float4 per
+// thread, 32 threads per token), the gain (and bias) of the SAME chunks and the wave's whole weight share (4 | 8 k-steps x WN fragments)
+// are requested in the first instructions; two-pass statistics like nn.LayerNorm by 32-lane shuffles; ONE barrier in front of the MFMAs.
+// The general kernel fetched the gain after the statistics (a dependent L2 round trip) and half of its row loads were clamped dead
+// elements at C = 1024.  C4T = float4 chunks per thread (C / 128).
+template <int C4T, int WN>
+SF_DEV void lin4_ln_body(const FConvArgs& a, const int bid) {
+  constexpr int NT = 512, TPR = 32;                    // 16 tokens x 32 threads
+  constexpr int KSL = C4T * 4;                         // 32-channel k-steps: C / 32 = 32 | 64
+  constexpr int KW = KSL / 8;                          // per wave: 4 | 8
+  constexpr int F = WN;
+  SF_DYN_LDS(lds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int MT = a.B;
+  int mt, nt;
+  fconv_tile_of(a, bid, MT, mt, nt);
+  const long m0 = (long)mt * 16;
+  const int row = tid / TPR, part = tid - row * TPR;
+  const long m = m0 + row;
+  // ---- (1) every load of the launch: the token's row, gain / bias of the same chunks, the weight share, the epilogue operands
+  f32x4 v[C4T], g[C4T], bt[C4T];
+  const float* xr = a.s1.p + m * a.s1.C;
+#pragma unroll
+  for (int u = 0; u < C4T; ++u) v[u] = *reinterpret_cast<const f32x4*>(xr + (part + u * TPR) * 4);
+#pragma unroll
+  for (int u = 0; u < C4T; ++u) g[u] = *reinterpret_cast<const f32x4*>(a.gamma + (part + u * TPR) * 4);
+  const float* betap = a.beta ? a.beta : a.gamma;      // selected address, unconditional loads (no load under a run-time branch)
+#pragma unroll
+  for (int u = 0; u < C4T; ++u) bt[u] = *reinterpret_cast<const f32x4*>(betap + (part + u * TPR) * 4);
+  const bf16x8* wbase[WN];
+#pragma unroll
+  for (int ni = 0; ni < WN; ++ni) {
+    int nf = nt * WN + ni;
+    if (nf > a.n_frags - 1) nf = a.n_frags - 1;
+    wbase[ni] = a.w + (long)nf * a.KS * 64 + lane;
+  }
+  bf16x8 fb[KW][WN];
+#pragma unroll
+  for (int i = 0; i < KW; ++i)
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+#if SF_NT_W
+      fb[i][ni] = __builtin_nontemporal_load(&wbase[ni][(long)(wave * KW + i) * 64]);
+#else
+      fb[i][ni] = wbase[ni][(long)(wave * KW + i) * 64];
+#endif
+    }
+  const int my_nf = nt * WN + wave;                    // wave f < F finalises fragment f
+  const bool fin = wave < F && my_nf < a.n_frags;
+  const int n = (my_nf < a.n_frags ? my_nf : a.n_frags - 1) * 16 + (lane & 15);
+  const int nc = n < a.Cout ? n : a.Cout - 1;
+  const long mrow = m0 + (lane >> 4) * 4;
+  const float bvq = (a.bias ? a.bias : a.gamma)[a.bias ? nc : 0];
+  const float bv = a.bias ? bvq : 0.0f;
+  float rv[4];
+  {
+    const float* rp = a.resid ? a.resid : a.out;        // selected address; out is always readable
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float q = rp[(mrow + r) * a.ldc + a.co_off + nc];
+      rv[r] = a.resid ? q : 0.0f;
+    }
+    if (a.accum) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rv[r] += a.out[(mrow + r) * a.ldc + a.co_off + nc];
+    }
+  }
+  // ---- (2) two-pass statistics of the token over its 32 threads
+  float sm = 0.0f;
+#pragma unroll
+  for (int u = 0; u < C4T; ++u) {
+    if (a.pre_gelu) { v[u][0] = sf_gelu(v[u][0]); v[u][1] = sf_gelu(v[u][1]); v[u][2] = sf_gelu(v[u][2]); v[u][3] = sf_gelu(v[u][3]); }
+    sm += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+  }
+  const float mean = sf_group_sum(sm, TPR) / (float)(C4T * 128);
+  float sq = 0.0f;
+#pragma unroll
+  for (int u = 0; u < C4T; ++u) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float d = v[u][j] - mean; sq = fmaf(d, d, sq); }
+  }
+  const float rstd = sf_rsqrt(sf_group_sum(sq, TPR) / (float)(C4T * 128) + a.eps);
+  // ---- (3) normalise (gain, bias), optional SiLU, bf16 into the frame [token][channel]
+#pragma unroll
+  for (int u = 0; u < C4T; ++u) {
+    f32x4 y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = (v[u][j] - mean) * rstd * g[u][j];
+    if (a.beta) y += bt[u];
+    if (a.silu) { y[0] = sf_silu_fast(y[0]); y[1] = sf_silu_fast(y[1]); y[2] = sf_silu_fast(y[2]); y[3] = sf_silu_fast(y[3]); }
+    bf16x4 o;
+    o[0] = (sf_opnd)y[0]; o[1] = (sf_opnd)y[1]; o[2] = (sf_opnd)y[2]; o[3] = (sf_opnd)y[3];
+    *reinterpret_cast<bf16x4*>(lds + (long)row * a.pix_stride + (part + u * TPR) * 8) = o;
+  }
+  sf_sync();
+  // ---- (4) this wave's k-steps
+  f32x4 acc[WN];
+#pragma unroll
+  for (int ni = 0; ni < WN; ++ni) acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const char* abase = lds + (long)(lane & 15) * a.pix_stride + (lane >> 4) * 16;
+#pragma unroll
+  for (int i = 0; i < KW; ++i) {
+    const bf16x8 fa = *reinterpret_cast<const bf16x8*>(abase + (wave * KW + i) * 64);
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) acc[ni] = sf_mfma16(fa, fb[i][ni], acc[ni]);
+  }
+  // ---- (5) the 8 K-slices meet in LDS; wave f finalises fragment f: bias, residual, GELU, output, statistics slots
+  float* red = reinterpret_cast<float*>(lds + a.red_off);         // [wave][frag][r][lane]
+#pragma unroll
+  for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((wave * F + ni) * 4 + r) * 64 + lane] = acc[ni][r];
+  sf_sync();
+  if (fin) {
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float sacc = 0.0f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) sacc += red[((w * F + wave) * 4 + r) * 64 + lane];
+      if (n < a.Cout) {
+        float y = sacc + bv + rv[r];
+        if (a.out_gelu) y = sf_gelu(y);
+        a.out[(mrow + r) * a.ldc + a.co_off + n] = y;
+        s1 += y;
+        s2 = fmaf(y, y, s2);
+      }
+    }
+    if (a.slots_out) {
+      s1 = sf_wave_sum(s1);
+      s2 = sf_wave_sum(s2);
+      if (lane == 0) {
+        float* slo = a.slots_out + ((m0 >> 4) * (long)(a.ldc >> 4) + (a.co_off >> 4) + my_nf) * 2;
+        slo[0] = s1;
+        slo[1] = s2;
+      }
+    }
+  }
+}
+
+template <int C4T, int WN>
+SF_KERNEL(512) void k_lin4_ln(FConvArgs a) {
+  sf_touch_kernarg<(int)sizeof(FConvArgs)>();
+  lin4_ln_body<C4T, WN>(a, (int)blockIdx.x);
+}

@@ -251,6 +251,15 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
 
 static inline int fconv_pipe_ept(const FConvArgs& a) { return (a.TR + 2) * a.W / 8; }
 
+// k_lin4_ln (fused_conv4.h, r05): LayerNorm -> Linear on the 16-token map, plain source of 1024 | 2048 channels; returns C4T (8 | 16) or 0
+static inline int lin4_c4t(const sf_op& op, const FConvArgs& a, int WM, int WN) {
+  if (op.flags & (16 | 32 | 64 | 128)) return 0;
+  if (a.norm != FNORM_LN || a.H != 4 || a.W != 4 || a.k != 1 || a.TR != 4 || WM != 1 || (WN != 1 && WN != 2)) return 0;
+  if (a.S != 1 || a.s1.mode != 0 || a.s2.C || a.dbg || a.logit_part || (a.C != 1024 && a.C != 2048) || a.s1.scale != 1.0f) return 0;
+  if (((uintptr_t)a.gamma | (uintptr_t)a.beta | (uintptr_t)a.s1.p) & 15) return 0;
+  return a.C / 128;
+}
+
 // k_conv4_gn (fused_conv4.h, r05) takes the op when it is the 4x4 level's GroupNorm-self 3x3 conv in the geometry the kernel is written
 // for; returns CS4 (64 | 128) or 0 = the general kernel.  Op flag 128 (planner attribute Unet.conv4 = False) keeps the general kernel.
 static inline int conv4_cs4(const sf_op& op, const FConvArgs& a, int WM, int WN) {

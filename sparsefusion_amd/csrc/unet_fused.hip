@@ -34,6 +34,15 @@ static int launch_conv4(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStre
   return SF_OK;
 }
 
+template <int C4T, int WN>
+static int launch_lin4(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStream_t st) {
+  static unsigned mask = 0;
+  if (int rc = allow_big_lds(k_lin4_ln<C4T, WN>, lds, mask)) return rc;
+  k_lin4_ln<C4T, WN><<<grid, 512, lds, st>>>(a);
+  SF_CHECK_LAUNCH("lin4_ln");
+  return SF_OK;
+}
+
 template <int WM, int WN, int EPT, bool POOL>
 static int launch_fconv_pipe(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStream_t st) {
   static unsigned mask = 0;
@@ -59,6 +68,11 @@ static int run_fconv(const sf_op& op, hipStream_t st) {
 #define SF_TRY4(c4_, lz_) if (cs4 == c4_ && a.s1.mode == lz_) return launch_conv4<c4_, lz_>(a, grid, lds, st);
     SF_TRY4(64, 0) SF_TRY4(64, 1) SF_TRY4(64, 2) SF_TRY4(128, 0) SF_TRY4(128, 1) SF_TRY4(128, 2)
 #undef SF_TRY4
+  }
+  if (const int c4t = lin4_c4t(op, a, WM, WN)) {       // r05: LayerNorm -> Linear of the 16-token map on its own kernel
+#define SF_TRYL(c_, wn_) if (c4t == c_ && WN == wn_) return launch_lin4<c_, wn_>(a, grid, lds, st);
+    SF_TRYL(8, 1) SF_TRYL(8, 2) SF_TRYL(16, 1) SF_TRYL(16, 2)
+#undef SF_TRYL
   }
 #define SF_TRY(wm, wn, d, nm_, lz_) \
   if (WM == wm && WN == wn && a.norm == nm_ && a.s1.mode == lz_) return launch_fconv<wm, wn, d, nm_, lz_>(a, grid, lds, st);

@@ -424,6 +424,12 @@ CONV_CASES = {
     "pipe_gn_slots_8x8_tr4_resid": dict(B=2, H=8, W=8, C1=128, C2=128, Cout=48, k=3, norm=GN_SLOTS, WM=2, WN=1, resid=True, seed=43, pipe=True),
     "pipe_pair_gn_slots_16x16_tr2": dict(B=2, H=16, W=16, C1=128, C2=128, Cout=64, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=44, pipe=True, pair=True),
     "raw_1x1_res_conv_8x8_tr4": dict(B=2, H=8, W=8, C1=64, C2=64, Cout=32, k=1, norm=NONE, WM=2, WN=2, silu=False, slots=False, seed=45),
+    # r05: the shapes k_lin4_ln takes (csrc/fused_conv4.h: plain source of 1024 | 2048 channels on the 16-token map): ff1 with its GELU
+    # epilogue, ff2 with residual and two n-fragments per tile, a bias-carrying LayerNorm, two images
+    "lin4_ln_ff1_1024_gelu": dict(B=1, H=4, W=4, C1=1024, C2=0, Cout=48, k=1, norm=LN, WM=1, WN=1, silu=False, out_gelu=True, seed=81),
+    "lin4_ln_ff2_2048_resid_wn2": dict(B=2, H=4, W=4, C1=2048, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=2, silu=False, resid=True, seed=82),
+    "lin4_ln_bias_1024_b2": dict(B=2, H=4, W=4, C1=1024, C2=0, Cout=32, k=1, norm=LN, WM=1, WN=1, silu=False, ln_bias=True, accum=True, seed=83),
+    "lin4_shape_on_the_general_kernel": dict(B=1, H=4, W=4, C1=1024, C2=0, Cout=48, k=1, norm=LN, WM=1, WN=1, silu=False, out_gelu=True, seed=81, general=True),
     "layernorm_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=1, silu=False, seed=6, out_gelu=True),
     "layernorm_lazy_splitk_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=1, silu=False, lazy=1, seed=7),
     "gelu_layernorm_bias_linear": dict(B=2, H=4, W=4, C1=128, C2=0, Cout=64, k=1, norm=LN, WM=1, WN=2, silu=False, pre_gelu=True,

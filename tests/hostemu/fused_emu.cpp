@@ -102,6 +102,12 @@ extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
       SF_TRY4(64, 0) SF_TRY4(64, 1) SF_TRY4(64, 2) SF_TRY4(128, 0) SF_TRY4(128, 1) SF_TRY4(128, 2)
 #undef SF_TRY4
     }
+    if (const int c4t = lin4_c4t(*op, a, WM, WN)) {
+#define SF_TRYL(c_, wn_) \
+      if (c4t == c_ && WN == wn_) { hipemu::launch(grid, 512, lds, [&] { k_lin4_ln<c_, wn_>(a); }); ++g_conv4_launches; return 0; }
+      SF_TRYL(8, 1) SF_TRYL(8, 2) SF_TRYL(16, 1) SF_TRYL(16, 2)
+#undef SF_TRYL
+    }
 #define SF_TRY(wm, wn, d, nm_, lz_) \
     if (WM == wm && WN == wn && a.norm == nm_ && a.s1.mode == lz_) { emu_fconv<wm, wn, d, nm_, lz_>(a, grid, lds); return 0; }
     SF_FCONV_VARIANTS(SF_TRY)

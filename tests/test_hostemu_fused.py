@@ -85,3 +85,8 @@ def test_the_4x4_geometry_runs_on_k_conv4_gn():
     fc.run_conv_case("emu", **fc.CONV_CASES["conv4_geometry_on_the_general_kernel"])
     fc.run_conv_case("emu", **fc.CONV_CASES["gn_self_sliced_lazy_splitk_4x4"])
     assert n1 == n0 + 1 and fused.lib().emu_conv4_launches() == n1
+    fc.run_conv_case("emu", **fc.CONV_CASES["lin4_ln_ff1_1024_gelu"])           # k_lin4_ln counts on the same counter
+    n2 = fused.lib().emu_conv4_launches()
+    fc.run_conv_case("emu", **fc.CONV_CASES["lin4_shape_on_the_general_kernel"])
+    fc.run_conv_case("emu", **fc.CONV_CASES["layernorm_linear"])
+    assert n2 == n1 + 1 and fused.lib().emu_conv4_launches() == n2
