@@ -607,7 +607,11 @@ class _Plan:
         # (k_gca_pool_rc) on the materialised input instead of as a second round of workgroups re-reducing conv1's lazy source
         late_rc = (cin != cout and gca and H == 4 and getattr(self.u, "res_conv_beside_pool", True) and gr[1:4] == (1, 1, 1)
                    and cout % 64 == 0 and cout <= 2048 and cin <= 4096)    # (LDS: 16 pixels x cin operands beside the pooling's 9 KB)
-        pair = pair and not late_rc
+        # r05: conv1 of the 4x4 level runs on k_conv4_gn where its geometry fits (csrc/fused_conv4.h); the pair kernel is the general one,
+        # so such a block emits conv1 and its res_conv as two launches (26.7 us as a pair against ~10 + 9.3 us)
+        conv4_geom = (H == 4 and getattr(self.u, "conv4", True) and g1[1:3] == (1, 1) and g1[3] > 1 and cin // g1[3] in (256, 512)
+                      and (cin // 8) * 2 == cin // g1[3])
+        pair = pair and not late_rc and not conv4_geom
         lz = self.fconv(x, skip, H, f"{name}.block1.project.weight", f"{name}.block1.project.bias", h, cout, 3, norm, g1,
                         gname=f"{name}.block1.groupnorm", want_slots=slots, pair_first=pair)
         rc = None

@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+O=$GRAFT_REPO_ROOT/gpurun_out/r5l; mkdir -p $O
+export TMPDIR=/tmp
+for b in 1 4; do echo "== B=$b"; timeout 300 python tools/unet_time.py $b 2>&1 | grep "sampler path"; done | tee $O/unet_time.log
+timeout 300 python tools/graph_ablate.py 1 2>&1 | grep -v amdgpu.ids | head -34 | tee $O/graph_ablate_b1.log
+timeout 900 python -m pytest tests/test_gpu_unet.py tests/test_gpu_fused.py -x -q 2>&1 | grep -v amdgpu.ids | tail -4 | tee $O/tests_unet.log
