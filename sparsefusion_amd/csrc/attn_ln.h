@@ -46,6 +46,61 @@ SF_KERNEL(256) void k_layernorm(const float* __restrict__ in, const float* __res
   }
 }
 
+// Few long rows (r05; the post-attention LayerNorm + residual of the UNet's transformer blocks: 16 rows of 1024 channels, one launch per
+// attention): one WAVE per row, NV float4 per lane (C = 256 NV), the row, the gain (bias) and the residual requested in the first
+// instructions, two shuffle reductions, no block barrier, no load behind a branch.  k_layernorm above fetches scalars under `c < C`,
+// the gain after the statistics, and crosses two barriers: 5.2 us per launch in the eval graph.  Same arithmetic (two-pass variance, fp32).
+template <int NV>
+SF_KERNEL(256) void k_layernorm_wave(const float* __restrict__ in, const float* __restrict__ gain, const float* __restrict__ bias,
+                                     void* __restrict__ out, const float* __restrict__ resid, int R, float eps, int pre_gelu, int out_f32) {
+  constexpr int C = 256 * NV;
+  const int lane = threadIdx.x & 63;
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const bool live = row < R;
+  if (!live) row = R - 1;                                  // (clamped: every wave runs the same instruction stream)
+  f32x4 v[NV], g[NV], bq[NV], rq[NV];
+  const float* x = in + row * C;
+  const float* bp = bias ? bias : gain;
+  const float* rp = resid ? resid + row * C : x;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + (lane + 64 * u) * 4);
+#pragma unroll
+  for (int u = 0; u < NV; ++u) g[u] = *reinterpret_cast<const f32x4*>(gain + (lane + 64 * u) * 4);
+#pragma unroll
+  for (int u = 0; u < NV; ++u) bq[u] = *reinterpret_cast<const f32x4*>(bp + (lane + 64 * u) * 4);
+#pragma unroll
+  for (int u = 0; u < NV; ++u) rq[u] = *reinterpret_cast<const f32x4*>(rp + (lane + 64 * u) * 4);
+  float s = 0.0f;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    if (pre_gelu) { v[u][0] = sf_gelu(v[u][0]); v[u][1] = sf_gelu(v[u][1]); v[u][2] = sf_gelu(v[u][2]); v[u][3] = sf_gelu(v[u][3]); }
+    s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+  }
+  const float mean = sf_wave_sum(s) / (float)C;
+  float q = 0.0f;
+#pragma unroll
+  for (int u = 0; u < NV; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float d = v[u][j] - mean; q = fmaf(d, d, q); }
+  const float rstd = sf_rsqrt(sf_wave_sum(q) / (float)C + eps);
+  if (!live) return;
+#pragma unroll
+  for (int u = 0; u < NV; ++u) {
+    f32x4 y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = (v[u][j] - mean) * rstd * g[u][j];
+    if (bias) y += bq[u];
+    if (out_f32) {
+      if (resid) y += rq[u];
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + row * C + (lane + 64 * u) * 4) = y;
+    } else {
+      bf16x4 o;
+      o[0] = (sf_opnd)y[0]; o[1] = (sf_opnd)y[1]; o[2] = (sf_opnd)y[2]; o[3] = (sf_opnd)y[3];
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<sf_opnd*>(out) + row * C + (lane + 64 * u) * 4) = o;
+    }
+  }
+}
+
 // Many short rows (the EFT transformers: 122 880 rows of 256 channels): one WAVE per row, four channels per lane, no block barrier --
 // the block-per-row kernel above spends its time in two barriers and one element per thread (91 us for 252 MB moved, r04 trace); this one
 // is one load, two shuffle reductions and one store per lane.  Same arithmetic (two-pass variance, fp32).  C == 256 only.

@@ -287,6 +287,64 @@ SF_KERNEL(256) void k_gca_gate(GcaGateArgs a) {
   }
 }
 
+// k_gca_gate with the hidden width as a template parameter (r05; HID = 128 | 256 | 512 = every GlobalContext block of the canonical UNet):
+// the trip loop of k_gca_gate has a run-time count with loads inside -- at HID = 512 two dependent round trips, at HID = 128 half of its
+// 24 loads clamped -- here all W2 fragments and hidden-vector pieces of the lane are requested together with the tile's operands.
+template <int HID>
+SF_KERNEL(256) void k_gca_gate_t(GcaGateArgs a) {
+  sf_touch_kernarg<(int)sizeof(GcaGateArgs)>();
+  constexpr int NTR = (HID + 255) / 256, U = HID >= 256 ? 8 : HID / 32;
+  const int CF = a.C >> 4;
+  const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gw >= (a.M >> 4) * CF) return;
+  const int mf = gw / CF, cf = gw - mf * CF;
+  const int b = (mf * 16) / a.HW;
+  const long m = (long)mf * 16 + (lane >> 2);
+  const int c = cf * 16 + (lane & 3) * 4;
+  const f32x4 hv = *reinterpret_cast<const f32x4*>(a.h2 + m * a.C + c);
+  const f32x4 rv = *reinterpret_cast<const f32x4*>(a.res + m * a.C + c);
+  const int ch = cf * 16 + (lane & 15), q = lane >> 4;
+  const float bias = a.b2[ch];
+  bf16x8 w[NTR][U];
+  f32x4 h0[NTR][U], h1[NTR][U];
+  const sf_opnd* wr = a.W2 + (long)ch * a.Kp2 + q * 8;
+  const float* hr = a.hid + (long)b * HID + q * 8;
+#pragma unroll
+  for (int t = 0; t < NTR; ++t)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = t * 256 + u * 32;
+      w[t][u] = *reinterpret_cast<const bf16x8*>(wr + k);
+      h0[t][u] = *reinterpret_cast<const f32x4*>(hr + k);
+      h1[t][u] = *reinterpret_cast<const f32x4*>(hr + k + 4);
+    }
+  float g = 0.0f;
+#pragma unroll
+  for (int t = 0; t < NTR; ++t)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g = fmaf((float)w[t][u][j], h0[t][u][j], g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g = fmaf((float)w[t][u][4 + j], h1[t][u][j], g);
+    }
+  g += sf_shfl_xor(g, 16);
+  g += sf_shfl_xor(g, 32);
+  g = sf_sigmoid(g + bias);
+  f32x4 gv;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) gv[j] = sf_shfl(g, (lane & 3) * 4 + j);
+  const f32x4 v = hv * gv + rv;
+  *reinterpret_cast<f32x4*>(a.out + m * a.C + c) = v;
+  if (a.slots) {
+    float sm = (v[0] + v[1]) + (v[2] + v[3]);
+    float sq = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
+    sm = sf_wave_sum(sm);
+    sq = sf_wave_sum(sq);
+    if (lane == 0) { a.slots[(long)gw * 2] = sm; a.slots[(long)gw * 2 + 1] = sq; }
+  }
+}
+
 // Measured and not kept (r04): net0 + gate as ONE launch on the C <= 512 levels, every workgroup recomputing the hidden vector
 // (k_gca_ng: 64 KB of pooled partials + 64-256 KB of W0 per workgroup, then its 16 fragments).  Parity-green, 11 launches fewer,
 // and SLOWER: B = 1 eval 1.243 -> 1.336 ms (+8.5 us per block; B = 4: 1.974 -> 2.052): the redundant matvec is a chain of

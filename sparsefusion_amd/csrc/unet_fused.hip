@@ -185,6 +185,9 @@ static int run_gca(const sf_op& op, hipStream_t st) {
     else if (na.chunks <= 32) k_gca_net0<32><<<grid, 256, 0, st>>>(na);
     else k_gca_net0<64><<<grid, 256, 0, st>>>(na);
   }
+  else if (ga.HID == 128 && !(op.i[5] & 1)) k_gca_gate_t<128><<<grid, 256, 0, st>>>(ga);      // r05: compile-time hidden width (i[5] & 1: keep k_gca_gate, parity tests)
+  else if (ga.HID == 256 && !(op.i[5] & 1)) k_gca_gate_t<256><<<grid, 256, 0, st>>>(ga);
+  else if (ga.HID == 512 && !(op.i[5] & 1)) k_gca_gate_t<512><<<grid, 256, 0, st>>>(ga);
   else k_gca_gate<<<grid, 256, 0, st>>>(ga);
   SF_CHECK_LAUNCH("gca");
   return SF_OK;

@@ -709,6 +709,15 @@ static int run_ln(const sf_op& op, hipStream_t st) {
     return SF_OK;
   }
   if (op.p[5]) SF_FAIL(SF_ERR_INVALID, "layernorm: the operand-type twin output exists for >= 1024 rows of 256 channels only");
+  if (R <= 256 && (C == 512 || C == 1024 || C == 2048) && !(op.flags & 4) &&       // r05: few long rows (flag 4: keep k_layernorm, parity tests)
+      !(((uintptr_t)op.p[0] | (uintptr_t)op.p[1] | (uintptr_t)op.p[2] | (uintptr_t)op.p[3] | (uintptr_t)op.p[4]) & 15)) {
+    const uint32_t grid = sf_div_up(R, 4);
+    if (C == 512) k_layernorm_wave<2><<<grid, 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3], (const float*)op.p[4], R, op.f[0], op.flags & 1, (op.flags & 2) ? 1 : 0);
+    else if (C == 1024) k_layernorm_wave<4><<<grid, 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3], (const float*)op.p[4], R, op.f[0], op.flags & 1, (op.flags & 2) ? 1 : 0);
+    else k_layernorm_wave<8><<<grid, 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3], (const float*)op.p[4], R, op.f[0], op.flags & 1, (op.flags & 2) ? 1 : 0);
+    SF_CHECK_LAUNCH("layernorm_wave");
+    return SF_OK;
+  }
   k_layernorm<<<R, 256, 0, st>>>((const float*)op.p[0], (const float*)op.p[1], (const float*)op.p[2], op.p[3],
                                               (const float*)op.p[4], R, C, op.f[0], op.flags & 1, (op.flags & 2) ? 1 : 0);
   SF_CHECK_LAUNCH("layernorm");

@@ -400,7 +400,7 @@ class _Plan:
         self.need(x)
         self.need(resid)
         assert twin is None or (out_f32 and C == 256 and rows >= 1024)
-        self.op(OP_LN, (1 if gelu else 0) | (2 if out_f32 else 0),
+        self.op(OP_LN, (1 if gelu else 0) | (2 if out_f32 else 0) | (0 if getattr(self.u, "ln_wave", True) else 4),
                 p=(x.ptr, self.wptr(gname), self.wptr(bname) if bname else 0, out.ptr, resid.ptr if resid else 0, twin.ptr if twin else 0),
                 i=(rows, C), f=(eps,))
         out.twin = twin
@@ -686,7 +686,7 @@ class _Plan:
         self.op(OP_GCA, 2, p=(pp, pm, self.wptr(f"{name}.gca.net.0.weight"), self.wptr(f"{name}.gca.net.0.bias"),
                               hid.ptr), i=(B, cout, (cout + 7) // 8 * 8, hidc, chunks))
         self.op(OP_GCA, 3, p=(h2.ptr, res.ptr, hid.ptr, self.wptr(f"{name}.gca.net.2.weight"), self.wptr(f"{name}.gca.net.2.bias"),
-                              out.ptr, out.slots or 0), i=(rows, cout, HW, hidc, (hidc + 7) // 8 * 8))
+                              out.ptr, out.slots or 0), i=(rows, cout, HW, hidc, (hidc + 7) // 8 * 8, 0 if getattr(self.u, "gate_t", True) else 1))
 
     def gca_gate(self, name, h2, cout):
         """GlobalContext gate of h2 (imagen_pytorch.py:916-941): softmax-pooled context -> two 1x1 convs -> sigmoid."""
@@ -1138,6 +1138,8 @@ class Unet(nn.Module):
         self.fconv_pipe = True              # slot-GroupNorm 3x3 convs on k_conv_fused_pipe (staging || matrix work)
         self.producer_slots = True          # r04: k_init_x / the Upsample epilogue leave their consumers' statistics slots, the final conv's split-K reduction writes NCHW (False: the r03 k_slots / k_unpack_out launches; parity tests)
         self.attn_in_out_proj = True        # the 16-token attention core in the prologue of its output projection (False: k_attn16 launch; parity tests)
+        self.ln_wave = True                 # r05: LayerNorm of <= 256 rows of 512 | 1024 | 2048 channels on k_layernorm_wave (False: op flag 4 = k_layernorm)
+        self.gate_t = True                  # r05: GlobalContext gate with a compile-time hidden width (k_gca_gate_t; False: k_gca_gate)
         self.conv4 = True                   # r05: the 4x4 level's GroupNorm-self 3x3 convs on k_conv4_gn (csrc/fused_conv4.h); False: op flag 128 = k_conv_fused (parity tests)
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches
         self._pack_cache = None

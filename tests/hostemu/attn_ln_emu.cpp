@@ -12,7 +12,14 @@ extern "C" void emu_layernorm(const float* in, const float* gain, const float* b
     hipemu::launch((unsigned)((R + 3) / 4), 256, 0, [&] { k_layernorm_w256(in, gain, bias, out, resid, R, eps, pre_gelu, out_f32, nullptr); });
     return;
   }
-  hipemu::launch((unsigned)R, 256, 0, [&] { k_layernorm(in, gain, bias, out, resid, R, C, eps, pre_gelu, out_f32); });
+  if (R <= 256 && (C == 512 || C == 1024 || C == 2048) && !(pre_gelu & 4)) {     // the launcher's rule (unet_ops.hip::run_ln); bit 2 of pre_gelu = flag 4
+    const unsigned grid = (unsigned)((R + 3) / 4);
+    if (C == 512) hipemu::launch(grid, 256, 0, [&] { k_layernorm_wave<2>(in, gain, bias, out, resid, R, eps, pre_gelu & 1, out_f32); });
+    else if (C == 1024) hipemu::launch(grid, 256, 0, [&] { k_layernorm_wave<4>(in, gain, bias, out, resid, R, eps, pre_gelu & 1, out_f32); });
+    else hipemu::launch(grid, 256, 0, [&] { k_layernorm_wave<8>(in, gain, bias, out, resid, R, eps, pre_gelu & 1, out_f32); });
+    return;
+  }
+  hipemu::launch((unsigned)R, 256, 0, [&] { k_layernorm(in, gain, bias, out, resid, R, C, eps, pre_gelu & 1, out_f32); });
 }
 
 // segment s: keys ks[s] / values vs[s] with (rows, row_stride, batch_stride, head_stride) in geo[4 s ..]

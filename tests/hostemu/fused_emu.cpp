@@ -138,6 +138,9 @@ extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
       else if (na.chunks <= 32) hipemu::launch(grid, 256, 0, [&] { k_gca_net0<32>(na); });
       else hipemu::launch(grid, 256, 0, [&] { k_gca_net0<64>(na); });
     }
+    else if (ga.HID == 128 && !(op->i[5] & 1)) hipemu::launch(grid, 256, 0, [&] { k_gca_gate_t<128>(ga); });
+    else if (ga.HID == 256 && !(op->i[5] & 1)) hipemu::launch(grid, 256, 0, [&] { k_gca_gate_t<256>(ga); });
+    else if (ga.HID == 512 && !(op->i[5] & 1)) hipemu::launch(grid, 256, 0, [&] { k_gca_gate_t<512>(ga); });
     else hipemu::launch(grid, 256, 0, [&] { k_gca_gate(ga); });
     return 0;
   }

@@ -333,7 +333,8 @@ def test_gn_act(B, H, C1, C2, with_ss):
 
 @pytest.mark.parametrize("R,C,gelu,bias,f32,res", [(16, 1024, False, False, False, False), (32, 2048, True, False, False, False),
                                                      (4, 256, False, True, True, False), (48, 1024, False, False, True, True),
-                                                     (7, 64, False, False, True, False),
+                                                     (7, 64, False, False, True, False), (16, 1024, 4, True, True, True), (300, 512, False, False, True, False),
+                                                     # ((16 | 32 | 48) x (1024 | 2048): k_layernorm_wave since r05; gelu = 4 = op flag 4: k_layernorm on that shape; 300 rows: k_layernorm)
                                                      (4099, 256, False, True, True, True), (2048, 256, True, False, False, False)])      # k_layernorm_w256 (EFT: many 256-channel rows)
 def test_layernorm(R, C, gelu, bias, f32, res):
     g = torch.Generator().manual_seed(R + C)
@@ -341,9 +342,9 @@ def test_layernorm(R, C, gelu, bias, f32, res):
     gain, b = 1 + 0.2 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g)
     r = torch.randn(R, C, generator=g)
     out = torch.empty(R, C, dtype=torch.float32 if f32 else torch.bfloat16, device=DEV)
-    _run([_op(3, (1 if gelu else 0) | (2 if f32 else 0), p=(x.to(DEV), gain.to(DEV), b.to(DEV) if bias else None, out,
-                                                            r.to(DEV) if res else None), i=(R, C), f=(1e-5,))])
-    y = F.gelu(x) if gelu else x
+    _run([_op(3, int(gelu) | (2 if f32 else 0), p=(x.to(DEV), gain.to(DEV), b.to(DEV) if bias else None, out,
+                                                 r.to(DEV) if res else None), i=(R, C), f=(1e-5,))])
+    y = F.gelu(x) if (int(gelu) & 1) else x
     ref = (y - y.mean(-1, keepdim=True)) * (y.var(-1, unbiased=False, keepdim=True) + 1e-5).rsqrt() * gain
     if bias:
         ref = ref + b

@@ -28,7 +28,8 @@ def _lib():
 
 
 @pytest.mark.parametrize("R,Cc,gelu,bias,resid,out_f32", [(16, 1024, False, True, True, True), (5, 192, True, False, False, False),
-                                                         (3, 2048, False, True, False, False),
+                                                         (3, 2048, False, True, False, False),      # (512 | 1024 | 2048 channels, <= 256 rows: k_layernorm_wave, r05)
+                                                         (6, 512, True, False, True, True), (16, 1024, 4, True, True, True),      # gelu = 4: flag 4, k_layernorm on the same shape
                                                          (10, 256, False, True, True, True), (7, 256, True, False, False, False)])      # k_layernorm_w256
 def test_layernorm_kernel(R, Cc, gelu, bias, resid, out_f32):
     lib = _lib()
@@ -36,7 +37,7 @@ def test_layernorm_kernel(R, Cc, gelu, bias, resid, out_f32):
     x, gain = torch.randn(R, Cc, generator=g) * 2 + 0.5, torch.randn(Cc, generator=g)
     b = torch.randn(Cc, generator=g) if bias else None
     r = torch.randn(R, Cc, generator=g) if resid else None
-    xin = F.gelu(x) if gelu else x
+    xin = F.gelu(x) if (int(gelu) & 1) else x
     want = F.layer_norm(xin, (Cc,), gain, b, 1e-5)
     if resid:
         want = want + r
