@@ -214,6 +214,75 @@ SF_KERNEL(256) void k_gca_net0(GcaNetArgs a) {
   gca_net0_body<NCK>(a, pooled, wgt);
 }
 
+// k_gca_net0 with the channel count and the chunk capacity as template parameters (r05; C = 256 | 512 | 1024 with 8 | 16 | 64 chunks = every
+// GlobalContext block of the canonical UNet).  Against k_gca_net0: the row biases are requested with everything else (they were a
+// dependent load in front of the store: one more L2 round trip at the tail), every wave forms the chunks' softmax weights itself from
+// part_ms (no wave-0 section, no block barrier in front of the merge: a per-wave LDS copy and a wave-level hand-off), weight loads are
+// unconditional (clamped address, zero weight) instead of sixteen branches.  Same arithmetic.
+template <int C, int NCK>
+SF_KERNEL(256) void k_gca_net0_t(GcaNetArgs a) {
+  sf_touch_kernarg<(int)sizeof(GcaNetArgs)>();
+  SF_SHARED float pooled[C];
+  SF_SHARED float wgt[4][64];
+  constexpr int KIT = C > 512 ? C / 512 : 1;                 // 16-byte weight loads per row and lane
+  constexpr int CI = C / 256;                                 // channels per thread in the merge
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int rb = (a.HID + 15) / 16;
+  const int b = blockIdx.x / rb, r0 = (blockIdx.x - b * rb) * 16;
+  bf16x8 w[4][KIT];
+  float bq[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = r0 + wave * 4 + rr, rc = r < a.HID ? r : a.HID - 1;
+    bq[rr] = a.b0[rc];
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int k = lane * 8 + it * 512;
+      w[rr][it] = *reinterpret_cast<const bf16x8*>(a.W0 + (long)rc * a.Kp + (k < C ? k : 0));
+    }
+  }
+  const float* pp = a.part_pool + (long)b * a.chunks * C;
+  float pj[CI][NCK];
+#pragma unroll
+  for (int ci = 0; ci < CI; ++ci)
+#pragma unroll
+    for (int j = 0; j < NCK; ++j) pj[ci][j] = pp[(long)(j < a.chunks ? j : a.chunks - 1) * C + tid + ci * 256];
+  {
+    const bool on = lane < a.chunks;
+    const int jl = on ? lane : a.chunks - 1;
+    const float mq = a.part_ms[((long)b * a.chunks + jl) * 2], sq = a.part_ms[((long)b * a.chunks + jl) * 2 + 1];
+    const float mj = on ? mq : -INFINITY, sj = on ? sq : 0.0f;
+    const float M = sf_wave_max(mj);
+    const float wj = on ? sf_exp(mj - M) : 0.0f;
+    const float Z = sf_wave_sum(wj * sj);
+    wgt[wave][lane] = on ? wj / Z : 0.0f;                     // 0 beyond the last chunk; every wave keeps its own copy
+  }
+  sf_wave_sync();
+#pragma unroll
+  for (int ci = 0; ci < CI; ++ci) {
+    float sacc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NCK; ++j) sacc = fmaf(wgt[wave][j], pj[ci][j], sacc);
+    pooled[tid + ci * 256] = sacc;
+  }
+  sf_sync();
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = r0 + wave * 4 + rr;
+    float acc = 0.0f;
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int k = lane * 8 + it * 512;
+      if (k < C) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = fmaf((float)w[rr][it][j], pooled[k + j], acc);
+      }
+    }
+    acc = sf_wave_sum(acc);
+    if (lane == 0 && r < a.HID) a.hid[(long)b * a.HID + r] = sf_silu(acc + bq[rr]);
+  }
+}
+
 struct GcaGateArgs {
   const float* h2;
   const float* res;

@@ -328,7 +328,7 @@ static inline int fconv_pair_setup(const sf_op& op1, const sf_op& op2, FConvPair
 // SF_OP_GCA operands (flags = stage)
 //   1 POOL  p: 0 h2  1 split-K slabs or null  2 conv bias or null  3 logit_part  4 part_pool  5 part_ms
 //           i: 0 M  1 C  2 HW  3 CH (pixels per chunk)  4 chunks per image  5 nparts  6 groups  7 npad
-//   2 NET0  p: 0 part_pool  1 part_ms  2 W0 bf16 [HID][Kp]  3 b0  4 hid ;  i: 0 B  1 C  2 Kp  3 HID  4 chunks
+//   2 NET0  p: 0 part_pool  1 part_ms  2 W0 bf16 [HID][Kp]  3 b0  4 hid ;  i: 0 B  1 C  2 Kp  3 HID  4 chunks  5 bit 0: keep k_gca_net0 (the canonical (C, chunks) run k_gca_net0_t otherwise)
 //   3 GATE  p: 0 h2  1 res  2 hid  3 W2 bf16 [C][Kp2]  4 b2  5 out  6 slots or null ;  i: 0 M  1 C  2 HW  3 HID  4 Kp2  5 bit 0: keep k_gca_gate (HID = 128 | 256 | 512 run k_gca_gate_t otherwise)
 static inline int gca_setup(const sf_op& op, GcaPoolArgs& pa, GcaNetArgs& na, GcaGateArgs& ga, uint32_t& grid, char* err, size_t errn) {
 #define GC_FAIL(...) do { snprintf(err, errn, __VA_ARGS__); return 1; } while (0)

@@ -180,6 +180,10 @@ static int run_gca(const sf_op& op, hipStream_t st) {
   if (gca_setup(op, pa, na, ga, grid, sf_err_buf, sizeof(sf_err_buf))) return SF_ERR_INVALID;
   if (op.flags == 1) k_gca_pool<<<grid, 256, 0, st>>>(pa);
   else if (op.flags == 2) {
+    // r05: compile-time (C, chunk capacity) for the canonical UNet's blocks (i[5] & 1: keep k_gca_net0, parity tests)
+#define SF_TRYN(c_, n_) if (!(op.i[5] & 1) && na.C == c_ && na.Kp == c_ && na.chunks <= n_ && (n_ == 8 || na.chunks > n_ / 2)) { k_gca_net0_t<c_, n_><<<grid, 256, 0, st>>>(na); SF_CHECK_LAUNCH("gca_net0_t"); return SF_OK; }
+    SF_TRYN(256, 64) SF_TRYN(256, 8) SF_TRYN(512, 16) SF_TRYN(512, 8) SF_TRYN(1024, 8)
+#undef SF_TRYN
     if (na.chunks <= 8) k_gca_net0<8><<<grid, 256, 0, st>>>(na);
     else if (na.chunks <= 16) k_gca_net0<16><<<grid, 256, 0, st>>>(na);
     else if (na.chunks <= 32) k_gca_net0<32><<<grid, 256, 0, st>>>(na);

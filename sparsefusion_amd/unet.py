@@ -684,7 +684,7 @@ class _Plan:
         if want_slots:
             out.slots = self.misc.alloc(rows // 16 * (cout // 16) * 2 * 4)
         self.op(OP_GCA, 2, p=(pp, pm, self.wptr(f"{name}.gca.net.0.weight"), self.wptr(f"{name}.gca.net.0.bias"),
-                              hid.ptr), i=(B, cout, (cout + 7) // 8 * 8, hidc, chunks))
+                              hid.ptr), i=(B, cout, (cout + 7) // 8 * 8, hidc, chunks, 0 if getattr(self.u, "gate_t", True) else 1))
         self.op(OP_GCA, 3, p=(h2.ptr, res.ptr, hid.ptr, self.wptr(f"{name}.gca.net.2.weight"), self.wptr(f"{name}.gca.net.2.bias"),
                               out.ptr, out.slots or 0), i=(rows, cout, HW, hidc, (hidc + 7) // 8 * 8, 0 if getattr(self.u, "gate_t", True) else 1))
 

@@ -366,7 +366,9 @@ ATTN_CASES = {"self_context": dict(B=2, cross=False, context=True, seed=61), "se
 GCA_CASES = {"4x4_lazy": dict(B=2, H=4, C=128, lazy=True),
              "4x4_lazy_res_conv_beside_pool": dict(B=2, H=4, C=128, lazy=True, seed=21, rc=(96, 64)),
              "4x4_res_conv_beside_pool_no_skip": dict(B=1, H=4, C=64, seed=22, rc=(128, 0)), "8x8": dict(B=1, H=8, C=64, seed=1), "16x16": dict(B=1, H=16, C=64, seed=2),
-             "8x8_hid128_gate_t": dict(B=2, H=8, C=256, seed=31),       # r05: HID = 128 | 256 | 512 run k_gca_gate_t (compile-time hidden width)
+             "8x8_hid128_gate_t": dict(B=2, H=8, C=256, seed=31),
+             "32x32_c256_64_chunks_net0_t": dict(B=1, H=32, C=256, seed=32, epilogue_chunks=True),      # k_gca_net0_t<256, 64>
+             "16x16_c512_16_chunks_net0_t": dict(B=1, H=16, C=512, seed=33, epilogue_chunks=True),      # k_gca_net0_t<512, 16>, k_gca_gate_t<256>       # r05: HID = 128 | 256 | 512 run k_gca_gate_t (compile-time hidden width)
              "8x8_c192_b2": dict(B=2, H=8, C=192, seed=8),
              "32x32_epilogue_chunks": dict(B=2, H=32, C=64, seed=11, epilogue_chunks=True),
              "16x16_epilogue_chunks": dict(B=1, H=16, C=320, seed=12, epilogue_chunks=True),

@@ -133,6 +133,9 @@ extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
     if (gca_setup(*op, pa, na, ga, grid, err, (size_t)errn)) return 1;
     if (op->flags == 1) hipemu::launch(grid, 256, 0, [&] { k_gca_pool(pa); });
     else if (op->flags == 2) {
+#define SF_TRYN(c_, n_) if (!(op->i[5] & 1) && na.C == c_ && na.Kp == c_ && na.chunks <= n_ && (n_ == 8 || na.chunks > n_ / 2)) { hipemu::launch(grid, 256, 0, [&] { k_gca_net0_t<c_, n_>(na); }); return 0; }
+      SF_TRYN(256, 64) SF_TRYN(256, 8) SF_TRYN(512, 16) SF_TRYN(512, 8) SF_TRYN(1024, 8)
+#undef SF_TRYN
       if (na.chunks <= 8) hipemu::launch(grid, 256, 0, [&] { k_gca_net0<8>(na); });
       else if (na.chunks <= 16) hipemu::launch(grid, 256, 0, [&] { k_gca_net0<16>(na); });
       else if (na.chunks <= 32) hipemu::launch(grid, 256, 0, [&] { k_gca_net0<32>(na); });
