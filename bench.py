@@ -323,7 +323,7 @@ def unet_roofline(hp, B=1):
     all_conv_bytes = int(sum(_op_weight_bytes(o) for o in ops if o.type in (OP_CONV, OP_FCONV)))
     achieved = fconv_bytes / (fconv_ms * 1e-3) / 1e9
     tflops = fconv_flops / (fconv_ms * 1e-3) / 1e12
-    return {"bound": "hbm", "kernel": "k_conv_fused / k_conv_fused_pipe / _pair / k_gca_pool_rc (GroupNorm | LayerNorm + conv in one launch)",
+    return {"bound": "hbm", "kernel": "k_conv_fused / k_conv_fused_pipe / _pair / k_gca_pool_rc / k_conv4_gn / k_lin4_ln (GroupNorm | LayerNorm + conv in one launch)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
             "traffic_note": "not collected in this run (--no-traffic, B > 1 or a multi-rank run): see profiles/r04_unet_eval_b1_pmc.json",
@@ -362,12 +362,12 @@ def measure_fconv_traffic(timeout_s=240):
         tot, n = 0.0, 0
         for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(f)):
-                if ("k_conv_fused" in r["Kernel_Name"] or "k_gca_pool_rc" in r["Kernel_Name"]) and r["Counter_Name"] == "FETCH_SIZE":
+                if any(k in r["Kernel_Name"] for k in ("k_conv_fused", "k_gca_pool_rc", "k_conv4_gn", "k_lin4_ln")) and r["Counter_Name"] == "FETCH_SIZE":
                     tot += float(r["Counter_Value"])
                     n += 1
         if not n:
             return None, "the counter pass recorded no k_conv_fused dispatch"
-        return int(tot / n * 1024 * 2), ("mean FETCH_SIZE over %d k_conv_fused* dispatches of a child process (3 evals, B = 1) under rocprofv3 --kernel-trace "
+        return int(tot / n * 1024 * 2), ("mean FETCH_SIZE over %d fused-conv dispatches (k_conv_fused* / k_conv4_gn / k_lin4_ln) of a child process (3 evals, B = 1) under rocprofv3 --kernel-trace "
                                          "--pmc FETCH_SIZE, KiB x 1024 x 2 (gfx950: the counter reports half of a wide coalesced read)" % n)
     except Exception as e:                                            # noqa: BLE001 -- a bench line without counters is still a bench line
         return None, "counter pass failed: %r" % (e,)
