@@ -93,6 +93,7 @@ class HotPath:
         self.optim = FusedAdam(self.ngp.get_params(lr=5e-4))              # torch.optim.Adam arithmetic, one launch per step
         from sparsefusion_amd.distributed import FlatGradBucket
         self.grads = FlatGradBucket(self.ngp.parameters())       # .grad = views of one flat buffer: zero-copy all-reduce
+        self.multi = world > 1                                   # collectives are issued (bench main sets it for the single-rank RCCL run as well)
         self.check_replicas = world > 1                          # cheap (two 4-element collectives per step): on by default
         self.time_collectives = False
         unet = Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2),
@@ -182,20 +183,20 @@ class HotPath:
         cannot overlap the novel-view render: that render reads the parameters the optimiser step behind this reduce writes
         (distillation.py:247 -> :282), so the collective is issued asynchronously only to keep the host ahead, and waited
         on the stream right before the step."""
-        if self.world > 1 and self.time_collectives:
+        if self.multi and self.time_collectives:
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         work = self.grads.all_reduce(async_op=True)
         if work is not None:
             work.wait()                                          # stream-side wait for RCCL (host returns at once)
-        if self.world > 1 and self.time_collectives:
+        if self.multi and self.time_collectives:
             torch.cuda.synchronize()
             self.coll_us["all_reduce_grads"].append((time.perf_counter() - t0) * 1e6)
 
     def verify_replicas(self):
         """all ranks hold bit-identical NGP parameters?  Two small collectives and a host sync: called ONCE, after the timed region
         (r04 ran it inside every timed step)."""
-        if self.check_replicas and self.world > 1:
+        if self.check_replicas and self.multi:
             from sparsefusion_amd.distributed import replicas_identical
             self.replicas_ok = replicas_identical(self.ngp)
             assert self.replicas_ok, "NGP replicas diverged"
@@ -225,11 +226,11 @@ class HotPath:
         with torch.no_grad():
             latents = self.vae.encode(img256 * 2 - 1).mode() * self.z_scale          # distillation.py:299
             from sparsefusion_amd.distributed import all_gather_latents
-            if self.world > 1 and self.time_collectives:
+            if self.multi and self.time_collectives:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
             self.step_latents = all_gather_latents(latents)        # latents of all novel views of this step (8(e))
-            if self.world > 1 and self.time_collectives:
+            if self.multi and self.time_collectives:
                 torch.cuda.synchronize()
                 self.coll_us["all_gather_latents"].append((time.perf_counter() - t0) * 1e6)
             mt = self.draw_max_thres()
@@ -513,7 +514,11 @@ def main():
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # SF_BENCH_FORCE_DIST=1 (with SF_DIST_SINGLE_RANK_COLLECTIVES=1 for sparsefusion_amd.distributed): ONE rank still initialises
+    # the process group and issues every collective of the step -- the only way a 1-GPU box can put RCCL under this code path
+    # (tests/test_gpu_bench_multirank.py::test_single_rank_rccl)
+    multi_rank = world > 1 or os.environ.get("SF_BENCH_FORCE_DIST") == "1"
+    if multi_rank:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)         # RCCL over xGMI
@@ -529,12 +534,13 @@ def main():
     n_in = 6 if args.config == 2 else 2
     hp = HotPath(dev, rank, world, args.max_thres, args.views_per_gpu, n_input_views=n_in, eft_features=args.config == 2,
                  unet_operand="f16" if args.config == 4 else None, thres_range=thres_range)
-    hp.check_replicas = (world > 1 or args.check_replicas) and not args.no_check_replicas
+    hp.multi = multi_rank
+    hp.check_replicas = (multi_rank or args.check_replicas) and not args.no_check_replicas
     for _ in range(args.warmup):
         hp.step()
 
     def barrier():
-        if world > 1:
+        if multi_rank:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -544,7 +550,7 @@ def main():
         hp.step()
     barrier()
     dt = torch.tensor([time.time() - t0], device=dev)
-    if world > 1:
+    if multi_rank:
         torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
     ms_per_step = float(dt) / args.steps * 1e3
     hp.verify_replicas()                                            # once, OUTSIDE the timed region
@@ -563,7 +569,7 @@ def main():
             hp.step()
         barrier()
         dt32 = torch.tensor([time.time() - t0], device=dev)
-        if world > 1:
+        if multi_rank:
             torch.distributed.all_reduce(dt32, op=torch.distributed.ReduceOp.MAX)
         ms32 = float(dt32) / 2 * 1e3
         total32 = {"workload": "BASELINE configs[3]: 32 novel views per step in total, block-sharded %d per GPU over %d GPU(s) (UNet at B = %d), "
@@ -573,7 +579,7 @@ def main():
         hp.set_views(1)
         hp._sctx = None
     multi = None
-    if world > 1:                                                   # after the timed region: what the collectives cost, on every rank
+    if multi_rank:                                                  # after the timed region: what the collectives cost, on every rank
         import torch.distributed as dist
         hp.time_collectives = True
         for _ in range(2):
@@ -699,7 +705,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.max_thres)
         print(json.dumps(res))
-    if world > 1:
+    if multi_rank:
         torch.distributed.destroy_process_group()
 
 

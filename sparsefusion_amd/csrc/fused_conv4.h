@@ -170,6 +170,238 @@ SF_KERNEL(512) void k_conv4_gn(FConvArgs a) {
   conv4_gn_body<CS4, LAZY>(a, (int)blockIdx.x);
 }
 
+// k_conv4_gn_mb: the same op for NB = 2 | 4 images per workgroup (r05, B >= 2).  With one image per workgroup every image's 256 workgroups
+// stream the layer's weights again (B = 4: 19.5 us per launch against 7.5 at B = 1, two to four rounds of workgroups); here the workgroup of
+// (slice, n-tile) holds its weight share ONCE and the images ride side by side through every phase -- NB frames in LDS, one statistics
+// barrier for all of them, each weight fragment meets NB A fragments (the images are extra rows of the MFMA's M side), waves 0 .. NB - 1
+// finalise one image each.  A first batched form that WALKED the images (one chain after the other) was slower than one image per
+// workgroup (24.3 us, profiles/r05_conv4_batch_ab.log): the chains must overlap, not queue.
+// Registers bound how many images' lazy gathers are in flight together (a split-K element is 5 float4 loads + the thread's bias): SETS
+// images at a time, the set of image ib is re-issued for image ib + SETS as soon as it is combined; the per-image scale / shift rows are
+// requested behind the last image's gather, into the registers a combined set leaves.  LDS: frame ib at ib * a.buf_bytes, red = [NB][8][4][64].
+template <int CS4, int LAZY, int NB>
+SF_DEV void conv4_gn_mb_body(const FConvArgs& a, const int bid) {
+  constexpr int NT = 512, NE = CS4 / 32, CPS = CS4 / 8, KW = 9 * CPS / 8, W = CS4 / 2, NSEG = NT / W, FW = 6;
+  constexpr int K = LAZY == 1 ? 5 : (LAZY == 2 ? 3 : 1);   // loads per element (split-K: slabs 0..3 + residual; its bias is one load per THREAD)
+  constexpr int SETS = (NB * NE * K * 4 <= 112) ? NB : ((2 * NE * K * 4 <= 112 && NB >= 2) ? 2 : 1);
+  SF_DYN_LDS(lds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles = (a.B / NB) * a.n_tiles;
+  const int s = bid / tiles, t = bid - s * tiles;
+  const int nt = t % a.n_tiles, b0 = (t / a.n_tiles) * NB;
+  const int c0 = s * (CS4 * 4);
+  const float sc1 = a.s1.scale, sc2 = a.s2.scale;
+  const int c4 = tid & (CS4 - 1), c = c0 + c4 * 4;
+  const int px0 = tid / CS4;
+
+  // ---- (1) loads: the first SETS images' elements, gamma / beta, the weight share.  The element gather is FGather's (fused_kernels.h:
+  // selected addresses, 0 | 1 weights, no control flow, the same summation order) with the per-THREAD parts hoisted: the channel chunk c
+  // is fixed, so the weights and a split-K source's bias are loaded / formed once, not per element
+  // A slice lies in ONE source (host: s1.C % Cs == 0), so `first` is uniform over the workgroup: the base pointers are scalar selects and
+  // every load is (scalar base) + (one 32-bit element offset per lane) -- the four slabs of an element share their offset register.
+  const bool first = c0 < a.s1.C;
+  const unsigned cc = first ? (unsigned)c : (unsigned)(c - a.s1.C);
+  const int gl = a.s1.groups - 1;
+  const long gstride = (long)a.M * a.s1.npad;
+  float gw[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) gw[g] = first ? (g <= gl ? 1.0f : 0.0f) : (g == 0 ? 1.0f : 0.0f);
+  const float wbias = (LAZY == 1 && first && a.s1.b) ? 1.0f : 0.0f, wres = (LAZY == 1 && first && a.s1.r) ? 1.0f : 0.0f;
+  const float* base[K];                                 // uniform
+  unsigned ld[K];                                       // row stride of each load's tensor, in floats
+  if constexpr (LAZY == 0) {
+    base[0] = first ? a.s1.p : a.s2.p;
+    ld[0] = first ? a.s1.C : a.s2.C;
+  } else if constexpr (LAZY == 1) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      base[g] = first ? a.s1.a + (g < gl ? g : gl) * gstride : a.s2.p;
+      ld[g] = first ? a.s1.npad : a.s2.C;
+    }
+    base[4] = first ? (a.s1.r ? a.s1.r : a.s1.a) : a.s2.p;
+    ld[4] = first ? (a.s1.r ? a.s1.C : a.s1.npad) : a.s2.C;
+  } else {
+    base[0] = first ? a.s1.a : a.s2.p;
+    base[1] = first ? a.s1.b : a.s2.p;
+    base[2] = first ? a.s1.r : a.s2.p;
+    ld[0] = ld[2] = first ? a.s1.C : a.s2.C;
+    ld[1] = ld[0];
+  }
+  f32x4 gt[SETS][NE][K];
+  auto issue = [&](int set, int u, unsigned m) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const unsigned row = (LAZY == 2 && k == 1 && first) ? (m >> 4) : m;        // the gate is one row per image
+      gt[set][u][k] = *reinterpret_cast<const f32x4*>(base[k] + (row * ld[k] + cc));
+    }
+  };
+  f32x4 qbias = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (LAZY == 1) qbias = *reinterpret_cast<const f32x4*>((first && a.s1.b) ? a.s1.b + cc : a.gamma + c);
+  auto combine = [&](int set, int u) -> f32x4 {
+    if constexpr (LAZY == 0) return gt[set][u][0];
+    else if constexpr (LAZY == 1) {                       // order of k_splitk_reduce: bias, slab 0, 1, .., residual (second source: t[0] alone)
+      f32x4 r = qbias * wbias;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) r += gt[set][u][g] * gw[g];
+      r += gt[set][u][4] * wres;
+      return r;
+    } else return first ? gt[set][u][0] * gt[set][u][1] + gt[set][u][2] : gt[set][u][0];
+  };
+#pragma unroll
+  for (int ib = 0; ib < SETS; ++ib)
+#pragma unroll
+    for (int u = 0; u < NE; ++u) issue(ib, u, (unsigned)((b0 + ib) * 16 + px0 + u * (NT / CS4)));
+  const int shoff = a.ss ? a.C : 0;
+  f32x4 qg = *reinterpret_cast<const f32x4*>(a.gamma + c);
+  f32x4 qb = *reinterpret_cast<const f32x4*>(a.beta + c);
+  const int nf = nt < a.n_frags ? nt : a.n_frags - 1;
+  const int n = nf * 16 + (lane & 15);
+  float wkq = (a.wk ? a.wk : a.gamma)[a.wk && n < a.Cout ? n : 0];     // context-logit weight of this output channel: first used in (7)
+  const bf16x8* wbase = a.w + ((long)nf * a.KS + s * CPS) * 64 + lane;
+  bf16x8 fb[KW];
+#pragma unroll
+  for (int i = 0; i < KW; ++i) {
+    const int j = wave * KW + i, tap = j / CPS, ccl = j - tap * CPS;
+#if SF_NT_W
+    fb[i] = __builtin_nontemporal_load(&wbase[(long)(tap * a.cchunks + ccl) * 64]);
+#else
+    fb[i] = wbase[(long)(tap * a.cchunks + ccl) * 64];
+#endif
+  }
+
+  // ---- (2) zero padding of the NB frames: 20 border pixels each, 8 threads per pixel
+  for (int q = tid >> 3; q < NB * FW * FW; q += NT / 8) {
+    const int ib = q / (FW * FW), qq = q - ib * (FW * FW);
+    const int fr = qq / FW, fx = qq - fr * FW;
+    if (fr == 0 || fr == FW - 1 || fx == 0 || fx == FW - 1) {
+      char* dst = lds + (long)ib * a.buf_bytes + (long)qq * a.pix_stride;
+      for (int c8 = (tid & 7); c8 < CS4 / 2; c8 += 8) *reinterpret_cast<bf16x8*>(dst + c8 * 16) = sf_zero8();
+    }
+  }
+
+  // ---- (3) element values and segment sums, image by image; a combined set goes out again for image ib + SETS
+  const float scl = first ? sc1 : sc2;
+  f32x4 v[NB][NE], qsc[NB], qsh[NB];
+  float* misc = reinterpret_cast<float*>(lds + a.misc_off);
+  float* part = misc + 160;                              // [NB][NSEG][2]
+#pragma unroll
+  for (int ib = 0; ib < NB; ++ib) {
+    float sm = 0.0f, sq = 0.0f;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      v[ib][u] = combine(ib % SETS, u);
+      const f32x4 w = v[ib][u] * scl;
+      sm += (w[0] + w[1]) + (w[2] + w[3]);
+      sq = fmaf(w[0], w[0], sq); sq = fmaf(w[1], w[1], sq); sq = fmaf(w[2], w[2], sq); sq = fmaf(w[3], w[3], sq);
+    }
+    if (ib + SETS < NB) {
+#pragma unroll
+      for (int u = 0; u < NE; ++u) issue(ib % SETS, u, (unsigned)((b0 + ib + SETS) * 16 + px0 + u * (NT / CS4)));
+    }
+    if (ib == NB - 2) {
+      // the images' scale / shift rows go out HERE, into the registers the combined set leaves, behind the last image's gather: they
+      // arrive under its sums and the barrier (requested at entry they cost 8 NB registers at the kernel's peak: spills at NB = 4)
+      const float* ssb = a.ss ? a.ss : a.gamma;                        // any valid address when there is no scale / shift
+      const unsigned sstr = a.ss ? (unsigned)a.ss_stride : 0u;
+#pragma unroll
+      for (int jb = 0; jb < NB; ++jb) {
+        qsc[jb] = *reinterpret_cast<const f32x4*>(ssb + ((unsigned)(b0 + jb) * sstr + (unsigned)c));
+        qsh[jb] = *reinterpret_cast<const f32x4*>(ssb + ((unsigned)(b0 + jb) * sstr + (unsigned)(shoff + c)));
+      }
+    }
+    sm = sf_group_sum(sm, W);
+    sq = sf_group_sum(sq, W);
+    if ((lane & (W - 1)) == 0) { part[2 * (ib * NSEG + tid / W)] = sm; part[2 * (ib * NSEG + tid / W) + 1] = sq; }
+  }
+  sf_sync();
+  // ---- (4) + (5) per image: (mean, rstd) of this thread's group, the affine in registers, normalise / activate / bf16 into frame ib
+  const int gi = c4 / W;
+#pragma unroll
+  for (int ib = 0; ib < NB; ++ib) {
+    double S = 0.0, Q = 0.0;
+#pragma unroll
+    for (int k = 0; k < NSEG / 2; ++k) {
+      S += (double)part[2 * (ib * NSEG + 2 * k + gi)];
+      Q += (double)part[2 * (ib * NSEG + 2 * k + gi) + 1];
+    }
+    const double mean_d = S * a.inv_n;
+    double var = Q * a.inv_n - mean_d * mean_d;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)mean_d, rstd = sf_rsqrt((float)var + a.eps);
+    f32x4 A, Bv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float A0 = rstd * qg[j], scj = a.ss ? qsc[ib][j] + 1.0f : 1.0f, shj = a.ss ? qsh[ib][j] : 0.0f;
+      A[j] = A0 * scj;
+      Bv[j] = (qb[j] - mean * A0) * scj + shj;
+    }
+    char* frame = lds + (long)ib * a.buf_bytes;
+#pragma unroll
+    for (int u = 0; u < NE; ++u) {
+      const int p = px0 + u * (NT / CS4), py = p >> 2, pxx = p & 3;
+      if (LAZY && nt == 0 && first && a.s1.p) *reinterpret_cast<f32x4*>(a.s1.p + ((long)(b0 + ib) * 16 + p) * a.s1.C + c) = v[ib][u];
+      f32x4 y = (v[ib][u] * scl) * A + Bv;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float sv = sf_silu_fast(y[j]);
+        y[j] = a.silu ? sv : y[j];
+      }
+      bf16x4 o;
+      o[0] = (sf_opnd)y[0]; o[1] = (sf_opnd)y[1]; o[2] = (sf_opnd)y[2]; o[3] = (sf_opnd)y[3];
+      *reinterpret_cast<bf16x4*>(frame + (long)((py + 1) * FW + pxx + 1) * a.pix_stride + c4 * 8) = o;
+    }
+  }
+  sf_sync();
+
+  // ---- (6) main loop: every weight fragment of this wave meets the NB images' A fragments
+  f32x4 acc[NB];
+#pragma unroll
+  for (int ib = 0; ib < NB; ++ib) acc[ib] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int pA = lane & 15;
+  const char* abase = lds + (long)((pA >> 2) * FW + (pA & 3)) * a.pix_stride + (lane >> 4) * 16;
+#pragma unroll
+  for (int i = 0; i < KW; ++i) {
+    const int j = wave * KW + i, tap = j / CPS, ccl = j - tap * CPS;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const long off = (long)(ky * FW + kx) * a.pix_stride + ccl * 64;
+    bf16x8 fa[NB];
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib) fa[ib] = *reinterpret_cast<const bf16x8*>(abase + (long)ib * a.buf_bytes + off);
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib) acc[ib] = sf_mfma16(fa[ib], fb[i], acc[ib]);
+  }
+  // ---- (7) the 8 K-slices meet in LDS; wave ib stores the slab tile of image ib
+  float* red = reinterpret_cast<float*>(lds + a.red_off);         // [image][wave][r][lane]
+#pragma unroll
+  for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((ib * 8 + wave) * 4 + r) * 64 + lane] = acc[ib][r];
+  sf_sync();
+  SF_USE_FROM_HERE(wkq);
+  const float wkv = a.wk ? wkq : 0.0f;
+  if (wave < NB && nt < a.n_frags) {
+    const long mrow = (long)(b0 + wave) * 16 + (lane >> 4) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float sacc = 0.0f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) sacc += red[((wave * 8 + w) * 4 + r) * 64 + lane];
+      if (a.logit_part) {
+        float lp = sacc * wkv;
+        lp += sf_shfl_xor(lp, 1); lp += sf_shfl_xor(lp, 2); lp += sf_shfl_xor(lp, 4); lp += sf_shfl_xor(lp, 8);
+        if ((lane & 15) == 0) a.logit_part[((long)s * a.n_frags + nt) * a.M + mrow + r] = lp;
+      }
+      a.ws[((long)s * a.M + mrow + r) * a.npad + n] = sacc;
+    }
+  }
+}
+
+template <int CS4, int LAZY, int NB>
+SF_KERNEL(512) void k_conv4_gn_mb(FConvArgs a) {
+  sf_touch_kernarg<(int)sizeof(FConvArgs)>();
+  conv4_gn_mb_body<CS4, LAZY, NB>(a, (int)blockIdx.x);
+}
+
 // k_lin4_ln: LayerNorm -> Linear on the 16-token map (the transformer blocks of the 4x4 level: merged q | k | v projection, ff1 with its
 // GELU epilogue, ff2 with its residual; external/imagen_pytorch.py:480-566, :944-1010) -- the same op, operands and LDS layout as
 // k_conv_fused<1, WN, ., FNORM_LN, 0, 8> for a plain source of C = 1024 | 2048 channels, built like k_conv4_gn: the row (8 | 16 float4 per

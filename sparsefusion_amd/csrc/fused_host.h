@@ -15,7 +15,7 @@
 //   f: 0 eps  1 s1.scale  2 s2.scale
 //   norm == FNORM_ATTN (the attention core as the prologue of its output projection; k = 1, 4x4 map, C1 = 512 = 8 heads x 64):
 //      p: 0 q rows [B * 16][ldq] (instead of a source tensor)  19..21 key pointers of the <= 3 key / value segments
-//      i: 19 ldq  20 + 4 s .. 23 + 4 s: rows, row_stride, batch_stride, head_stride of segment s (rows = 0: unused)
+//      i: 19 ldq (other norms: bit 0 = keep one image per workgroup where k_conv4_gn_mb would take the op)  20 + 4 s .. 23 + 4 s: rows, row_stride, batch_stride, head_stride of segment s (rows = 0: unused)
 //      f: 3 + s: value offset of segment s in floats (v = k + offset)  6: softmax scale
 // SF_OP_SLOTS operands
 //   p: 0 x (or h)  1 gate [B, C] or null  2 res  3 out (gate / split-K mode)  4 slots  5 split-K slabs or null  6 conv bias or null
@@ -270,6 +270,33 @@ static inline int conv4_cs4(const sf_op& op, const FConvArgs& a, int WM, int WN)
   if (a.s1.mode == 1 && a.s1.groups > 4) return 0;
   if (((uintptr_t)a.gamma | (uintptr_t)a.beta | (uintptr_t)a.ss) & 15 || (a.ss && a.ss_stride % 4)) return 0;      // float4 affine operands
   return a.cps * 8;
+}
+
+// (CS4, LAZY, NB) of k_conv4_gn_mb
+#define SF_CONV4_MB_VARIANTS(X) \
+  X(64, 0, 2) X(64, 0, 4) X(64, 1, 2) X(64, 1, 4) X(64, 2, 2) X(64, 2, 4) X(128, 0, 2) X(128, 2, 2)
+
+// k_conv4_gn_mb (fused_conv4.h, r05): NB = 2 | 4 images per workgroup for an op that fits k_conv4_gn at B >= 2.  Returns NB and rewrites the
+// LDS layout (NB frames, a reduction buffer per image) and the grid, or 0 = one image per workgroup.  Op field i[19] bit 0 (planner
+// attribute Unet.conv4_mb = False; FNORM_ATTN ops use i[19] otherwise) keeps k_conv4_gn.
+static inline int conv4_mb_setup(const sf_op& op, FConvArgs& a, int cs4, uint32_t& grid, uint32_t& lds_bytes) {
+  if ((op.i[19] & 1) || a.B < 2) return 0;
+  if (a.s1.C % (cs4 * 4)) return 0;                                         // a slice lies in ONE source: the kernel selects its base pointers per workgroup
+  if ((long)a.M * (a.s1.mode == 1 ? a.s1.npad : a.s1.C) >= (1L << 30)) return 0;     // 32-bit element offsets
+  int nb = 0;
+  if (cs4 == 64) nb = a.B % 4 == 0 ? 4 : (a.B % 2 == 0 ? 2 : 0);
+  else if (cs4 == 128 && a.s1.mode != 1) nb = a.B % 2 == 0 ? 2 : 0;       // two 36-pixel x 512-channel frames: 76 KB; a split-K source at Cs = 512
+                                                                            // stays on k_conv4_gn (18 weight fragments + one image's 80 gather registers: 256 + 90 spilled)
+  if (!nb) return 0;
+  const uint32_t frame = (36u * (uint32_t)a.pix_stride + 15u) & ~15u;
+  const uint32_t red = (uint32_t)nb * frame, misc = red + (uint32_t)nb * 8192u, total = misc + 640 + 2048;
+  if (total > SF_LDS_MAX) return 0;
+  a.buf_bytes = (int)frame;
+  a.red_off = (int)red;
+  a.tab_off = a.misc_off = (int)misc;                                       // no affine table: the affine lives in registers
+  lds_bytes = total;
+  grid = (uint32_t)a.S * (uint32_t)(a.B / nb) * (uint32_t)a.n_tiles;
+  return nb;
 }
 
 // (WM, WN, EPT) of k_conv_fused_pipe_rc: the pipelined tiles with registers to spare for the res_conv's accumulators and ring slot

@@ -120,6 +120,7 @@ static inline void sf_vmcnt() {
 static inline void sf_lds_barrier() { hipemu::syncthreads(); }
 #define SF_SCHED_GROUP(mask, n) do { } while (0)
 #define SF_LGKM0() do { } while (0)
+#define SF_USE_FROM_HERE(x) do { } while (0)
 static inline void sf_glds_done() { if (sf_glds_lane[threadIdx.x].n) { fprintf(stderr, "LDS-DMA loads still in flight at kernel end\n"); abort(); } }
 static const uint32_t sf_zero128[32] __attribute__((aligned(128))) = {0};
 #else
@@ -188,6 +189,10 @@ SF_DEV void sf_glds_done() {}
 // scheduling hint: the next n instructions of class `mask` (0x008 MFMA, 0x100 LDS read) go here, in program order of the groups
 #define SF_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #define SF_LGKM0() __builtin_amdgcn_s_waitcnt(0xc07f)      // lgkmcnt(0), visible to the compiler's own counting
+// pins the first use of a loaded VGPR value to this point of the program: whatever is computed from x cannot be scheduled (and waited
+// for) earlier.  hipcc moved the one-dword load of k_conv4_gn_mb's context-logit weight to the kernel's first instruction and waited for it
+// there -- a cold round trip in front of every other load of the launch -- when the select on it stood next to the load.
+#define SF_USE_FROM_HERE(x) asm volatile("" : "+v"(x))
 __device__ __attribute__((aligned(128))) static const uint32_t sf_zero128[32] = {0};      // one zero line: an out-of-image pixel's 8 lanes read it like any other line
 #endif
 

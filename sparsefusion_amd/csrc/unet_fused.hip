@@ -34,6 +34,15 @@ static int launch_conv4(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStre
   return SF_OK;
 }
 
+template <int CS4, int LAZY, int NB>
+static int launch_conv4_mb(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStream_t st) {
+  static unsigned mask = 0;
+  if (int rc = allow_big_lds(k_conv4_gn_mb<CS4, LAZY, NB>, lds, mask)) return rc;
+  k_conv4_gn_mb<CS4, LAZY, NB><<<grid, 512, lds, st>>>(a);
+  SF_CHECK_LAUNCH("conv4_gn_mb");
+  return SF_OK;
+}
+
 template <int C4T, int WN>
 static int launch_lin4(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStream_t st) {
   static unsigned mask = 0;
@@ -65,6 +74,12 @@ static int run_fconv(const sf_op& op, hipStream_t st) {
     SF_FAIL(SF_ERR_INVALID, "fconv pipe: no kernel variant for tile %dx%d, %d staging elements", WM, WN, EPT);
   }
   if (const int cs4 = conv4_cs4(op, a, WM, WN)) {       // r05: the 4x4 level's GroupNorm-self conv on its own kernel (fused_conv4.h)
+    if (const int nb = conv4_mb_setup(op, a, cs4, grid, lds)) {       // B >= 2: NB images per workgroup share its weight slice
+#define SF_TRY4M(c4_, lz_, nb_) if (cs4 == c4_ && a.s1.mode == lz_ && nb == nb_) return launch_conv4_mb<c4_, lz_, nb_>(a, grid, lds, st);
+      SF_CONV4_MB_VARIANTS(SF_TRY4M)
+#undef SF_TRY4M
+      SF_FAIL(SF_ERR_INVALID, "fconv: no k_conv4_gn_mb variant for Cs4 %d lazy %d x %d images", cs4, a.s1.mode, nb);
+    }
 #define SF_TRY4(c4_, lz_) if (cs4 == c4_ && a.s1.mode == lz_) return launch_conv4<c4_, lz_>(a, grid, lds, st);
     SF_TRY4(64, 0) SF_TRY4(64, 1) SF_TRY4(64, 2) SF_TRY4(128, 0) SF_TRY4(128, 1) SF_TRY4(128, 2)
 #undef SF_TRY4

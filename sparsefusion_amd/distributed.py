@@ -12,8 +12,19 @@ the replicas identical and let every rank see the whole batch of rendered latent
 torch.distributed's "nccl" backend IS RCCL on ROCm (xGMI inside a node); the same code runs on "gloo"
 for the CPU tests.  Messages are small (<= 8 MB), so one flat buffer per step is the right granularity
 for the point-to-point xGMI fabric (per-link bound ring of 7 hops would dominate otherwise)."""
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _no_exchange(group=None):
+    """True when there is nobody to exchange with: no process group, or a group of one rank.  SF_DIST_SINGLE_RANK_COLLECTIVES=1
+    makes a one-rank group issue its collectives anyway -- a 1-GPU box can then put RCCL under every call site of this module
+    (`tests/test_gpu_bench_multirank.py::test_single_rank_rccl`); results are the inputs, by definition of the collectives."""
+    if not dist.is_initialized():
+        return True
+    return dist.get_world_size(group) == 1 and os.environ.get("SF_DIST_SINGLE_RANK_COLLECTIVES") != "1"
 
 
 def shard_views(n_views, rank, world):
@@ -27,7 +38,7 @@ def all_gather_latents(latents, group=None, check=False):
     """[V, C, H, W] on every rank -> [world*V, C, H, W] in rank order.  V must be the same on every rank
     (`all_gather_into_tensor` has no ragged form): pad the short shards of an uneven `shard_views` split, or pass
     check=True to have the ranks compare their V first (one tiny extra collective)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if _no_exchange(group):
         return latents
     world = dist.get_world_size(group)
     if check:
@@ -96,7 +107,7 @@ class FlatGradBucket:
     def all_reduce(self, group=None, average=True, async_op=False):
         """In-place sum (mean) over the group; returns the work handle when async_op (wait before optimizer.step)."""
         self.check_bound()
-        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        if _no_exchange(group):
             return None
         if average:
             self.flat.div_(dist.get_world_size(group))           # before the sum: same result, and the async form needs no epilogue
@@ -106,7 +117,7 @@ class FlatGradBucket:
 def replicas_identical(module, group=None):
     """True when every rank holds bit-identical parameters: MAX and MIN over the ranks of an fp64 checksum and of the
     parameter extrema agree.  Two 4-element collectives; meant for a per-step assertion in multi-GPU runs."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if _no_exchange(group):
         return True
     ps = [p.detach() for p in module.parameters()]
     sig = torch.stack([sum(p.double().sum() for p in ps), sum((p.double() ** 2).sum() for p in ps),
@@ -121,7 +132,7 @@ def all_reduce_grads(params, group=None, average=True):
     """In-place mean (or sum) of the .grad of `params` over the group with ONE flat collective (generic form: gathers into
     a temporary; the hot path uses FlatGradBucket).  Parameters without a gradient contribute zeros, so every rank
     reduces the same layout."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if _no_exchange(group):
         return
     params = [p for p in params if p.requires_grad]
     for p in params:
@@ -142,7 +153,7 @@ def all_reduce_grads(params, group=None, average=True):
 
 def broadcast_params(module, src=0, group=None):
     """Make every replica start from rank `src`'s parameters (one flat broadcast)."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if _no_exchange(group):
         return
     ps = [p.data for p in module.parameters()]
     flat = torch.cat([p.reshape(-1) for p in ps])

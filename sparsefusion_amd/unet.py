@@ -477,10 +477,11 @@ class _Plan:
         if not cand:
             return None
         S = next((d for d in cand if MT * n_frags * d >= 256), cand[-1])
-        if (B <= getattr(self.u, "conv4_slices_max_batch", 4) and getattr(self.u, "conv4", True) and norm == FNORM_GN_SELF and H == 4 and k == 3
-                and C in (1024, 2048) and 4 in cand):
+        if ((B <= getattr(self.u, "conv4_slices_max_batch", 4) or (getattr(self.u, "conv4_mb", True) and B % 2 == 0)) and getattr(self.u, "conv4", True)
+                and norm == FNORM_GN_SELF and H == 4 and k == 3 and C in (1024, 2048) and 4 in cand):
             S = 4               # r05: keep k_conv4_gn's 4-slice geometry where the workgroup count alone would pick fewer slices (B = 2: S = 2, B = 4:
-                                # S = 1, both on the general kernel): B = 2 eval 1.287 -> 1.240 ms, B = 4 1.734 -> 1.730 (profiles/r05_conv4_batch_ab.log)
+                                # S = 1, both on the general kernel): B = 2 eval 1.287 -> 1.240 ms, B = 4 1.734 -> 1.730 (profiles/r05_conv4_batch_ab.log);
+                                # even B of any size: k_conv4_gn_mb, 2 | 4 images per workgroup on one weight slice (csrc/fused_conv4.h)
         WN = 2 if (n_frags % 2 == 0 and MT * (n_frags // 2) * S >= 256 and lds_bytes(S, 2) <= LDS_MAX and norm != FNORM_GN_SELF) else 1
         return TR, WM, WN, S
 
@@ -571,6 +572,8 @@ class _Plan:
             ap = tuple(sk for sk, *_ in segs)
             ai = (ldq,) + tuple(v for _, _, rows, rs, bs, hs in segs for v in (rows, rs, bs, hs))
             af = tuple((sv - sk) // 4 for sk, sv, *_ in segs) + (scale,)
+        elif norm == FNORM_GN_SELF and not getattr(self.u, "conv4_mb", True):
+            ai = (1,)                                           # i[19] bit 0: one image per workgroup (k_conv4_gn) where k_conv4_gn_mb would take the op
         self.op(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0) | (8 if out_gelu else 0) | (16 if pair_first else 0)
                 | (32 if pipe else 0) | (64 if pool is not None else 0) | (0 if getattr(self.u, "conv4", True) else 128),
                 p=(x_ptr, lp[0], lp[1], lp[2], x.slots or 0, skip.ptr if skip else 0, (skip.slots or 0) if skip else 0,
@@ -1144,6 +1147,7 @@ class Unet(nn.Module):
         self.attn_in_out_proj = True        # the 16-token attention core in the prologue of its output projection (False: k_attn16 launch; parity tests)
         self.ln_wave = True                 # r05: LayerNorm of <= 256 rows of 512 | 1024 | 2048 channels on k_layernorm_wave (False: op flag 4 = k_layernorm)
         self.gate_t = True                  # r05: GlobalContext gate with a compile-time hidden width (k_gca_gate_t; False: k_gca_gate)
+        self.conv4_mb = True                # r05: even B: the 4x4 GroupNorm-self convs run 2 | 4 images per workgroup (k_conv4_gn_mb; False = op field i[19] bit 0)
         self.conv4_slices_max_batch = 4     # r05: up to this batch the 4x4 GroupNorm-self convs keep 4 input-channel slices (= k_conv4_gn's geometry); 0 = the workgroup-count rule alone
         self.conv4 = True                   # r05: the 4x4 level's GroupNorm-self 3x3 convs on k_conv4_gn (csrc/fused_conv4.h); False: op flag 128 = k_conv_fused (parity tests)
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches

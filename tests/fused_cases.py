@@ -53,7 +53,7 @@ def run_ops(ops, backend):
 
 def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, silu=True, ss=True, accum=False, resid=False,
                   slots=True, pre_gelu=False, ln_bias=False, seed=0, G=8, scale2=2 ** -0.5, tol=4e-3, dbg=None, reps=1, logits=False,
-                  out_gelu=False, pair=False, pipe=False, pool=False, general=False):
+                  out_gelu=False, pair=False, pipe=False, pool=False, general=False, one_image=False):
     dev = "cpu" if backend == "emu" else "cuda:0"
     d = lambda t: None if t is None else t.to(dev)
     g = torch.Generator().manual_seed(seed)
@@ -119,7 +119,8 @@ def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, 
     op = fused.mkop(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0) | (8 if out_gelu else 0) | (32 if pipe else 0)
                     | (64 if pool else 0) | (128 if general else 0),     # 128: keep the general kernel (r05: k_conv4_gn takes the 4x4 geometry otherwise)
                     p=(s1["p"], s1["a"], s1["b"], s1["r"], sl1, x2_d, sl2, wp, bias_d, out, res_d, wsl, slots_out, gamma_d, beta_d, ssv_d, dbg, wk_d, lpart),
-                    i=(B, H, W, C1, C2, Cout, ldc, co_off, k, s1["mode"], s1["groups"], s1["npad"], norm, G, TR, WM, WN, S, 2 * C),
+                    i=(B, H, W, C1, C2, Cout, ldc, co_off, k, s1["mode"], s1["groups"], s1["npad"], norm, G, TR, WM, WN, S, 2 * C)
+                    + ((1,) if one_image else ()),      # i[19] bit 0: one image per workgroup (k_conv4_gn) where k_conv4_gn_mb would take the op
                     f=(1e-5, 1.0, scale2))
     ops = [op]
     if pair:          # conv1 || res_conv in one launch (k_conv_fused_pair): a 1x1 conv of the RAW concat next to the normalised 3x3 one
@@ -395,6 +396,17 @@ CONV_CASES = {
     "conv4_gn_concat_gate_2048": dict(B=1, H=4, W=4, C1=1024, C2=1024, Cout=16, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=2, seed=72),
     "conv4_gn_plain_1024_b2": dict(B=2, H=4, W=4, C1=1024, C2=0, Cout=16, k=3, norm=GN_SELF, WM=1, WN=1, S=4, ss=False, silu=False, seed=73),
     "conv4_gn_concat_lazy_2048": dict(B=1, H=4, W=4, C1=1024, C2=1024, Cout=16, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=1, seed=74, logits=True),
+    # r05: B >= 2 in that geometry runs k_conv4_gn_mb -- NB = 2 | 4 images per workgroup share its weight slice (B % 4 == 0 at Cs = 256: 4, other
+    # even B: 2; Cs = 512: 2); every lazy mode (a split-K element's six loads bound how many images' gathers fly together: 2 at Cs = 256, 1 at
+    # Cs = 512), several image groups per (slice, n-tile), logits; `one_image=True` = the same op on k_conv4_gn
+    "conv4_mb_lazy_splitk_1024_b4": dict(B=4, H=4, W=4, C1=1024, C2=0, Cout=32, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=1, seed=75, logits=True),
+    "conv4_mb_gate_1024_b8": dict(B=8, H=4, W=4, C1=1024, C2=0, Cout=16, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=2, seed=76),
+    "conv4_mb_lazy_splitk_1024_b6": dict(B=6, H=4, W=4, C1=1024, C2=0, Cout=16, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=1, seed=77, logits=True),
+    "conv4_mb_concat_lazy_2048_b2": dict(B=2, H=4, W=4, C1=1024, C2=1024, Cout=16, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=1, seed=78, logits=True),
+    "conv4_mb_concat_gate_2048_b4": dict(B=4, H=4, W=4, C1=1024, C2=1024, Cout=32, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=2, seed=79),
+    "conv4_mb_concat_plain_2048_b2": dict(B=2, H=4, W=4, C1=1024, C2=1024, Cout=16, k=3, norm=GN_SELF, WM=1, WN=1, S=4, seed=80, ss=False),
+    "conv4_mb_concat_lazy_512_512_b4": dict(B=4, H=4, W=4, C1=512, C2=512, Cout=16, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=1, seed=81),
+    "conv4_one_image_per_workgroup_b4": dict(B=4, H=4, W=4, C1=1024, C2=0, Cout=16, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=1, seed=75, one_image=True),
     "conv4_geometry_on_the_general_kernel": dict(B=1, H=4, W=4, C1=1024, C2=0, Cout=16, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=1, seed=71, general=True),
     # 8x8 level: 2-row tiles with halo rows from neighbouring tiles, statistics from producer slots, final epilogue + slots
     "gn_slots_concat_8x8": dict(B=1, H=8, W=8, C1=128, C2=128, Cout=32, k=3, norm=GN_SLOTS, WM=1, WN=1, resid=True, seed=2),

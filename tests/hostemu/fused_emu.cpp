@@ -19,7 +19,8 @@ static void emu_fconv_pair(const FConvPairArgs& p, uint32_t grid, uint32_t lds) 
   hipemu::launch(grid, SF_FCONV_WAVES * 64, lds, [&] { k_conv_fused_pair<WM, WN, D, NORM, LAZY, SF_FCONV_WAVES>(p); });
 }
 
-static int g_conv4_launches = 0;
+static int g_conv4_launches = 0, g_conv4_mb_launches = 0;
+extern "C" int emu_conv4_mb_launches() { return g_conv4_mb_launches; }  // ops that ran on k_conv4_gn_mb (several images per workgroup)
 extern "C" int emu_conv4_launches() { return g_conv4_launches; }  // how many ops ran on k_conv4_gn (tests assert the path was taken)
 static int g_rc_launches = 0;
 extern "C" int emu_rc_launches() { return g_rc_launches; }      // how many pairs ran as k_conv_fused_pipe_rc (tests assert the path was taken)
@@ -97,6 +98,14 @@ extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
       return 1;
     }
     if (const int cs4 = conv4_cs4(*op, a, WM, WN)) {        // the same dispatch as unet_fused.hip::run_fconv (r05: k_conv4_gn)
+      if (const int nb = conv4_mb_setup(*op, a, cs4, grid, lds)) {
+#define SF_TRY4M(c4_, lz_, nb_) \
+        if (cs4 == c4_ && a.s1.mode == lz_ && nb == nb_) { hipemu::launch(grid, 512, lds, [&] { k_conv4_gn_mb<c4_, lz_, nb_>(a); }); ++g_conv4_mb_launches; return 0; }
+        SF_CONV4_MB_VARIANTS(SF_TRY4M)
+#undef SF_TRY4M
+        snprintf(err, errn, "fconv: no k_conv4_gn_mb variant");
+        return 1;
+      }
 #define SF_TRY4(c4_, lz_) \
       if (cs4 == c4_ && a.s1.mode == lz_) { hipemu::launch(grid, 512, lds, [&] { k_conv4_gn<c4_, lz_>(a); }); ++g_conv4_launches; return 0; }
       SF_TRY4(64, 0) SF_TRY4(64, 1) SF_TRY4(64, 2) SF_TRY4(128, 0) SF_TRY4(128, 1) SF_TRY4(128, 2)

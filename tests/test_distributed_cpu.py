@@ -118,3 +118,44 @@ def test_shard_views_partition():
         assert sum(parts, []) == list(range(n))
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
     assert shard_views(32, 3, 8) == [12, 13, 14, 15]               # BASELINE config 4: 4 views per GPU
+
+
+_ONE_RANK_GLOO = r"""
+import torch, torch.distributed as dist
+from sparsefusion_amd import distributed as D
+dist.init_process_group("gloo", rank=0, world_size=1)
+assert not D._no_exchange()                      # SF_DIST_SINGLE_RANK_COLLECTIVES=1: a one-rank group still issues its collectives
+lat = torch.randn(2, 4, 32, 32)
+out = D.all_gather_latents(lat, check=True)
+assert out.data_ptr() != lat.data_ptr() and torch.equal(out, lat)
+net = torch.nn.Linear(8, 4)
+b = D.FlatGradBucket(net.parameters())
+b.zero()
+net(torch.randn(3, 8)).sum().backward()
+ref = b.flat.clone()
+w = b.all_reduce(async_op=True)
+assert w is not None
+w.wait()
+assert torch.equal(b.flat, ref)
+D.all_reduce_grads(list(net.parameters()))
+D.broadcast_params(net)
+assert D.replicas_identical(net) is True
+dist.destroy_process_group()
+print("ONE_RANK_OK")
+"""
+
+
+def test_one_rank_group_issues_its_collectives_on_request():
+    """The switch the single-rank RCCL tests of tests/test_gpu_bench_multirank.py rely on, on gloo: without it a one-rank group
+    short-cuts every helper (nothing to exchange), with it the collectives run and return their inputs."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + os.getpid() % 90), SF_DIST_SINGLE_RANK_COLLECTIVES="1",
+               PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    out = subprocess.run([sys.executable, "-c", _ONE_RANK_GLOO], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ONE_RANK_OK" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+    env.pop("SF_DIST_SINGLE_RANK_COLLECTIVES")
+    out = subprocess.run([sys.executable, "-c", _ONE_RANK_GLOO.replace("assert not D._no_exchange()", "assert D._no_exchange(); print('ONE_RANK_OK'); raise SystemExit(0)")],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ONE_RANK_OK" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])

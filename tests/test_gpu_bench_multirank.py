@@ -1,7 +1,8 @@
 """Dry run of the multi-rank path of bench.py on ONE GPU: two ranks share cuda:0, the collectives go through gloo
 (SF_BENCH_BACKEND=gloo) -- exercises view sharding (--total-views, strong scaling), the latent all-gather, the in-place
 all-reduce of the flat NGP gradient buffer, the replica check (once, after the timed region) and the max-over-ranks timing / JSON line.
-RCCL itself only runs on the driver's multi-GPU node."""
+RCCL with more than one rank only runs on the driver's multi-GPU node; the last two tests put RCCL under the same call sites with ONE rank
+(a one-rank group that issues its collectives anyway: SF_BENCH_FORCE_DIST / SF_DIST_SINGLE_RANK_COLLECTIVES)."""
 import json
 import os
 import subprocess
@@ -102,3 +103,68 @@ def test_default_max_thres_is_drawn_per_step():
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert "drawn per step" in res["config"]["workload"] and res["config"]["unet_evals_per_step"] == 51 and res["value"] > 0
+
+
+_HELPERS_ON_RCCL = r"""
+import torch, torch.distributed as dist
+from sparsefusion_amd import distributed as D
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1 and not D._no_exchange()
+g = torch.Generator(device="cpu").manual_seed(3)
+lat = torch.randn(4, 4, 32, 32, generator=g).to(dev)
+out = D.all_gather_latents(lat, check=True)
+assert out.data_ptr() != lat.data_ptr() and torch.equal(out, lat)             # went through all_gather_into_tensor
+net = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.Linear(64, 16)).to(dev)
+bucket = D.FlatGradBucket(net.parameters())
+bucket.zero()
+net(torch.randn(8, 32, generator=g).to(dev)).square().sum().backward()
+ref = bucket.flat.clone()
+work = bucket.all_reduce(async_op=True)
+assert work is not None
+work.wait()
+torch.cuda.synchronize()
+assert torch.equal(bucket.flat, ref)                                           # mean over one rank
+gr = [p.grad.clone() for p in net.parameters()]
+D.all_reduce_grads(list(net.parameters()))
+assert all(torch.equal(a, p.grad) for a, p in zip(gr, net.parameters()))
+w0 = [p.detach().clone() for p in net.parameters()]
+D.broadcast_params(net)
+assert all(torch.equal(a, p) for a, p in zip(w0, net.parameters()))
+assert D.replicas_identical(net) is True                                       # fp64 MAX / MIN all-reduces
+dist.barrier()
+dist.destroy_process_group()
+print("RCCL_SINGLE_RANK_OK")
+"""
+
+
+def _single_rank_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("SF_BENCH_BACKEND",)}
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 90),
+               SF_DIST_SINGLE_RANK_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    return env
+
+
+def test_single_rank_rccl_under_the_distributed_helpers():
+    """Every call site of sparsefusion_amd.distributed on the "nccl" (= RCCL) backend with device tensors: all_gather_into_tensor, the
+    asynchronous in-place all-reduce of the flat gradient bucket, the generic gradient all-reduce, the flat broadcast, the fp64 MAX / MIN
+    replica check, barrier -- one rank, so every result must equal its input."""
+    out = subprocess.run([sys.executable, "-c", _HELPERS_ON_RCCL], env=_single_rank_env(), cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL_SINGLE_RANK_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
+
+
+def test_single_rank_rccl():
+    """bench.py's multi-rank path -- process group on the "nccl" backend with device_id, latent all-gather, flat gradient all-reduce twice a
+    step on RCCL's stream while the step's hipGraphs and side streams run, barrier + max-over-ranks timing, replica check -- with ONE rank
+    on the box's one GPU."""
+    env = _single_rank_env()
+    env["SF_BENCH_FORCE_DIST"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--max-thres", "0.06",
+           "--no-cpu-baseline", "--no-traffic", "--no-also-measured"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    mg = res["multi_gpu"]
+    assert mg["backend"] == "nccl" and mg["world_size_seen"] == 1 and mg["replicas_identical"] is True
+    assert mg["all_gather_latents_us"] > 0 and mg["all_reduce_grads_us"] > 0 and res["n_gpus"] == 1 and res["value"] > 0

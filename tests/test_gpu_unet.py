@@ -214,6 +214,31 @@ def test_r04_fusions_match_the_r03_plan():
     assert rel_err(y_new, y_old) < TOL_REL and rel_err(y_new, y_ref) < TOL_REL and rel_err(y_old, y_ref) < TOL_REL
 
 
+@pytest.mark.parametrize("B", [1, 4])
+def test_r05_specialised_kernels_match_the_general_kernels(B):
+    """The kernels of round 5 -- k_conv4_gn / k_lin4_ln at the 4x4 level, k_layernorm_wave, k_gca_gate_t / k_gca_net0_t, and from B = 2 on
+    k_conv4_gn_mb (2 | 4 images per workgroup on one weight slice) -- against the plans that keep the general kernels behind the planner
+    attributes (`conv4_mb`, then `conv4` / `ln_wave` / `gate_t`): same values to the bf16 tolerance, every plan within the oracle tolerance."""
+    name = "canonical"
+    sd = state(name)
+    net = _unet(name, sd)
+    g = torch.Generator().manual_seed(58)
+    x, cond = torch.randn(B, 4, 32, 32, generator=g), torch.randn(B, 256, 32, 32, generator=g)
+    ls = unet_ref.log_snr(torch.tensor([0.45, 0.9, 0.1, 0.62][:B]))
+    with torch.no_grad():
+        y_ref = unet_ref.unet_forward(sd, x, ls, cond)
+    ys = {}
+    for tag, attrs in (("r05", {}), ("one_image_per_workgroup", dict(conv4_mb=False)),
+                       ("general_kernels", dict(conv4_mb=False, conv4=False, ln_wave=False, gate_t=False))):
+        for k, v in attrs.items():
+            setattr(net, k, v)
+        net.drop_plans()
+        ys[tag] = net.forward_with_cond_scale(x.to(DEV), ls.to(DEV), cond_images=cond.to(DEV)).cpu()
+        r, c = rel_err(ys[tag], y_ref), cosine(ys[tag], y_ref)
+        print(f"B={B} {tag}: rel L2 vs oracle {r:.3e} cosine {c:.6f}; vs the r05 plan {rel_err(ys[tag], ys['r05']):.3e}")
+        assert torch.isfinite(ys[tag]).all() and r < TOL_REL and c > TOL_COS and rel_err(ys[tag], ys["r05"]) < TOL_REL
+
+
 def test_time_table_is_cached_per_schedule_until_the_weights_change():
     """Unet.time_table(log_snrs, key=): the time path is a function of the weights and the schedule only, so a sampler that passes a
     key (PLMSSampler: the tuple of its times) gets the same read-only table on every trajectory; load_state_dict / .to() drop it."""
