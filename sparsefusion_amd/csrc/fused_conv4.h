@@ -411,7 +411,7 @@ SF_KERNEL(512) void k_conv4_gn_mb(FConvArgs a) {
 // elements at C = 1024.  C4T = float4 chunks per thread (C / 128).
 template <int C4T, int WN>
 SF_DEV void lin4_ln_body(const FConvArgs& a, const int bid) {
-  constexpr int NT = 512, TPR = 32;                    // 16 tokens x 32 threads
+  constexpr int TPR = 32;                              // 512 threads = 16 tokens x 32 threads
   constexpr int KSL = C4T * 4;                         // 32-channel k-steps: C / 32 = 32 | 64
   constexpr int KW = KSL / 8;                          // per wave: 4 | 8
   constexpr int F = WN;

@@ -286,7 +286,7 @@ static inline int conv4_mb_setup(const sf_op& op, FConvArgs& a, int cs4, uint32_
   int nb = 0;
   if (cs4 == 64) nb = a.B % 4 == 0 ? 4 : (a.B % 2 == 0 ? 2 : 0);
   else if (cs4 == 128 && a.s1.mode != 1) nb = a.B % 2 == 0 ? 2 : 0;       // two 36-pixel x 512-channel frames: 76 KB; a split-K source at Cs = 512
-                                                                            // stays on k_conv4_gn (18 weight fragments + one image's 80 gather registers: 256 + 90 spilled)
+                                                                            // stays on k_conv4_gn (18 weight fragments + one image's 80 gather registers: 256 VGPRs + 8 spilled; measured neutral at B = 4, not kept)
   if (!nb) return 0;
   const uint32_t frame = (36u * (uint32_t)a.pix_stride + 15u) & ~15u;
   const uint32_t red = (uint32_t)nb * frame, misc = red + (uint32_t)nb * 8192u, total = misc + 640 + 2048;

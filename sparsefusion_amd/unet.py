@@ -585,6 +585,11 @@ class _Plan:
             out.lazy = ("splitk", ws, bias, res, S, n_frags * 16, wi)
             self.ws_owners[wi] = out
             out.slots = None
+            thr = getattr(self.u, "conv4_reduce_min_batch", 0)
+            if thr and B >= thr and H == 4 and norm == FNORM_GN_SELF and logit is None:
+                self.need(out)      # r05: reduce the slabs in their own launch -- the consuming conv's 64 n-tile workgroups then gather one float4 per
+                                    # element instead of five (~100 MB of L2 reads per consuming launch at B = 4): B = 4 eval 1.693 -> 1.681 ms,
+                                    # B = 32 7.24 -> 6.86 ms (profiles/r05_conv4_mb_ab.log); at B = 1 the extra launch costs more than the gather
         return lp, li
 
     def pipe_ok(self, C1, C2, H, geom, norm, k, silu=True):
@@ -1147,6 +1152,7 @@ class Unet(nn.Module):
         self.attn_in_out_proj = True        # the 16-token attention core in the prologue of its output projection (False: k_attn16 launch; parity tests)
         self.ln_wave = True                 # r05: LayerNorm of <= 256 rows of 512 | 1024 | 2048 channels on k_layernorm_wave (False: op flag 4 = k_layernorm)
         self.gate_t = True                  # r05: GlobalContext gate with a compile-time hidden width (k_gca_gate_t; False: k_gca_gate)
+        self.conv4_reduce_min_batch = 4     # r05: from this batch on a 4x4 split-K conv1 is reduced by its own launch instead of by conv2's gather (0 = never)
         self.conv4_mb = True                # r05: even B: the 4x4 GroupNorm-self convs run 2 | 4 images per workgroup (k_conv4_gn_mb; False = op field i[19] bit 0)
         self.conv4_slices_max_batch = 4     # r05: up to this batch the 4x4 GroupNorm-self convs keep 4 input-channel slices (= k_conv4_gn's geometry); 0 = the workgroup-count rule alone
         self.conv4 = True                   # r05: the 4x4 level's GroupNorm-self 3x3 convs on k_conv4_gn (csrc/fused_conv4.h); False: op flag 128 = k_conv_fused (parity tests)

@@ -217,8 +217,8 @@ def test_r04_fusions_match_the_r03_plan():
 @pytest.mark.parametrize("B", [1, 4])
 def test_r05_specialised_kernels_match_the_general_kernels(B):
     """The kernels of round 5 -- k_conv4_gn / k_lin4_ln at the 4x4 level, k_layernorm_wave, k_gca_gate_t / k_gca_net0_t, and from B = 2 on
-    k_conv4_gn_mb (2 | 4 images per workgroup on one weight slice) -- against the plans that keep the general kernels behind the planner
-    attributes (`conv4_mb`, then `conv4` / `ln_wave` / `gate_t`): same values to the bf16 tolerance, every plan within the oracle tolerance."""
+    k_conv4_gn_mb (2 | 4 images per workgroup on one weight slice) and from B = 4 on the own reduction launch of a 4x4 split-K conv1 --
+    against the plans behind the planner attributes (`conv4_reduce_min_batch`, `conv4_mb`, then `conv4` / `ln_wave` / `gate_t`: the general kernels): same values to the bf16 tolerance, every plan within the oracle tolerance."""
     name = "canonical"
     sd = state(name)
     net = _unet(name, sd)
@@ -228,7 +228,7 @@ def test_r05_specialised_kernels_match_the_general_kernels(B):
     with torch.no_grad():
         y_ref = unet_ref.unet_forward(sd, x, ls, cond)
     ys = {}
-    for tag, attrs in (("r05", {}), ("one_image_per_workgroup", dict(conv4_mb=False)),
+    for tag, attrs in (("r05", {}), ("conv2_gathers_conv1s_slabs", dict(conv4_reduce_min_batch=0)), ("one_image_per_workgroup", dict(conv4_mb=False)),
                        ("general_kernels", dict(conv4_mb=False, conv4=False, ln_wave=False, gate_t=False))):
         for k, v in attrs.items():
             setattr(net, k, v)
