@@ -291,3 +291,40 @@ def test_every_planned_fused_conv_has_a_kernel_variant():
                 assert norm == 0                                  # the res_conv half runs inside its partner's instantiation
             else:
                 assert (WM, WN, norm, lazy) in plain, (B, k, WM, WN, norm, lazy)
+
+
+def test_4x4_level_rules_for_more_than_one_image():
+    """r05: the 4x4 GroupNorm-self convs keep the 4-slice geometry of k_conv4_gn / k_conv4_gn_mb up to B = 4 and at every even
+    B (the workgroup-count rule alone gives 2 slices at B = 2 and 1 from B = 4 on); from B = 4 on a split-K conv1 is reduced by its own
+    launch, so no 4x4 conv gathers another 4x4 conv's slabs; the planner attributes restore the older plans, `conv4_mb = False` marks the ops
+    (i[19] bit 0: one image per workgroup) and leaves the slice count to the workgroup rule beyond B = 4."""
+    from sparsefusion_amd import unet as U
+    net = U.Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2), layer_attns=(False, False, False, True),
+                 layer_cross_attns=(False,) * 4, cond_images_channels=256, attn_pool_text=False)
+
+    def convs4(B):
+        ops = U._Plan(net, B, CPU).build().ops
+        c4 = [o for o in ops if o.type == U.OP_FCONV and o.i[12] == U.FNORM_GN_SELF and o.i[1] == 4 and o.i[8] == 3]
+        return ops, c4
+
+    ops1, c1 = convs4(1)
+    assert len(c1) == 16 and all(o.i[17] == 4 and o.i[19] == 0 for o in c1)
+    n_red1 = sum(o.type == U.OP_SPLITK_REDUCE for o in ops1)
+    for B in (2, 4, 8, 32):
+        ops, c4 = convs4(B)
+        assert len(c4) == 16 and all(o.i[17] == 4 and o.i[19] == 0 for o in c4), B
+        n_red = sum(o.type == U.OP_SPLITK_REDUCE for o in ops)
+        lazy_splitk = sum(o.i[9] == 1 for o in c4)
+        if B >= 4:
+            assert n_red >= n_red1 + 8 and lazy_splitk < sum(o.i[9] == 1 for o in c1), (B, n_red, n_red1, lazy_splitk)
+        else:
+            assert n_red == n_red1, (B, n_red, n_red1)
+    assert all(o.i[17] == 4 for o in convs4(3)[1]) and all(o.i[17] < 4 for o in convs4(5)[1])        # odd B: up to conv4_slices_max_batch only
+    net.conv4_mb = False
+    _, c8 = convs4(8)
+    assert all(o.i[17] < 4 and o.i[19] == 1 for o in c8)                      # (1 slice; 2 where a 2048-channel frame needs them)
+    _, c4 = convs4(4)
+    assert all(o.i[17] == 4 and o.i[19] == 1 for o in c4)
+    net.conv4_mb, net.conv4_reduce_min_batch = True, 0
+    ops4, c4 = convs4(4)
+    assert sum(o.type == U.OP_SPLITK_REDUCE for o in ops4) == n_red1 and sum(o.i[9] == 1 for o in c4) == sum(o.i[9] == 1 for o in c1)
