@@ -281,6 +281,15 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
   const int HW = a.H * a.W;
   const long mb = (long)b * HW;           // first pixel row of this image
   const float sc1 = a.s1.scale, sc2 = a.s2.scale;     // as values: a select between two kernarg FIELDS becomes a scratch array
+#if SF_EARLY_BIAS
+  float bias_early = 0.0f;
+  if (NORM == FNORM_ATTN || NORM == FNORM_NONE) {      // (compile-time) the bias of this wave's fragment, in flight under the whole prologue
+    int enf = nt * WN + (wave % WN);
+    if (enf > a.n_frags - 1) enf = a.n_frags - 1;
+    const int en = enf * 16 + (lane & 15);
+    bias_early = (a.bias ? a.bias : reinterpret_cast<const float*>(a.w))[(a.bias && en < a.Cout) ? en : 0];
+  }
+#endif
 
   // ---- weight stream: this wave's k-steps [k0, k1) of the slice-local list (tap-major, then 32-channel chunk)
   const int KSl = a.k * a.k * a.cps;
@@ -899,7 +908,12 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
   if (fin && n < a.Cout) {
     if (a.logit_part) wkv = a.wk[n];
     if (a.S == 1) {
+#if SF_EARLY_BIAS
+      if (NORM == FNORM_ATTN || NORM == FNORM_NONE) bv = a.bias ? bias_early : 0.0f;
+      else if (a.bias) bv = a.bias[n];
+#else
       if (a.bias) bv = a.bias[n];
+#endif
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long o = (mrow + r) * a.ldc + a.co_off + n;

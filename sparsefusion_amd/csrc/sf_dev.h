@@ -9,6 +9,9 @@
 #ifndef SF_KA_TOUCH
 #define SF_KA_TOUCH 1          // 0: A/B switch of sf_touch_kernarg
 #endif
+#ifndef SF_EARLY_BIAS
+#define SF_EARLY_BIAS 0        // 1: k_conv_igemm and the un-normalised / attention forms of k_conv_fused request their bias in the first instructions
+#endif                         // (unconditional load from a selected address) instead of in front of the epilogue (A/B: profiles/r05_early_bias_ab.log)
 typedef __attribute__((ext_vector_type(8))) sf_opnd bf16x8;
 typedef __attribute__((ext_vector_type(4))) sf_opnd bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;

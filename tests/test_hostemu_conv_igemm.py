@@ -13,7 +13,7 @@ import torch.nn.functional as F
 from hostemu import fused
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostemu")
-SO = os.path.join(HERE, "_build", "libconv_igemm_emu.so")
+SO = os.path.join(HERE, "_build", "libconv_igemm_emu" + "".join("_" + d.replace("=", "") for d in fused._DEFS) + ".so")      # SF_EMU_DEFINES: an A/B harness build
 pytestmark = pytest.mark.skipif(not fused.available(), reason="host clang not found")
 
 
@@ -23,7 +23,7 @@ def _lib():
     if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(s) for s in srcs):
         os.makedirs(os.path.dirname(SO), exist_ok=True)
         subprocess.check_call([fused.CLANG, "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + HERE, "-Wall", "-Wno-unused-function",
-                               "-ffp-contract=off", srcs[0], "-o", SO, "-lpthread"])
+                               "-ffp-contract=off"] + ["-D" + d for d in fused._DEFS] + [srcs[0], "-o", SO, "-lpthread"])
     return C.CDLL(SO)
 
 
