@@ -586,8 +586,9 @@ class _Plan:
             self.ws_owners[wi] = out
             out.slots = None
             thr = getattr(self.u, "conv4_reduce_min_batch", 0)
-            if thr and B >= thr and H == 4 and norm == FNORM_GN_SELF and logit is None:
-                self.need(out)      # r05: reduce the slabs in their own launch -- the consuming conv's 64 n-tile workgroups then gather one float4 per
+            if thr and B >= thr and H == 4 and norm == FNORM_GN_SELF and logit is None and not pair_first:
+                self.need(out)      # (a paired conv1 is followed by its res_conv in the SAME launch: no op may stand between them -- resnet_fused reduces after the pair)
+                                    # r05: reduce the slabs in their own launch -- the consuming conv's 64 n-tile workgroups then gather one float4 per
                                     # element instead of five (~100 MB of L2 reads per consuming launch at B = 4): B = 4 eval 1.693 -> 1.681 ms,
                                     # B = 32 7.24 -> 6.86 ms (profiles/r05_conv4_mb_ab.log); at B = 1 the extra launch costs more than the gather
         return lp, li
@@ -634,6 +635,9 @@ class _Plan:
                                                      FNORM_NONE, gr, silu=False, pair_lazy=lz if pair else None, pair_first=first)
             if not late_rc:
                 emit_rc()
+                thr = getattr(self.u, "conv4_reduce_min_batch", 0)
+                if pair and thr and B >= thr and H == 4 and norm == FNORM_GN_SELF and h.lazy is not None and h.lazy[0] == "splitk":
+                    self.need(h)                                        # the own-launch reduction of fconv(), behind the pair
         if cross:
             h = self.cross_attention(f"{name}.cross_attn.fn", h)
         ss_ptr = self.ss.ptr + self.u.ss_offset[name] * 4

@@ -228,10 +228,13 @@ def test_r05_specialised_kernels_match_the_general_kernels(B):
     with torch.no_grad():
         y_ref = unet_ref.unet_forward(sd, x, ls, cond)
     ys = {}
+    switches = ("conv4_reduce_min_batch", "conv4_mb", "conv4", "ln_wave", "gate_t")
+    defaults = {k: getattr(net, k) for k in switches}
     for tag, attrs in (("r05", {}), ("conv2_gathers_conv1s_slabs", dict(conv4_reduce_min_batch=0)), ("one_image_per_workgroup", dict(conv4_mb=False)),
-                       ("general_kernels", dict(conv4_mb=False, conv4=False, ln_wave=False, gate_t=False))):
-        for k, v in attrs.items():
-            setattr(net, k, v)
+                       ("general_conv4_own_reduce", dict(conv4=False)),      # (r06: the pair + own-reduction plan the advisor found broken at B = 4)
+                       ("general_kernels", dict(conv4_mb=False, conv4=False, ln_wave=False, gate_t=False, conv4_reduce_min_batch=0))):
+        for k in switches:                                   # every variant differs from the default plan by the switches it names only
+            setattr(net, k, attrs.get(k, defaults[k]))
         net.drop_plans()
         ys[tag] = net.forward_with_cond_scale(x.to(DEV), ls.to(DEV), cond_images=cond.to(DEV)).cpu()
         r, c = rel_err(ys[tag], y_ref), cosine(ys[tag], y_ref)

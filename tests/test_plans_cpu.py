@@ -293,6 +293,30 @@ def test_every_planned_fused_conv_has_a_kernel_variant():
                 assert (WM, WN, norm, lazy) in plain, (B, k, WM, WN, norm, lazy)
 
 
+def test_a_paired_conv_is_followed_by_its_partner():
+    """A conv emitted with flag 16 (first half of a pair) shares its launch with the NEXT op: sf_plan_fused_pair takes ops[k + 1], which
+    must be the res_conv (OP_FCONV) or the pooling launch (OP_GCA).  r05's own-launch split-K reduction once stood between the two
+    (B = 5, 7 by default; B = 4 .. 6 with conv4 = False): every batch size 1 .. 9 under every planner switch that shapes the 4x4 level."""
+    from sparsefusion_amd import unet as U
+    net = U.Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2), layer_attns=(False, False, False, True),
+                 layer_cross_attns=(False,) * 4, cond_images_channels=256, attn_pool_text=False)
+    switches = ("conv4", "res_conv_beside_pool", "conv4_mb", "pair_res_conv")
+    defaults = {k: getattr(net, k, True) for k in switches}
+    n_pairs = 0
+    for attrs in ({}, {"conv4": False}, {"res_conv_beside_pool": False}, {"conv4_mb": False}, {"conv4": False, "res_conv_beside_pool": False}):
+        for k in switches:
+            setattr(net, k, attrs.get(k, defaults[k]))
+        for B in range(1, 10):
+            ops = U._Plan(net, B, CPU).build().ops
+            for k, o in enumerate(ops):
+                if o.type == U.OP_FCONV and o.flags & 16:
+                    n_pairs += 1
+                    assert ops[k + 1].type in (U.OP_FCONV, U.OP_GCA), (attrs, B, k, ops[k + 1].type)
+                    if ops[k + 1].type == U.OP_FCONV:
+                        assert ops[k + 1].i[8] == 1 and ops[k + 1].i[12] == U.FNORM_NONE, (attrs, B, k)      # the 1x1 res_conv
+    assert n_pairs > 100
+
+
 def test_4x4_level_rules_for_more_than_one_image():
     """r05: the 4x4 GroupNorm-self convs keep the 4-slice geometry of k_conv4_gn / k_conv4_gn_mb up to B = 4 and at every even
     B (the workgroup-count rule alone gives 2 slices at B = 2 and 1 from B = 4 on); from B = 4 on a split-K conv1 is reduced by its own
