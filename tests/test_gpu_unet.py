@@ -188,6 +188,73 @@ def test_plan_switches_match_oracle(switch):
     assert torch.isfinite(y).all() and r < TOL_REL and c > TOL_COS and rel_err(y, y_def) < TOL_REL
 
 
+@pytest.mark.parametrize("B", [8, 16, 32])
+def test_large_batch_default_plans_match_oracle(B):
+    """The plans the strong-scaling lines are timed on (`also_measured.config3_total32`: 32 views on one GPU; N = 2 / 4 ranks: 16 / 8 per
+    GPU) against the fp32 oracle with the same bounds as B = 1 (imagen_pytorch.py:1470-1671).  These batch sizes are the first to reach
+    the hybrid ResnetBlocks (GroupNorm pass + k_conv3_halo from 8192 pixel rows on), k_conv4_gn_mb with 4 images per workgroup, the own
+    split-K reduction launches of the 4x4 level and the WN = 2 attention-prologue projection; the test asserts the plan contains them, so
+    that a planner change cannot silently move the timed plan off the tested kernels."""
+    from sparsefusion_amd import unet as U
+    name = "canonical"
+    sd = state(name)
+    net = _unet(name, sd)
+    g = torch.Generator().manual_seed(600 + B)
+    x, cond = torch.randn(B, 4, 32, 32, generator=g), torch.randn(B, 256, 32, 32, generator=g)
+    ls = unet_ref.log_snr(torch.rand(B, generator=g) * 0.98 + 0.01)
+    with torch.no_grad():
+        y_ref = unet_ref.unet_forward(sd, x, ls, cond)
+    y = net.forward_with_cond_scale(x.to(DEV), ls.to(DEV), cond_images=cond.to(DEV)).cpu()
+    ops = net._plan(B, torch.device(DEV)).ops
+    halo = [o for o in ops if o.type == U.OP_CONV and o.i[14] >= 256 and o.i[9] == 3]
+    gn_pass = [o for o in ops if o.type == U.OP_GN_ACT]
+    c4 = [o for o in ops if o.type == U.OP_FCONV and o.i[12] == U.FNORM_GN_SELF and o.i[1] == 4 and o.i[8] == 3]
+    attn = [o for o in ops if o.type == U.OP_FCONV and o.i[12] == U.FNORM_ATTN]
+    n_red = sum(o.type == U.OP_SPLITK_REDUCE for o in ops)
+    print(f"B={B}: {len(ops)} ops; {len(halo)} LDS-tiled 3x3 convs, {len(gn_pass)} GroupNorm passes, {len(c4)} 4x4 GroupNorm-self convs "
+          f"(slices {sorted({o.i[17] for o in c4})}), {n_red} reductions, attention WN {sorted({o.i[16] for o in attn})}")
+    assert len(halo) >= 8 and len(gn_pass) >= 8                                      # the 32x32 level (B = 8) / + the 16x16 level (B >= 16) left the fused kernels
+    if B >= 32:
+        assert len(halo) >= 16
+    assert len(c4) == 16 and all(o.i[17] == 4 and o.i[19] == 0 for o in c4)          # k_conv4_gn_mb: 4 slices, images side by side
+    assert n_red >= 8 and attn and all(o.i[16] == 2 for o in attn)                   # own reductions; WN = 2 attention projection
+    r, c = rel_err(y, y_ref), cosine(y, y_ref)
+    worst = max(rel_err(y[b:b + 1], y_ref[b:b + 1]) for b in range(B))
+    print(f"B={B}: rel L2 vs oracle {r:.3e} cosine {c:.6f}; worst image {worst:.3e}")
+    assert torch.isfinite(y).all() and r < TOL_REL and c > TOL_COS and worst < TOL_REL
+    # the batch plan and the one-image plan agree per image to the same bf16 bound (other tiles, other summation orders)
+    y0 = net.forward_with_cond_scale(x[B - 1:].to(DEV), ls[B - 1:].to(DEV), cond_images=cond[B - 1:].to(DEV)).cpu()
+    assert rel_err(y0, y[B - 1:]) < TOL_REL
+
+
+def test_plms_batch8_trajectory_matches_oracle_sampler():
+    """51-eval PLMS trajectory at B = 8 (the per-GPU batch of the N = 4 scaling line; first batch on the hybrid plan) against the fp32
+    oracle sampler (oracle/unet_ref.plms_sample, pinned to the reference's PLMSSampler by tests/test_oracle_unet.py) with shared noise
+    (external/plms.py:54-119): stated trajectory tolerance relative L2 < 3e-2, cosine > 0.9995, per image too."""
+    from sparsefusion_amd.vldm import DDPM
+    from sparsefusion_amd.plms import PLMSSampler
+    name, B, max_thres = "canonical", 8, 0.5
+    sd = state(name)
+    unet = _unet(name, sd)
+    vldm = DDPM(channels=4, unets=(unet,), conditional_encoder=None, conditional_embed_dim=None, image_sizes=(32,),
+                timesteps=500, cond_drop_prob=0.1, pred_objectives='noise', conditional=False, auto_normalize_img=False,
+                clip_output=True, dynamic_thresholding=False, dynamic_thresholding_percentile=.68, clip_value=10).to(DEV)
+    gg = torch.Generator().manual_seed(808)
+    lat = 0.5 * torch.randn(B, 4, 32, 32, generator=gg)
+    cond = torch.randn(B, 256, 32, 32, generator=gg)
+    noises = [torch.randn(B, 4, 32, 32, generator=gg) for _ in range(unet_ref.plms_noise_count(max_thres))]
+    with torch.no_grad():
+        img_ref, xn_ref, nz_ref, acp_ref, n_evals = unet_ref.plms_sample(lambda z, l: unet_ref.unet_forward(sd, z, l, cond), lat, max_thres, noises)
+    assert n_evals == 51
+    img, xn, nz, acp = PLMSSampler(vldm, 50).sample(lat.to(DEV), cond_images=cond.to(DEV), use_tqdm=False, return_noise=True,
+                                                    max_thres=max_thres, noises=[n.to(DEV) for n in noises])
+    assert torch.equal(nz.cpu(), nz_ref) and torch.allclose(xn.cpu(), xn_ref, atol=1e-5)
+    rr, cc = rel_err(img.cpu(), img_ref), cosine(img.cpu(), img_ref)
+    worst = max(rel_err(img[b:b + 1].cpu(), img_ref[b:b + 1]) for b in range(B))
+    print(f"plms canonical B=8 (51 evals) vs oracle sampler: rel {rr:.3e} cos {cc:.6f}; worst image {worst:.3e}")
+    assert rr < 3e-2 and cc > 0.9995 and worst < 5e-2 and float(img.abs().max()) <= 10.0
+
+
 def test_r04_fusions_match_the_r03_plan():
     """The launch fusions of round 4 -- attention core in the prologue of its output projection, statistics slots from k_init_x and
     the Upsample epilogue, NCHW output from the final split-K reduction, the 4x4 res_conv beside the GlobalContext pooling launch --
