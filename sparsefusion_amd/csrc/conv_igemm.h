@@ -36,14 +36,6 @@ SF_KERNEL(256) void k_conv_igemm(ConvArgs a) {
   for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
     for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if SF_EARLY_BIAS
-  float bias_early[WN];                                // in flight under the whole k-loop (was a cold round trip in front of the stores)
-#pragma unroll
-  for (int ni = 0; ni < WN; ++ni) {
-    const int en = min(nt * WN + ni, a.n_frags - 1) * 16 + (lane & 15);
-    bias_early[ni] = (a.bias ? a.bias : reinterpret_cast<const float*>(a.w))[(a.bias && en < a.Cout) ? en : 0];
-  }
-#endif
 
   const int cgrp = (lane >> 4) * 8;
   int ks = k0;
@@ -179,11 +171,7 @@ SF_KERNEL(256) void k_conv_igemm(ConvArgs a) {
       if (a.pixshuf && a.slots_out) {             // (lanes beyond Cout / M contribute zeros; the host checks 16 | Cout / 4, 16 | M)
         float sm = 0.0f, sq = 0.0f;
         if (n < a.Cout) {
-#if SF_EARLY_BIAS
-          const float bq = a.bias ? bias_early[ni] : 0.0f;
-#else
           const float bq = a.bias ? a.bias[n] : 0.0f;
-#endif
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int m = (mt * WM + mi) * 16 + (lane >> 4) * 4 + r;
@@ -201,11 +189,7 @@ SF_KERNEL(256) void k_conv_igemm(ConvArgs a) {
         }
       }
       if (n >= a.Cout) continue;
-#if SF_EARLY_BIAS
-      const float bv = a.bias ? bias_early[ni] : 0.0f;
-#else
       const float bv = a.bias ? a.bias[n] : 0.0f;
-#endif
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = (mt * WM + mi) * 16 + (lane >> 4) * 4 + r;

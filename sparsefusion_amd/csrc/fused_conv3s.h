@@ -1,0 +1,498 @@
+// k_conv3s: the slot-GroupNorm 3x3 convs of the 8x8 / 16x16 / 32x32 levels (external/imagen_pytorch.py:641-662: GroupNorm(8) -> x * (scale + 1)
+// + shift -> SiLU -> Conv2d 3x3) for the geometries that recur in every eval: one plain source, Cout = C in {256, 512, 1024}.  Same op,
+// operands, outputs (values to the fp32 summation order, statistics slots, pooled GlobalContext fragments) as k_conv_fused_pipe
+// (fused_pipe.h), the general kernel, which stays for every other shape and behind the planner attribute Unet.conv3s.  r06.
+//
+// Why.  In the replayed eval graph a 32x32 256 -> 256 launch of the general kernel costs 11.6 us: boundary 2.05, entry -> statistics 1.4,
+// first chunk staged 1.2, "pipelined chunks" 4.1, epilogue 1.5 (profiles/r03_fconv_pipe_phases.log, r05_graph_ablate_b1.log).  The 4.1 us
+// are two phases of ~2 us for 1.2 us of staging and 0.3 us of matrix work: the matrix waves' weight ring is ONE chunk deep, so every
+// revolution waits a full L2 / HBM round trip (~1.3 us) for loads issued half a microsecond earlier, and a deeper ring did not fit the
+// general kernel (221-244 VGPRs: run-time tile shapes keep ~60 registers of addressing alive).  Here, as in k_conv4_gn (r05):
+//   * everything that shapes the instruction stream is a template parameter (map size, channels, tile, chunk count): per-tap LDS and
+//     weight offsets are immediates, the chunk loop is unrolled, no run-time branch stands in front of a load;
+//   * every load the launch can issue up front is requested in its first instructions: statistics slots, RD chunks of weights per
+//     matrix wave (RD = 2: ALL weights of a 256-channel layer), NB chunks of activations + their affine operands per staging wave,
+//     bias and residual rows of the finalising waves;
+//   * the affine (rstd * gamma * (scale + 1), ...) lives in the staging thread's registers (its channel chunk is fixed): no LDS
+//     table, ONE barrier between the statistics and the first staged chunk;
+//   * K is split over the 4 matrix waves by 32-channel sub-chunk (wave w = sub-chunk w of every 128-channel chunk, all 9 taps), so
+//     tap offsets are compile-time and the sub-chunk is one base register;
+//   * the pixel tile may be 2-D (TW < W): a 4 x 8 tile of the 32x32 map stages a 6 x 10 frame (60 pixels) where the 1 x 32 strip stages
+//     3 x 32 + zero columns (96): the staging VALU (SiLU: two quarter-rate transcendentals per element, every n-tile re-normalises the
+//     pixels it needs) is what bounds these launches once the weights are there.  Slots and pooled fragments are indexed by
+//     (tile, m-fragment): their consumers sum over all fragments of an image, whatever pixels a fragment holds.
+#pragma once
+#include "fused_kernels.h"
+#ifndef C3S_DBG
+#define C3S_DBG 0
+#endif
+
+template <int HL, int C, int TWL, int WM, int WN, bool POOL>
+struct Conv3sGeom {
+  static constexpr int H = 1 << HL, W = H, HW = H * W, TW = 1 << TWL, TH = 16 * WM / TW;
+  static constexpr bool FULLW = TW == W;
+  static constexpr int FR = TH + 2, FW = TW + 2;
+  static constexpr int SW = FULLW ? TW : TW + 2;            // staged columns of a frame row (a full-width strip's side columns are always zero)
+  static constexpr int NPX = FR * SW, EPT = (NPX + 7) / 8;  // staged pixels; elements (float4 of one pixel) per staging thread and chunk
+  static constexpr int CC = 128, NCH = C / CC, KS = 9 * (C / 32);
+  static constexpr int PSTR = 288;                          // bytes per frame pixel: 128 operand-type channels + 32 (stride = 32 mod 256)
+  static constexpr int BUF = ((FR * FW + 1) * PSTR + 15) / 16 * 16;      // + 1 spare pixel (dead staging elements)
+  static constexpr int F = WM * WN, FT = F + (POOL ? WM : 0);
+  static constexpr int RED_OFF = 2 * BUF, MISC_OFF = RED_OFF + 4 * FT * 1024, WEFF_OFF = MISC_OFF + 256;
+  static constexpr int LDS_BYTES = WEFF_OFF + (POOL ? KS * 64 : 0);
+  static constexpr int NTILES = C / (16 * WN), MTI = (H / TH) * (W / TW);
+  static constexpr int G = 8, CG = C / G, NCF = CG / 16, NMF = HW / 16, SCNT = NMF * NCF, NSL = (SCNT + 63) / 64;
+  static constexpr int RD = (C3S_DBG & 4) ? 1 : (NCH < 2 ? 1 : (WN >= 4 ? 1 : 2));                        // weight ring depth in chunks (9 * WN fragments per chunk and wave)
+  static constexpr int NB0 = (C3S_DBG & 8) ? 2 : (EPT <= 4 ? 4 : (EPT <= 8 ? 3 : 2)), NB = NB0 < NCH ? NB0 : NCH;      // staging batches (chunks) in registers
+  static constexpr int NPW = RD * 9 * WN, NPS = NB * (EPT + 4), NP = NPW > NPS ? NPW : NPS;
+  static_assert(TH * TW == 16 * WM && TH >= 1 && TH <= H && TW <= W && TW >= 4, "tile = 16 * WM pixels");
+  static_assert(C % 128 == 0 && CG % 32 == 0 && NSL <= 4, "channels");
+  static_assert(LDS_BYTES <= 163840, "LDS");
+};
+
+template <int HL, int C, int TWL, int WM, int WN, bool POOL>
+SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
+  using Gm = Conv3sGeom<HL, C, TWL, WM, WN, POOL>;
+  constexpr int H = Gm::H, W = Gm::W, HW = Gm::HW, TW = Gm::TW, TH = Gm::TH, FR = Gm::FR, FW = Gm::FW, SW = Gm::SW, NPX = Gm::NPX, EPT = Gm::EPT;
+  constexpr int CC = Gm::CC, NCH = Gm::NCH, PSTR = Gm::PSTR, BUF = Gm::BUF, F = Gm::F, FT = Gm::FT, RD = Gm::RD, NB = Gm::NB, NP = Gm::NP;
+  constexpr int NTILES = Gm::NTILES, MTI = Gm::MTI, CG = Gm::CG, NCF = Gm::NCF, NMF = Gm::NMF, SCNT = Gm::SCNT, NSL = Gm::NSL;
+  constexpr bool FULLW = Gm::FULLW;
+  constexpr int NT = 512, NWM = 4;
+  SF_DYN_LDS(lds);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = sf_uniform(tid >> 6);
+  const bool mx_role = wave < NWM;
+
+  // ---- which tile: workgroups t, t + 8, ... share an XCD; XCD x owns the n-tiles == x (mod 8) of ALL pixel tiles (fconv_tile_of, R = 1)
+  const int MT = a.B * MTI;
+  int mt, nt;
+  if (NTILES % 8 == 0) {
+    const int x = bid & 7, j = bid >> 3;
+    const int q = j / MT;
+    mt = j - q * MT;
+    nt = x + 8 * q;
+  } else {
+    nt = bid % NTILES;
+    mt = bid / NTILES;
+  }
+  const int b = mt / MTI, ti = mt - b * MTI;
+  const int trow = ti / (W / TW), tcol = ti - trow * (W / TW);
+  const int row0 = trow * TH, col0 = tcol * TW;
+  const int mb = b * HW;
+  float* misc = reinterpret_cast<float*>(lds + Gm::MISC_OFF);       // [8][2] = (mean, rstd) of the image's groups
+
+  // ---- (1) statistics slots of group `wave` of image b: the head of the critical path (slots -> statistics -> first staged chunk)
+  f32x2 sl[NSL];
+#pragma unroll
+  for (int u = 0; u < NSL; ++u) {
+    int i = lane + u * 64;
+    if (i > SCNT - 1) i = SCNT - 1;
+    const int mf = i / NCF, cfa = wave * NCF + (i - mf * NCF);
+    sl[u] = *reinterpret_cast<const f32x2*>(a.s1.slots + ((long)(b * NMF + mf) * (C / 16) + cfa) * 2);
+  }
+
+  // ---- (2) ONE register pool for both roles (declared apart, the compiler allocates their sum): the weight ring of a matrix wave,
+  //          the staging batches (EPT activations + gamma, beta, scale, shift of the chunk) of a staging wave
+  f32x4 pool[NP];
+  // matrix wave w: sub-chunk w of every chunk; k-step (tap, chunk c, w) of fragment nf sits at ((nf * KS) + tap * C / 32 + 4 c + w) * 64 + lane
+  const bf16x8* wbase[WN];
+#pragma unroll
+  for (int ni = 0; ni < WN; ++ni) wbase[ni] = a.w + ((long)(nt * WN + ni) * Gm::KS + (mx_role ? wave : 0)) * 64 + lane;
+  auto wload = [&](int c, int tap, int ni) -> f32x4 {
+    if (C3S_DBG & 32) return __builtin_bit_cast(f32x4, wbase[ni][(tap * (C / 32) + 4 * c) * 64]);
+    return __builtin_bit_cast(f32x4, __builtin_nontemporal_load(&wbase[ni][(tap * (C / 32) + 4 * c) * 64]));
+  };
+  // staging thread: float4 channel chunk tcx of every 128-channel chunk, frame pixels tp, tp + 8, ...
+  const int ts = tid - NWM * 64;
+  const int tcx = ts & 31, tp = ts >> 5;
+  int soff[EPT];                                         // source element offset of element e (pixel * C + tcx * 4), a safe pixel when dead
+  int loff[EPT];                                         // LDS byte offset of element e inside a frame buffer (the spare pixel when dead)
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) {
+    const int pi = tp + e * 8;
+    const int fr = pi / SW, fxs = pi - fr * SW;
+    const int r = row0 - 1 + fr, x = col0 + fxs - (FULLW ? 0 : 1);
+    const bool in = pi < NPX && r >= 0 && r < H && x >= 0 && x < W;
+    soff[e] = (mb + (in ? r * W + x : row0 * W + col0)) * C + tcx * 4;
+    loff[e] = (in ? fr * FW + fxs + (FULLW ? 1 : 0) : FR * FW) * PSTR + tcx * 8;
+  }
+  const float* ssrow = a.ss ? a.ss + (long)b * a.ss_stride : a.gamma;      // any valid address when there is no scale / shift
+  const int shoff = a.ss ? C : 0;
+  auto issue = [&](int c, int vo) {
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) pool[vo + e] = *reinterpret_cast<const f32x4*>(a.s1.p + soff[e] + c * CC);
+    const int cg = c * CC + tcx * 4;
+    pool[vo + EPT + 0] = *reinterpret_cast<const f32x4*>(a.gamma + cg);
+    pool[vo + EPT + 1] = *reinterpret_cast<const f32x4*>(a.beta + cg);
+    pool[vo + EPT + 2] = *reinterpret_cast<const f32x4*>(ssrow + cg);
+    pool[vo + EPT + 3] = *reinterpret_cast<const f32x4*>(ssrow + shoff + cg);
+  };
+  if (mx_role) {
+#pragma unroll
+    for (int d = 0; d < RD; ++d)
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) pool[(d * 9 + tap) * WN + ni] = wload(d, tap, ni);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) issue(j, j * (EPT + 4));
+  }
+
+  // ---- (3) epilogue operands of the finalising waves: fragment f = wave, wave + 8, ... (NFW per wave)
+  constexpr int NFW = (F + 7) / 8;
+  float bv[NFW], rv[NFW][4];
+  int orow[NFW];                                         // first output pixel row (global m) of the lane's 4 rows of fragment f
+#pragma unroll
+  for (int q = 0; q < NFW; ++q) {
+    const int f = wave + q * 8, fc = f < F ? f : F - 1;
+    const int mi = fc / WN, ni = fc - mi * WN;
+    const int n = (nt * WN + ni) * 16 + (lane & 15);
+    const int p0 = mi * 16 + (lane >> 4) * 4;
+    orow[q] = mb + (row0 + p0 / TW) * W + col0 + (p0 & (TW - 1));
+    bv[q] = a.bias[n];
+    const float* rp = a.resid ? a.resid : a.bias;        // unconditional loads from a selected address (a load under `if` drains the queue at the merge)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = rp[a.resid ? (long)(orow[q] + r) * C + n : n];
+      rv[q][r] = a.resid ? v : 0.0f;
+    }
+  }
+
+  // ---- (4) zero padding: frame pixels outside the image, in both buffers; 8 threads per pixel
+  for (int q = tid >> 3; q < FR * FW; q += NT / 8) {
+    const int fr = q / FW, fx = q - fr * FW;
+    const int r = row0 - 1 + fr, x = col0 - 1 + fx;
+    if (r < 0 || r >= H || x < 0 || x >= W) {
+      char* dst = lds + q * PSTR;
+      for (int c8 = (tid & 7); c8 < CC / 8; c8 += 8) {
+        *reinterpret_cast<bf16x8*>(dst + c8 * 16) = sf_zero8();
+        *reinterpret_cast<bf16x8*>(dst + BUF + c8 * 16) = sf_zero8();
+      }
+    }
+  }
+  if (POOL && mx_role && !(C3S_DBG & 1)) {                                 // the w_eff table (KS k-steps x 32 operand-type values) into LDS
+    const bf16x8* src = reinterpret_cast<const bf16x8*>(a.weff);
+    bf16x8* dst = reinterpret_cast<bf16x8*>(lds + Gm::WEFF_OFF);
+    for (int i = tid; i < Gm::KS * 4; i += NWM * 64) dst[i] = src[i];
+  }
+
+  // ---- (5) statistics: wave g sums the producer's (sum, sum of squares) slots of group g (8 groups = 8 waves)
+  {
+    float sm = 0.0f, sq = 0.0f;
+#pragma unroll
+    for (int u = 0; u < NSL; ++u) {
+      const bool live = lane + u * 64 < SCNT;
+      sm += live ? sl[u][0] : 0.0f;
+      sq += live ? sl[u][1] : 0.0f;
+    }
+    sm = sf_wave_sum(sm);
+    sq = sf_wave_sum(sq);
+    if (lane == 0) {
+      const double rn = a.inv_n;
+      const double mean = (double)sm * rn;
+      double var = (double)sq * rn - mean * mean;
+      if (var < 0.0) var = 0.0;
+      misc[2 * wave] = (float)mean;
+      misc[2 * wave + 1] = sf_rsqrt((float)var + a.eps);
+    }
+  }
+  sf_sync();
+
+#if (C3S_DBG & 4096) && !defined(SF_HOST_EMU)
+  float dbg_mean[8], dbg_rstd[8];
+  for (int q = 0; q < 8; ++q) { dbg_mean[q] = 0.f; dbg_rstd[q] = 0.f; }
+#endif
+  // ---- (6) the pipeline: phase 0 stages chunk 0; phase c + 1 multiplies chunk c while chunk c + 1 is staged; one barrier per phase
+  auto consume = [&](int c, int vo) {
+    const int gi = (c * CC + tcx * 4) / CG;
+    const float mean = misc[2 * gi], rstd = misc[2 * gi + 1];
+#if (C3S_DBG & 4096) && !defined(SF_HOST_EMU)
+    if (a.dbg) {                                           // debug: the statistics as this thread reads them now, against a second read and the group's true values at the end
+      const float mean2 = reinterpret_cast<const volatile float*>(misc)[2 * gi], rstd2 = reinterpret_cast<const volatile float*>(misc)[2 * gi + 1];
+      dbg_mean[c < 8 ? c : 7] = mean; dbg_rstd[c < 8 ? c : 7] = rstd;
+      {                                                    // the batch's registers against what memory holds
+        const int cg0 = c * CC + tcx * 4;
+        for (int q = 0; q < EPT + 4; ++q) {
+          const float* src = q < EPT ? a.s1.p + soff[q] + c * CC : (q == EPT ? a.gamma + cg0 : (q == EPT + 1 ? a.beta + cg0 : (q == EPT + 2 ? ssrow + cg0 : ssrow + shoff + cg0)));
+          for (int j = 0; j < 4; ++j) {
+            const float tv = src[j], rv_ = pool[vo + q][j];
+            if (tv != rv_) {
+              const unsigned long long k = atomicAdd((unsigned long long*)a.dbg, 1ull);
+              if (k < 30) {
+                float* rec = reinterpret_cast<float*>(a.dbg + 1) + k * 12;
+                rec[0] = (float)tid; rec[1] = (float)q; rec[2] = (float)c; rec[3] = (float)j; rec[4] = rv_; rec[5] = tv; rec[6] = (float)vo;
+                rec[7] = 0; rec[8] = 0; rec[9] = 0; rec[10] = (float)bid; rec[11] = 0;
+              }
+            }
+          }
+        }
+      }
+      if (mean2 != mean || rstd2 != rstd) atomicAdd((unsigned long long*)a.dbg + 200, 1ull);
+    }
+#endif
+    f32x4 A = pool[vo + EPT] * rstd;
+    f32x4 sc = pool[vo + EPT + 2] + 1.0f, sh = pool[vo + EPT + 3];
+    if (!a.ss) { sc = f32x4{1.f, 1.f, 1.f, 1.f}; sh = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const f32x4 Bv = (pool[vo + EPT + 1] - A * mean) * sc + sh;
+    A = A * sc;
+    char* buf = lds + (c & 1) * BUF;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      f32x4 y = pool[vo + e] * A + Bv;
+      const f32x4 t = y * -1.4426950408889634f;
+      f32x4 ex;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ex[j] = sf_exp2(t[j]);
+      ex = ex + 1.0f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ex[j] = sf_rcp(ex[j]);
+      y = y * ex;
+      bf16x4 o;
+      o[0] = (sf_opnd)y[0]; o[1] = (sf_opnd)y[1]; o[2] = (sf_opnd)y[2]; o[3] = (sf_opnd)y[3];
+      *reinterpret_cast<bf16x4*>(buf + loff[e]) = o;
+#if (C3S_DBG & 1024) && !defined(SF_HOST_EMU)
+      if (a.dbg && loff[e] != FR * FW * PSTR + tcx * 8) {     // debug (live elements only: dead ones share the spare pixel): the same element again, by another instruction sequence, and what sits in LDS now
+        const f32x4 y2 = pool[vo + e] * A + Bv;
+        const bf16x4 back = *reinterpret_cast<const volatile bf16x4*>(buf + loff[e]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float s2 = y2[j] / (1.0f + __expf(-y2[j]));
+          const float got = (float)back[j];
+          if (!(fabsf(got - s2) <= 0.02f * fabsf(s2) + 0.02f)) {
+            const unsigned long long k = atomicAdd((unsigned long long*)a.dbg, 1ull);
+            if (k < 30) {
+              float* rec = reinterpret_cast<float*>(a.dbg + 1) + k * 12;
+              rec[0] = (float)tid; rec[1] = (float)e; rec[2] = (float)c; rec[3] = (float)j; rec[4] = got; rec[5] = s2; rec[6] = y[j];
+              rec[7] = pool[vo + e][j]; rec[8] = A[j]; rec[9] = Bv[j]; rec[10] = (float)bid; rec[11] = ex[j];
+            }
+          }
+        }
+      }
+#endif
+    }
+  };
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 accl[POOL ? WM : 1];                              // POOL: context-logit fragment of every m-fragment (column 0 = the logit)
+#pragma unroll
+  for (int mi = 0; mi < (POOL ? WM : 1); ++mi) accl[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (mx_role) {
+    int abase[WM];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi) {
+      const int p = mi * 16 + (lane & 15);
+      abase[mi] = ((p / TW) * FW + (p & (TW - 1))) * PSTR + (lane >> 4) * 16 + wave * 64;
+    }
+    const char* weffL = lds + Gm::WEFF_OFF + wave * 64 + (lane >> 4) * 16;
+    const bool col0l = (lane & 15) == 0;
+    sf_sync();                                            // phase 0: chunk 0 is being staged
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const char* buf = lds + (c & 1) * BUF;
+      constexpr int dummy = 0; (void)dummy;
+      const int d = c % RD;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        bf16x8 fa[WM];
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8*>(buf + abase[mi] + (ky * FW + kx) * PSTR);
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < WN; ++ni)
+            acc[mi][ni] = sf_mfma16_nc(fa[mi], __builtin_bit_cast(bf16x8, pool[(d * 9 + tap) * WN + ni]), acc[mi][ni]);      // (sf_dev.h: result disjoint from its sources)
+        if (c + RD < NCH) {                               // (compile-time after unrolling) refill the slot with chunk c + RD
+#pragma unroll
+          for (int ni = 0; ni < WN; ++ni) pool[(d * 9 + tap) * WN + ni] = wload(c + RD, tap, ni);
+        }
+        if (POOL && !(C3S_DBG & (2 | 64))) {                                       // one more MFMA per m-fragment: B = w_eff of the k-step in column 0, zero elsewhere
+          bf16x8 wl = *reinterpret_cast<const bf16x8*>(weffL + (tap * (C / 32) + 4 * c) * 64);
+          if (C3S_DBG & 128) wl = __builtin_bit_cast(bf16x8, f32x4{1.f, 2.f, 3.f, 4.f});
+          if ((C3S_DBG & 256) && !col0l) wl = sf_zero8();
+#pragma unroll
+          for (int mi = 0; mi < WM; ++mi) accl[mi] = sf_mfma16_nc(fa[mi], wl, accl[mi]);
+        }
+      }
+      if (POOL && (C3S_DBG & 64)) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap - ky * 3;
+          bf16x8 wl = *reinterpret_cast<const bf16x8*>(weffL + (tap * (C / 32) + 4 * c) * 64);
+          if (!col0l) wl = sf_zero8();
+#pragma unroll
+          for (int mi = 0; mi < WM; ++mi) {
+            const bf16x8 fa2 = *reinterpret_cast<const bf16x8*>(buf + abase[mi] + (ky * FW + kx) * PSTR);
+            accl[mi] = sf_mfma16_nc(fa2, wl, accl[mi]);
+          }
+        }
+      }
+      sf_sync();
+    }
+  } else {
+    consume(0, 0);
+    sf_sync();                                            // phase 0 done
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (c + 1 < NCH) {
+        if (c + NB < NCH) issue(c + NB, (c % NB) * (EPT + 4));       // batch c % NB was consumed in the previous phase
+        consume(c + 1, ((c + 1) % NB) * (EPT + 4));
+      }
+      sf_sync();
+    }
+  }
+
+#if (C3S_DBG & 8192) && !defined(SF_HOST_EMU)
+  if (a.dbg) {                                           // debug: both frame buffers of every workgroup, as they are after the chunk loop
+    uint32_t* dump = reinterpret_cast<uint32_t*>(a.dbg) + (long)bid * (2 * BUF / 4);
+    for (int i = tid; i < 2 * BUF / 4; i += NT) dump[i] = reinterpret_cast<const volatile uint32_t*>(lds)[i];
+  }
+  sf_sync();
+#endif
+#if (C3S_DBG & 4096) && !defined(SF_HOST_EMU)
+  if (!mx_role && a.dbg) {
+    for (int c = 0; c < NCH && c < 8; ++c) {
+      const int gi = (c * CC + tcx * 4) / CG;
+      const float mean = misc[2 * gi], rstd = misc[2 * gi + 1];
+      if (mean != dbg_mean[c] || rstd != dbg_rstd[c]) {
+        const unsigned long long k = atomicAdd((unsigned long long*)a.dbg, 1ull);
+        if (k < 30) {
+          float* rec = reinterpret_cast<float*>(a.dbg + 1) + k * 12;
+          rec[0] = (float)tid; rec[1] = (float)gi; rec[2] = (float)c; rec[3] = 0; rec[4] = dbg_mean[c]; rec[5] = mean; rec[6] = dbg_rstd[c];
+          rec[7] = rstd; rec[8] = 0; rec[9] = 0; rec[10] = (float)bid; rec[11] = 0;
+        }
+      }
+    }
+  }
+  sf_sync();
+#endif
+#if (C3S_DBG & 2048) && !defined(SF_HOST_EMU)
+  if (!mx_role && a.dbg) {                               // debug: are the last two chunks still in their buffers as they were staged?
+    for (int c = NCH - 2; c < NCH; ++c) {
+      const int cg = c * CC + tcx * 4;
+      const int gi = cg / CG;
+      const float mean = misc[2 * gi], rstd = misc[2 * gi + 1];
+      f32x4 A = *reinterpret_cast<const f32x4*>(a.gamma + cg) * rstd;
+      f32x4 sc = *reinterpret_cast<const f32x4*>(ssrow + cg) + 1.0f, sh = *reinterpret_cast<const f32x4*>(ssrow + shoff + cg);
+      if (!a.ss) { sc = f32x4{1.f, 1.f, 1.f, 1.f}; sh = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      const f32x4 Bv = (*reinterpret_cast<const f32x4*>(a.beta + cg) - A * mean) * sc + sh;
+      A = A * sc;
+      for (int e = 0; e < EPT; ++e) {
+        if (loff[e] == FR * FW * PSTR + tcx * 8) continue;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(a.s1.p + soff[e] + c * CC);
+        const f32x4 y2 = x * A + Bv;
+        const bf16x4 back = *reinterpret_cast<const volatile bf16x4*>(lds + (c & 1) * BUF + loff[e]);
+        for (int j = 0; j < 4; ++j) {
+          const float s2 = y2[j] / (1.0f + __expf(-y2[j])), got = (float)back[j];
+          if (!(fabsf(got - s2) <= 0.02f * fabsf(s2) + 0.02f)) {
+            const unsigned long long k = atomicAdd((unsigned long long*)a.dbg, 1ull);
+            if (k < 30) {
+              float* rec = reinterpret_cast<float*>(a.dbg + 1) + k * 12;
+              rec[0] = (float)tid; rec[1] = (float)e; rec[2] = (float)c; rec[3] = (float)j; rec[4] = got; rec[5] = s2; rec[6] = y2[j];
+              rec[7] = x[j]; rec[8] = A[j]; rec[9] = Bv[j]; rec[10] = (float)bid; rec[11] = (float)loff[e];
+              // what the same location held two chunks ago (chunk c - 2 of the same buffer), and the other buffer's current value
+              const int c2 = c - 2, cg2 = c2 * CC + tcx * 4, gi2 = cg2 / CG;
+              const float m2 = misc[2 * gi2], r2 = misc[2 * gi2 + 1];
+              const float a2 = a.gamma[cg2 + j] * r2, scj = a.ss ? ssrow[cg2 + j] + 1.0f : 1.0f, shj = a.ss ? ssrow[shoff + cg2 + j] : 0.0f;
+              const float yy = a.s1.p[soff[e] + c2 * CC + j] * (a2 * scj) + ((a.beta[cg2 + j] - a2 * m2) * scj + shj);
+              rec[6] = yy / (1.0f + __expf(-yy));
+              rec[9] = (float)(*reinterpret_cast<const volatile bf16x4*>(lds + ((c + 1) & 1) * BUF + loff[e]))[j];
+            }
+          }
+        }
+      }
+    }
+  }
+  sf_sync();
+#endif
+  // ---- (7) epilogue: the 4 K-slices meet in LDS; wave w finalises fragments w, w + 8, ...
+  float* red = reinterpret_cast<float*>(lds + Gm::RED_OFF);         // [matrix wave][frag][r][lane]
+  if (mx_role) {
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * FT + mi * WN + ni) * 4 + r) * 64 + lane] = acc[mi][ni][r];
+    if (POOL) {
+#pragma unroll
+      for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[((wave * FT + F + mi) * 4 + r) * 64 + lane] = accl[mi][r];
+    }
+  }
+  sf_sync();
+#pragma unroll
+  for (int q = 0; q < NFW; ++q) {
+    const int f = wave + q * 8;
+    if (f < F) {
+      const int mi = f / WN, ni = f - mi * WN;
+      const int nf = nt * WN + ni;
+      const int n = nf * 16 + (lane & 15);
+      float sm = 0.0f, sqv = 0.0f, y4[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int idx = (f * 4 + r) * 64 + lane;
+        float sacc = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NWM; ++w) sacc += red[idx + w * FT * 256];
+        const float y = sacc + bv[q] + rv[q][r];
+        a.out[(long)(orow[q] + r) * C + n] = y;
+        y4[r] = y;
+        sm += y;
+        sqv = fmaf(y, y, sqv);
+      }
+      const int mfrag = (mb >> 4) + ti * WM + mi;         // fragment index of (image, tile, m-fragment): consumers sum over an image's fragments
+      if (a.slots_out) {
+        sm = sf_wave_sum(sm);
+        sqv = sf_wave_sum(sqv);
+        if (lane == 0) {
+          float* slo = a.slots_out + ((long)mfrag * (C / 16) + nf) * 2;
+          slo[0] = sm;
+          slo[1] = sqv;
+        }
+      }
+      if (POOL) {
+        // GlobalContext pooling of this fragment (imagen_pytorch.py:916-941): its 16 pixels are one softmax chunk.  The logit fragment's
+        // column 0 sits in lanes 0 / 16 / 32 / 48 (rows 4 g .. 4 g + 3): every lane fetches the logits of ITS rows from lane (lane & 48)
+        float l[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int idx = ((F + mi) * 4 + r) * 64 + lane;
+          float sacc = 0.0f;
+#pragma unroll
+          for (int w = 0; w < NWM; ++w) sacc += red[idx + w * FT * 256];
+          l[r] = sf_shfl(sacc, lane & 48);
+        }
+        float mx = fmaxf(fmaxf(l[0], l[1]), fmaxf(l[2], l[3]));
+        mx = fmaxf(mx, sf_shfl_xor(mx, 16));
+        mx = fmaxf(mx, sf_shfl_xor(mx, 32));
+        float es = 0.0f, pv = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = sf_exp(l[r] - mx);
+          es += e;
+          pv = fmaf(e, y4[r], pv);
+        }
+        es += sf_shfl_xor(es, 16); es += sf_shfl_xor(es, 32);
+        pv += sf_shfl_xor(pv, 16); pv += sf_shfl_xor(pv, 32);
+        if (lane < 16) a.pool_part[(long)mfrag * C + n] = pv;
+        if (lane == 0 && nf == 0) {
+          float* ms = a.pool_part + (long)(a.M >> 4) * C + (long)mfrag * 2;
+          ms[0] = mx;
+          ms[1] = es;
+        }
+      }
+    }
+  }
+}
+
+template <int HL, int C, int TWL, int WM, int WN, bool POOL>
+SF_KERNEL(512) void k_conv3s(FConvArgs a) {
+  sf_touch_kernarg<(int)sizeof(FConvArgs)>();
+  conv3s_body<HL, C, TWL, WM, WN, POOL>(a, (int)blockIdx.x);
+}

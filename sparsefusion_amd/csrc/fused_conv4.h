@@ -61,11 +61,7 @@ SF_DEV void conv4_gn_body(const FConvArgs& a, const int bid) {
 #pragma unroll
   for (int i = 0; i < KW; ++i) {
     const int j = wave * KW + i, tap = j / CPS, ccl = j - tap * CPS;
-#if SF_NT_W
     fb[i] = __builtin_nontemporal_load(&wbase[(long)(tap * a.cchunks + ccl) * 64]);
-#else
-    fb[i] = wbase[(long)(tap * a.cchunks + ccl) * 64];
-#endif
   }
 
   // ---- (2) zero padding of the frame: the 20 border pixels, 8 threads per pixel
@@ -262,11 +258,7 @@ SF_DEV void conv4_gn_mb_body(const FConvArgs& a, const int bid) {
 #pragma unroll
   for (int i = 0; i < KW; ++i) {
     const int j = wave * KW + i, tap = j / CPS, ccl = j - tap * CPS;
-#if SF_NT_W
     fb[i] = __builtin_nontemporal_load(&wbase[(long)(tap * a.cchunks + ccl) * 64]);
-#else
-    fb[i] = wbase[(long)(tap * a.cchunks + ccl) * 64];
-#endif
   }
 
   // ---- (2) zero padding of the NB frames: 20 border pixels each, 8 threads per pixel
@@ -445,11 +437,7 @@ SF_DEV void lin4_ln_body(const FConvArgs& a, const int bid) {
   for (int i = 0; i < KW; ++i)
 #pragma unroll
     for (int ni = 0; ni < WN; ++ni) {
-#if SF_NT_W
       fb[i][ni] = __builtin_nontemporal_load(&wbase[ni][(long)(wave * KW + i) * 64]);
-#else
-      fb[i][ni] = wbase[ni][(long)(wave * KW + i) * 64];
-#endif
     }
   const int my_nf = nt * WN + wave;                    // wave f < F finalises fragment f
   const bool fin = wave < F && my_nf < a.n_frags;

@@ -24,22 +24,13 @@
 struct FDiv { uint32_t d, magic; };
 SF_DEV uint32_t fdiv(uint32_t n, FDiv f) { return f.d == 1 ? n : (uint32_t)(((uint64_t)n * f.magic) >> 32); }
 
-#ifndef SF_STAGE_U
-#define SF_STAGE_U 2           // float4 loads per staging batch and thread; two batches are live (one in flight, one in the VALU).
-                               // Measured r02 (UNet eval, B = 1): U = 8 / 4 / 2 -> 1.79 / 1.65 / 1.62 ms: the prologue is instruction-issue
-                               // bound (a wave64 VALU op occupies its SIMD for 4 cycles), so the shorter unrolled body wins
-#endif
-#ifndef SF_NT_W
-#define SF_NT_W 1              // non-temporal (streaming) weight loads: every weight byte is used once per eval, keeping it out of the
-                               // L2's retained set leaves the activations / slots there (measured r02: 1.62 -> 1.54 ms per eval)
-#endif
-#ifndef SF_RING_POS
-#define SF_RING_POS 1          // weight-ring issue point of the slot / plain prologue: 0 before the first staging batch, 1 after it, 2 after staging
-#endif
-#ifndef SF_FCX
-#define SF_FCX 0               // measurement builds of tools/exp/fconv4_knockout.hip: phase knock-outs of the 4x4 GroupNorm-self kernel (0 = product)
-#endif
-#define FCX_IS(n) (SF_FCX == (n) || (SF_FCX >= 1000 && (((SF_FCX - 1000) >> (n)) & 1)))      // >= 1000: a bit mask of knock-outs
+// Settled by measurement (the A/B switches these were live in r02-r05; their builds are in the history at c0adaa6 and the numbers in DESIGN.md):
+// * staging batches of the fused prologue: 2 float4 loads per thread, two batches live (r02: 8 / 4 / 2 -> 1.79 / 1.65 / 1.62 ms per eval: the
+//   prologue is instruction-issue bound, the shorter unrolled body wins);
+// * weights are streamed with non-temporal loads everywhere (every byte is used once per eval; keeping it out of the L2's retained set
+//   leaves the activations / slots there: r02 1.62 -> 1.54 ms per eval);
+// * the weight ring of the slot / plain prologue is requested after the first staging batch.
+constexpr int SF_STAGE_U = 2;
 enum { FNORM_NONE = 0, FNORM_GN_SELF = 1, FNORM_GN_SLOTS = 2, FNORM_LN = 3, FNORM_ATTN = 4 };
 
 // FNORM_ATTN: the A operand of an attention output projection IS the attention core's result, computed in the prologue
@@ -201,10 +192,6 @@ struct FGather {
       t[5] = *reinterpret_cast<const f32x4*>(first ? rp : p2);
       w[4] = (first && a.s1.b) ? 1.0f : 0.0f;
       w[5] = (first && a.s1.r) ? 1.0f : 0.0f;
-#if FCX_IS(2)
-#pragma unroll
-      for (int g = 1; g < 6; ++g) { t[g] = f32x4{0.f, 0.f, 0.f, 0.f}; w[g] = 0.0f; }
-#endif
     } else {
       const int c1 = first ? c : 0;
       const float* hp = a.s1.a + m * a.s1.C + c1;
@@ -263,9 +250,6 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
 #define FC_STAMP(k) do { } while (0)
 #endif
   FC_STAMP(0);
-#if FCX_IS(8)
-  if (a.B > 0) return;
-#endif
   // ---- which tile
   const int MT = a.B * a.mt_per_img;
   const int tiles = MT * a.n_tiles;
@@ -281,15 +265,6 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
   const int HW = a.H * a.W;
   const long mb = (long)b * HW;           // first pixel row of this image
   const float sc1 = a.s1.scale, sc2 = a.s2.scale;     // as values: a select between two kernarg FIELDS becomes a scratch array
-#if SF_EARLY_BIAS
-  float bias_early = 0.0f;
-  if (NORM == FNORM_ATTN || NORM == FNORM_NONE) {      // (compile-time) the bias of this wave's fragment, in flight under the whole prologue
-    int enf = nt * WN + (wave % WN);
-    if (enf > a.n_frags - 1) enf = a.n_frags - 1;
-    const int en = enf * 16 + (lane & 15);
-    bias_early = (a.bias ? a.bias : reinterpret_cast<const float*>(a.w))[(a.bias && en < a.Cout) ? en : 0];
-  }
-#endif
 
   // ---- weight stream: this wave's k-steps [k0, k1) of the slice-local list (tap-major, then 32-channel chunk)
   const int KSl = a.k * a.k * a.cps;
@@ -305,13 +280,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
   }
   auto wload = [&](int j, int ni) -> bf16x8 {
     const int tap = (int)fdiv((uint32_t)j, a.d_cps), ccl = j - tap * a.cps;
-#if FCX_IS(1)
-    return sf_zero8();
-#elif SF_NT_W
     return __builtin_nontemporal_load(&wbase[ni][(long)(tap * a.cchunks + ccl) * 64]);
-#else
-    return wbase[ni][(long)(tap * a.cchunks + ccl) * 64];
-#endif
   };
   bf16x8 fb[D][WN];
   // fill the ring: the HBM / L2 weight stream runs under the rest of the prologue.  The loads are UNCONDITIONAL (indices
@@ -396,14 +365,10 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
 #pragma unroll
     for (int k = 0; k < TABN; ++k) {
       const int cl = tid + k * NT, cc = c0 + (cl < Cs ? cl : Cs - 1);
-#if FCX_IS(4)
-      tg[k] = 1.0f; tb[k] = 0.0f; tsc[k] = (float)cc * 1e-9f; tsh[k] = 0.0f; (void)ssrow; (void)shoff;
-#else
       tg[k] = a.gamma[cc];
       tb[k] = a.beta[cc];
       tsc[k] = ssrow[cc];
       tsh[k] = ssrow[shoff + cc];
-#endif
     }
   }
   auto build_table = [&]() {
@@ -436,10 +401,8 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
     // a select, not a branch: the U elements of a staging batch must stay in one basic block to interleave
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-#if !FCX_IS(5)
       const float sv = sf_silu_fast(v[j]);
       v[j] = a.silu ? sv : v[j];
-#endif
     }
     bf16x4 o;
     o[0] = (sf_opnd)v[0]; o[1] = (sf_opnd)v[1]; o[2] = (sf_opnd)v[2]; o[3] = (sf_opnd)v[3];
@@ -462,9 +425,6 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
     // loaded ONCE into registers (issued before the weight ring, so one round trip covers the whole prologue), group sums
     // meet in LDS, then the registers are normalised straight into the frame.
     FC_STAMP(1);
-#if FCX_IS(3)
-    if (tid < 16) { misc[16 + 2 * tid] = 0.0f; misc[17 + 2 * tid] = 1.0f; }
-#else
     if (a.det_w) {
       // deterministic group sums: a thread's elements share one channel chunk (NT % (Cs/4) == 0), hence one group; det_w
       // adjacent lanes lie in one group -> segment sums by shuffles, one partial per segment, fixed-order final sum.
@@ -553,7 +513,6 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
         misc[17 + 2 * tid] = sf_rsqrt((float)var + a.eps);
       }
     }
-#endif
     sf_sync();
     build_table();
     sf_sync();
@@ -565,9 +524,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
         const int p = (int)fdiv((uint32_t)i, a.d_cs4), c4 = i - p * Cs4;
         const int py = p >> a.logW, px = p - (py << a.logW);
         const int c = c0 + c4 * 4;
-#if !FCX_IS(9)
         if (nt == 0 && LAZY && c < a.s1.C) *reinterpret_cast<f32x4*>(a.s1.p + (mb + p) * a.s1.C + c) = v[u];
-#endif
         f32x4 A, Bv;
         affine_of(c4 * 4, A, Bv);
         finish(v[u] * (c < a.s1.C ? sc1 : sc2), (py + h) * FW + px + h, c4 * 4, 0, A, Bv);
@@ -833,16 +790,11 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
         slsc[u] = live ? (f1 ? sc1 : sc2) : 0.0f;
       }
     };
-    // issue order: slots of this wave's first group, first staging batch, weight ring (SF_RING_POS 0: ring first)
+    // issue order: slots of this wave's first group, first staging batch, weight ring
     if (NORM == FNORM_GN_SLOTS && wave < ngs) slot_loads(wave, lane);
-#if SF_RING_POS == 0
-    FC_PREFETCH();
-#endif
     chan(0);
     issue(tp, va, fpa, mxa);
-#if SF_RING_POS == 1
     FC_PREFETCH();
-#endif
     FC_STAMP(1);
     if (NORM == FNORM_GN_SLOTS) {
       // one wave per group sums the (sum, sum of squares) slots of image b: 4 independent slot loads in flight per lane
@@ -888,9 +840,6 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
     };
     if (a.silu) run(FConst<1>());
     else run(FConst<0>());
-#if SF_RING_POS == 2
-    FC_PREFETCH();
-#endif
   }
   sf_sync();
   FC_STAMP(3);
@@ -908,12 +857,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
   if (fin && n < a.Cout) {
     if (a.logit_part) wkv = a.wk[n];
     if (a.S == 1) {
-#if SF_EARLY_BIAS
-      if (NORM == FNORM_ATTN || NORM == FNORM_NONE) bv = a.bias ? bias_early : 0.0f;
-      else if (a.bias) bv = a.bias[n];
-#else
       if (a.bias) bv = a.bias[n];
-#endif
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long o = (mrow + r) * a.ldc + a.co_off + n;
@@ -960,11 +904,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
-#if FCX_IS(6)
-          for (int ni = 0; ni < WN; ++ni) { acc[mi][ni][0] += (float)fa[mi][0] + (float)fb[u][ni][0]; }
-#else
           for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = sf_mfma16(fa[mi], fb[u][ni], acc[mi][ni]);
-#endif
         if (j + D < k1) {
 #pragma unroll
           for (int ni = 0; ni < WN; ++ni) fb[u][ni] = wload(j + D, ni);     // refill the ring slot just consumed
@@ -994,11 +934,7 @@ SF_DEV void conv_fused_body(const FConvArgs& a, const int bid) {
       const int idx = (f * 4 + r) * 64 + lane;
       float sacc = 0.0f;
 #pragma unroll
-#if FCX_IS(7)
-      for (int w = 0; w < 1; ++w) sacc += red[idx + w * F * 256];
-#else
       for (int w = 0; w < NW; ++w) sacc += red[idx + w * F * 256];
-#endif
       v[r] = sacc;
     }
     if (a.logit_part) {                      // bias terms are the same for every pixel: they cancel in the softmax

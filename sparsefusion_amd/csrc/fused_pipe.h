@@ -77,11 +77,7 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
     woff[i] = (tap * a.cchunks + ccl) * 64;
   }
   auto wload = [&](int c, int i, int ni) -> bf16x8 {
-#if SF_NT_W
     return __builtin_nontemporal_load(&wbase[ni][woff[i] + c * (CC / 32) * 64]);
-#else
-    return wbase[ni][woff[i] + c * (CC / 32) * 64];
-#endif
   };
   // ONE register pool for both roles (the ring of the matrix waves, the two staging batches of the others): declared as
   // separate arrays the compiler keeps both alive across the role-independent code and allocates their SUM
@@ -179,11 +175,7 @@ SF_DEV void conv_fused_pipe_body(const FConvArgs& a, const int bid) {
     rcw[ni] = RC ? a.rc_w + ((long)nf * a.cchunks + (mx_role ? wave : 0)) * 64 + lane : nullptr;
   }
   auto rcload = [&](int c, int ni) -> bf16x8 {
-#if SF_NT_W
     return __builtin_nontemporal_load(&rcw[ni][(long)c * (CC / 32) * 64]);
-#else
-    return rcw[ni][(long)c * (CC / 32) * 64];
-#endif
   };
   if (mx_role) {
 #pragma unroll

@@ -61,12 +61,31 @@ static int launch_fconv_pipe(const FConvArgs& a, uint32_t grid, uint32_t lds, hi
   return SF_OK;
 }
 
+template <int HL, int C, int TWL, int WM, int WN, bool POOL>
+static int launch_conv3s(const FConvArgs& a, uint32_t grid, hipStream_t st) {
+  static unsigned mask = 0;
+  constexpr uint32_t lds = Conv3sGeom<HL, C, TWL, WM, WN, POOL>::LDS_BYTES;
+  if (int rc = allow_big_lds(k_conv3s<HL, C, TWL, WM, WN, POOL>, lds, mask)) return rc;
+  k_conv3s<HL, C, TWL, WM, WN, POOL><<<grid, 512, lds, st>>>(a);
+  SF_CHECK_LAUNCH("conv3s");
+  return SF_OK;
+}
+
 static int run_fconv(const sf_op& op, hipStream_t st) {
   FConvArgs a;
   int WM, WN;
   uint32_t grid, lds;
   if (fconv_setup(op, a, WM, WN, grid, lds, sf_err_buf, sizeof(sf_err_buf))) return SF_ERR_INVALID;
   if (op.flags & 32) {
+    const int twl = conv3s_twl(op, a, WM, WN);            // r06: the recurring geometries on their own kernel (fused_conv3s.h)
+    if (twl >= 0) {
+#define SF_TRY3(hl_, c_, twl_, wm_, wn_) \
+      if (a.H == (1 << hl_) && a.C == c_ && twl == twl_ && WM == wm_ && WN == wn_) \
+        return a.weff ? launch_conv3s<hl_, c_, twl_, wm_, wn_, true>(a, grid, st) : launch_conv3s<hl_, c_, twl_, wm_, wn_, false>(a, grid, st);
+      SF_CONV3S_VARIANTS(SF_TRY3)
+#undef SF_TRY3
+    }
+    if ((op.i[19] >> 2) || WN > 2) SF_FAIL(SF_ERR_INVALID, "fconv pipe: no k_conv3s variant for the %d-wide tile %dx%d of a %d-channel %dx%d map", op.i[19] >> 2, WM, WN, a.C, a.H, a.W);
     const int EPT = fconv_pipe_ept(a);
 #define SF_TRYP(wm, wn, ept) if (WM == wm && WN == wn && EPT == ept) return a.weff ? launch_fconv_pipe<wm, wn, ept, true>(a, grid, lds, st) : launch_fconv_pipe<wm, wn, ept, false>(a, grid, lds, st);
     SF_FCONV_PIPE_VARIANTS(SF_TRYP)

@@ -24,6 +24,9 @@ OP_FCONV, OP_SLOTS, OP_GCA, OP_INITX, OP_GN_FINALIZE = 14, 15, 16, 17, 18
 # (WM, WN, norm of conv1) for which k_conv_fused_pair is instantiated (csrc/fused_host.h SF_FCONV_PAIR_VARIANTS); FNORM_GN_SELF = 1, _SLOTS = 2
 PAIR_TILES = {(1, 1, 1), (1, 1, 2), (1, 2, 2), (2, 2, 2), (4, 2, 2)}
 # (WM, WN, (TR + 2) * W / 8) for which k_conv_fused_pipe is instantiated (SF_FCONV_PIPE_VARIANTS)
+# (log2 H, C = Cout, log2 tile width, WM, WN) of k_conv3s (csrc/fused_host.h SF_CONV3S_VARIANTS; tests/test_plans_cpu.py compares the two tables)
+CONV3S_VARIANTS = {(5, 256, 5, 2, 2), (5, 256, 3, 2, 2), (4, 256, 4, 1, 1), (4, 256, 2, 1, 1), (4, 512, 4, 1, 2), (4, 512, 2, 1, 2),
+                   (3, 512, 3, 1, 1), (3, 1024, 3, 1, 1), (5, 256, 5, 4, 2), (5, 256, 3, 4, 2), (5, 256, 3, 4, 4)}
 PIPE_TILES = {(1, 1, 4), (1, 2, 4), (1, 1, 6), (1, 2, 6), (2, 1, 6), (2, 2, 6), (2, 1, 8), (2, 2, 8), (2, 1, 12), (2, 2, 12), (4, 1, 16), (4, 2, 16)}
 FNORM_NONE, FNORM_GN_SELF, FNORM_GN_SLOTS, FNORM_LN, FNORM_ATTN = range(5)      # csrc/fused_kernels.h
 ATTN_LDS_BYTES = 8 * 16 * 36 * 4 + 2 * 8 * 4 * 68 * 4      # SF_ATTN_LDS_BYTES: scratch of the attention prologue (FNORM_ATTN)
@@ -574,6 +577,16 @@ class _Plan:
             af = tuple((sv - sk) // 4 for sk, sv, *_ in segs) + (scale,)
         elif norm == FNORM_GN_SELF and not getattr(self.u, "conv4_mb", True):
             ai = (1,)                                           # i[19] bit 0: one image per workgroup (k_conv4_gn) where k_conv4_gn_mb would take the op
+        elif pipe:
+            # r06: the recurring single-source geometries run on k_conv3s (csrc/fused_conv3s.h; the host takes the op when a variant of its
+            # shape exists).  i[19] bit 1 keeps the general pipelined kernel, bits 2.. = tile width of a 2-D pixel tile (0 = full-width strips)
+            code = 0 if getattr(self.u, "conv3s", True) else 2
+            tw = getattr(self.u, f"conv3s_tw{H}", 0)
+            if (code == 0 and tw and tw != H and C2 == 0 and Cout == C1 and ldc == Cout and co_off == 0 and not accum and not out_gelu and not pre_gelu
+                    and not pair_first and pair_lazy is None and (logit is None or pool is not None) and bname
+                    and (H.bit_length() - 1, C1, tw.bit_length() - 1, WM, WN) in CONV3S_VARIANTS):
+                code |= tw << 2
+            ai = (code,)
         self.op(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0) | (8 if out_gelu else 0) | (16 if pair_first else 0)
                 | (32 if pipe else 0) | (64 if pool is not None else 0) | (0 if getattr(self.u, "conv4", True) else 128),
                 p=(x_ptr, lp[0], lp[1], lp[2], x.slots or 0, skip.ptr if skip else 0, (skip.slots or 0) if skip else 0,
@@ -1159,6 +1172,8 @@ class Unet(nn.Module):
         self.conv4_reduce_min_batch = 4     # r05: from this batch on a 4x4 split-K conv1 is reduced by its own launch instead of by conv2's gather (0 = never)
         self.conv4_mb = True                # r05: even B: the 4x4 GroupNorm-self convs run 2 | 4 images per workgroup (k_conv4_gn_mb; False = op field i[19] bit 0)
         self.conv4_slices_max_batch = 4     # r05: up to this batch the 4x4 GroupNorm-self convs keep 4 input-channel slices (= k_conv4_gn's geometry); 0 = the workgroup-count rule alone
+        self.conv3s = True                  # r06: the recurring single-source slot-GroupNorm 3x3 convs on k_conv3s (compile-time geometry, csrc/fused_conv3s.h); False: op field i[19] bit 1 = k_conv_fused_pipe
+        self.conv3s_tw32, self.conv3s_tw16, self.conv3s_tw8 = 8, 4, 0      # r06: tile width of k_conv3s's 2-D pixel tiles per map size (0 = full-width strips)
         self.conv4 = True                   # r05: the 4x4 level's GroupNorm-self 3x3 convs on k_conv4_gn (csrc/fused_conv4.h); False: op flag 128 = k_conv_fused (parity tests)
         self.use_hip_graph = True           # replay one captured hipGraph per eval instead of ~370 host launches
         self._pack_cache = None

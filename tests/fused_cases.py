@@ -53,7 +53,9 @@ def run_ops(ops, backend):
 
 def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, silu=True, ss=True, accum=False, resid=False,
                   slots=True, pre_gelu=False, ln_bias=False, seed=0, G=8, scale2=2 ** -0.5, tol=4e-3, dbg=None, reps=1, logits=False,
-                  out_gelu=False, pair=False, pipe=False, pool=False, general=False, one_image=False):
+                  out_gelu=False, pair=False, pipe=False, pool=False, general=False, one_image=False, tw=None, keep_pipe=False):
+    """tw (r06): run the op on k_conv3s with a tw-pixel-wide tile (W = full-width strips): plain output rows, op field i[19] = tw << 2;
+    keep_pipe: the same op with i[19] bit 1 set = the general pipelined kernel."""
     dev = "cpu" if backend == "emu" else "cuda:0"
     d = lambda t: None if t is None else t.to(dev)
     g = torch.Generator().manual_seed(seed)
@@ -95,7 +97,7 @@ def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, 
     bias = rn(Cout)
     ref = to_rows(F.conv2d(bf(y), bf(w), None, padding=k // 2))
     # ---- op
-    ldc, co_off = (Cout, 0) if pool else (Cout + 32, 16)     # epilogue pooling wants the bare conv output
+    ldc, co_off = (Cout, 0) if (pool or tw is not None) else (Cout + 32, 16)     # epilogue pooling / k_conv3s want the bare conv output
     out0 = rn(M, ldc)
     out = d(out0.clone())
     res = rn(M, ldc) if resid else None
@@ -120,7 +122,7 @@ def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, 
                     | (64 if pool else 0) | (128 if general else 0),     # 128: keep the general kernel (r05: k_conv4_gn takes the 4x4 geometry otherwise)
                     p=(s1["p"], s1["a"], s1["b"], s1["r"], sl1, x2_d, sl2, wp, bias_d, out, res_d, wsl, slots_out, gamma_d, beta_d, ssv_d, dbg, wk_d, lpart),
                     i=(B, H, W, C1, C2, Cout, ldc, co_off, k, s1["mode"], s1["groups"], s1["npad"], norm, G, TR, WM, WN, S, 2 * C)
-                    + ((1,) if one_image else ()),      # i[19] bit 0: one image per workgroup (k_conv4_gn) where k_conv4_gn_mb would take the op
+                    + ((1,) if one_image else ((((0 if tw == W else tw) << 2) | (2 if keep_pipe else 0),) if tw is not None else ())),      # i[19] bit 0: one image per workgroup (k_conv4_gn) where k_conv4_gn_mb would take the op; bit 1 / bits 2..: k_conv3s
                     f=(1e-5, 1.0, scale2))
     ops = [op]
     if pair:          # conv1 || res_conv in one launch (k_conv_fused_pair): a 1x1 conv of the RAW concat next to the normalised 3x3 one
@@ -183,7 +185,9 @@ def run_conv_case(backend, B, H, W, C1, C2, Cout, k, norm, WM, WN, S=1, lazy=0, 
     if slots_out is not None:
         sl = slots_of(out[:, co_off:co_off + Cout].contiguous(), M, Cout)
         got_sl = slots_out.cpu()[:, co_off // 16:co_off // 16 + Cout // 16]
-        assert torch.allclose(got_sl, sl, rtol=1e-4, atol=2e-3), "output slots wrong"
+        if tw is not None and tw != W:                   # 2-D tiles: a fragment holds a 16-pixel patch, not 16 consecutive pixels; consumers sum per image
+            sl, got_sl = sl.view(B, HW // 16, Cout // 16, 2).sum(1), got_sl.reshape(B, HW // 16, Cout // 16, 2).sum(1)
+        assert torch.allclose(got_sl, sl, rtol=1e-4, atol=2e-3 * (1 if tw is None or tw == W else HW // 16) ** 0.5), "output slots wrong"
     return e
 
 
@@ -482,4 +486,23 @@ CONV_CASES_FULL = {
     "unet_pipe_pool_8x8_1024": dict(B=1, H=8, W=8, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=59, pipe=True, pool=True),
     "unet_b4_pipe_pool_16x16_512": dict(B=4, H=16, W=16, C1=512, C2=0, Cout=512, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=60, pipe=True, pool=True),
     "unet_b4_4x4": dict(B=4, H=4, W=4, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SELF, WM=1, WN=1, S=1, seed=16),
+    # r06: k_conv3s (csrc/fused_conv3s.h), the recurring single-source geometries with compile-time shapes: full-width strips (tw = W) and
+    # 2-D tiles (tw < W), with / without residual, scale-shift, epilogue pooling; `keep_pipe` = the same op on the general pipelined kernel
+    "conv3s_32x32_256_strip": dict(B=1, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=90, pipe=True, tw=32),
+    "conv3s_32x32_256_tile4x8_resid": dict(B=1, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=91, pipe=True, tw=8, resid=True),
+    "conv3s_32x32_256_tile4x8_pool": dict(B=1, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=92, pipe=True, tw=8, pool=True),
+    "conv3s_32x32_256_strip_pool_no_ss": dict(B=1, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=93, pipe=True, tw=32, pool=True, ss=False),
+    "conv3s_16x16_256_strip": dict(B=2, H=16, W=16, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=94, pipe=True, tw=16, resid=True),
+    "conv3s_16x16_256_tile4x4_pool": dict(B=1, H=16, W=16, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=95, pipe=True, tw=4, pool=True),
+    "conv3s_16x16_512_tile4x4": dict(B=1, H=16, W=16, C1=512, C2=0, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=2, seed=96, pipe=True, tw=4, resid=True),
+    "conv3s_16x16_512_strip_pool": dict(B=1, H=16, W=16, C1=512, C2=0, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=2, seed=97, pipe=True, tw=16, pool=True),
+    "conv3s_16x16_512_tile4x4_pool": dict(B=1, H=16, W=16, C1=512, C2=0, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=2, seed=103, pipe=True, tw=4, pool=True),
+    "conv3s_8x8_1024_resid": dict(B=1, H=8, W=8, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=104, pipe=True, tw=8, resid=True),
+    "conv3s_8x8_512_pool": dict(B=1, H=8, W=8, C1=512, C2=0, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=105, pipe=True, tw=8, pool=True),
+    "conv3s_8x8_512": dict(B=2, H=8, W=8, C1=512, C2=0, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=98, pipe=True, tw=8, resid=True),
+    "conv3s_8x8_1024_pool": dict(B=1, H=8, W=8, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=99, pipe=True, tw=8, pool=True),
+    "conv3s_b2_32x32_256_tile8x8_wn2": dict(B=2, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=4, WN=2, seed=100, pipe=True, tw=8, pool=True),
+    "conv3s_b2_32x32_256_tile8x8_wn4": dict(B=2, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=4, WN=4, seed=101, pipe=True, tw=8, resid=True),
+    "conv3s_b2_32x32_256_tile8x8_wn4_pool": dict(B=2, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=4, WN=4, seed=102, pipe=True, tw=8, pool=True),
+    "conv3s_geometry_on_the_general_kernel": dict(B=1, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=90, pipe=True, tw=32, keep_pipe=True),
 }

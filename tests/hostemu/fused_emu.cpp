@@ -22,6 +22,8 @@ static void emu_fconv_pair(const FConvPairArgs& p, uint32_t grid, uint32_t lds) 
 static int g_conv4_launches = 0, g_conv4_mb_launches = 0;
 extern "C" int emu_conv4_mb_launches() { return g_conv4_mb_launches; }  // ops that ran on k_conv4_gn_mb (several images per workgroup)
 extern "C" int emu_conv4_launches() { return g_conv4_launches; }  // how many ops ran on k_conv4_gn (tests assert the path was taken)
+static int g_conv3s_launches = 0;
+extern "C" int emu_conv3s_launches() { return g_conv3s_launches; }      // ops that ran on k_conv3s (tests assert the path was taken)
 static int g_rc_launches = 0;
 extern "C" int emu_rc_launches() { return g_rc_launches; }      // how many pairs ran as k_conv_fused_pipe_rc (tests assert the path was taken)
 
@@ -85,6 +87,19 @@ extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
     uint32_t grid, lds;
     if (fconv_setup(*op, a, WM, WN, grid, lds, err, (size_t)errn)) return 1;
     if (op->flags & 32) {
+      const int twl = conv3s_twl(*op, a, WM, WN);          // the same dispatch as unet_fused.hip::run_fconv (r06: k_conv3s)
+      if (twl >= 0) {
+#define SF_TRY3(hl_, c_, twl_, wm_, wn_) \
+        if (a.H == (1 << hl_) && a.C == c_ && twl == twl_ && WM == wm_ && WN == wn_) { \
+          if (a.weff) hipemu::launch(grid, 512, Conv3sGeom<hl_, c_, twl_, wm_, wn_, true>::LDS_BYTES, [&] { k_conv3s<hl_, c_, twl_, wm_, wn_, true>(a); }); \
+          else hipemu::launch(grid, 512, Conv3sGeom<hl_, c_, twl_, wm_, wn_, false>::LDS_BYTES, [&] { k_conv3s<hl_, c_, twl_, wm_, wn_, false>(a); }); \
+          ++g_conv3s_launches; \
+          return 0; \
+        }
+        SF_CONV3S_VARIANTS(SF_TRY3)
+#undef SF_TRY3
+      }
+      if ((op->i[19] >> 2) || WN > 2) { snprintf(err, errn, "fconv pipe: no k_conv3s variant"); return 1; }
       const int EPT = fconv_pipe_ept(a);
 #define SF_TRYP(wm, wn, ept) \
       if (WM == wm && WN == wn && EPT == ept) { \

@@ -97,3 +97,17 @@ def test_the_4x4_geometry_runs_on_k_conv4_gn():
     fc.run_conv_case("emu", **fc.CONV_CASES["lin4_shape_on_the_general_kernel"])
     fc.run_conv_case("emu", **fc.CONV_CASES["layernorm_linear"])
     assert n2 == n1 + 1 and fused.lib().emu_conv4_launches() == n2
+
+
+CONV3S_ON_CPU = sorted(n for n in fc.CONV_CASES_FULL if n.startswith("conv3s_"))
+
+
+@pytest.mark.parametrize("name", CONV3S_ON_CPU)
+def test_conv3s_on_cpu_threads(name):
+    """r06: k_conv3s (csrc/fused_conv3s.h) exists for the UNet's own layer shapes only, so its emulation cases are full-size (1-3 s each on
+    the fiber scheduler): every instantiated tile family -- strips and 2-D tiles, WN = 1 / 2 / 4, with residual, scale-shift, epilogue pooling
+    -- against the torch reference; the op must have taken that kernel (and the general one under op field i[19] bit 1)."""
+    n0 = fused.lib().emu_conv3s_launches()
+    fc.run_conv_case("emu", **fc.CONV_CASES_FULL[name])
+    took = fused.lib().emu_conv3s_launches() - n0
+    assert took == (0 if fc.CONV_CASES_FULL[name].get("keep_pipe") else 1)

@@ -1,6 +1,6 @@
 """HBM fetch of the UNet eval's fused-conv launches by kernel class and by source (r05, the r04 review's item 5).
 
-Input: rocprofv3 --kernel-trace --pmc FETCH_SIZE counter CSVs of `SF_FCX_PLAIN=<variant> tools/fconv4_knockout.py 1` runs (N plain evals):
+Input: rocprofv3 --kernel-trace --pmc FETCH_SIZE counter CSVs of `SF_FCX_PLAIN=<variant> tools/fconv4_knockout.py 1` runs (N plain evals; that driver and its phase knock-out builds of the r05 headers were retired in r06 -- `git show c0adaa6:tools/fconv4_knockout.py`):
   argv[1] = directory of the PRODUCT run, argv[2] = directory of the run whose 15 4x4 GroupNorm-self launches load no weights (variant 1),
   argv[3] (optional) = calibration factor of FETCH_SIZE on nt dwordx4 weight streams (tools/exp/weight_prefetch_chain.hip under the counter).
 The dispatches of an eval are joined with the plan's launches BY POSITION (between two k_init_x dispatches, copies skipped), every launch is
