@@ -324,10 +324,10 @@ def unet_roofline(hp, B=1):
     all_conv_bytes = int(sum(_op_weight_bytes(o) for o in ops if o.type in (OP_CONV, OP_FCONV)))
     achieved = fconv_bytes / (fconv_ms * 1e-3) / 1e9
     tflops = fconv_flops / (fconv_ms * 1e-3) / 1e12
-    return {"bound": "hbm", "kernel": "k_conv_fused / k_conv_fused_pipe / _pair / k_gca_pool_rc / k_conv4_gn / k_lin4_ln (GroupNorm | LayerNorm + conv in one launch)",
+    return {"bound": "hbm", "kernel": "k_conv3s / k_conv_fused / k_conv_fused_pipe / _pair / _rc / k_gca_pool_rc / k_conv4_gn / k_lin4_ln (GroupNorm | LayerNorm + conv in one launch)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
-            "traffic_note": "not collected in this run (--no-traffic, B > 1 or a multi-rank run): see profiles/r04_unet_eval_b1_pmc.json",
+            "traffic_note": "not collected in this run (--no-traffic, B > 1 or a multi-rank run): see profiles/r06_unet_eval_b1_pmc.json",
             "batch": B, "launches": n_launch, "ops": len(idx), "avg_launch_us": round(fconv_ms / n_launch * 1e3, 2),
             "algorithmic_bytes_per_launch": fconv_bytes // n_launch, "algorithmic_bytes_per_eval": fconv_bytes,
             "fused_conv_ms_per_eval": round(fconv_ms, 4),
@@ -339,41 +339,23 @@ def unet_roofline(hp, B=1):
                            "frac": round(all_conv_bytes / (eval_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
 
 
-def measure_fconv_traffic(timeout_s=240):
-    """HBM bytes fetched per fused-conv launch, from the PMC counters, for `roofline.traffic`: a child process replays three B = 1 evals
-    (tools/unet_eval_loop.py, plain launches) under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` -- its own counter pass with the kernel
-    trace only, as MI355X_MICROARCH.md prescribes -- and the mean over all k_conv_fused* dispatches is corrected x2 (FETCH_SIZE reports
-    half of a wide coalesced streaming read on gfx950; KiB units).  Returns (bytes or None, note)."""
-    import csv
-    import glob
-    import shutil
-    import subprocess
-    import tempfile
-    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
-    out = tempfile.mkdtemp(prefix="sf_pmc_", dir="/tmp")
+def measure_fconv_counters(timeout_s=300):
+    """PMC figures of the fused-conv family for `roofline.traffic`, `roofline.mfma_busy` and `roofline.hbm_gbs_counter` (north_star: "rocprof HBM
+    GB/s and MFMA-busy counters"): a child process replays three B = 1 evals (tools/unet_eval_loop.py, plain launches) under rocprofv3, three
+    passes of `--kernel-trace --pmc <one group>` -- FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES + SQ_WAIT_ANY + SQ_WAVE_CYCLES + GRBM_GUI_ACTIVE,
+    counters in their own runs as MI355X_MICROARCH.md prescribes (tools/unet_pmc.py; FETCH_SIZE x 2: the counter reports half of a wide coalesced
+    read on gfx950).  Returns (dict or None, note)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
-        env = dict(os.environ, TMPDIR="/tmp")
-        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
-            env.pop(k, None)
-        subprocess.run([exe, "--kernel-trace", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", out, "--", sys.executable,
-                        os.path.join(ROOT, "tools", "unet_eval_loop.py"), "1", "3"], cwd="/tmp", env=env, timeout=timeout_s,
-                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
-        tot, n = 0.0, 0
-        for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
-            for r in csv.DictReader(open(f)):
-                if any(k in r["Kernel_Name"] for k in ("k_conv_fused", "k_gca_pool_rc", "k_conv4_gn", "k_lin4_ln")) and r["Counter_Name"] == "FETCH_SIZE":
-                    tot += float(r["Counter_Value"])
-                    n += 1
-        if not n:
-            return None, "the counter pass recorded no k_conv_fused dispatch"
-        return int(tot / n * 1024 * 2), ("mean FETCH_SIZE over %d fused-conv dispatches (k_conv_fused* / k_conv4_gn / k_lin4_ln) of a child process (3 evals, B = 1) under rocprofv3 --kernel-trace "
-                                         "--pmc FETCH_SIZE, KiB x 1024 x 2 (gfx950: the counter reports half of a wide coalesced read)" % n)
+        import unet_pmc
+        acc = unet_pmc.collect(1, 3, timeout_s=timeout_s)
+        d = unet_pmc.summarise(acc, 3, pred=lambda k: any(s_ in k for s_ in unet_pmc.FUSED)).get("selected")
+        if not d or d.get("fetch_bytes_per_dispatch") is None:
+            return None, "the counter passes recorded no fused-conv dispatch"
+        return d, ("per-dispatch means over the fused-conv dispatches (k_conv_fused* / k_conv3s / k_conv4_gn / k_lin4_ln / k_gca_pool_rc) of a child process "
+                   "(3 evals, B = 1, plain launches) under rocprofv3 --kernel-trace --pmc, one counter group per pass; FETCH_SIZE KiB x 1024 x 2 (gfx950)")
     except Exception as e:                                            # noqa: BLE001 -- a bench line without counters is still a bench line
-        return None, "counter pass failed: %r" % (e,)
-    finally:
-        shutil.rmtree(out, ignore_errors=True)
+        return None, "counter passes failed: %r" % (e,)
 
 
 def lds_conv_roofline(hp):
@@ -646,9 +628,15 @@ def main():
             res["breakdown_ms"]["unet_eval_in_sampler_B%d" % Bv] = round(time_region(lambda: hp.unet.eval_prepared(ctx_b, x_b, 1), 20), 3)
         res["roofline"] = unet_roofline(hp, args.views_per_gpu)    # the batch the step ran the UNet at (configs[3]: B = 4: both rooflines)
         if world == 1 and args.views_per_gpu == 1 and not args.no_traffic:
-            res["roofline"]["traffic"], res["roofline"]["traffic_note"] = measure_fconv_traffic()
-            if res["roofline"]["traffic"]:
-                res["roofline"]["traffic_over_algorithmic"] = round(res["roofline"]["traffic"] / res["roofline"]["algorithmic_bytes_per_launch"], 3)
+            pmc, res["roofline"]["traffic_note"] = measure_fconv_counters()
+            if pmc:
+                rf = res["roofline"]
+                rf["traffic"] = pmc["fetch_bytes_per_dispatch"]
+                rf["traffic_over_algorithmic"] = round(rf["traffic"] / rf["algorithmic_bytes_per_launch"], 3)
+                rf["mfma_busy"] = pmc.get("mfma_busy")                       # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)
+                rf["hbm_gbs_counter"] = pmc.get("hbm_gbs_counter")           # (FETCH x 2 + WRITE) / mean plain-launch duration of the trace: a lower bound of the in-graph rate
+                rf["hbm_frac_counter"] = round(pmc["hbm_gbs_counter"] / HBM_PEAK_GBS, 4) if pmc.get("hbm_gbs_counter") else None
+                rf["counters"] = pmc
         we = res["roofline"]["whole_eval"]
         # the eval as the sampler pays it, at top level (r04 review): against the conv / linear weights the replayed body streams
         # (the time-MLP / time-token weights are hoisted into Unet.time_table once per schedule) and

@@ -21,11 +21,10 @@
 //     3 x 32 + zero columns (96): the staging VALU (SiLU: two quarter-rate transcendentals per element, every n-tile re-normalises the
 //     pixels it needs) is what bounds these launches once the weights are there.  Slots and pooled fragments are indexed by
 //     (tile, m-fragment): their consumers sum over all fragments of an image, whatever pixels a fragment holds.
+//
+// One hazard met on the way (r06): see the comment at the affine computation in `consume`.
 #pragma once
 #include "fused_kernels.h"
-#ifndef C3S_DBG
-#define C3S_DBG 0
-#endif
 
 template <int HL, int C, int TWL, int WM, int WN, bool POOL>
 struct Conv3sGeom {
@@ -42,8 +41,8 @@ struct Conv3sGeom {
   static constexpr int LDS_BYTES = WEFF_OFF + (POOL ? KS * 64 : 0);
   static constexpr int NTILES = C / (16 * WN), MTI = (H / TH) * (W / TW);
   static constexpr int G = 8, CG = C / G, NCF = CG / 16, NMF = HW / 16, SCNT = NMF * NCF, NSL = (SCNT + 63) / 64;
-  static constexpr int RD = (C3S_DBG & 4) ? 1 : (NCH < 2 ? 1 : (WN >= 4 ? 1 : 2));                        // weight ring depth in chunks (9 * WN fragments per chunk and wave)
-  static constexpr int NB0 = (C3S_DBG & 8) ? 2 : (EPT <= 4 ? 4 : (EPT <= 8 ? 3 : 2)), NB = NB0 < NCH ? NB0 : NCH;      // staging batches (chunks) in registers
+  static constexpr int RD = NCH < 2 ? 1 : (WN >= 4 ? 1 : 2);                        // weight ring depth in chunks (9 * WN fragments per chunk and wave)
+  static constexpr int NB0 = EPT <= 4 ? 4 : (EPT <= 8 ? 3 : 2), NB = NB0 < NCH ? NB0 : NCH;      // staging batches (chunks) in registers
   static constexpr int NPW = RD * 9 * WN, NPS = NB * (EPT + 4), NP = NPW > NPS ? NPW : NPS;
   static_assert(TH * TW == 16 * WM && TH >= 1 && TH <= H && TW <= W && TW >= 4, "tile = 16 * WM pixels");
   static_assert(C % 128 == 0 && CG % 32 == 0 && NSL <= 4, "channels");
@@ -99,7 +98,6 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
 #pragma unroll
   for (int ni = 0; ni < WN; ++ni) wbase[ni] = a.w + ((long)(nt * WN + ni) * Gm::KS + (mx_role ? wave : 0)) * 64 + lane;
   auto wload = [&](int c, int tap, int ni) -> f32x4 {
-    if (C3S_DBG & 32) return __builtin_bit_cast(f32x4, wbase[ni][(tap * (C / 32) + 4 * c) * 64]);
     return __builtin_bit_cast(f32x4, __builtin_nontemporal_load(&wbase[ni][(tap * (C / 32) + 4 * c) * 64]));
   };
   // staging thread: float4 channel chunk tcx of every 128-channel chunk, frame pixels tp, tp + 8, ...
@@ -171,7 +169,7 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
       }
     }
   }
-  if (POOL && mx_role && !(C3S_DBG & 1)) {                                 // the w_eff table (KS k-steps x 32 operand-type values) into LDS
+  if (POOL && mx_role) {                                 // the w_eff table (KS k-steps x 32 operand-type values) into LDS
     const bf16x8* src = reinterpret_cast<const bf16x8*>(a.weff);
     bf16x8* dst = reinterpret_cast<bf16x8*>(lds + Gm::WEFF_OFF);
     for (int i = tid; i < Gm::KS * 4; i += NWM * 64) dst[i] = src[i];
@@ -199,43 +197,32 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
   }
   sf_sync();
 
-#if (C3S_DBG & 4096) && !defined(SF_HOST_EMU)
-  float dbg_mean[8], dbg_rstd[8];
-  for (int q = 0; q < 8; ++q) { dbg_mean[q] = 0.f; dbg_rstd[q] = 0.f; }
-#endif
   // ---- (6) the pipeline: phase 0 stages chunk 0; phase c + 1 multiplies chunk c while chunk c + 1 is staged; one barrier per phase
   auto consume = [&](int c, int vo) {
     const int gi = (c * CC + tcx * 4) / CG;
     const float mean = misc[2 * gi], rstd = misc[2 * gi + 1];
-#if (C3S_DBG & 4096) && !defined(SF_HOST_EMU)
-    if (a.dbg) {                                           // debug: the statistics as this thread reads them now, against a second read and the group's true values at the end
-      const float mean2 = reinterpret_cast<const volatile float*>(misc)[2 * gi], rstd2 = reinterpret_cast<const volatile float*>(misc)[2 * gi + 1];
-      dbg_mean[c < 8 ? c : 7] = mean; dbg_rstd[c < 8 ? c : 7] = rstd;
-      {                                                    // the batch's registers against what memory holds
-        const int cg0 = c * CC + tcx * 4;
-        for (int q = 0; q < EPT + 4; ++q) {
-          const float* src = q < EPT ? a.s1.p + soff[q] + c * CC : (q == EPT ? a.gamma + cg0 : (q == EPT + 1 ? a.beta + cg0 : (q == EPT + 2 ? ssrow + cg0 : ssrow + shoff + cg0)));
-          for (int j = 0; j < 4; ++j) {
-            const float tv = src[j], rv_ = pool[vo + q][j];
-            if (tv != rv_) {
-              const unsigned long long k = atomicAdd((unsigned long long*)a.dbg, 1ull);
-              if (k < 30) {
-                float* rec = reinterpret_cast<float*>(a.dbg + 1) + k * 12;
-                rec[0] = (float)tid; rec[1] = (float)q; rec[2] = (float)c; rec[3] = (float)j; rec[4] = rv_; rec[5] = tv; rec[6] = (float)vo;
-                rec[7] = 0; rec[8] = 0; rec[9] = 0; rec[10] = (float)bid; rec[11] = 0;
-              }
-            }
-          }
-        }
-      }
-      if (mean2 != mean || rstd2 != rstd) atomicAdd((unsigned long long*)a.dbg + 200, 1ull);
+    // y = x * A + Bv  ==  ((x - mean) * rstd * gamma + beta) * (scale + 1) + shift.  Component by component, every intermediate pinned to a register
+    // of its own: the f32x4 form of these lines (v_pk_mul_f32 / v_pk_fma_f32 fed straight from the ds_read_b64 pair that holds mean / rstd, through
+    // op_sel broadcasts) gave wrong EVEN components in lanes 16-31 / 48-63 of some staging waves ON THE GPU -- 1-3 % output error in 3 of the 20
+    // variants, moving with register allocation and with what the matrix wave of the same SIMD was doing; exact in the lane emulation.  Found by
+    // reading the staged frames back (tools/exp/conv3s_{probe,kmask,lds_dump}.py, commit cfdf51f): the batch registers and the statistics were
+    // right, the affine was not.  Each of {this scalar form, the packed form on splat vectors, mean / rstd passed through an empty asm first,
+    // affine operands loaded here instead of with the batch} is exact on all variants; not root-caused further.
+    f32x4 A, Bv;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float aj = pool[vo + EPT][j] * rstd;
+      SF_USE_FROM_HERE(aj);
+      float scj = a.ss ? pool[vo + EPT + 2][j] + 1.0f : 1.0f, shj = a.ss ? pool[vo + EPT + 3][j] : 0.0f;
+      SF_USE_FROM_HERE(scj);
+      SF_USE_FROM_HERE(shj);
+      float bj = (pool[vo + EPT + 1][j] - aj * mean) * scj + shj;
+      SF_USE_FROM_HERE(bj);
+      aj = aj * scj;
+      SF_USE_FROM_HERE(aj);
+      A[j] = aj;
+      Bv[j] = bj;
     }
-#endif
-    f32x4 A = pool[vo + EPT] * rstd;
-    f32x4 sc = pool[vo + EPT + 2] + 1.0f, sh = pool[vo + EPT + 3];
-    if (!a.ss) { sc = f32x4{1.f, 1.f, 1.f, 1.f}; sh = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    const f32x4 Bv = (pool[vo + EPT + 1] - A * mean) * sc + sh;
-    A = A * sc;
     char* buf = lds + (c & 1) * BUF;
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -251,25 +238,6 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
       bf16x4 o;
       o[0] = (sf_opnd)y[0]; o[1] = (sf_opnd)y[1]; o[2] = (sf_opnd)y[2]; o[3] = (sf_opnd)y[3];
       *reinterpret_cast<bf16x4*>(buf + loff[e]) = o;
-#if (C3S_DBG & 1024) && !defined(SF_HOST_EMU)
-      if (a.dbg && loff[e] != FR * FW * PSTR + tcx * 8) {     // debug (live elements only: dead ones share the spare pixel): the same element again, by another instruction sequence, and what sits in LDS now
-        const f32x4 y2 = pool[vo + e] * A + Bv;
-        const bf16x4 back = *reinterpret_cast<const volatile bf16x4*>(buf + loff[e]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float s2 = y2[j] / (1.0f + __expf(-y2[j]));
-          const float got = (float)back[j];
-          if (!(fabsf(got - s2) <= 0.02f * fabsf(s2) + 0.02f)) {
-            const unsigned long long k = atomicAdd((unsigned long long*)a.dbg, 1ull);
-            if (k < 30) {
-              float* rec = reinterpret_cast<float*>(a.dbg + 1) + k * 12;
-              rec[0] = (float)tid; rec[1] = (float)e; rec[2] = (float)c; rec[3] = (float)j; rec[4] = got; rec[5] = s2; rec[6] = y[j];
-              rec[7] = pool[vo + e][j]; rec[8] = A[j]; rec[9] = Bv[j]; rec[10] = (float)bid; rec[11] = ex[j];
-            }
-          }
-        }
-      }
-#endif
     }
   };
   f32x4 acc[WM][WN];
@@ -293,7 +261,6 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const char* buf = lds + (c & 1) * BUF;
-      constexpr int dummy = 0; (void)dummy;
       const int d = c % RD;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
@@ -305,30 +272,16 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
         for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
           for (int ni = 0; ni < WN; ++ni)
-            acc[mi][ni] = sf_mfma16_nc(fa[mi], __builtin_bit_cast(bf16x8, pool[(d * 9 + tap) * WN + ni]), acc[mi][ni]);      // (sf_dev.h: result disjoint from its sources)
+            acc[mi][ni] = sf_mfma16(fa[mi], __builtin_bit_cast(bf16x8, pool[(d * 9 + tap) * WN + ni]), acc[mi][ni]);
         if (c + RD < NCH) {                               // (compile-time after unrolling) refill the slot with chunk c + RD
 #pragma unroll
           for (int ni = 0; ni < WN; ++ni) pool[(d * 9 + tap) * WN + ni] = wload(c + RD, tap, ni);
         }
-        if (POOL && !(C3S_DBG & (2 | 64))) {                                       // one more MFMA per m-fragment: B = w_eff of the k-step in column 0, zero elsewhere
-          bf16x8 wl = *reinterpret_cast<const bf16x8*>(weffL + (tap * (C / 32) + 4 * c) * 64);
-          if (C3S_DBG & 128) wl = __builtin_bit_cast(bf16x8, f32x4{1.f, 2.f, 3.f, 4.f});
-          if ((C3S_DBG & 256) && !col0l) wl = sf_zero8();
-#pragma unroll
-          for (int mi = 0; mi < WM; ++mi) accl[mi] = sf_mfma16_nc(fa[mi], wl, accl[mi]);
-        }
-      }
-      if (POOL && (C3S_DBG & 64)) {
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int ky = tap / 3, kx = tap - ky * 3;
+        if (POOL) {                                       // one more MFMA per m-fragment: B = w_eff of the k-step in column 0, zero elsewhere
           bf16x8 wl = *reinterpret_cast<const bf16x8*>(weffL + (tap * (C / 32) + 4 * c) * 64);
           if (!col0l) wl = sf_zero8();
 #pragma unroll
-          for (int mi = 0; mi < WM; ++mi) {
-            const bf16x8 fa2 = *reinterpret_cast<const bf16x8*>(buf + abase[mi] + (ky * FW + kx) * PSTR);
-            accl[mi] = sf_mfma16_nc(fa2, wl, accl[mi]);
-          }
+          for (int mi = 0; mi < WM; ++mi) accl[mi] = sf_mfma16(fa[mi], wl, accl[mi]);
         }
       }
       sf_sync();
@@ -346,69 +299,6 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
     }
   }
 
-#if (C3S_DBG & 8192) && !defined(SF_HOST_EMU)
-  if (a.dbg) {                                           // debug: both frame buffers of every workgroup, as they are after the chunk loop
-    uint32_t* dump = reinterpret_cast<uint32_t*>(a.dbg) + (long)bid * (2 * BUF / 4);
-    for (int i = tid; i < 2 * BUF / 4; i += NT) dump[i] = reinterpret_cast<const volatile uint32_t*>(lds)[i];
-  }
-  sf_sync();
-#endif
-#if (C3S_DBG & 4096) && !defined(SF_HOST_EMU)
-  if (!mx_role && a.dbg) {
-    for (int c = 0; c < NCH && c < 8; ++c) {
-      const int gi = (c * CC + tcx * 4) / CG;
-      const float mean = misc[2 * gi], rstd = misc[2 * gi + 1];
-      if (mean != dbg_mean[c] || rstd != dbg_rstd[c]) {
-        const unsigned long long k = atomicAdd((unsigned long long*)a.dbg, 1ull);
-        if (k < 30) {
-          float* rec = reinterpret_cast<float*>(a.dbg + 1) + k * 12;
-          rec[0] = (float)tid; rec[1] = (float)gi; rec[2] = (float)c; rec[3] = 0; rec[4] = dbg_mean[c]; rec[5] = mean; rec[6] = dbg_rstd[c];
-          rec[7] = rstd; rec[8] = 0; rec[9] = 0; rec[10] = (float)bid; rec[11] = 0;
-        }
-      }
-    }
-  }
-  sf_sync();
-#endif
-#if (C3S_DBG & 2048) && !defined(SF_HOST_EMU)
-  if (!mx_role && a.dbg) {                               // debug: are the last two chunks still in their buffers as they were staged?
-    for (int c = NCH - 2; c < NCH; ++c) {
-      const int cg = c * CC + tcx * 4;
-      const int gi = cg / CG;
-      const float mean = misc[2 * gi], rstd = misc[2 * gi + 1];
-      f32x4 A = *reinterpret_cast<const f32x4*>(a.gamma + cg) * rstd;
-      f32x4 sc = *reinterpret_cast<const f32x4*>(ssrow + cg) + 1.0f, sh = *reinterpret_cast<const f32x4*>(ssrow + shoff + cg);
-      if (!a.ss) { sc = f32x4{1.f, 1.f, 1.f, 1.f}; sh = f32x4{0.f, 0.f, 0.f, 0.f}; }
-      const f32x4 Bv = (*reinterpret_cast<const f32x4*>(a.beta + cg) - A * mean) * sc + sh;
-      A = A * sc;
-      for (int e = 0; e < EPT; ++e) {
-        if (loff[e] == FR * FW * PSTR + tcx * 8) continue;
-        const f32x4 x = *reinterpret_cast<const f32x4*>(a.s1.p + soff[e] + c * CC);
-        const f32x4 y2 = x * A + Bv;
-        const bf16x4 back = *reinterpret_cast<const volatile bf16x4*>(lds + (c & 1) * BUF + loff[e]);
-        for (int j = 0; j < 4; ++j) {
-          const float s2 = y2[j] / (1.0f + __expf(-y2[j])), got = (float)back[j];
-          if (!(fabsf(got - s2) <= 0.02f * fabsf(s2) + 0.02f)) {
-            const unsigned long long k = atomicAdd((unsigned long long*)a.dbg, 1ull);
-            if (k < 30) {
-              float* rec = reinterpret_cast<float*>(a.dbg + 1) + k * 12;
-              rec[0] = (float)tid; rec[1] = (float)e; rec[2] = (float)c; rec[3] = (float)j; rec[4] = got; rec[5] = s2; rec[6] = y2[j];
-              rec[7] = x[j]; rec[8] = A[j]; rec[9] = Bv[j]; rec[10] = (float)bid; rec[11] = (float)loff[e];
-              // what the same location held two chunks ago (chunk c - 2 of the same buffer), and the other buffer's current value
-              const int c2 = c - 2, cg2 = c2 * CC + tcx * 4, gi2 = cg2 / CG;
-              const float m2 = misc[2 * gi2], r2 = misc[2 * gi2 + 1];
-              const float a2 = a.gamma[cg2 + j] * r2, scj = a.ss ? ssrow[cg2 + j] + 1.0f : 1.0f, shj = a.ss ? ssrow[shoff + cg2 + j] : 0.0f;
-              const float yy = a.s1.p[soff[e] + c2 * CC + j] * (a2 * scj) + ((a.beta[cg2 + j] - a2 * m2) * scj + shj);
-              rec[6] = yy / (1.0f + __expf(-yy));
-              rec[9] = (float)(*reinterpret_cast<const volatile bf16x4*>(lds + ((c + 1) & 1) * BUF + loff[e]))[j];
-            }
-          }
-        }
-      }
-    }
-  }
-  sf_sync();
-#endif
   // ---- (7) epilogue: the 4 K-slices meet in LDS; wave w finalises fragments w, w + 8, ...
   float* red = reinterpret_cast<float*>(lds + Gm::RED_OFF);         // [matrix wave][frag][r][lane]
   if (mx_role) {

@@ -134,7 +134,7 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
   if (a.C % 32 || a.s1.C % 32 || a.s1.C <= 0 || a.s2.C < 0) FC_FAIL("fconv: channel counts must be multiples of 32");
   if (a.s2.C && !a.s2.p) FC_FAIL("fconv: second source missing");
   if (a.TR < 1 || a.H % a.TR || a.TR * a.W != 16 * WM) FC_FAIL("fconv: tile of %d rows x %d != 16*WM (WM=%d)", a.TR, a.W, WM);
-  if (!((WM == 1 || WM == 2 || WM == 4) && (WN == 1 || WN == 2 || (WN == 4 && (op.flags & 32))))) FC_FAIL("fconv: unsupported wave tile %dx%d", WM, WN);      // (WN = 4: k_conv3s only)
+  if (!((WM == 1 || WM == 2 || WM == 4) && (WN == 1 || WN == 2))) FC_FAIL("fconv: unsupported wave tile %dx%d", WM, WN);
   a.cchunks = a.C / 32;
   if (a.cchunks % a.S) FC_FAIL("fconv: %d chunks do not split into %d slices", a.cchunks, a.S);
   a.cps = a.cchunks / a.S;
@@ -244,7 +244,7 @@ static inline int fconv_setup(const sf_op& op, FConvArgs& a, int& WM, int& WN, u
       a.weff_off = (int)lds_bytes;
       lds_bytes += (uint32_t)a.KS * 64;
     }
-    if (lds_bytes > SF_LDS_MAX && WN <= 2) FC_FAIL("fconv pipe: tile needs %u bytes of LDS", lds_bytes);      // (WN = 4: k_conv3s has its own layout)
+    if (lds_bytes > SF_LDS_MAX) FC_FAIL("fconv pipe: tile needs %u bytes of LDS", lds_bytes);
   }
   return 0;
 #undef FC_FAIL
@@ -281,14 +281,14 @@ static inline int conv4_cs4(const sf_op& op, const FConvArgs& a, int WM, int WN)
   X(4, 256, 4, 1, 1) X(4, 256, 2, 1, 1) \
   X(4, 512, 4, 1, 2) X(4, 512, 2, 1, 2) \
   X(3, 512, 3, 1, 1) X(3, 1024, 3, 1, 1) \
-  X(5, 256, 5, 4, 2) X(5, 256, 3, 4, 2) X(5, 256, 3, 4, 4)
+  X(5, 256, 5, 4, 2) X(5, 256, 3, 4, 2)
 
 // Does k_conv3s take this (pipelined, op flag 32) conv?  Returns the tile width's log2, or -1 = the general kernel.  Op field i[19]: bit 1 = keep
 // the general kernel (planner attribute Unet.conv3s = False), bits 2.. = tile width in pixels (0 = full-width strips of TR rows).
 static inline int conv3s_twl(const sf_op& op, const FConvArgs& a, int WM, int WN) {
   if (!(op.flags & 32) || (op.flags & (2 | 4 | 8 | 16)) || (op.i[19] & 2)) return -1;
   if (a.norm != FNORM_GN_SLOTS || a.k != 3 || a.S != 1 || a.s2.C || a.s1.mode || a.s1.scale != 1.0f || a.H != a.W || a.G != 8 || !a.silu) return -1;
-  if (a.Cout != a.C || a.ldc != a.Cout || a.co_off || a.accum || a.out_gelu || a.logit_part || (a.dbg && !(C3S_DBG & (1024 | 2048 | 4096 | 8192))) || !a.bias || !a.out) return -1;
+  if (a.Cout != a.C || a.ldc != a.Cout || a.co_off || a.accum || a.out_gelu || a.logit_part || a.dbg || !a.bias || !a.out) return -1;
   if (((uintptr_t)a.gamma | (uintptr_t)a.beta | (uintptr_t)a.ss | (uintptr_t)a.s1.p) & 15 || (a.ss && a.ss_stride % 4)) return -1;
   const int tw = (op.i[19] >> 2) ? (op.i[19] >> 2) : a.W;
   if (tw < 4 || tw > a.W || (tw & (tw - 1)) || (16 * WM) % tw || (16 * WM) / tw > a.H || a.H % ((16 * WM) / tw)) return -1;

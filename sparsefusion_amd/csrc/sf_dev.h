@@ -95,7 +95,6 @@ static inline f32x4 sf_mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   w->bar.wait();
   return d;
 }
-static inline f32x4 sf_mfma16_nc(bf16x8 a, bf16x8 b, f32x4 c) { return sf_mfma16(a, b, c); }
 // LDS-DMA (global_load_lds_dwordx4) under emulation.  The copy is DEFERRED until the sf_vmcnt<N>() that retires it (the latest moment
 // the hardware may land it: a read that does not sit behind the right counted wait + barrier sees stale data and the test fails);
 // HIPEMU_GLDS_IMMEDIATE=1 lands it at issue instead (the earliest moment: a buffer restaged while another wave still reads it shows).
@@ -153,19 +152,6 @@ SF_DEV f32x4 sf_mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mf
 #else
 SF_DEV f32x4 sf_mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 #endif
-// sf_mfma16 with a destination that shares NO register with its sources.  hipcc's register allocator may give a 16x16 MFMA (128-bit result:
-// no early-clobber in the instruction definition) a destination that PARTIALLY overlaps a source; on gfx950 the 8-pass v_mfma_f32_16x16x32
-// returns wrong sums when the destination starts two registers ABOVE an overlapping SrcC (r06: k_conv3s<3, 1024, .., POOL> and <4, 512, 2, .., POOL>,
-// 1-3 % error on the GPU, exact in the emulation; the 15 other variants, whose ISA has only the other overlap kinds -- C-2, B+-2 --, pass; the
-// pattern appears under register pressure, ~240 VGPRs).  The empty asm below reads c, a, b AND the result: all four are live at one point, so
-// the result's registers are disjoint from every source's; the MFMA itself stays a builtin (the compiler still inserts its wait states).
-// `tools/kernel_regs.py <src> --mfma-overlaps` lists the overlap kinds per kernel and fails on a "C+" one (tests/test_build_lint.py).
-SF_DEV f32x4 sf_mfma16_nc(bf16x8 a, bf16x8 b, f32x4 c) {
-  const f32x4 d = sf_mfma16(a, b, c);
-  const f32x4 av = __builtin_bit_cast(f32x4, a), bv = __builtin_bit_cast(f32x4, b);
-  asm volatile("" ::"v"(c), "v"(d), "v"(av), "v"(bv));
-  return d;
-}
 // Touch every 64-byte line of the kernel-argument segment with independent scalar loads and wait ONCE.  The compiler
 // fetches a large by-value argument struct piecemeal, each piece right before its first use and each behind its own
 // s_waitcnt: ~8 serialised cold misses of the scalar cache (~0.4 us each) in front of the first vector load of a 460-byte

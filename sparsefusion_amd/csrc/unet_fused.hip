@@ -85,7 +85,7 @@ static int run_fconv(const sf_op& op, hipStream_t st) {
       SF_CONV3S_VARIANTS(SF_TRY3)
 #undef SF_TRY3
     }
-    if ((op.i[19] >> 2) || WN > 2) SF_FAIL(SF_ERR_INVALID, "fconv pipe: no k_conv3s variant for the %d-wide tile %dx%d of a %d-channel %dx%d map", op.i[19] >> 2, WM, WN, a.C, a.H, a.W);
+    if (op.i[19] >> 2) SF_FAIL(SF_ERR_INVALID, "fconv pipe: no k_conv3s variant for the %d-wide tile %dx%d of a %d-channel %dx%d map", op.i[19] >> 2, WM, WN, a.C, a.H, a.W);
     const int EPT = fconv_pipe_ept(a);
 #define SF_TRYP(wm, wn, ept) if (WM == wm && WN == wn && EPT == ept) return a.weff ? launch_fconv_pipe<wm, wn, ept, true>(a, grid, lds, st) : launch_fconv_pipe<wm, wn, ept, false>(a, grid, lds, st);
     SF_FCONV_PIPE_VARIANTS(SF_TRYP)

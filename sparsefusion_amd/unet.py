@@ -26,7 +26,7 @@ PAIR_TILES = {(1, 1, 1), (1, 1, 2), (1, 2, 2), (2, 2, 2), (4, 2, 2)}
 # (WM, WN, (TR + 2) * W / 8) for which k_conv_fused_pipe is instantiated (SF_FCONV_PIPE_VARIANTS)
 # (log2 H, C = Cout, log2 tile width, WM, WN) of k_conv3s (csrc/fused_host.h SF_CONV3S_VARIANTS; tests/test_plans_cpu.py compares the two tables)
 CONV3S_VARIANTS = {(5, 256, 5, 2, 2), (5, 256, 3, 2, 2), (4, 256, 4, 1, 1), (4, 256, 2, 1, 1), (4, 512, 4, 1, 2), (4, 512, 2, 1, 2),
-                   (3, 512, 3, 1, 1), (3, 1024, 3, 1, 1), (5, 256, 5, 4, 2), (5, 256, 3, 4, 2), (5, 256, 3, 4, 4)}
+                   (3, 512, 3, 1, 1), (3, 1024, 3, 1, 1), (5, 256, 5, 4, 2), (5, 256, 3, 4, 2)}
 PIPE_TILES = {(1, 1, 4), (1, 2, 4), (1, 1, 6), (1, 2, 6), (2, 1, 6), (2, 2, 6), (2, 1, 8), (2, 2, 8), (2, 1, 12), (2, 2, 12), (4, 1, 16), (4, 2, 16)}
 FNORM_NONE, FNORM_GN_SELF, FNORM_GN_SLOTS, FNORM_LN, FNORM_ATTN = range(5)      # csrc/fused_kernels.h
 ATTN_LDS_BYTES = 8 * 16 * 36 * 4 + 2 * 8 * 4 * 68 * 4      # SF_ATTN_LDS_BYTES: scratch of the attention prologue (FNORM_ATTN)

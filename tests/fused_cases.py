@@ -496,13 +496,17 @@ CONV_CASES_FULL = {
     "conv3s_16x16_256_tile4x4_pool": dict(B=1, H=16, W=16, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=95, pipe=True, tw=4, pool=True),
     "conv3s_16x16_512_tile4x4": dict(B=1, H=16, W=16, C1=512, C2=0, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=2, seed=96, pipe=True, tw=4, resid=True),
     "conv3s_16x16_512_strip_pool": dict(B=1, H=16, W=16, C1=512, C2=0, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=2, seed=97, pipe=True, tw=16, pool=True),
-    "conv3s_16x16_512_tile4x4_pool": dict(B=1, H=16, W=16, C1=512, C2=0, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=2, seed=103, pipe=True, tw=4, pool=True),
     "conv3s_8x8_1024_resid": dict(B=1, H=8, W=8, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=104, pipe=True, tw=8, resid=True),
     "conv3s_8x8_512_pool": dict(B=1, H=8, W=8, C1=512, C2=0, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=105, pipe=True, tw=8, pool=True),
+    "conv3s_16x16_512_tile4x4_pool": dict(B=1, H=16, W=16, C1=512, C2=0, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=2, seed=103, pipe=True, tw=4, pool=True),
     "conv3s_8x8_512": dict(B=2, H=8, W=8, C1=512, C2=0, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=98, pipe=True, tw=8, resid=True),
     "conv3s_8x8_1024_pool": dict(B=1, H=8, W=8, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=99, pipe=True, tw=8, pool=True),
     "conv3s_b2_32x32_256_tile8x8_wn2": dict(B=2, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=4, WN=2, seed=100, pipe=True, tw=8, pool=True),
-    "conv3s_b2_32x32_256_tile8x8_wn4": dict(B=2, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=4, WN=4, seed=101, pipe=True, tw=8, resid=True),
-    "conv3s_b2_32x32_256_tile8x8_wn4_pool": dict(B=2, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=4, WN=4, seed=102, pipe=True, tw=8, pool=True),
+    "conv3s_16x16_256_strip_pool": dict(B=1, H=16, W=16, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=106, pipe=True, tw=16, pool=True),
+    "conv3s_16x16_256_tile4x4": dict(B=2, H=16, W=16, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=107, pipe=True, tw=4, resid=True, ss=False),
+    "conv3s_16x16_512_strip": dict(B=1, H=16, W=16, C1=512, C2=0, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=2, seed=108, pipe=True, tw=16),
+    "conv3s_b2_32x32_256_strip2_wn2": dict(B=2, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=4, WN=2, seed=109, pipe=True, tw=32, resid=True),
+    "conv3s_b2_32x32_256_strip2_wn2_pool": dict(B=2, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=4, WN=2, seed=110, pipe=True, tw=32, pool=True),
+    "conv3s_b3_32x32_256_tile8x8_wn2": dict(B=3, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=4, WN=2, seed=111, pipe=True, tw=8),
     "conv3s_geometry_on_the_general_kernel": dict(B=1, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=90, pipe=True, tw=32, keep_pipe=True),
 }

@@ -99,7 +99,7 @@ extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
         SF_CONV3S_VARIANTS(SF_TRY3)
 #undef SF_TRY3
       }
-      if ((op->i[19] >> 2) || WN > 2) { snprintf(err, errn, "fconv pipe: no k_conv3s variant"); return 1; }
+      if (op->i[19] >> 2) { snprintf(err, errn, "fconv pipe: no k_conv3s variant"); return 1; }
       const int EPT = fconv_pipe_ept(a);
 #define SF_TRYP(wm, wn, ept) \
       if (WM == wm && WN == wn && EPT == ept) { \

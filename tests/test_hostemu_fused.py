@@ -111,3 +111,4 @@ def test_conv3s_on_cpu_threads(name):
     fc.run_conv_case("emu", **fc.CONV_CASES_FULL[name])
     took = fused.lib().emu_conv3s_launches() - n0
     assert took == (0 if fc.CONV_CASES_FULL[name].get("keep_pipe") else 1)
+

@@ -293,6 +293,41 @@ def test_every_planned_fused_conv_has_a_kernel_variant():
                 assert (WM, WN, norm, lazy) in plain, (B, k, WM, WN, norm, lazy)
 
 
+def test_conv3s_tables_agree_and_the_b1_plan_uses_them():
+    """r06: the planner's CONV3S_VARIANTS and csrc/fused_host.h's SF_CONV3S_VARIANTS are one table; every variant has a GPU op case
+    (tests/fused_cases.py), with and without epilogue pooling; the canonical B = 1 plan sends its 29 single-source slot-GroupNorm 3x3 convs
+    there with the planned tile widths."""
+    import fused_cases as fc
+    from sparsefusion_amd import unet as U
+    txt = open(os.path.join(ROOT, "sparsefusion_amd", "csrc", "fused_host.h")).read()
+    body = re.search(r"#define SF_CONV3S_VARIANTS\(X\)((?:\s*\\\n(?:\s*X\([^)]*\))+)+)", txt).group(1)
+    host = {tuple(int(v) for v in m.split(",")) for m in re.findall(r"X\(([^)]*)\)", body)}
+    assert host == U.CONV3S_VARIANTS
+    covered = set()
+    for name, kw in fc.CONV_CASES_FULL.items():
+        if name.startswith("conv3s_") and not kw.get("keep_pipe"):
+            covered.add(((kw["H"].bit_length() - 1, kw["C1"], kw["tw"].bit_length() - 1, kw["WM"], kw["WN"]), bool(kw.get("pool"))))
+    for v in host:
+        assert (v, False) in covered, f"k_conv3s variant {v} has no GPU op case"
+        assert (v, True) in covered, f"k_conv3s variant {v} (POOL) has no GPU op case"
+    net = U.Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2), layer_attns=(False, False, False, True),
+                 layer_cross_attns=(False,) * 4, cond_images_channels=256, attn_pool_text=False)
+    ops = U._Plan(net, 1, CPU).build().ops
+    pipe = [o for o in ops if o.type == U.OP_FCONV and (o.flags & 32) and not (o.flags & 16)]
+    assert len(pipe) == 29
+    taken = 0
+    for o in pipe:
+        H, C, WM, WN, code, pool = o.i[1], o.i[3], o.i[15], o.i[16], o.i[19], bool(o.flags & 64)
+        tw = (code >> 2) or H
+        assert not (code & 2) and o.i[4] == 0 and o.i[5] == C
+        assert (H.bit_length() - 1, C, tw.bit_length() - 1, WM, WN) in host, (H, C, tw, WM, WN)
+        assert tw == {32: net.conv3s_tw32, 16: net.conv3s_tw16, 8: net.conv3s_tw8}[H] or tw == H
+        taken += 1
+    assert taken == 29
+    net.conv3s = False
+    assert all(o.i[19] & 2 for o in U._Plan(net, 1, CPU).build().ops if o.type == U.OP_FCONV and (o.flags & 32) and not (o.flags & 16))
+
+
 def test_a_paired_conv_is_followed_by_its_partner():
     """A conv emitted with flag 16 (first half of a pair) shares its launch with the NEXT op: sf_plan_fused_pair takes ops[k + 1], which
     must be the res_conv (OP_FCONV) or the pooling launch (OP_GCA).  r05's own-launch split-K reduction once stood between the two
