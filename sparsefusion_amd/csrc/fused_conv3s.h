@@ -26,8 +26,12 @@
 #pragma once
 #include "fused_kernels.h"
 
-template <int HL, int C, int TWL, int WM, int WN, bool POOL>
+// C1 + C2 input channels (C2 > 0: the virtual concat of a second source, scaled by s2.scale = 2^-1/2 for a skip connection), COUT output channels;
+// RC: the ResnetBlock's res_conv (1x1 conv of the RAW concat, imagen_pytorch.py:700-729) rides in the same workgroups, one more k-step per matrix
+// wave and chunk on a raw operand copy of the tile's own pixels (as k_conv_fused_pipe_rc, fused_pipe.h).
+template <int HL, int C1, int C2, int COUT, int TWL, int WM, int WN, bool POOL, bool RC>
 struct Conv3sGeom {
+  static constexpr int C = C1 + C2;
   static constexpr int H = 1 << HL, W = H, HW = H * W, TW = 1 << TWL, TH = 16 * WM / TW;
   static constexpr bool FULLW = TW == W;
   static constexpr int FR = TH + 2, FW = TW + 2;
@@ -36,22 +40,27 @@ struct Conv3sGeom {
   static constexpr int CC = 128, NCH = C / CC, KS = 9 * (C / 32);
   static constexpr int PSTR = 288;                          // bytes per frame pixel: 128 operand-type channels + 32 (stride = 32 mod 256)
   static constexpr int BUF = ((FR * FW + 1) * PSTR + 15) / 16 * 16;      // + 1 spare pixel (dead staging elements)
-  static constexpr int F = WM * WN, FT = F + (POOL ? WM : 0);
+  static constexpr int RAWB = RC ? ((16 * WM + 1) * PSTR + 15) / 16 * 16 : 0;      // RC: raw operand of the tile's own pixels (+ 1 spare), per buffer
+  static constexpr int F = WM * WN, FT = F + (POOL ? WM : 0) + (RC ? F : 0);
   static constexpr int RED_OFF = 2 * BUF, MISC_OFF = RED_OFF + 4 * FT * 1024, WEFF_OFF = MISC_OFF + 256;
-  static constexpr int LDS_BYTES = WEFF_OFF + (POOL ? KS * 64 : 0);
-  static constexpr int NTILES = C / (16 * WN), MTI = (H / TH) * (W / TW);
+  static constexpr int RAW_OFF = WEFF_OFF + (POOL ? KS * 64 : 0);
+  static constexpr int LDS_BYTES = RAW_OFF + 2 * RAWB;
+  static constexpr int NTILES = COUT / (16 * WN), MTI = (H / TH) * (W / TW);
   static constexpr int G = 8, CG = C / G, NCF = CG / 16, NMF = HW / 16, SCNT = NMF * NCF, NSL = (SCNT + 63) / 64;
-  static constexpr int RD = NCH < 2 ? 1 : (WN >= 4 ? 1 : 2);                        // weight ring depth in chunks (9 * WN fragments per chunk and wave)
-  static constexpr int NB0 = EPT <= 4 ? 4 : (EPT <= 8 ? 3 : 2), NB = NB0 < NCH ? NB0 : NCH;      // staging batches (chunks) in registers
-  static constexpr int NPW = RD * 9 * WN, NPS = NB * (EPT + 4), NP = NPW > NPS ? NPW : NPS;
+  static constexpr int KR = 9 + (RC ? 1 : 0);                                       // ring steps per matrix wave and chunk
+  static constexpr int RD = NCH < 2 ? 1 : ((WN >= 4 || (RC && WN >= 2)) ? 1 : 2);   // weight ring depth in chunks (KR * WN fragments per chunk and wave; RC: the second set of accumulators takes the registers of the second ring set)
+  static constexpr int NB0 = EPT <= 4 ? (RC ? 3 : 4) : (EPT <= 8 ? 3 : 2), NB = NB0 < NCH ? NB0 : NCH;      // staging batches (chunks) in registers
+  static constexpr int NPW = RD * KR * WN, NPS = NB * (EPT + 4), NP = NPW > NPS ? NPW : NPS;
   static_assert(TH * TW == 16 * WM && TH >= 1 && TH <= H && TW <= W && TW >= 4, "tile = 16 * WM pixels");
-  static_assert(C % 128 == 0 && CG % 32 == 0 && NSL <= 4, "channels");
+  static_assert(C1 % 128 == 0 && C2 % 128 == 0 && CG % 16 == 0 && NSL <= 4 && COUT % (16 * WN) == 0, "channels");
+  static_assert(!(POOL && RC), "a block's conv1 has no pooling epilogue");
   static_assert(LDS_BYTES <= 163840, "LDS");
 };
 
-template <int HL, int C, int TWL, int WM, int WN, bool POOL>
+template <int HL, int C1, int C2, int COUT, int TWL, int WM, int WN, bool POOL, bool RC>
 SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
-  using Gm = Conv3sGeom<HL, C, TWL, WM, WN, POOL>;
+  using Gm = Conv3sGeom<HL, C1, C2, COUT, TWL, WM, WN, POOL, RC>;
+  constexpr int C = Gm::C, KR = Gm::KR;
   constexpr int H = Gm::H, W = Gm::W, HW = Gm::HW, TW = Gm::TW, TH = Gm::TH, FR = Gm::FR, FW = Gm::FW, SW = Gm::SW, NPX = Gm::NPX, EPT = Gm::EPT;
   constexpr int CC = Gm::CC, NCH = Gm::NCH, PSTR = Gm::PSTR, BUF = Gm::BUF, F = Gm::F, FT = Gm::FT, RD = Gm::RD, NB = Gm::NB, NP = Gm::NP;
   constexpr int NTILES = Gm::NTILES, MTI = Gm::MTI, CG = Gm::CG, NCF = Gm::NCF, NMF = Gm::NMF, SCNT = Gm::SCNT, NSL = Gm::NSL;
@@ -82,12 +91,17 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
 
   // ---- (1) statistics slots of group `wave` of image b: the head of the critical path (slots -> statistics -> first staged chunk)
   f32x2 sl[NSL];
+  float slsc[NSL];                                       // scale of the slot's source (sums x scale, sums of squares x scale^2)
 #pragma unroll
   for (int u = 0; u < NSL; ++u) {
     int i = lane + u * 64;
     if (i > SCNT - 1) i = SCNT - 1;
     const int mf = i / NCF, cfa = wave * NCF + (i - mf * NCF);
-    sl[u] = *reinterpret_cast<const f32x2*>(a.s1.slots + ((long)(b * NMF + mf) * (C / 16) + cfa) * 2);
+    const bool first = C2 == 0 || cfa < C1 / 16;           // the group's 16-channel fragments may lie in either source (a group can straddle the seam)
+    const float* sp = first ? a.s1.slots + ((long)(b * NMF + mf) * (C1 / 16) + cfa) * 2
+                            : a.s2.slots + ((long)(b * NMF + mf) * ((C2 ? C2 : 16) / 16) + (cfa - C1 / 16)) * 2;
+    sl[u] = *reinterpret_cast<const f32x2*>(sp);
+    slsc[u] = first ? 1.0f : a.s2.scale;
   }
 
   // ---- (2) ONE register pool for both roles (declared apart, the compiler allocates their sum): the weight ring of a matrix wave,
@@ -97,28 +111,42 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
   const bf16x8* wbase[WN];
 #pragma unroll
   for (int ni = 0; ni < WN; ++ni) wbase[ni] = a.w + ((long)(nt * WN + ni) * Gm::KS + (mx_role ? wave : 0)) * 64 + lane;
+  // RC: k-step (chunk c, sub-chunk w) of the res_conv's fragment nf sits at (nf * C / 32 + 4 c + w) * 64 + lane
+  const bf16x8* rcw[WN];
+#pragma unroll
+  for (int ni = 0; ni < WN; ++ni) rcw[ni] = RC ? a.rc_w + ((long)(nt * WN + ni) * (C / 32) + (mx_role ? wave : 0)) * 64 + lane : nullptr;
+  auto rcload = [&](int c, int ni) -> f32x4 { return __builtin_bit_cast(f32x4, __builtin_nontemporal_load(&rcw[ni][4 * c * 64])); };
   auto wload = [&](int c, int tap, int ni) -> f32x4 {
     return __builtin_bit_cast(f32x4, __builtin_nontemporal_load(&wbase[ni][(tap * (C / 32) + 4 * c) * 64]));
   };
   // staging thread: float4 channel chunk tcx of every 128-channel chunk, frame pixels tp, tp + 8, ...
   const int ts = tid - NWM * 64;
   const int tcx = ts & 31, tp = ts >> 5;
-  int soff[EPT];                                         // source element offset of element e (pixel * C + tcx * 4), a safe pixel when dead
+  int spix[EPT];                                         // source pixel of element e (a safe pixel when dead)
   int loff[EPT];                                         // LDS byte offset of element e inside a frame buffer (the spare pixel when dead)
+  int roff[RC ? EPT : 1];                                // RC: byte offset inside a raw-operand buffer (own pixels; the spare raw pixel otherwise)
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     const int pi = tp + e * 8;
     const int fr = pi / SW, fxs = pi - fr * SW;
     const int r = row0 - 1 + fr, x = col0 + fxs - (FULLW ? 0 : 1);
     const bool in = pi < NPX && r >= 0 && r < H && x >= 0 && x < W;
-    soff[e] = (mb + (in ? r * W + x : row0 * W + col0)) * C + tcx * 4;
+    spix[e] = mb + (in ? r * W + x : row0 * W + col0);
     loff[e] = (in ? fr * FW + fxs + (FULLW ? 1 : 0) : FR * FW) * PSTR + tcx * 8;
+    if (RC) {
+      const int tx = fxs - (FULLW ? 0 : 1);
+      const bool own = in && fr >= 1 && fr <= TH && tx >= 0 && tx < TW;
+      roff[e] = (own ? (fr - 1) * TW + tx : 16 * WM) * PSTR + tcx * 8;
+    }
   }
   const float* ssrow = a.ss ? a.ss + (long)b * a.ss_stride : a.gamma;      // any valid address when there is no scale / shift
   const int shoff = a.ss ? C : 0;
+  const float sc2 = a.s2.scale;
   auto issue = [&](int c, int vo) {
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) pool[vo + e] = *reinterpret_cast<const f32x4*>(a.s1.p + soff[e] + c * CC);
+    for (int e = 0; e < EPT; ++e)                           // (c is a compile-time constant after unrolling: the chunk lies in ONE source)
+      pool[vo + e] = c * CC < C1 ? *reinterpret_cast<const f32x4*>(a.s1.p + spix[e] * C1 + c * CC + tcx * 4)
+                                 : *reinterpret_cast<const f32x4*>(a.s2.p + spix[e] * (C2 ? C2 : 4) + (c * CC - C1) + tcx * 4);
     const int cg = c * CC + tcx * 4;
     pool[vo + EPT + 0] = *reinterpret_cast<const f32x4*>(a.gamma + cg);
     pool[vo + EPT + 1] = *reinterpret_cast<const f32x4*>(a.beta + cg);
@@ -129,9 +157,9 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
 #pragma unroll
     for (int d = 0; d < RD; ++d)
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap)
+      for (int tap = 0; tap < KR; ++tap)
 #pragma unroll
-        for (int ni = 0; ni < WN; ++ni) pool[(d * 9 + tap) * WN + ni] = wload(d, tap, ni);
+        for (int ni = 0; ni < WN; ++ni) pool[(d * KR + tap) * WN + ni] = tap < 9 ? wload(d, tap, ni) : rcload(d, ni);
   } else {
 #pragma unroll
     for (int j = 0; j < NB; ++j) issue(j, j * (EPT + 4));
@@ -139,7 +167,7 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
 
   // ---- (3) epilogue operands of the finalising waves: fragment f = wave, wave + 8, ... (NFW per wave)
   constexpr int NFW = (F + 7) / 8;
-  float bv[NFW], rv[NFW][4];
+  float bv[NFW], rv[NFW][4], rcb[NFW];
   int orow[NFW];                                         // first output pixel row (global m) of the lane's 4 rows of fragment f
 #pragma unroll
   for (int q = 0; q < NFW; ++q) {
@@ -149,10 +177,11 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
     const int p0 = mi * 16 + (lane >> 4) * 4;
     orow[q] = mb + (row0 + p0 / TW) * W + col0 + (p0 & (TW - 1));
     bv[q] = a.bias[n];
+    rcb[q] = RC ? (a.rc_bias ? a.rc_bias : a.bias)[n] : 0.0f;
     const float* rp = a.resid ? a.resid : a.bias;        // unconditional loads from a selected address (a load under `if` drains the queue at the merge)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float v = rp[a.resid ? (long)(orow[q] + r) * C + n : n];
+      const float v = rp[a.resid ? (long)(orow[q] + r) * COUT + n : n];
       rv[q][r] = a.resid ? v : 0.0f;
     }
   }
@@ -181,8 +210,8 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
 #pragma unroll
     for (int u = 0; u < NSL; ++u) {
       const bool live = lane + u * 64 < SCNT;
-      sm += live ? sl[u][0] : 0.0f;
-      sq += live ? sl[u][1] : 0.0f;
+      sm += live ? sl[u][0] * slsc[u] : 0.0f;
+      sq += live ? sl[u][1] * (slsc[u] * slsc[u]) : 0.0f;
     }
     sm = sf_wave_sum(sm);
     sq = sf_wave_sum(sq);
@@ -213,12 +242,15 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
     for (int j = 0; j < 4; ++j) {
       float aj = pool[vo + EPT][j] * rstd;
       SF_USE_FROM_HERE(aj);
+      const float srcs = c * CC < C1 ? 1.0f : sc2;             // the affine applies to the SCALED source value: fold the scale into the slope
       float scj = a.ss ? pool[vo + EPT + 2][j] + 1.0f : 1.0f, shj = a.ss ? pool[vo + EPT + 3][j] : 0.0f;
       SF_USE_FROM_HERE(scj);
       SF_USE_FROM_HERE(shj);
       float bj = (pool[vo + EPT + 1][j] - aj * mean) * scj + shj;
       SF_USE_FROM_HERE(bj);
       aj = aj * scj;
+      SF_USE_FROM_HERE(aj);
+      aj = aj * srcs;
       SF_USE_FROM_HERE(aj);
       A[j] = aj;
       Bv[j] = bj;
@@ -238,6 +270,12 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
       bf16x4 o;
       o[0] = (sf_opnd)y[0]; o[1] = (sf_opnd)y[1]; o[2] = (sf_opnd)y[2]; o[3] = (sf_opnd)y[3];
       *reinterpret_cast<bf16x4*>(buf + loff[e]) = o;
+      if (RC) {                                            // the res_conv's A operand: the raw (scaled) value of the tile's own pixels
+        const f32x4 rw = pool[vo + e] * (c * CC < C1 ? 1.0f : sc2);
+        bf16x4 q;
+        q[0] = (sf_opnd)rw[0]; q[1] = (sf_opnd)rw[1]; q[2] = (sf_opnd)rw[2]; q[3] = (sf_opnd)rw[3];
+        *reinterpret_cast<bf16x4*>(lds + Gm::RAW_OFF + (c & 1) * Gm::RAWB + roff[e]) = q;
+      }
     }
   };
   f32x4 acc[WM][WN];
@@ -245,6 +283,11 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
   for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
     for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc2[RC ? WM : 1][RC ? WN : 1];                   // RC: the res_conv's accumulators
+#pragma unroll
+  for (int mi = 0; mi < (RC ? WM : 1); ++mi)
+#pragma unroll
+    for (int ni = 0; ni < (RC ? WN : 1); ++ni) acc2[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 accl[POOL ? WM : 1];                              // POOL: context-logit fragment of every m-fragment (column 0 = the logit)
 #pragma unroll
   for (int mi = 0; mi < (POOL ? WM : 1); ++mi) accl[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -272,16 +315,30 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
         for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
           for (int ni = 0; ni < WN; ++ni)
-            acc[mi][ni] = sf_mfma16(fa[mi], __builtin_bit_cast(bf16x8, pool[(d * 9 + tap) * WN + ni]), acc[mi][ni]);
+            acc[mi][ni] = sf_mfma16(fa[mi], __builtin_bit_cast(bf16x8, pool[(d * KR + tap) * WN + ni]), acc[mi][ni]);
         if (c + RD < NCH) {                               // (compile-time after unrolling) refill the slot with chunk c + RD
 #pragma unroll
-          for (int ni = 0; ni < WN; ++ni) pool[(d * 9 + tap) * WN + ni] = wload(c + RD, tap, ni);
+          for (int ni = 0; ni < WN; ++ni) pool[(d * KR + tap) * WN + ni] = wload(c + RD, tap, ni);
         }
         if (POOL) {                                       // one more MFMA per m-fragment: B = w_eff of the k-step in column 0, zero elsewhere
           bf16x8 wl = *reinterpret_cast<const bf16x8*>(weffL + (tap * (C / 32) + 4 * c) * 64);
           if (!col0l) wl = sf_zero8();
 #pragma unroll
           for (int mi = 0; mi < WM; ++mi) accl[mi] = sf_mfma16(fa[mi], wl, accl[mi]);
+        }
+      }
+      if (RC) {                                            // k-step 10 of this wave: raw operand, sub-chunk `wave`, the res_conv's weights
+        const char* rb = lds + Gm::RAW_OFF + (c & 1) * Gm::RAWB + wave * 64 + (lane >> 4) * 16;
+        bf16x8 fr_[WM];
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) fr_[mi] = *reinterpret_cast<const bf16x8*>(rb + (mi * 16 + (lane & 15)) * PSTR);
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < WN; ++ni) acc2[mi][ni] = sf_mfma16(fr_[mi], __builtin_bit_cast(bf16x8, pool[(d * KR + 9) * WN + ni]), acc2[mi][ni]);
+        if (c + RD < NCH) {
+#pragma unroll
+          for (int ni = 0; ni < WN; ++ni) pool[(d * KR + 9) * WN + ni] = rcload(c + RD, ni);
         }
       }
       sf_sync();
@@ -314,6 +371,14 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[((wave * FT + F + mi) * 4 + r) * 64 + lane] = accl[mi][r];
     }
+    if (RC) {
+#pragma unroll
+      for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[((wave * FT + F + mi * WN + ni) * 4 + r) * 64 + lane] = acc2[mi][ni][r];
+    }
   }
   sf_sync();
 #pragma unroll
@@ -331,7 +396,14 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
 #pragma unroll
         for (int w = 0; w < NWM; ++w) sacc += red[idx + w * FT * 256];
         const float y = sacc + bv[q] + rv[q][r];
-        a.out[(long)(orow[q] + r) * C + n] = y;
+        a.out[(long)(orow[q] + r) * COUT + n] = y;
+        if (RC) {                                          // res_conv output of this fragment: plain rows [M][COUT]
+          const int idx2 = ((F + f) * 4 + r) * 64 + lane;
+          float s2 = 0.0f;
+#pragma unroll
+          for (int w = 0; w < NWM; ++w) s2 += red[idx2 + w * FT * 256];
+          a.rc_out[(long)(orow[q] + r) * COUT + n] = s2 + rcb[q];
+        }
         y4[r] = y;
         sm += y;
         sqv = fmaf(y, y, sqv);
@@ -341,7 +413,7 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
         sm = sf_wave_sum(sm);
         sqv = sf_wave_sum(sqv);
         if (lane == 0) {
-          float* slo = a.slots_out + ((long)mfrag * (C / 16) + nf) * 2;
+          float* slo = a.slots_out + ((long)mfrag * (COUT / 16) + nf) * 2;
           slo[0] = sm;
           slo[1] = sqv;
         }
@@ -370,9 +442,9 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
         }
         es += sf_shfl_xor(es, 16); es += sf_shfl_xor(es, 32);
         pv += sf_shfl_xor(pv, 16); pv += sf_shfl_xor(pv, 32);
-        if (lane < 16) a.pool_part[(long)mfrag * C + n] = pv;
+        if (lane < 16) a.pool_part[(long)mfrag * COUT + n] = pv;
         if (lane == 0 && nf == 0) {
-          float* ms = a.pool_part + (long)(a.M >> 4) * C + (long)mfrag * 2;
+          float* ms = a.pool_part + (long)(a.M >> 4) * COUT + (long)mfrag * 2;
           ms[0] = mx;
           ms[1] = es;
         }
@@ -382,7 +454,17 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
 }
 
 template <int HL, int C, int TWL, int WM, int WN, bool POOL>
+using Conv3sGeom1 = Conv3sGeom<HL, C, 0, C, TWL, WM, WN, POOL, false>;
+
+template <int HL, int C, int TWL, int WM, int WN, bool POOL>
 SF_KERNEL(512) void k_conv3s(FConvArgs a) {
   sf_touch_kernarg<(int)sizeof(FConvArgs)>();
-  conv3s_body<HL, C, TWL, WM, WN, POOL>(a, (int)blockIdx.x);
+  conv3s_body<HL, C, 0, C, TWL, WM, WN, POOL, false>(a, (int)blockIdx.x);
+}
+
+// conv1 of a ResnetBlock whose input is the concat of two sources, with the block's res_conv in the same workgroups
+template <int HL, int C1, int C2, int COUT, int TWL, int WM, int WN>
+SF_KERNEL(512) void k_conv3s_rc(FConvArgs a) {
+  sf_touch_kernarg<(int)sizeof(FConvArgs)>();
+  conv3s_body<HL, C1, C2, COUT, TWL, WM, WN, false, true>(a, (int)blockIdx.x);
 }

@@ -275,13 +275,15 @@ static inline int conv4_cs4(const sf_op& op, const FConvArgs& a, int WM, int WN)
 
 // k_conv3s (fused_conv3s.h, r06): the recurring single-source slot-GroupNorm 3x3 convs on a kernel with compile-time geometry.
 // (HL = log2 of the map side, C = Cout, TWL = log2 of the tile width, WM, WN): the first block = the B = 1 plan's layers as full-width
-// strips and as 2-D tiles, the second = the 64-pixel tiles of B >= 2.
+// strips and as 2-D tiles, the second = the 64-pixel tiles of B >= 2 at 32x32, the third = the 32-pixel tiles of B >= 2 at 16x16 (8 x 4 pixels) and 8x8 (4 rows).
 #define SF_CONV3S_VARIANTS(X) \
   X(5, 256, 5, 2, 2) X(5, 256, 3, 2, 2) \
   X(4, 256, 4, 1, 1) X(4, 256, 2, 1, 1) \
   X(4, 512, 4, 1, 2) X(4, 512, 2, 1, 2) \
   X(3, 512, 3, 1, 1) X(3, 1024, 3, 1, 1) \
-  X(5, 256, 5, 4, 2) X(5, 256, 3, 4, 2)
+  X(5, 256, 5, 4, 2) X(5, 256, 3, 4, 2) \
+  X(4, 256, 2, 2, 1) X(4, 256, 2, 2, 2) X(4, 512, 2, 2, 2) \
+  X(3, 512, 3, 2, 1) X(3, 1024, 3, 2, 1) X(3, 1024, 3, 2, 2)
 
 // Does k_conv3s take this (pipelined, op flag 32) conv?  Returns the tile width's log2, or -1 = the general kernel.  Op field i[19]: bit 1 = keep
 // the general kernel (planner attribute Unet.conv3s = False), bits 2.. = tile width in pixels (0 = full-width strips of TR rows).
@@ -291,6 +293,35 @@ static inline int conv3s_twl(const sf_op& op, const FConvArgs& a, int WM, int WN
   if (a.Cout != a.C || a.ldc != a.Cout || a.co_off || a.accum || a.out_gelu || a.logit_part || a.dbg || !a.bias || !a.out) return -1;
   if (((uintptr_t)a.gamma | (uintptr_t)a.beta | (uintptr_t)a.ss | (uintptr_t)a.s1.p) & 15 || (a.ss && a.ss_stride % 4)) return -1;
   const int tw = (op.i[19] >> 2) ? (op.i[19] >> 2) : a.W;
+  if (tw < 4 || tw > a.W || (tw & (tw - 1)) || (16 * WM) % tw || (16 * WM) / tw > a.H || a.H % ((16 * WM) / tw)) return -1;
+  int twl = 0;
+  while ((1 << twl) < tw) ++twl;
+  return twl;
+}
+
+// k_conv3s_rc: conv1 of a ResnetBlock on the concat of two sources with the block's res_conv in the same workgroups (the pipelined pairs of the
+// B = 1 plan).  (HL, C1, C2, COUT, TWL, WM, WN): the 2-D tiles at 32x32 / 16x16 (their full-width strips need more registers than a wave has: 35 / 4
+// spilled VGPRs, not instantiated), the 2-row strip at 8x8.
+#define SF_CONV3S_RC_VARIANTS(X) \
+  X(5, 256, 256, 256, 3, 2, 2) \
+  X(4, 512, 256, 512, 2, 1, 2) \
+  X(3, 1024, 512, 1024, 3, 1, 1) \
+  X(5, 256, 256, 256, 3, 4, 2) X(4, 512, 256, 512, 2, 2, 2) X(3, 1024, 512, 1024, 3, 2, 2)
+
+// The res_conv `b` can ride in conv1 `a`'s workgroups: a 1x1 un-normalised conv of the same raw sources onto plain rows of the same width
+static inline bool fconv_rc_compatible(const FConvArgs& a, const FConvArgs& b) {
+  return !(a.weff || a.logit_part || b.k != 1 || b.norm != FNORM_NONE || b.S != 1 || b.Cout != a.Cout || b.ldc != b.Cout || b.co_off ||
+           b.resid || b.accum || b.slots_out || b.out_gelu || b.silu || b.logit_part || !b.out || b.s1.mode || a.s1.mode ||
+           b.s1.p != a.s1.p || b.s2.p != a.s2.p || b.s1.C != a.s1.C || b.s2.C != a.s2.C || b.s1.scale != a.s1.scale || b.s2.scale != a.s2.scale);
+}
+
+// Does k_conv3s_rc take this pipelined pair (op1 = conv1 with flag 16, b = its res_conv as set up by fconv_setup)?  Tile width's log2 or -1.
+static inline int conv3s_rc_twl(const sf_op& op1, const FConvArgs& a, const FConvArgs& b, int WM, int WN) {
+  if (!(op1.flags & 32) || !(op1.flags & 16) || (op1.flags & (2 | 4 | 8 | 64)) || (op1.i[19] & 2)) return -1;
+  if (a.norm != FNORM_GN_SLOTS || a.k != 3 || a.S != 1 || !a.s2.C || !a.s2.p || !a.s2.slots || a.s1.mode || a.s1.scale != 1.0f || a.H != a.W || a.G != 8 || !a.silu) return -1;
+  if (a.ldc != a.Cout || a.co_off || a.accum || a.out_gelu || a.logit_part || a.weff || a.dbg || !a.bias || !a.out || !fconv_rc_compatible(a, b)) return -1;
+  if (((uintptr_t)a.gamma | (uintptr_t)a.beta | (uintptr_t)a.ss | (uintptr_t)a.s1.p | (uintptr_t)a.s2.p) & 15 || (a.ss && a.ss_stride % 4)) return -1;
+  const int tw = (op1.i[19] >> 2) ? (op1.i[19] >> 2) : a.W;
   if (tw < 4 || tw > a.W || (tw & (tw - 1)) || (16 * WM) % tw || (16 * WM) / tw > a.H || a.H % ((16 * WM) / tw)) return -1;
   int twl = 0;
   while ((1 << twl) < tw) ++twl;
@@ -342,10 +373,7 @@ static inline int conv4_mb_setup(const sf_op& op, FConvArgs& a, int cs4, uint32_
 // Measured (profiles/r04_pipe_rc_merge_ab.log): B = 1 eval 1.233 -> 1.190 ms, B = 2 1.417 -> 1.401, B = 4 1.908 -> 1.876 (its 32x32 pairs
 // run the WM = 4 tile, which keeps the two-kernel launch); a pair launch 22-23 -> 17-18 us.
 static inline bool fconv_pipe_rc_merge(FConvArgs& a, const FConvArgs& b, int WM, int WN, uint32_t& lds_bytes) {
-  if (WM > 2 || a.weff || a.logit_part || b.k != 1 || b.norm != FNORM_NONE || b.S != 1 || b.Cout != a.Cout || b.ldc != b.Cout || b.co_off ||
-      b.resid || b.accum || b.slots_out || b.out_gelu || b.silu || b.logit_part || !b.out || b.s1.mode || a.s1.mode ||
-      b.s1.p != a.s1.p || b.s2.p != a.s2.p || b.s1.C != a.s1.C || b.s2.C != a.s2.C || b.s1.scale != a.s1.scale || b.s2.scale != a.s2.scale)
-    return false;
+  if (WM > 2 || !fconv_rc_compatible(a, b)) return false;
   const uint32_t raw = (((uint32_t)(16 * WM + 1) * a.pix_stride) + 15) & ~15u;
   // LDS: [frames][red: + WM * WN fragments per matrix wave][table][misc][raw operand x 2]
   const int red_old = 1024 * (SF_FCONV_WAVES / 2) * (WM * WN), red_new = 1024 * (SF_FCONV_WAVES / 2) * (2 * WM * WN);

@@ -64,10 +64,20 @@ static int launch_fconv_pipe(const FConvArgs& a, uint32_t grid, uint32_t lds, hi
 template <int HL, int C, int TWL, int WM, int WN, bool POOL>
 static int launch_conv3s(const FConvArgs& a, uint32_t grid, hipStream_t st) {
   static unsigned mask = 0;
-  constexpr uint32_t lds = Conv3sGeom<HL, C, TWL, WM, WN, POOL>::LDS_BYTES;
+  constexpr uint32_t lds = Conv3sGeom1<HL, C, TWL, WM, WN, POOL>::LDS_BYTES;
   if (int rc = allow_big_lds(k_conv3s<HL, C, TWL, WM, WN, POOL>, lds, mask)) return rc;
   k_conv3s<HL, C, TWL, WM, WN, POOL><<<grid, 512, lds, st>>>(a);
   SF_CHECK_LAUNCH("conv3s");
+  return SF_OK;
+}
+
+template <int HL, int C1, int C2, int COUT, int TWL, int WM, int WN>
+static int launch_conv3s_rc(const FConvArgs& a, uint32_t grid, hipStream_t st) {
+  static unsigned mask = 0;
+  constexpr uint32_t lds = Conv3sGeom<HL, C1, C2, COUT, TWL, WM, WN, false, true>::LDS_BYTES;
+  if (int rc = allow_big_lds(k_conv3s_rc<HL, C1, C2, COUT, TWL, WM, WN>, lds, mask)) return rc;
+  k_conv3s_rc<HL, C1, C2, COUT, TWL, WM, WN><<<grid, 512, lds, st>>>(a);
+  SF_CHECK_LAUNCH("conv3s_rc");
   return SF_OK;
 }
 
@@ -175,6 +185,19 @@ int sf_plan_fused_pair(const sf_op* op1, const sf_op* op2, void* stream) {
       FConvArgs a1;
       int wm1, wn1;
       uint32_t g1, l1;
+      if (!fconv_setup(*op1, a1, wm1, wn1, g1, l1, sf_err_buf, sizeof(sf_err_buf))) {       // r06: the B = 1 plan's pairs on k_conv3s_rc (fused_conv3s.h)
+        const int twl = conv3s_rc_twl(*op1, a1, p.b, WM, WN);
+        if (twl >= 0) {
+          a1.rc_w = p.b.w; a1.rc_bias = p.b.bias; a1.rc_out = p.b.out;
+#define SF_TRY3R(hl_, c1_, c2_, co_, twl_, wm_, wn_) \
+          if (a1.H == (1 << hl_) && a1.s1.C == c1_ && a1.s2.C == c2_ && a1.Cout == co_ && twl == twl_ && WM == wm_ && WN == wn_) \
+            return launch_conv3s_rc<hl_, c1_, c2_, co_, twl_, wm_, wn_>(a1, g1, (hipStream_t)stream);
+          SF_CONV3S_RC_VARIANTS(SF_TRY3R)
+#undef SF_TRY3R
+          a1.rc_w = nullptr; a1.rc_bias = nullptr; a1.rc_out = nullptr;
+        }
+        if (op1->i[19] >> 2) SF_FAIL(SF_ERR_INVALID, "fconv pipe pair: no k_conv3s_rc variant for the %d-wide tile %dx%d of a %d + %d -> %d channel %dx%d map", op1->i[19] >> 2, WM, WN, a1.s1.C, a1.s2.C, a1.Cout, a1.H, a1.W);
+      }
       if (!fconv_setup(*op1, a1, wm1, wn1, g1, l1, sf_err_buf, sizeof(sf_err_buf)) && fconv_pipe_rc_merge(a1, p.b, WM, WN, l1)) {
 #define SF_TRYR(wm, wn, ept) if (WM == wm && WN == wn && EPT == ept) return launch_fconv_pipe_rc<wm, wn, ept>(a1, g1, l1, (hipStream_t)stream);
         SF_FCONV_PIPE_RC_VARIANTS(SF_TRYR)

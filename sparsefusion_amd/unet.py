@@ -26,7 +26,11 @@ PAIR_TILES = {(1, 1, 1), (1, 1, 2), (1, 2, 2), (2, 2, 2), (4, 2, 2)}
 # (WM, WN, (TR + 2) * W / 8) for which k_conv_fused_pipe is instantiated (SF_FCONV_PIPE_VARIANTS)
 # (log2 H, C = Cout, log2 tile width, WM, WN) of k_conv3s (csrc/fused_host.h SF_CONV3S_VARIANTS; tests/test_plans_cpu.py compares the two tables)
 CONV3S_VARIANTS = {(5, 256, 5, 2, 2), (5, 256, 3, 2, 2), (4, 256, 4, 1, 1), (4, 256, 2, 1, 1), (4, 512, 4, 1, 2), (4, 512, 2, 1, 2),
-                   (3, 512, 3, 1, 1), (3, 1024, 3, 1, 1), (5, 256, 5, 4, 2), (5, 256, 3, 4, 2)}
+                   (3, 512, 3, 1, 1), (3, 1024, 3, 1, 1), (5, 256, 5, 4, 2), (5, 256, 3, 4, 2),
+                   (4, 256, 2, 2, 1), (4, 256, 2, 2, 2), (4, 512, 2, 2, 2), (3, 512, 3, 2, 1), (3, 1024, 3, 2, 1), (3, 1024, 3, 2, 2)}
+# (log2 H, C1, C2, Cout, log2 tile width, WM, WN) of k_conv3s_rc (SF_CONV3S_RC_VARIANTS): conv1 on a concat + the block's res_conv in one set of workgroups
+CONV3S_RC_VARIANTS = {(5, 256, 256, 256, 3, 2, 2), (4, 512, 256, 512, 2, 1, 2), (3, 1024, 512, 1024, 3, 1, 1),
+                      (5, 256, 256, 256, 3, 4, 2), (4, 512, 256, 512, 2, 2, 2), (3, 1024, 512, 1024, 3, 2, 2)}
 PIPE_TILES = {(1, 1, 4), (1, 2, 4), (1, 1, 6), (1, 2, 6), (2, 1, 6), (2, 2, 6), (2, 1, 8), (2, 2, 8), (2, 1, 12), (2, 2, 12), (4, 1, 16), (4, 2, 16)}
 FNORM_NONE, FNORM_GN_SELF, FNORM_GN_SLOTS, FNORM_LN, FNORM_ATTN = range(5)      # csrc/fused_kernels.h
 ATTN_LDS_BYTES = 8 * 16 * 36 * 4 + 2 * 8 * 4 * 68 * 4      # SF_ATTN_LDS_BYTES: scratch of the attention prologue (FNORM_ATTN)
@@ -586,6 +590,9 @@ class _Plan:
                     and not pair_first and pair_lazy is None and (logit is None or pool is not None) and bname
                     and (H.bit_length() - 1, C1, tw.bit_length() - 1, WM, WN) in CONV3S_VARIANTS):
                 code |= tw << 2
+            elif (code == 0 and pair_first and C2 and ldc == Cout and co_off == 0 and not accum and not out_gelu and not pre_gelu and logit is None and bname
+                    and (H.bit_length() - 1, C1, C2, Cout, (tw or H).bit_length() - 1, WM, WN) in CONV3S_RC_VARIANTS):
+                code |= (tw if tw != H else 0) << 2                # the pair runs on k_conv3s_rc (the host checks that the res_conv fits)
             ai = (code,)
         self.op(OP_FCONV, (1 if silu else 0) | (2 if pre_gelu else 0) | (4 if accum else 0) | (8 if out_gelu else 0) | (16 if pair_first else 0)
                 | (32 if pipe else 0) | (64 if pool is not None else 0) | (0 if getattr(self.u, "conv4", True) else 128),

@@ -508,5 +508,25 @@ CONV_CASES_FULL = {
     "conv3s_b2_32x32_256_strip2_wn2": dict(B=2, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=4, WN=2, seed=109, pipe=True, tw=32, resid=True),
     "conv3s_b2_32x32_256_strip2_wn2_pool": dict(B=2, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=4, WN=2, seed=110, pipe=True, tw=32, pool=True),
     "conv3s_b3_32x32_256_tile8x8_wn2": dict(B=3, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=4, WN=2, seed=111, pipe=True, tw=8),
+    # B >= 2 tiles at 16x16 (8 rows x 4 columns) and 8x8 (4 rows)
+    "conv3s_b2_16x16_256_tile8x4": dict(B=2, H=16, W=16, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=1, seed=130, pipe=True, tw=4, resid=True),
+    "conv3s_b2_16x16_256_tile8x4_pool": dict(B=2, H=16, W=16, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=1, seed=131, pipe=True, tw=4, pool=True),
+    "conv3s_b4_16x16_256_tile8x4_wn2": dict(B=4, H=16, W=16, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=132, pipe=True, tw=4),
+    "conv3s_b4_16x16_256_tile8x4_wn2_pool": dict(B=4, H=16, W=16, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=133, pipe=True, tw=4, pool=True, ss=False),
+    "conv3s_b2_16x16_512_tile8x4": dict(B=2, H=16, W=16, C1=512, C2=0, Cout=512, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=134, pipe=True, tw=4, resid=True),
+    "conv3s_b2_16x16_512_tile8x4_pool": dict(B=2, H=16, W=16, C1=512, C2=0, Cout=512, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=135, pipe=True, tw=4, pool=True),
+    "conv3s_b2_8x8_512_rows4": dict(B=2, H=8, W=8, C1=512, C2=0, Cout=512, k=3, norm=GN_SLOTS, WM=2, WN=1, seed=136, pipe=True, tw=8),
+    "conv3s_b2_8x8_512_rows4_pool": dict(B=2, H=8, W=8, C1=512, C2=0, Cout=512, k=3, norm=GN_SLOTS, WM=2, WN=1, seed=137, pipe=True, tw=8, pool=True),
+    "conv3s_b2_8x8_1024_rows4": dict(B=2, H=8, W=8, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SLOTS, WM=2, WN=1, seed=138, pipe=True, tw=8, resid=True),
+    "conv3s_b2_8x8_1024_rows4_pool": dict(B=2, H=8, W=8, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SLOTS, WM=2, WN=1, seed=139, pipe=True, tw=8, pool=True),
+    "conv3s_b4_8x8_1024_rows4_wn2": dict(B=4, H=8, W=8, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=140, pipe=True, tw=8),
+    "conv3s_b4_8x8_1024_rows4_wn2_pool": dict(B=4, H=8, W=8, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=141, pipe=True, tw=8, pool=True),
+    "conv3s_rc_b2_32x32_512_tile8x8": dict(B=2, H=32, W=32, C1=256, C2=256, Cout=256, k=3, norm=GN_SLOTS, WM=4, WN=2, seed=142, pipe=True, pair=True, tw=8, ss=False),
+    "conv3s_rc_b2_16x16_768_tile8x4": dict(B=2, H=16, W=16, C1=512, C2=256, Cout=512, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=143, pipe=True, pair=True, tw=4, ss=False),
+    "conv3s_rc_b4_8x8_1536_rows4": dict(B=4, H=8, W=8, C1=1024, C2=512, Cout=1024, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=144, pipe=True, pair=True, tw=8, ss=False),
+    # r06: k_conv3s_rc -- conv1 on the concat of two sources + the block's res_conv in the same workgroups (the pipelined pairs of the B = 1 plan)
+    "conv3s_rc_32x32_512_tile4x8": dict(B=2, H=32, W=32, C1=256, C2=256, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=121, pipe=True, pair=True, tw=8, ss=False),
+    "conv3s_rc_16x16_768_tile4x4": dict(B=1, H=16, W=16, C1=512, C2=256, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=2, seed=123, pipe=True, pair=True, tw=4),
+    "conv3s_rc_8x8_1536": dict(B=1, H=8, W=8, C1=1024, C2=512, Cout=1024, k=3, norm=GN_SLOTS, WM=1, WN=1, seed=124, pipe=True, pair=True, tw=8, ss=False),
     "conv3s_geometry_on_the_general_kernel": dict(B=1, H=32, W=32, C1=256, C2=0, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=90, pipe=True, tw=32, keep_pipe=True),
 }

@@ -50,6 +50,22 @@ static int emu_run_pair(const sf_op* op1, const sf_op* op2, char* err, int errn)
       FConvArgs a1;
       int wm1, wn1;
       uint32_t g1, l1;
+      if (!fconv_setup(*op1, a1, wm1, wn1, g1, l1, err, (size_t)errn)) {       // the same dispatch as unet_fused.hip (r06: k_conv3s_rc)
+        const int twl = conv3s_rc_twl(*op1, a1, p.b, WM, WN);
+        if (twl >= 0) {
+          a1.rc_w = p.b.w; a1.rc_bias = p.b.bias; a1.rc_out = p.b.out;
+#define SF_TRY3R(hl_, c1_, c2_, co_, twl_, wm_, wn_) \
+          if (a1.H == (1 << hl_) && a1.s1.C == c1_ && a1.s2.C == c2_ && a1.Cout == co_ && twl == twl_ && WM == wm_ && WN == wn_) { \
+            hipemu::launch(g1, 512, Conv3sGeom<hl_, c1_, c2_, co_, twl_, wm_, wn_, false, true>::LDS_BYTES, [&] { k_conv3s_rc<hl_, c1_, c2_, co_, twl_, wm_, wn_>(a1); }); \
+            ++g_conv3s_launches; \
+            return 0; \
+          }
+          SF_CONV3S_RC_VARIANTS(SF_TRY3R)
+#undef SF_TRY3R
+          a1.rc_w = nullptr; a1.rc_bias = nullptr; a1.rc_out = nullptr;
+        }
+        if (op1->i[19] >> 2) { snprintf(err, errn, "fconv pipe pair: no k_conv3s_rc variant"); return 1; }
+      }
       if (!fconv_setup(*op1, a1, wm1, wn1, g1, l1, err, (size_t)errn) && fconv_pipe_rc_merge(a1, p.b, WM, WN, l1)) {
 #define SF_TRYR(wm, wn, ept) \
         if (WM == wm && WN == wn && EPT == ept) { \
@@ -91,8 +107,8 @@ extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
       if (twl >= 0) {
 #define SF_TRY3(hl_, c_, twl_, wm_, wn_) \
         if (a.H == (1 << hl_) && a.C == c_ && twl == twl_ && WM == wm_ && WN == wn_) { \
-          if (a.weff) hipemu::launch(grid, 512, Conv3sGeom<hl_, c_, twl_, wm_, wn_, true>::LDS_BYTES, [&] { k_conv3s<hl_, c_, twl_, wm_, wn_, true>(a); }); \
-          else hipemu::launch(grid, 512, Conv3sGeom<hl_, c_, twl_, wm_, wn_, false>::LDS_BYTES, [&] { k_conv3s<hl_, c_, twl_, wm_, wn_, false>(a); }); \
+          if (a.weff) hipemu::launch(grid, 512, Conv3sGeom1<hl_, c_, twl_, wm_, wn_, true>::LDS_BYTES, [&] { k_conv3s<hl_, c_, twl_, wm_, wn_, true>(a); }); \
+          else hipemu::launch(grid, 512, Conv3sGeom1<hl_, c_, twl_, wm_, wn_, false>::LDS_BYTES, [&] { k_conv3s<hl_, c_, twl_, wm_, wn_, false>(a); }); \
           ++g_conv3s_launches; \
           return 0; \
         }

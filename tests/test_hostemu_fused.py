@@ -106,7 +106,8 @@ CONV3S_ON_CPU = sorted(n for n in fc.CONV_CASES_FULL if n.startswith("conv3s_"))
 def test_conv3s_on_cpu_threads(name):
     """r06: k_conv3s (csrc/fused_conv3s.h) exists for the UNet's own layer shapes only, so its emulation cases are full-size (1-3 s each on
     the fiber scheduler): every instantiated tile family -- strips and 2-D tiles, WN = 1 / 2 / 4, with residual, scale-shift, epilogue pooling
-    -- against the torch reference; the op must have taken that kernel (and the general one under op field i[19] bit 1)."""
+    -- and the conv1 + res_conv pairs on two sources (k_conv3s_rc) against the torch reference; the op must have taken that kernel (and the
+    general one under op field i[19] bit 1)."""
     n0 = fused.lib().emu_conv3s_launches()
     fc.run_conv_case("emu", **fc.CONV_CASES_FULL[name])
     took = fused.lib().emu_conv3s_launches() - n0

@@ -303,9 +303,15 @@ def test_conv3s_tables_agree_and_the_b1_plan_uses_them():
     body = re.search(r"#define SF_CONV3S_VARIANTS\(X\)((?:\s*\\\n(?:\s*X\([^)]*\))+)+)", txt).group(1)
     host = {tuple(int(v) for v in m.split(",")) for m in re.findall(r"X\(([^)]*)\)", body)}
     assert host == U.CONV3S_VARIANTS
+    body = re.search(r"#define SF_CONV3S_RC_VARIANTS\(X\)((?:\s*\\\n(?:\s*X\([^)]*\))+)+)", txt).group(1)
+    host_rc = {tuple(int(v) for v in m.split(",")) for m in re.findall(r"X\(([^)]*)\)", body)}
+    assert host_rc == U.CONV3S_RC_VARIANTS
+    covered_rc = {(kw["H"].bit_length() - 1, kw["C1"], kw["C2"], kw["Cout"], kw["tw"].bit_length() - 1, kw["WM"], kw["WN"])
+                  for name, kw in fc.CONV_CASES_FULL.items() if name.startswith("conv3s_rc_")}
+    assert host_rc <= covered_rc, host_rc - covered_rc
     covered = set()
     for name, kw in fc.CONV_CASES_FULL.items():
-        if name.startswith("conv3s_") and not kw.get("keep_pipe"):
+        if name.startswith("conv3s_") and not name.startswith("conv3s_rc_") and not kw.get("keep_pipe"):
             covered.add(((kw["H"].bit_length() - 1, kw["C1"], kw["tw"].bit_length() - 1, kw["WM"], kw["WN"]), bool(kw.get("pool"))))
     for v in host:
         assert (v, False) in covered, f"k_conv3s variant {v} has no GPU op case"
@@ -324,6 +330,11 @@ def test_conv3s_tables_agree_and_the_b1_plan_uses_them():
         assert tw == {32: net.conv3s_tw32, 16: net.conv3s_tw16, 8: net.conv3s_tw8}[H] or tw == H
         taken += 1
     assert taken == 29
+    pairs = [o for o in ops if o.type == U.OP_FCONV and (o.flags & 32) and (o.flags & 16)]
+    assert len(pairs) == 9                                         # conv1 + res_conv of the blocks that change width: all on k_conv3s_rc
+    for o in pairs:
+        H, tw = o.i[1], (o.i[19] >> 2) or o.i[1]
+        assert (H.bit_length() - 1, o.i[3], o.i[4], o.i[5], tw.bit_length() - 1, o.i[15], o.i[16]) in host_rc, (H, o.i[3], o.i[4], o.i[5], tw)
     net.conv3s = False
     assert all(o.i[19] & 2 for o in U._Plan(net, 1, CPU).build().ops if o.type == U.OP_FCONV and (o.flags & 32) and not (o.flags & 16))
 
