@@ -37,7 +37,8 @@
 // output tensor or -1.  Host-checked: Cout, ldc, co_off are multiples of 4.
 template <int BNF, int LDS_BYTES, bool GN, class Pix>
 SF_DEV void conv_tile_epilogue(const ConvArgs& a, char* lds, const f32x4 (&acc)[4][BNF / 2], const bool loader, const int wm, const int wn,
-                               const int lane, const int nt, const int mt, double* __restrict__ gn_part, const int gn_cg, Pix pix) {
+                               const int lane, const int nt, const int mt, double* __restrict__ gn_part, const int gn_cg, Pix pix,
+                               const int grp = 0) {
   constexpr int WNF = BNF / 2;
   constexpr int COLS = 16 * BNF, F4 = COLS / 4, RPP = 512 / F4, PITCH = COLS + 4;      // pitch = 4 mod 8 floats: the four row groups of a
   static_assert(128 * PITCH * 4 <= LDS_BYTES, "the output tile fits the staging buffers");   // fragment store land on disjoint banks
@@ -57,8 +58,38 @@ SF_DEV void conv_tile_epilogue(const ConvArgs& a, char* lds, const f32x4 (&acc)[
   const int c4 = tid % F4, r0 = tid / F4;
   const int col = nt * COLS + c4 * 4;
   const bool cok = col < a.Cout;
+  if (a.groups > 1) {                              // split-K (r06, k_conv_glds only): the partial tile -> workspace [grp][m][npad], as k_conv_igemm
+    const long Mrows = (long)a.B * a.Ho * a.Wo;    // leaves it (no bias: the reduction adds it); pix(row) is the row index m here
+    if (col < a.npad) {
+#pragma unroll 4
+      for (int row = r0; row < 128; row += RPP) {
+        const long m = pix(row);
+        if (m >= 0) *reinterpret_cast<f32x4*>(a.ws + (grp * Mrows + m) * a.npad + col) = *reinterpret_cast<const f32x4*>(ot + row * PITCH + c4 * 4);
+      }
+    }
+    return;
+  }
   f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
   if (cok && a.bias) bv = *reinterpret_cast<const f32x4*>(a.bias + col);
+  if (a.pixshuf) {                                 // SiLU + PixelShuffle(2) of an Upsample (conv_igemm.h's epilogue): the float4 = the 2 x 2 output
+    if (cok) {                                     // pixels of channel col / 4; adjacent threads write adjacent channels
+      const int hw = a.Ho * a.Wo;
+#pragma unroll 4
+      for (int row = r0; row < 128; row += RPP) {
+        const long m = pix(row);
+        if (m < 0) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ot + row * PITCH + c4 * 4) + bv;
+        const int b = (int)(m / hw), rr = (int)(m - (long)b * hw);
+        const int oy = rr / a.Wo, ox = rr - oy * a.Wo;
+        float* o = a.out + (((long)b * (2 * a.Ho) + 2 * oy) * (2 * a.Wo) + 2 * ox) * a.ldc + a.co_off + (col >> 2);
+        o[0] = sf_silu(v[0]);
+        o[a.ldc] = sf_silu(v[1]);
+        o[(long)2 * a.Wo * a.ldc] = sf_silu(v[2]);
+        o[(long)(2 * a.Wo + 1) * a.ldc] = sf_silu(v[3]);
+      }
+    }
+    return;
+  }
   float gs = 0.0f, gq = 0.0f;                      // (GN) sums of this thread's four columns over its rows
 #pragma unroll 4
   for (int row = r0; row < 128; row += RPP) {
@@ -121,11 +152,15 @@ SF_DEV void conv_glds_body(const ConvArgs& a, double* __restrict__ gn_part, cons
   const int wm = (wave >> 1) & 1, wn = wave & 1;
   // XCD-aware tile order (8 XCDs, workgroups are dealt round-robin)
   const int tiles = a.m_tiles * a.n_tiles;
-  int t = blockIdx.x;
-  if (tiles % 8 == 0) t = (blockIdx.x & 7) * (tiles >> 3) + (blockIdx.x >> 3);
+  const int grp = a.groups > 1 ? sf_uniform((int)blockIdx.x / tiles) : 0;      // split-K (r06): group g takes stages [g S / groups, (g + 1) S / groups)
+  const int bid = (int)blockIdx.x - grp * tiles;
+  int t = bid;
+  if (tiles % 8 == 0) t = (bid & 7) * (tiles >> 3) + (bid >> 3);
   const int nt = t % a.n_tiles, mt = t / a.n_tiles;
   const int M = a.B * a.Ho * a.Wo;
-  const int S = a.KS >> 1;                        // stages of one tap x 64 channels (KS is even: Cin % 64 == 0)
+  const int S_all = a.KS >> 1;                    // stages of one tap x 64 channels (KS is even: Cin % 64 == 0)
+  const int s_lo = a.groups > 1 ? (int)((long)grp * S_all / a.groups) : 0;
+  const int S = (a.groups > 1 ? (int)((long)(grp + 1) * S_all / a.groups) : S_all) - s_lo;      // stages of THIS workgroup
 
   f32x4 acc[4][WNF];
 #pragma unroll
@@ -170,7 +205,8 @@ SF_DEV void conv_glds_body(const ConvArgs& a, double* __restrict__ gn_part, cons
     }
     // stages are issued strictly in order: (tap, 64-channel chunk) and the ring slot advance incrementally
     const int cpairs = a.cchunks >> 1;                     // host-checked: Cin is a multiple of 64
-    int i_ks = 0, i_cc = 0, i_ky = 0, i_kx = 0, i_buf = 0;
+    const int tap0 = s_lo / cpairs;
+    int i_ks = 2 * s_lo, i_cc = s_lo - tap0 * cpairs, i_ky = tap0 / a.kw, i_kx = tap0 - (tap0 / a.kw) * a.kw, i_buf = 0;
     auto issue_next = [&]() {
       char* sb = lds + i_buf * STAGE;
 #pragma unroll
@@ -241,7 +277,7 @@ SF_DEV void conv_glds_body(const ConvArgs& a, double* __restrict__ gn_part, cons
     }
   }
   conv_tile_epilogue<BNF, NST * STAGE, GN>(a, lds, acc, loader, wm, wn, lane, nt, mt, gn_part, gn_cg,
-                                           [&](int row) -> long { const int m = mt * 128 + row; return m < M ? (long)m : -1L; });
+                                           [&](int row) -> long { const int m = mt * 128 + row; return m < M ? (long)m : -1L; }, grp);
 }
 
 template <int BNF, int NST, bool GN>

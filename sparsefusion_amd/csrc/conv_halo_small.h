@@ -1,0 +1,210 @@
+// k_conv3_halo_sm: the 3x3 / stride 1 / pad 1 conv of WHOLE small maps (4x4 or 8x8 pixels) on k_conv3_halo's machinery (conv_halo.h: halo
+// frame of a 64-channel chunk staged ONCE by LDS-DMA, nine shifted window reads, weight ring of conv_glds.h, chunk-major K loop) -- the 4x4
+// level of the UNet at B >= 16 and every conv a large-batch plan runs on maps narrower than k_conv3_halo's 16-pixel tile rows.  r06.
+//
+// Why: with GroupNorm as its own pass these layers are plain [M = 16 B .. 64 B] x [9 Cin] x [Cout] GEMMs; on k_conv_glds (im2col staging:
+// the A operand once per (tap, chunk) = 9 x the pixels) a B = 32, 1024 -> 1024 layer moves 226 MB L2 -> LDS for 19 MB of weights and runs at
+// 33 us = 293 TFLOP/s, bound by that traffic.  Here a workgroup's 128 pixels are 8 whole 4x4 maps (or 2 whole 8x8 maps): per 64-channel
+// chunk their zero-framed 6x6 (10x10) frames -- 288 (200) pixel slots, 36 (25) KiB -- are staged once and the nine taps read windows of
+// them, so the A side falls to 1.0x (the frame's zero border is the zero line, not memory) and the launch moves ~90 MB.
+//
+// Fragment rows.  An MFMA A fragment is 16 pixels; which pixel sits in which row is free as long as the epilogue agrees.  ds_read_b128
+// serves lanes {0-3, 12-15} of one k-group together with lanes {4-11} of the next (MI355X_MICROARCH.md, LDS), and with the slot layout of
+// conv_halo.h (128 B per slot, 16-byte chunk c of slot p at position c ^ (p & 7)) a read is conflict-free iff each of those two lane sets
+// holds eight slots that differ mod 8 -- for every tap, since a tap adds a constant.  4x4 map, frame pitch 6: rows {0, 2} of the map are
+// distinct mod 8 and so are rows {1, 3}: fragment row r holds map row (0, 1, 3, 2)[r >> 2], column r & 3.  8x8 map, pitch 10, a fragment =
+// two map rows: fragment rows {0-3, 12-15} hold the 8 columns of the first map row, rows {4-11} those of the second.  (Checked
+// exhaustively over fragments x taps x k-steps x lane groups: tests/test_hostemu_conv_lds.py::test_small_map_halo_reads_are_conflict_free.)
+//
+// Split-K: group g of `groups` takes the 64-channel chunks [g P / groups, (g + 1) P / groups) of the P = Cin / 64, all nine taps each, and
+// leaves its slab in the workspace [group][row][npad] like k_conv_igemm (conv_tile_epilogue).  Waves as in k_conv3_halo: 0..3 multiply
+// (2 x 2: four fragments x 8*BNF channels each), 4, 5 stream the weight ring, 6, 7 stage the frames of the NEXT chunk.
+// Needs: k = 3, stride 1, pad 1, H = W in {4, 8}, Cin % 64 == 0, operand-type activations; no GroupNorm partials, no upsampled view.
+#pragma once
+#include "conv_glds.h"
+
+template <int MAPL>
+struct HaloSm {
+  static constexpr int SIDE = 1 << MAPL, FW = SIDE + 2, FPX = FW * FW;      // map side, frame side, slots per image
+  static constexpr int IMGS = 128 / (SIDE * SIDE);                         // whole maps per 128-pixel tile: 8 | 2
+  static constexpr int SLOTS = IMGS * FPX, NLD = (SLOTS + 7) / 8;          // 288 | 200 slots; LDS-DMA loads of 8 slots per chunk: 36 | 25
+  static constexpr int NLW = (NLD + 1) / 2;                                // ... per frame-loader wave
+  static constexpr int A_BYTES = NLD * 8 * 128;
+  static_assert(MAPL == 2 || MAPL == 3, "4x4 or 8x8 maps");
+  // slot (relative to the tile's first frame) of fragment `fi`'s row `r`, before the tap offset ky * FW + kx
+  static SF_DEV int frag_slot(int fi, int r) {
+    if (MAPL == 2) return fi * FPX + ((r >> 2) ^ ((r >> 3) & 1)) * FW + (r & 3);                       // map rows 0, 1, 3, 2
+    const int second = (r >> 2) == 1 || (r >> 2) == 2;                                                  // fragment rows 4 .. 11: the second map row
+    return (fi >> 2) * FPX + (2 * (fi & 3) + second) * FW + (second ? r - 4 : (r & 3) + ((r >> 3) << 2));
+  }
+  // output row (pixel index inside the 128-pixel tile, images in order, row-major) of tile row `row` = 16 * fragment + r
+  static SF_DEV int tile_pixel(int row) {
+    const int fi = row >> 4, r = row & 15;
+    if (MAPL == 2) return fi * 16 + ((r >> 2) ^ ((r >> 3) & 1)) * 4 + (r & 3);
+    const int second = (r >> 2) == 1 || (r >> 2) == 2;
+    return fi * 16 + second * 8 + (second ? r - 4 : (r & 3) + ((r >> 3) << 2));
+  }
+};
+
+template <int BNF, int NST, int MAPL>
+SF_DEV void conv_halo_sm_body(const ConvArgs& a) {
+  static_assert(NST == 3 || NST == 4, "weight ring depth 3 or 4");
+  static_assert(BNF == 4 || BNF == 8, "64 or 128 output channels per workgroup");
+  using Gm = HaloSm<MAPL>;
+  constexpr int WNF = BNF / 2;
+  constexpr int G = BNF;                        // LDS-DMA loads per weight-loader wave and stage
+  constexpr int SIDE = Gm::SIDE, FW = Gm::FW, FPX = Gm::FPX, IMGS = Gm::IMGS, NLW = Gm::NLW, NLD = Gm::NLD;
+  constexpr int A_BYTES = Gm::A_BYTES, B_STAGE = BNF * 2 * 1024;
+  constexpr int LDS_BYTES = 2 * A_BYTES + NST * B_STAGE;
+  SF_DYN_LDS(lds);
+  const int lane = threadIdx.x & 63, wave = sf_uniform((int)(threadIdx.x >> 6));
+  const bool loader = wave >= 4;
+  const int wm = (wave >> 1) & 1, wn = wave & 1;
+  const int tiles = a.m_tiles * a.n_tiles;
+  const int grp = a.groups > 1 ? sf_uniform((int)blockIdx.x / tiles) : 0;
+  const int bid = (int)blockIdx.x - grp * tiles;
+  int t = bid;
+  if (tiles % 8 == 0) t = (bid & 7) * (tiles >> 3) + (bid >> 3);
+  const int nt = t % a.n_tiles, mt = t / a.n_tiles;
+  const int P = a.cchunks >> 1;                                                                  // 64-channel chunks
+  const int h_lo = a.groups > 1 ? (int)((long)grp * P / a.groups) : 0;
+  const int h_hi = a.groups > 1 ? (int)((long)(grp + 1) * P / a.groups) : P;
+  const int S = 9 * (h_hi - h_lo);
+  const int M = a.B * SIDE * SIDE;
+
+  f32x4 acc[4][WNF];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int n = 0; n < WNF; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (wave >= 6) {
+    // ---- frame loaders: wave 6 stages loads [0, NLW), wave 7 loads [NLW, NLD); one load = 8 slots x 128 B, 8 lanes per slot
+    const int g0 = (wave - 6) * NLW;
+    const sf_opnd* src[NLW];
+    int step[NLW];                               // 64 channels on per chunk for a pixel inside its map, 0 for the zero line
+#pragma unroll
+    for (int j = 0; j < NLW; ++j) {
+      const int p = (g0 + j) * 8 + (lane >> 3);
+      const int img = p / FPX, q = p - img * FPX;
+      const int fr = q / FW, fc = q - fr * FW;
+      const int y = fr - 1, x = fc - 1, bimg = mt * IMGS + img;
+      const bool ok = (img < IMGS) & (bimg < a.B) & (y >= 0) & (y < SIDE) & (x >= 0) & (x < SIDE);
+      const int chunk = (lane & 7) ^ (p & 7);
+      const sf_opnd* in = reinterpret_cast<const sf_opnd*>(a.in) + (((long)(ok ? bimg : 0) * SIDE + (ok ? y : 0)) * SIDE + (ok ? x : 0)) * a.Cin + chunk * 8;
+      src[j] = ok ? in : reinterpret_cast<const sf_opnd*>(sf_zero128) + (lane & 7) * 8;
+      step[j] = ok ? 64 : 0;
+    }
+    const int nld = min(NLW, NLD - g0);
+    auto issue_tile = [&](int h) {
+      char* ab = lds + ((h - h_lo) & 1) * A_BYTES + g0 * 1024;
+#pragma unroll
+      for (int j = 0; j < NLW; ++j)
+        if (j < nld) sf_glds16(ab + j * 1024, src[j] + (long)h * step[j]);
+    };
+    issue_tile(h_lo);
+    int tap = 0, h = h_lo;
+    for (int s = 0; s < S; ++s) {
+      if (tap == 0) sf_vmcnt<0>();               // the frames of chunk h (issued nine stages ago) have landed
+      sf_lds_barrier();
+      if (tap == 0 && h + 1 < h_hi) issue_tile(h + 1);      // into the buffer chunk h - 1 was read from
+      if (++tap == 9) { tap = 0; ++h; }
+    }
+    sf_vmcnt<0>();
+    sf_glds_done();
+  } else if (wave >= 4) {
+    // ---- weight loaders: the ring of conv_glds.h, stage (chunk h, tap) = k-steps (tap * cchunks + 2h, + 1)
+    const int lw = wave - 4;
+    const bf16x8* wbase[WNF];
+#pragma unroll
+    for (int j = 0; j < WNF; ++j) {
+      const int nf = min(nt * BNF + WNF * lw + j, a.n_frags - 1);
+      wbase[j] = a.w + (long)nf * a.KS * 64 + lane;
+    }
+    int i_tap = 0, i_h = h_lo, i_buf = 0;
+    auto issue_next = [&]() {
+      char* sb = lds + 2 * A_BYTES + i_buf * B_STAGE;
+      const long kk = (long)i_tap * a.cchunks + 2 * i_h;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < WNF; ++j) sf_glds16(sb + ((WNF * lw + j) * 2 + u) * 1024, wbase[j] + (kk + u) * 64);
+      if (++i_tap == 9) { i_tap = 0; ++i_h; }
+      if (++i_buf == NST) i_buf = 0;
+    };
+    for (int p = 0; p < NST - 1 && p < S; ++p) issue_next();
+    for (int s = 0; s < S; ++s) {
+      const int newer = S - 1 - s;
+      if (newer >= NST - 2) sf_vmcnt<G * (NST - 2)>();
+      else if (NST == 4 && newer == 1) sf_vmcnt<G>();
+      else sf_vmcnt<0>();
+      sf_lds_barrier();
+      if (s + NST - 1 < S) issue_next();
+    }
+    sf_vmcnt<0>();
+    sf_glds_done();
+  } else {
+    // ---- matrix waves: fragments wm*4 .. wm*4+3 x WNF n-fragments.  Byte offset of this lane's 16 bytes of fragment i at tap (ky, kx), k-step 0
+    // (k-step 1 = the chunk 4 positions on: offset ^ 64), computed once: the tap loop is unrolled, the indices are static
+    int aoff[4][9];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = Gm::frag_slot(wm * 4 + i, lane & 15);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int p = b + (tap / 3) * FW + (tap % 3);
+        aoff[i][tap] = p * 128 + (((lane >> 4) ^ (p & 7)) << 4);
+      }
+    }
+    int r_buf = 0;
+    SF_LGKM0();
+    for (int h = h_lo; h < h_hi; ++h) {
+      const char* ab = lds + ((h - h_lo) & 1) * A_BYTES;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        sf_lds_barrier();
+        const char* sb = lds + 2 * A_BYTES + r_buf * B_STAGE + lane * 16;
+        bf16x8 fa[2][4], fb[2][WNF];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          fa[u][0] = *reinterpret_cast<const bf16x8*>(ab + (aoff[0][tap] ^ (u << 6)));
+#pragma unroll
+          for (int n = 0; n < WNF; ++n) fb[u][n] = *reinterpret_cast<const bf16x8*>(sb + ((wn * WNF + n) * 2 + u) * 1024);
+#pragma unroll
+          for (int i = 1; i < 4; ++i) fa[u][i] = *reinterpret_cast<const bf16x8*>(ab + (aoff[i][tap] ^ (u << 6)));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int n = 0; n < WNF; ++n) acc[i][n] = sf_mfma16(fa[u][i], fb[u][n], acc[i][n]);
+        constexpr int NRD = 2 * (4 + WNF);
+        SF_SCHED_GROUP(0x100, 4);
+#pragma unroll
+        for (int q = 0; q < NRD - 4; ++q) { SF_SCHED_GROUP(0x008, 1); SF_SCHED_GROUP(0x100, 1); }
+        SF_SCHED_GROUP(0x008, 8 * WNF - (NRD - 4));
+        if (++r_buf == NST) r_buf = 0;
+      }
+    }
+  }
+  conv_tile_epilogue<BNF, LDS_BYTES, false>(a, lds, acc, loader, wm, wn, lane, nt, mt, nullptr, 0, [&](int row) -> long {
+    const int m = mt * 128 + Gm::tile_pixel(row);
+    return m < M ? (long)m : -1L;
+  }, grp);
+}
+
+template <int BNF, int NST, int MAPL>
+SF_KERNEL(512, 1) void k_conv3_halo_sm(ConvArgs a) {
+  sf_touch_kernarg<(int)sizeof(ConvArgs)>();
+  conv_halo_sm_body<BNF, NST, MAPL>(a);
+}
+
+static inline uint32_t conv_halo_sm_lds_bytes(int bnf, int nst, int mapl) {
+  const int slots = (mapl == 2 ? 8 * 36 : 2 * 100);
+  return 2u * ((slots + 7) / 8) * 1024 + (uint32_t)nst * bnf * 2 * 1024;
+}
+static inline bool conv_halo_sm_ok(const ConvArgs& a) {
+  return a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.Ho == a.H && a.Wo == a.W && a.H == a.W && (a.H == 4 || a.H == 8) &&
+         a.Cin % 64 == 0 && !a.ups && a.groups >= 1 && a.groups <= a.Cin / 64;
+}

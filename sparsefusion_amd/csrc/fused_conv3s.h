@@ -40,16 +40,17 @@ struct Conv3sGeom {
   static constexpr int CC = 128, NCH = C / CC, KS = 9 * (C / 32);
   static constexpr int PSTR = 288;                          // bytes per frame pixel: 128 operand-type channels + 32 (stride = 32 mod 256)
   static constexpr int BUF = ((FR * FW + 1) * PSTR + 15) / 16 * 16;      // + 1 spare pixel (dead staging elements)
-  static constexpr int RAWB = RC ? ((16 * WM + 1) * PSTR + 15) / 16 * 16 : 0;      // RC: raw operand of the tile's own pixels (+ 1 spare), per buffer
+  static constexpr int RAWB = RC ? ((TH * FW + 1) * PSTR + 15) / 16 * 16 : 0;      // RC: raw operand of the tile's own rows in the frame's pixel order (+ 1 spare), per buffer
   static constexpr int F = WM * WN, FT = F + (POOL ? WM : 0) + (RC ? F : 0);
-  static constexpr int RED_OFF = 2 * BUF, MISC_OFF = RED_OFF + 4 * FT * 1024, WEFF_OFF = MISC_OFF + 256;
+  // the K-slice reduction buffer of the epilogue lies OVER the frame buffers: it is written behind the chunk loop's last barrier, when no frame is read any more
+  static constexpr int RED_OFF = 0, RED_BYTES = 4 * FT * 1024, MISC_OFF = (2 * BUF > RED_BYTES ? 2 * BUF : RED_BYTES), WEFF_OFF = MISC_OFF + 256;
   static constexpr int RAW_OFF = WEFF_OFF + (POOL ? KS * 64 : 0);
   static constexpr int LDS_BYTES = RAW_OFF + 2 * RAWB;
   static constexpr int NTILES = COUT / (16 * WN), MTI = (H / TH) * (W / TW);
   static constexpr int G = 8, CG = C / G, NCF = CG / 16, NMF = HW / 16, SCNT = NMF * NCF, NSL = (SCNT + 63) / 64;
   static constexpr int KR = 9 + (RC ? 1 : 0);                                       // ring steps per matrix wave and chunk
-  static constexpr int RD = NCH < 2 ? 1 : ((WN >= 4 || (RC && WN >= 2)) ? 1 : 2);   // weight ring depth in chunks (KR * WN fragments per chunk and wave; RC: the second set of accumulators takes the registers of the second ring set)
-  static constexpr int NB0 = EPT <= 4 ? (RC ? 3 : 4) : (EPT <= 8 ? 3 : 2), NB = NB0 < NCH ? NB0 : NCH;      // staging batches (chunks) in registers
+  static constexpr int RD = NCH < 2 ? 1 : ((WN >= 4 || (RC && WN >= 2) || (NCH >= 8 && WM * WN >= 4)) ? 1 : 2);   // weight ring depth in chunks (KR * WN fragments per chunk and wave; RC: the second set of accumulators takes the registers of the second ring set)
+  static constexpr int NB0 = EPT <= 4 ? (RC ? 3 : 4) : ((EPT <= 8 && !(NCH >= 8 && WM >= 2)) ? 3 : 2), NB = NB0 < NCH ? NB0 : NCH;      // staging batches (chunks) in registers
   static constexpr int NPW = RD * KR * WN, NPS = NB * (EPT + 4), NP = NPW > NPS ? NPW : NPS;
   static_assert(TH * TW == 16 * WM && TH >= 1 && TH <= H && TW <= W && TW >= 4, "tile = 16 * WM pixels");
   static_assert(C1 % 128 == 0 && C2 % 128 == 0 && CG % 16 == 0 && NSL <= 4 && COUT % (16 * WN) == 0, "channels");
@@ -124,7 +125,6 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
   const int tcx = ts & 31, tp = ts >> 5;
   int spix[EPT];                                         // source pixel of element e (a safe pixel when dead)
   int loff[EPT];                                         // LDS byte offset of element e inside a frame buffer (the spare pixel when dead)
-  int roff[RC ? EPT : 1];                                // RC: byte offset inside a raw-operand buffer (own pixels; the spare raw pixel otherwise)
 #pragma unroll
   for (int e = 0; e < EPT; ++e) {
     const int pi = tp + e * 8;
@@ -133,11 +133,6 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
     const bool in = pi < NPX && r >= 0 && r < H && x >= 0 && x < W;
     spix[e] = mb + (in ? r * W + x : row0 * W + col0);
     loff[e] = (in ? fr * FW + fxs + (FULLW ? 1 : 0) : FR * FW) * PSTR + tcx * 8;
-    if (RC) {
-      const int tx = fxs - (FULLW ? 0 : 1);
-      const bool own = in && fr >= 1 && fr <= TH && tx >= 0 && tx < TW;
-      roff[e] = (own ? (fr - 1) * TW + tx : 16 * WM) * PSTR + tcx * 8;
-    }
   }
   const float* ssrow = a.ss ? a.ss + (long)b * a.ss_stride : a.gamma;      // any valid address when there is no scale / shift
   const int shoff = a.ss ? C : 0;
@@ -145,8 +140,8 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
   auto issue = [&](int c, int vo) {
 #pragma unroll
     for (int e = 0; e < EPT; ++e)                           // (c is a compile-time constant after unrolling: the chunk lies in ONE source)
-      pool[vo + e] = c * CC < C1 ? *reinterpret_cast<const f32x4*>(a.s1.p + spix[e] * C1 + c * CC + tcx * 4)
-                                 : *reinterpret_cast<const f32x4*>(a.s2.p + spix[e] * (C2 ? C2 : 4) + (c * CC - C1) + tcx * 4);
+      pool[vo + e] = c * CC < C1 ? *reinterpret_cast<const f32x4*>(a.s1.p + ((uint32_t)spix[e] * (uint32_t)C1 + (uint32_t)(c * CC + tcx * 4)))
+                                 : *reinterpret_cast<const f32x4*>(a.s2.p + ((uint32_t)spix[e] * (uint32_t)(C2 ? C2 : 4) + (uint32_t)(c * CC - C1 + tcx * 4)));      // unsigned 32-bit element offsets: scalar base + one VGPR per load (signed ones become 64-bit VGPR pairs kept alive across the chunks)
     const int cg = c * CC + tcx * 4;
     pool[vo + EPT + 0] = *reinterpret_cast<const f32x4*>(a.gamma + cg);
     pool[vo + EPT + 1] = *reinterpret_cast<const f32x4*>(a.beta + cg);
@@ -274,7 +269,10 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
         const f32x4 rw = pool[vo + e] * (c * CC < C1 ? 1.0f : sc2);
         bf16x4 q;
         q[0] = (sf_opnd)rw[0]; q[1] = (sf_opnd)rw[1]; q[2] = (sf_opnd)rw[2]; q[3] = (sf_opnd)rw[3];
-        *reinterpret_cast<bf16x4*>(lds + Gm::RAW_OFF + (c & 1) * Gm::RAWB + roff[e]) = q;
+        // frame rows 1 .. TH are the tile's own: the raw buffer keeps the frame's pixel order minus its first row; everything else -> the spare pixel
+        const int ro = loff[e] - FW * PSTR;
+        const bool own = ro >= 0 && ro < TH * FW * PSTR;
+        *reinterpret_cast<bf16x4*>(lds + Gm::RAW_OFF + (c & 1) * Gm::RAWB + (own ? ro : TH * FW * PSTR + tcx * 8)) = q;
       }
     }
   };
@@ -331,7 +329,10 @@ SF_DEV void conv3s_body(const FConvArgs& a, const int bid) {
         const char* rb = lds + Gm::RAW_OFF + (c & 1) * Gm::RAWB + wave * 64 + (lane >> 4) * 16;
         bf16x8 fr_[WM];
 #pragma unroll
-        for (int mi = 0; mi < WM; ++mi) fr_[mi] = *reinterpret_cast<const bf16x8*>(rb + (mi * 16 + (lane & 15)) * PSTR);
+        for (int mi = 0; mi < WM; ++mi) {
+          const int p = mi * 16 + (lane & 15);
+          fr_[mi] = *reinterpret_cast<const bf16x8*>(rb + ((p / TW) * FW + (p & (TW - 1)) + 1) * PSTR);      // (+ 1: the frame's left column)
+        }
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi)
 #pragma unroll

@@ -301,12 +301,12 @@ static inline int conv3s_twl(const sf_op& op, const FConvArgs& a, int WM, int WN
 
 // k_conv3s_rc: conv1 of a ResnetBlock on the concat of two sources with the block's res_conv in the same workgroups (the pipelined pairs of the
 // B = 1 plan).  (HL, C1, C2, COUT, TWL, WM, WN): the 2-D tiles at 32x32 / 16x16 (their full-width strips need more registers than a wave has: 35 / 4
-// spilled VGPRs, not instantiated), the 2-row strip at 8x8.
+// spilled VGPRs, not instantiated), the 2-row strip at 8x8.  The 32- / 64-pixel tiles of B >= 2 do not fit either (two sets of accumulators + the staging
+// batches: 38-91 spilled VGPRs): those pairs stay on k_conv_fused_pipe_rc / _pipe_pair.
 #define SF_CONV3S_RC_VARIANTS(X) \
   X(5, 256, 256, 256, 3, 2, 2) \
   X(4, 512, 256, 512, 2, 1, 2) \
-  X(3, 1024, 512, 1024, 3, 1, 1) \
-  X(5, 256, 256, 256, 3, 4, 2) X(4, 512, 256, 512, 2, 2, 2) X(3, 1024, 512, 1024, 3, 2, 2)
+  X(3, 1024, 512, 1024, 3, 1, 1)
 
 // The res_conv `b` can ride in conv1 `a`'s workgroups: a 1x1 un-normalised conv of the same raw sources onto plain rows of the same width
 static inline bool fconv_rc_compatible(const FConvArgs& a, const FConvArgs& b) {

@@ -91,3 +91,138 @@ SF_KERNEL(256) void k_gemm_rows(GemmRowsArgs a) {
       }
   }
 }
+
+// k_gemm_rows_ks (r06): the same product for the GlobalContext MLPs of the large-batch plans (rows = the 9 .. 64 images of the batch, N and K
+// 128 .. 1024).  k_gemm_rows runs N / 64 workgroups -- 8 for a 1024 -> 512 layer -- that each walk K in 128-column chunks behind two
+// workgroup barriers per chunk: 23 us for [32 x 1024] x [1024 x 512], 26 of them in a B = 32 eval.  Here a workgroup owns 16 output columns
+// (N / 16 workgroups) and its 4 waves split K by chunk (wave w: chunks w, w + 4, ...): a wave stages ITS chunk for itself in a wave-private LDS
+// slice (same-wave DS order, no workgroup barrier inside the K loop), so the dependent chain is 4x shorter and every staging load of a chunk is
+// in flight at once; one LDS reduction over the 4 waves at the end.  Only the rows that exist are staged.  Same arithmetic per product as
+// k_gemm_rows (hi + lo split of x, bf16 weights), another summation order over K (per wave, then over waves).
+#define GRK_WAVE_ELEMS (2 * 64 * GR_LD)                                   // hi + lo slices of one wave, operand-type elements
+#define GRK_LDS_BYTES (4 * GRK_WAVE_ELEMS * 2 + 3 * 16 * 64 * 4)           // + the reduction buffer [3 waves][4 fragments x 4 rows][64 lanes]
+
+SF_KERNEL(256) void k_gemm_rows_ks(GemmRowsArgs a) {
+  SF_DYN_LDS(lds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = sf_uniform(tid >> 6);
+  sf_opnd* hi = reinterpret_cast<sf_opnd*>(lds) + wave * GRK_WAVE_ELEMS;
+  sf_opnd* lo = hi + 64 * GR_LD;
+  float* red = reinterpret_cast<float*>(lds + 4 * GRK_WAVE_ELEMS * 2);
+  const int n = lane & 15, g = lane >> 4;
+  const int ncol = blockIdx.x * 16 + n;
+  const sf_opnd* __restrict__ wrow = a.W + (long)min(ncol, a.N - 1) * a.Kp;
+  const int MF = (a.M + 15) >> 4;
+  const bool vec = (a.ldx & 3) == 0 && (a.K & 7) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;      // float4 loads of whole 8-column pieces
+  f32x4 acc[4];
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf) acc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kc = wave * GR_KC; kc < a.K; kc += 4 * GR_KC) {
+    bf16x8 bw[GR_KC / 32];                          // the chunk's weight fragments, requested before its x rows are staged
+#pragma unroll
+    for (int ks = 0; ks < GR_KC / 32; ++ks) {
+      const int k0 = kc + ks * 32 + 8 * g;
+      bw[ks] = *reinterpret_cast<const bf16x8*>(wrow + min(k0, a.Kp - 8));
+      if (k0 >= a.Kp) bw[ks] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    const int lim = MF * 16 * (GR_KC / 8);
+    if (vec && kc + GR_KC <= a.K) {
+      // a whole chunk, float4 rows: ALL loads of the chunk first (a rolled loop waits for each pair before the next goes out: 8 L2 round
+      // trips per chunk at 32 rows -- measured 11 us per launch), then the hi / lo split
+      f32x4 xv[16][2];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int idx = lane + it * 64;
+        if (idx < lim) {
+          const int m = idx / (GR_KC / 8), k8 = (idx % (GR_KC / 8)) * 8;
+          const float* __restrict__ xr = a.x + (long)min(m, a.M - 1) * a.ldx + kc + k8;
+          xv[it][0] = *reinterpret_cast<const f32x4*>(xr);
+          xv[it][1] = *reinterpret_cast<const f32x4*>(xr + 4);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int idx = lane + it * 64;
+        if (idx < lim) {
+          const int m = idx / (GR_KC / 8), k8 = (idx % (GR_KC / 8)) * 8;
+          bf16x8 h, l;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float t = m < a.M ? xv[it][j >> 2][j & 3] : 0.0f;
+            if (a.in_silu) t = sf_silu(t);
+            const sf_opnd hb = (sf_opnd)t;
+            h[j] = hb;
+            l[j] = (sf_opnd)(t - (float)hb);
+          }
+          *reinterpret_cast<bf16x8*>(&hi[m * GR_LD + k8]) = h;
+          *reinterpret_cast<bf16x8*>(&lo[m * GR_LD + k8]) = l;
+        }
+      }
+    } else
+    for (int idx = lane; idx < MF * 16 * (GR_KC / 8); idx += 64) {
+      const int m = idx / (GR_KC / 8), k8 = (idx % (GR_KC / 8)) * 8;
+      const float* __restrict__ xr = a.x + (long)min(m, a.M - 1) * a.ldx;
+      float v[8];
+      if (vec && kc + k8 + 8 <= a.K) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(xr + kc + k8), q = *reinterpret_cast<const f32x4*>(xr + kc + k8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = p[j]; v[4 + j] = q[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = xr[min(kc + k8 + j, a.K - 1)];
+      }
+      bf16x8 h, l;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = (m < a.M && kc + k8 + j < a.K) ? v[j] : 0.0f;
+        if (a.in_silu) t = sf_silu(t);
+        const sf_opnd hb = (sf_opnd)t;
+        h[j] = hb;
+        l[j] = (sf_opnd)(t - (float)hb);
+      }
+      *reinterpret_cast<bf16x8*>(&hi[m * GR_LD + k8]) = h;
+      *reinterpret_cast<bf16x8*>(&lo[m * GR_LD + k8]) = l;
+    }
+    sf_wave_sync();
+    const int left = a.K - kc;
+    const int steps = left >= GR_KC ? GR_KC / 32 : (left + 31) / 32;
+#pragma unroll
+    for (int ks = 0; ks < GR_KC / 32; ++ks) {
+      if (ks < steps) {
+        const bf16x8 b = bw[ks];
+        const int col = ks * 32 + 8 * g;
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+          if (mf < MF) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&hi[(mf * 16 + n) * GR_LD + col]);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(&lo[(mf * 16 + n) * GR_LD + col]);
+            acc[mf] = sf_mfma16(ah, b, acc[mf]);
+            acc[mf] = sf_mfma16(al, b, acc[mf]);
+          }
+        }
+      }
+    }
+    sf_wave_sync();                                 // this wave's fragment reads are done before its next chunk overwrites the slice
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wave - 1) * 16 + mf * 4 + r) * 64 + lane] = acc[mf][r];
+  }
+  sf_sync();
+  if (wave != 0 || ncol >= a.N) return;
+  const float bv = a.bias ? a.bias[ncol] : 0.0f;
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = mf * 16 + 4 * g + r;
+      if (m < a.M) {
+        const int o = (mf * 4 + r) * 64 + lane;
+        float v = acc[mf][r] + red[o] + red[16 * 64 + o] + red[2 * 16 * 64 + o] + bv;
+        if (a.out_act == 1) v = sf_silu(v);
+        else if (a.out_act == 2) v = sf_sigmoid(v);
+        a.y[(long)m * a.ldy + ncol] = v;
+      }
+    }
+}

@@ -30,6 +30,7 @@
 #include "sf_dev.h"
 #include "gemm_rows.h"
 #include "conv_halo.h"
+#include "conv_halo_small.h"
 #include "conv_igemm.h"
 #include "attn_ln.h"
 #include <math.h>
@@ -240,6 +241,64 @@ __global__ __launch_bounds__(256) void k_gn_apply(const float* __restrict__ s1, 
     }
     *reinterpret_cast<bf16x4*>(out + ((long)b * HW + p) * C + c) = o;
     if (raw) *reinterpret_cast<bf16x4*>(raw + ((long)b * HW + p) * C + c) = r;
+  }
+}
+
+// k_gn_one (r06): statistics AND normalisation of one (image, group) in one workgroup, the slab held in registers between the two -- one
+// launch and one read of the tensor instead of two of each (the large-batch plans run 30-42 GroupNorm passes per eval: 0.86 of a 5.66 ms
+// B = 32 eval in k_gn_stats + k_gn_apply).  Same operands, lazy sources and outputs as the pair; the sums are taken per thread in fp32,
+// over the workgroup in double (another -- also fixed -- order than k_gn_stats' per-block atomics: reproducible run to run).
+// Taken when the grid B * G fills the chip (>= 256 workgroups) and a group's slab fits NT * NCH float4 registers (run_gn).
+template <int NT, int NCH>
+__global__ __launch_bounds__(NT) void k_gn_one(float* __restrict__ s1, const float* __restrict__ s2, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, const float* __restrict__ ss, sf_opnd* __restrict__ out,
+                                               sf_opnd* __restrict__ raw, int HW, int C1, int C2, int ss_stride, float eps, float s2_scale,
+                                               int no_silu, LazySrc lz, int G) {
+  __shared__ double red[2][NT / 64];
+  const int C = C1 + C2, Cg = C / G, cg4 = Cg / 4;
+  const int b = blockIdx.x / G, g = blockIdx.x - b * G;
+  const int chunks = HW * cg4;
+  f32x4 v[NCH];
+  float s = 0.0f, q = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int ch = threadIdx.x + k * NT;
+    v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ch < chunks) {
+      const int p = ch / cg4, c = g * Cg + (ch - p * cg4) * 4;
+      v[k] = (lz.mode && c < C1) ? lazy_load4(lz, s1, b, (long)b * HW + p, c, C1) : gn_load(s1, s2, b, HW, C1, C2, p, c, s2_scale);
+      s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+      q = fmaf(v[k][0], v[k][0], q); q = fmaf(v[k][1], v[k][1], q); q = fmaf(v[k][2], v[k][2], q); q = fmaf(v[k][3], v[k][3], q);
+    }
+  }
+  const double ds = (double)wave_sum(s), dq = (double)wave_sum(q);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wv] = ds; red[1][wv] = dq; }
+  __syncthreads();
+  double ts = 0.0, tq = 0.0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) { ts += red[0][w]; tq += red[1][w]; }
+  const double inv_n = 1.0 / ((double)HW * Cg);
+  const double m = ts * inv_n, var = tq * inv_n - m * m;
+  const float mean = (float)m, rstd = rsqrtf((float)(var > 0.0 ? var : 0.0) + eps);
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int ch = threadIdx.x + k * NT;
+    if (ch < chunks) {
+      const int p = ch / cg4, c = g * Cg + (ch - p * cg4) * 4;
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+      bf16x4 o, r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float y = (v[k][j] - mean) * rstd * ga[j] + be[j];
+        if (ss) y = y * (ss[(long)b * ss_stride + c + j] + 1.0f) + ss[(long)b * ss_stride + C + c + j];
+        if (!no_silu) y = silu_f(y);
+        o[j] = (sf_opnd)y;
+        r[j] = (sf_opnd)v[k][j];
+      }
+      *reinterpret_cast<bf16x4*>(out + ((long)b * HW + p) * C + c) = o;
+      if (raw) *reinterpret_cast<bf16x4*>(raw + ((long)b * HW + p) * C + c) = r;
+    }
   }
 }
 
@@ -545,9 +604,42 @@ static int launch_conv_halo_nst(const ConvArgs& a, int nblk, double* part, int c
   return nst == 3 ? launch_conv_halo<BNF, 3, GN>(a, nblk, part, cg, st) : launch_conv_halo<BNF, 4, GN>(a, nblk, part, cg, st);
 }
 
+// k_conv3_halo_sm (conv_halo_small.h): 3x3 / stride 1 / pad 1 layers on WHOLE 4x4 / 8x8 maps (8 / 2 maps per pixel tile), split-K over the 64-channel chunks
+template <int BNF, int NST, int MAPL>
+static int launch_conv_halo_sm(const ConvArgs& a, int nblk, hipStream_t st) {
+  static unsigned mask = 0;
+  const uint32_t lds = conv_halo_sm_lds_bytes(BNF, NST, MAPL);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "hipGetDevice failed");
+  if (dev >= 32 || !(mask & (1u << dev))) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3_halo_sm<BNF, NST, MAPL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      SF_FAIL(SF_ERR_LAUNCH, "hipFuncSetAttribute(max dynamic LDS) failed");
+    if (dev < 32) mask |= 1u << dev;
+  }
+  k_conv3_halo_sm<BNF, NST, MAPL><<<nblk, 512, lds, st>>>(a);
+  SF_CHECK_LAUNCH("conv3_halo_sm");
+  return SF_OK;
+}
+template <int BNF>
+static int launch_conv_halo_sm_nst(const ConvArgs& a, int nblk, int nst, hipStream_t st) {
+  if (a.H == 4) return nst == 3 ? launch_conv_halo_sm<BNF, 3, 2>(a, nblk, st) : launch_conv_halo_sm<BNF, 4, 2>(a, nblk, st);
+  return nst == 3 ? launch_conv_halo_sm<BNF, 3, 3>(a, nblk, st) : launch_conv_halo_sm<BNF, 4, 3>(a, nblk, st);
+}
+
 template <int BNF, bool GN>
 static int launch_conv_glds_nst(const ConvArgs& a, int nblk, double* part, int cg, int nst, hipStream_t st) {
   return nst == 3 ? launch_conv_glds<BNF, 3, GN>(a, nblk, part, cg, st) : launch_conv_glds<BNF, 4, GN>(a, nblk, part, cg, st);
+}
+
+// The tail of a split-K conv launch: the reduction over the group slabs (bias, residual, accumulate, ReLU / GELU, NCHW form), unless deferred
+static int conv_splitk_tail(const sf_op& op, const ConvArgs& a, int M, hipStream_t st) {
+  if (a.groups <= 1) return SF_OK;
+  if (!a.ws) SF_FAIL(SF_ERR_INVALID, "conv: split-K needs a workspace");
+  if (op.flags & 8) return SF_OK;      // reduction deferred to the consumer (LazySrc mode 1)
+  k_splitk_reduce<<<sf_grid_cap(sf_div_up((long)M * a.Cout, 256)), 256, 0, st>>>(a.ws, a.bias, a.resid, a.out, M, a.Cout, a.npad,
+                                                                                a.groups, a.ldc, a.co_off, a.accum, a.relu, a.out_nchw_hw);
+  SF_CHECK_LAUNCH("splitk_reduce");
+  return SF_OK;
 }
 
 static int run_conv(const sf_op& op, hipStream_t st) {
@@ -586,18 +678,32 @@ static int run_conv(const sf_op& op, hipStream_t st) {
   const bool f32 = (op.flags & 1) != 0;
   if (tile >= 256) {                                   // LDS-tiled large-M kernel: tile = 256 + 16 * sel + n-fragments per workgroup
     const int bnf = (tile - 256) & 15, sel = (tile - 256) >> 4;      // sel 0: the default kernel; 1: k_conv_lds; 3 / 4: k_conv_glds ring depth;
-    if (sel != 0 && sel != 1 && sel != 3 && sel != 4 && sel != 6 && sel != 7)                       // 6 / 7: k_conv3_halo with a 3 / 4 deep weight ring
+    if (sel != 0 && sel != 1 && sel != 3 && sel != 4 && sel != 6 && sel != 7 && sel != 8 && sel != 9)      // 6 / 7: k_conv3_halo with a 3 / 4 deep weight ring; 8 / 9: k_conv3_halo_sm
       SF_FAIL(SF_ERR_INVALID, "conv: unknown LDS kernel selector %d", sel);
     const bool glds_ok = !f32 && a.Cin % 64 == 0 && a.Cout % 4 == 0 && a.ldc % 4 == 0 && a.co_off % 4 == 0 && (bnf == 8 || bnf == 4);
     if (sel >= 3 && !glds_ok) SF_FAIL(SF_ERR_INVALID, "conv: k_conv_glds takes operand-type activations with Cin %% 64 == 0 and float4-aligned output rows only");
-    if (a.groups != 1 || a.pixshuf) SF_FAIL(SF_ERR_INVALID, "conv: the LDS-tiled kernel has no split-K / pixel-shuffle epilogue");
+    // r06: k_conv_lds / k_conv_glds take split-K groups over their stage range (workspace [grp][m][npad], as k_conv_igemm leaves it) and the
+    // SiLU + PixelShuffle(2) epilogue of an Upsample (the 4x4 level and the Upsample convs of the large-batch plans); k_conv3_halo does not
+    const bool special = a.groups != 1 || a.pixshuf;      // (a split-K launch leaves residual / accumulate / ReLU to the reduction)
+    if (special && ((op.flags & 128) || sel == 6 || sel == 7 || (a.groups != 1 && !a.ws) || (a.pixshuf && ((op.flags & 4) || op.p[4] || a.relu))))
+      SF_FAIL(SF_ERR_INVALID, "conv: split-K / pixel shuffle on the LDS-tiled kernels: no GroupNorm partials, not k_conv3_halo; no residual / accumulate / ReLU under the shuffle");
+    // whole 4x4 / 8x8 maps: k_conv3_halo_sm (the default for those layers; selectors 3 / 4 / 1 keep k_conv_glds / k_conv_lds for comparison)
+    const bool sm_ok = glds_ok && conv_halo_sm_ok(a) && !a.pixshuf && !(op.flags & 128);
+    if (sel >= 8 && !sm_ok) SF_FAIL(SF_ERR_INVALID, "conv: k_conv3_halo_sm takes 3x3 / stride 1 / pad 1 layers on 4x4 / 8x8 maps, groups <= Cin / 64");
+    const int sm = sel >= 8 ? sel - 5 : ((sel == 0 && sm_ok) ? conv_glds_depth() : 0);      // ring depth, 0 = not taken
+    if (!sm && a.groups > (((glds_ok && sel != 1) ? a.KS : a.KS + 1) >> 1)) SF_FAIL(SF_ERR_INVALID, "conv: more split-K groups than stages");
+    if (a.groups == 1 && a.pixshuf) a.ws = nullptr;      // (ws of an LDS-tiled launch without split-K = the operand-type twin)
     a.m_tiles = (a.m_frags + 7) / 8;
     a.n_tiles = (a.n_frags + bnf - 1) / bnf;
-    const int nblk = a.m_tiles * a.n_tiles;
-    const bool halo_ok = glds_ok && conv_halo_ok(a) && M % 128 == 0;
-    if (sel >= 6 && !halo_ok) SF_FAIL(SF_ERR_INVALID, "conv: k_conv3_halo takes 3x3 / stride 1 / pad 1 layers with W %% 16 == 0, H %% 8 == 0 only");
+    const int nblk = a.m_tiles * a.n_tiles * a.groups;
+    const bool halo_ok = glds_ok && conv_halo_ok(a) && M % 128 == 0 && !special;
+    if ((sel == 6 || sel == 7) && !halo_ok) SF_FAIL(SF_ERR_INVALID, "conv: k_conv3_halo takes 3x3 / stride 1 / pad 1 layers with W %% 16 == 0, H %% 8 == 0 only");
+    if (sm) {
+      if (int rc = bnf == 8 ? launch_conv_halo_sm_nst<8>(a, nblk, sm, st) : launch_conv_halo_sm_nst<4>(a, nblk, sm, st)) return rc;
+      return conv_splitk_tail(op, a, M, st);
+    }
     const int glds = (glds_ok && sel != 1 && sel < 6) ? (sel >= 3 ? sel : conv_glds_depth()) : 0;
-    const int halo = sel >= 6 ? sel - 3 : ((sel == 0 && halo_ok && glds && conv_halo_enabled()) ? glds : 0);      // ring depth of the halo kernel, 0 = not taken
+    const int halo = (sel == 6 || sel == 7) ? sel - 3 : ((sel == 0 && halo_ok && glds && conv_halo_enabled()) ? glds : 0);      // ring depth of the halo kernel, 0 = not taken
     if (op.flags & 128) {                                // the epilogue also leaves GroupNorm partial sums (conv_lds.h)
       double* part = (double*)op.p[6];
       const int cg = op.i[15];
@@ -616,7 +722,10 @@ static int run_conv(const sf_op& op, hipStream_t st) {
       return SF_OK;
     }
     if (halo) return bnf == 8 ? launch_conv_halo_nst<8, false>(a, nblk, nullptr, 0, halo, st) : launch_conv_halo_nst<4, false>(a, nblk, nullptr, 0, halo, st);
-    if (glds) return bnf == 8 ? launch_conv_glds_nst<8, false>(a, nblk, nullptr, 0, glds, st) : launch_conv_glds_nst<4, false>(a, nblk, nullptr, 0, glds, st);
+    if (glds) {
+      if (int rc = bnf == 8 ? launch_conv_glds_nst<8, false>(a, nblk, nullptr, 0, glds, st) : launch_conv_glds_nst<4, false>(a, nblk, nullptr, 0, glds, st)) return rc;
+      return conv_splitk_tail(op, a, M, st);
+    }
     if (bnf == 8) {
       if (f32) k_conv_lds<8, true><<<nblk, 256, 0, st>>>(a); else k_conv_lds<8, false><<<nblk, 256, 0, st>>>(a);
     } else if (bnf == 4) {
@@ -625,7 +734,7 @@ static int run_conv(const sf_op& op, hipStream_t st) {
       SF_FAIL(SF_ERR_INVALID, "conv: unsupported LDS tile %d", bnf);
     }
     SF_CHECK_LAUNCH("conv_lds");
-    return SF_OK;
+    return conv_splitk_tail(op, a, M, st);
   }
   switch (tile) {
     case 1 * 16 + 1: launch_conv<1, 1>(a, f32, blocks, st); break;
@@ -640,14 +749,7 @@ static int run_conv(const sf_op& op, hipStream_t st) {
     default: SF_FAIL(SF_ERR_INVALID, "conv: unsupported wave tile %dx%d", WM, WN);
   }
   SF_CHECK_LAUNCH("conv_igemm");
-  if (a.groups > 1) {
-    if (!a.ws) SF_FAIL(SF_ERR_INVALID, "conv: split-K needs a workspace");
-    if (op.flags & 8) return SF_OK;      // reduction deferred to the consumer (LazySrc mode 1)
-    k_splitk_reduce<<<sf_grid_cap(sf_div_up((long)M * a.Cout, 256)), 256, 0, st>>>(a.ws, a.bias, a.resid, a.out, M, a.Cout, a.npad,
-                                                                                  a.groups, a.ldc, a.co_off, a.accum, a.relu, a.out_nchw_hw);
-    SF_CHECK_LAUNCH("splitk_reduce");
-  }
-  return SF_OK;
+  return conv_splitk_tail(op, a, M, st);
 }
 
 // Lazy-source descriptor of an op: i[ibase] = mode, i[ibase+1] = groups, i[ibase+2] = npad ; p[8] = a, p[9] = b, p[10] = r.
@@ -670,6 +772,23 @@ static int run_gn(const sf_op& op, hipStream_t st) {
   LazySrc lz;
   if (int rc = lazy_from_op(op, 5, B * HW, lz)) return rc;
   const int c4 = C / 4;
+  // r06: one launch for statistics + normalisation when B * G workgroups are a fair share of the chip and a group's slab fits the registers of its
+  // workgroup (the large-batch UNet plans: G = 8, B >= 32; flag 4 = the two-launch form, flag 8 = this form at any B, for comparison)
+  if (!(op.flags & (2 | 4)) && (B * G >= 256 || (op.flags & 8)) && chunks <= 1024 * 16) {      // (measured: B = 32 eval 4.81 -> 4.66 ms; at 64 / 128 workgroups the pair wins: B = 8 2.46 vs 2.54 ms, B = 16 3.65 vs 3.68; flag 8 forces k_gn_one)
+    float* s1 = (float*)op.p[0];
+    const float *s2 = (const float*)op.p[1], *ga = (const float*)op.p[2], *be = (const float*)op.p[3], *ssp = (const float*)op.p[4];
+    sf_opnd *o = (sf_opnd*)op.p[5], *rw = (sf_opnd*)op.p[6];
+#define SF_GN_ONE(NT, NCH) k_gn_one<NT, NCH><<<B * G, NT, 0, st>>>(s1, s2, ga, be, ssp, o, rw, HW, C1, C2, op.i[4], op.f[0], op.f[1], op.flags & 1, lz, G)
+    if (chunks <= 256 * 2) SF_GN_ONE(256, 2);
+    else if (chunks <= 256 * 4) SF_GN_ONE(256, 4);
+    else if (chunks <= 256 * 8) SF_GN_ONE(256, 8);
+    else if (chunks <= 256 * 16) SF_GN_ONE(256, 16);
+    else if (chunks <= 1024 * 8) SF_GN_ONE(1024, 8);
+    else SF_GN_ONE(1024, 16);
+#undef SF_GN_ONE
+    SF_CHECK_LAUNCH("gn_one");
+    return SF_OK;
+  }
   if (op.flags & 2) {
     // the statistics are already in p[7] (k_gn_finalize over the producing conv's partial sums): no pass over the tensor
     if (op.p[1] || lz.mode) SF_FAIL(SF_ERR_INVALID, "gn_act: ready-made statistics need a plain single source");
@@ -731,6 +850,19 @@ static int run_gemv(const sf_op& op, hipStream_t st) {
     GemmRowsArgs a{(const float*)op.p[0], (const sf_opnd*)op.p[1], (const float*)op.p[2], (float*)op.p[3], M, N, op.i[2], op.i[3], op.i[4],
                    op.i[5], (int)(op.flags & 1), (int)((op.flags >> 1) & 3)};
     if (a.Kp < 8 || a.Kp % 8) SF_FAIL(SF_ERR_INVALID, "gemv: padded K must be a multiple of 8");
+    if (N <= 4096 && !(op.flags & 8)) {                         // r06: the GlobalContext MLPs of a large batch -- N / 16 workgroups, K split over the waves (flag 8: the first form)
+      static unsigned mask = 0;
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "hipGetDevice failed");
+      if (dev >= 32 || !(mask & (1u << dev))) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_rows_ks), hipFuncAttributeMaxDynamicSharedMemorySize, GRK_LDS_BYTES) != hipSuccess)
+          SF_FAIL(SF_ERR_LAUNCH, "gemv: cannot raise the dynamic LDS limit of k_gemm_rows_ks");
+        if (dev < 32) mask |= 1u << dev;
+      }
+      k_gemm_rows_ks<<<sf_div_up(N, 16), 256, GRK_LDS_BYTES, st>>>(a);
+      SF_CHECK_LAUNCH("gemm_rows_ks");
+      return SF_OK;
+    }
     k_gemm_rows<<<sf_div_up(N, 64), 256, 0, st>>>(a);
     SF_CHECK_LAUNCH("gemm_rows");
     return SF_OK;

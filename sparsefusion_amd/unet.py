@@ -29,8 +29,7 @@ CONV3S_VARIANTS = {(5, 256, 5, 2, 2), (5, 256, 3, 2, 2), (4, 256, 4, 1, 1), (4, 
                    (3, 512, 3, 1, 1), (3, 1024, 3, 1, 1), (5, 256, 5, 4, 2), (5, 256, 3, 4, 2),
                    (4, 256, 2, 2, 1), (4, 256, 2, 2, 2), (4, 512, 2, 2, 2), (3, 512, 3, 2, 1), (3, 1024, 3, 2, 1), (3, 1024, 3, 2, 2)}
 # (log2 H, C1, C2, Cout, log2 tile width, WM, WN) of k_conv3s_rc (SF_CONV3S_RC_VARIANTS): conv1 on a concat + the block's res_conv in one set of workgroups
-CONV3S_RC_VARIANTS = {(5, 256, 256, 256, 3, 2, 2), (4, 512, 256, 512, 2, 1, 2), (3, 1024, 512, 1024, 3, 1, 1),
-                      (5, 256, 256, 256, 3, 4, 2), (4, 512, 256, 512, 2, 2, 2), (3, 1024, 512, 1024, 3, 2, 2)}
+CONV3S_RC_VARIANTS = {(5, 256, 256, 256, 3, 2, 2), (4, 512, 256, 512, 2, 1, 2), (3, 1024, 512, 1024, 3, 1, 1)}
 PIPE_TILES = {(1, 1, 4), (1, 2, 4), (1, 1, 6), (1, 2, 6), (2, 1, 6), (2, 2, 6), (2, 1, 8), (2, 2, 8), (2, 1, 12), (2, 2, 12), (4, 1, 16), (4, 2, 16)}
 FNORM_NONE, FNORM_GN_SELF, FNORM_GN_SLOTS, FNORM_LN, FNORM_ATTN = range(5)      # csrc/fused_kernels.h
 ATTN_LDS_BYTES = 8 * 16 * 36 * 4 + 2 * 8 * 4 * 68 * 4      # SF_ATTN_LDS_BYTES: scratch of the attention prologue (FNORM_ATTN)
@@ -335,14 +334,12 @@ class _Plan:
         WM, WN, groups = self.u.conv_tiling(m_frags, n_frags, KS, pixshuf)
         accum = (out.ptr, co_off) in self.written
         self.written.add((out.ptr, co_off))
-        ws, wi = 0, 0
-        if groups > 1:
-            wi = self.acquire_ws(groups * M * n_frags * 16 * 4)   # a workspace about to be overwritten is reduced first
-            ws = self.ws_ptrs[wi]
         tile = WM * 16 + WN
+        twin_ws = 0
         # large-M layers (VAE, VGG, B >= 4): the LDS-tiled kernel, 128 pixels x 128 (or 64) channels per workgroup
         lds_min = getattr(self.u, "lds_conv_min_blocks", 0)
-        if lds_min and not pixshuf and n_frags >= 4:
+        mid = getattr(self.u, "lds_mid_min_rows", 0) if B >= getattr(self.u, "lds_mid_min_batch", 8) else 0
+        if lds_min and n_frags >= 4 and (not pixshuf or (mid and M >= mid and Cout % 4 == 0)):
             bnf = 8 if n_frags > 4 else 4
             blocks = ((m_frags + 7) // 8) * ((n_frags + bnf - 1) // bnf)
             if bnf == 8 and blocks < 256:                     # fewer tiles than CUs: halve the channel tile instead of idling CUs
@@ -350,11 +347,29 @@ class _Plan:
             # 3x3 layers k_conv3_halo takes (csrc/conv_halo.h) beat the weight-streaming kernel from 64 tiles on (measured 21 vs 29 us
             # on the 32x32 512->512 layer); everything else needs lds_min tiles
             halo = (k == 3 and stride == 1 and pad == 1 and not x_f32 and x.C % 64 == 0 and W % 16 == 0 and H % 8 == 0 and M % 128 == 0
-                    and Cout % 4 == 0 and ldc % 4 == 0 and co_off % 4 == 0 and (Ho, Wo) == (H, W))
-            if blocks >= (min(lds_min, 64) if halo else lds_min):
-                tile, groups, ws = 256 + bnf, 1, 0
+                    and Cout % 4 == 0 and ldc % 4 == 0 and co_off % 4 == 0 and (Ho, Wo) == (H, W) and not pixshuf)
+            if blocks >= (min(lds_min, 64) if halo else lds_min) and not pixshuf:
+                tile, groups = 256 + bnf, 1
                 if twin is not None and ldc == Cout and co_off == 0:
-                    ws = twin.ptr
+                    twin_ws = twin.ptr
+            elif mid and M >= mid:
+                # r06: M of a few hundred rows (the 4x4 level of B >= 8, the Upsample 1x1 convs): still 128-row MFMA tiles out of LDS, the
+                # workgroups that are missing come from split-K groups over the stage range (k_conv_lds / k_conv_glds; not under the
+                # pixel shuffle, whose epilogue writes the output itself) -- every weight byte is still fetched by ONE workgroup per pixel tile
+                glds_ok = not x_f32 and x.C % 64 == 0 and Cout % 4 == 0 and ldc % 4 == 0 and co_off % 4 == 0
+                stages = KS // 2 if glds_ok else (KS + 1) // 2
+                g = 1 if pixshuf else max(1, min(256 // blocks, stages // 4, 16))
+                if glds_ok and k == 3 and stride == 1 and pad == 1 and H == W and H in (4, 8) and not pixshuf:
+                    # whole 4x4 / 8x8 maps: k_conv3_halo_sm (csrc/conv_halo_small.h) splits K by 64-channel chunk, two chunks per group at least
+                    # (the frames of the second are staged under the taps of the first)
+                    g = max(1, min(256 // blocks, x.C // 128, 16))
+                tile, groups = 256 + bnf, g
+        ws, wi = 0, 0
+        if groups > 1:
+            wi = self.acquire_ws(groups * M * n_frags * 16 * 4)   # a workspace about to be overwritten is reduced first
+            ws = self.ws_ptrs[wi]
+        elif twin_ws:
+            ws = twin_ws
         defer = bool(defer and not relu and not gelu and 1 < groups <= 8 and not accum and not pixshuf and co_off == 0 and ldc == Cout == out.C and M == out.rows
                      and (self.u.lazy_consumers & 1))
         bias, res = self.wptr(bname) if bname else 0, resid.ptr if resid else 0
@@ -375,7 +390,7 @@ class _Plan:
         out.slots = slots or None
         self.last_conv_nchw = nchw
         out.writer = self.ops[-1] if (tile >= 256 and co_off == 0 and ldc == Cout == out.C and M == out.rows) else None
-        out.twin = twin if (twin is not None and tile >= 256 and ws == twin.ptr) else None
+        out.twin = twin if (twin is not None and tile >= 256 and groups == 1 and ws == twin.ptr) else None
         return Ho, Wo
 
     def gn_act(self, x, skip, gname, ss_ptr, out, raw=None, silu=True, groups=8, eps=1e-5):
@@ -396,7 +411,7 @@ class _Plan:
             wr.i[15] = cg
             self.op(OP_GN_FINALIZE, 0, p=(part, stats), i=(self.B, x.HW // 128, groups))
             ready = 2
-        self.op(OP_GN_ACT, (0 if silu else 1) | ready,
+        self.op(OP_GN_ACT, (0 if silu else 1) | ready | (0 if getattr(self.u, "gn_one", True) else 4),      # (flag 4: k_gn_stats + k_gn_apply even where k_gn_one fits)
                 p=(x.ptr, skip.ptr if skip else 0, self.wptr(gname + ".weight"), self.wptr(gname + ".bias"), ss_ptr, out.ptr,
                    raw.ptr if raw else 0, stats) + lp,
                 i=(self.B, x.HW, C1, C2, getattr(self.u, "tb_stride", 0)) + li + (groups,), f=(eps, SKIP_SCALE))
@@ -748,6 +763,9 @@ class _Plan:
         # large batches at the 32x32 / 16x16 levels: GroupNorm as its own pass + the 3x3 convs on k_conv3_halo (csrc/conv_halo.h, 700-950
         # TFLOP/s from 128 tiles on) beat the GroupNorm-fused weight-streaming kernels, which are built for M of a few tiles
         big = rows >= getattr(self.u, "unfused_min_rows", 1 << 30) and H % 16 == 0 and cin % 64 == 0 and cout % 64 == 0
+        # r06: the 4x4 / 8x8 levels of large batches likewise (their 3x3 convs then run on k_conv_glds with split-K groups, conv(): lds_mid_min_rows)
+        low = getattr(self.u, f"unfused_min_rows_{H}", 0) if H in (4, 8) else 0
+        big = big or bool(low and rows >= low and getattr(self.u, "lds_mid_min_rows", 0) and cin % 64 == 0 and cout % 64 == 0)
         if getattr(self.u, "fused", False) and not big:
             y = self.resnet_fused(name, x, skip, cout, H, gca, cross)
             if y is not None:
@@ -806,6 +824,8 @@ class _Plan:
         """Geometry of a fused linear on a 4x4 token map, or None (the first-round ops then run)."""
         if x.HW != 16 or x.rows != self.B * 16:
             return None
+        if x.rows >= getattr(self.u, "unfused_lin_min_rows", 1 << 30) and getattr(self.u, "lds_mid_min_rows", 0):
+            return None     # r06: enough token rows for 128-row MFMA tiles -- LayerNorm pass + LDS-tiled 1x1 convs (conv(): lds_mid_min_rows)
         return self.fused_geometry(4, x.C, N, norm, 1)
 
     def attention_fused(self, name, x, context, cross):
@@ -1160,6 +1180,12 @@ class Unet(nn.Module):
         self.tb_stride = (off + 63) // 64 * 64
         self.conv_waves_target = 1024       # waves wanted per conv launch (4 per CU) before split-K stops
         self.lds_conv_min_blocks = 96       # use k_conv_lds when a layer has at least this many 128 x 128 output tiles
+        self.lds_mid_min_rows = 128      # r06: convs of >= this many rows that have too few 128-row tiles for lds_conv_min_blocks run on the LDS-tiled kernels with split-K groups (_Plan.conv); 0 = off
+        self.gn_one = True               # r06: GroupNorm passes of B >= 32 plans (B * 8 >= 256 workgroups) in one launch (k_gn_one); False: k_gn_stats + k_gn_apply everywhere
+        self.lds_mid_min_batch = 8       # ... in plans of at least this many images (the B = 1 .. 4 plans keep their measured kernels)
+        self.unfused_min_rows_4 = 256    # r06: 4x4-level ResnetBlocks with B*16 >= this leave the fused kernels (as unfused_min_rows at 32x32 / 16x16; measured: B = 8 loses 0.12 ms, B = 16 gains 0.22, B = 32 0.49); 0 = never
+        self.unfused_min_rows_8 = 1024   # ... 8x8 level (k_conv3_halo_sm; measured: B = 8 loses 0.14 ms, B = 16 gains 0.04, B = 32 0.56)
+        self.unfused_lin_min_rows = 256      # r06: attention / feed-forward linears of the 4x4 level with >= this many token rows leave the fused kernels (measured: B = 16 3.683 -> 3.670 ms, B = 32 4.664 -> 4.472)
         self.unfused_min_rows = 8192     # ResnetBlocks with B*H*W >= this at the 32x32 / 16x16 levels leave the fused kernels (_Plan.resnet; measured r03: B = 8 eval 3.33 -> 2.96 ms, B = 32 11.5 -> 7.8 ms, B = 4 unchanged)
         self.lazy_consumers = 3             # bit 0: split-K reductions, bit 1: gated residuals are materialised by their first consumer
         # Planner attributes (plain Python attributes since r04 -- the SF_* environment switches of the r01-r03 A/B runs are retired;

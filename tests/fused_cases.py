@@ -521,9 +521,6 @@ CONV_CASES_FULL = {
     "conv3s_b2_8x8_1024_rows4_pool": dict(B=2, H=8, W=8, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SLOTS, WM=2, WN=1, seed=139, pipe=True, tw=8, pool=True),
     "conv3s_b4_8x8_1024_rows4_wn2": dict(B=4, H=8, W=8, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=140, pipe=True, tw=8),
     "conv3s_b4_8x8_1024_rows4_wn2_pool": dict(B=4, H=8, W=8, C1=1024, C2=0, Cout=1024, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=141, pipe=True, tw=8, pool=True),
-    "conv3s_rc_b2_32x32_512_tile8x8": dict(B=2, H=32, W=32, C1=256, C2=256, Cout=256, k=3, norm=GN_SLOTS, WM=4, WN=2, seed=142, pipe=True, pair=True, tw=8, ss=False),
-    "conv3s_rc_b2_16x16_768_tile8x4": dict(B=2, H=16, W=16, C1=512, C2=256, Cout=512, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=143, pipe=True, pair=True, tw=4, ss=False),
-    "conv3s_rc_b4_8x8_1536_rows4": dict(B=4, H=8, W=8, C1=1024, C2=512, Cout=1024, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=144, pipe=True, pair=True, tw=8, ss=False),
     # r06: k_conv3s_rc -- conv1 on the concat of two sources + the block's res_conv in the same workgroups (the pipelined pairs of the B = 1 plan)
     "conv3s_rc_32x32_512_tile4x8": dict(B=2, H=32, W=32, C1=256, C2=256, Cout=256, k=3, norm=GN_SLOTS, WM=2, WN=2, seed=121, pipe=True, pair=True, tw=8, ss=False),
     "conv3s_rc_16x16_768_tile4x4": dict(B=1, H=16, W=16, C1=512, C2=256, Cout=512, k=3, norm=GN_SLOTS, WM=1, WN=2, seed=123, pipe=True, pair=True, tw=4),

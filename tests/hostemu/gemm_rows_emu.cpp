@@ -14,3 +14,10 @@ extern "C" void emu_gemm_rows(const float* x, const uint16_t* W, const float* bi
   GemmRowsArgs a{x, reinterpret_cast<const __bf16*>(W), bias, y, M, N, K, Kp, ldx, ldy, in_silu, out_act};
   hipemu::launch((unsigned)((N + 63) / 64), 256, 0, [&] { k_gemm_rows(a); });
 }
+
+// r06: the K-sliced form (N / 16 workgroups, the 4 waves split K by chunk)
+extern "C" void emu_gemm_rows_ks(const float* x, const uint16_t* W, const float* bias, float* y, int M, int N, int K, int Kp, int ldx,
+                                 int ldy, int in_silu, int out_act) {
+  GemmRowsArgs a{x, reinterpret_cast<const __bf16*>(W), bias, y, M, N, K, Kp, ldx, ldy, in_silu, out_act};
+  hipemu::launch((unsigned)((N + 15) / 16), 256, GRK_LDS_BYTES, [&] { k_gemm_rows_ks(a); });
+}

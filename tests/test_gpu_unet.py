@@ -188,17 +188,22 @@ def test_plan_switches_match_oracle(switch):
     assert torch.isfinite(y).all() and r < TOL_REL and c > TOL_COS and rel_err(y, y_def) < TOL_REL
 
 
+@pytest.mark.parametrize("plan", ["default", "r05"])
 @pytest.mark.parametrize("B", [8, 16, 32])
-def test_large_batch_default_plans_match_oracle(B):
+def test_large_batch_default_plans_match_oracle(B, plan):
     """The plans the strong-scaling lines are timed on (`also_measured.config3_total32`: 32 views on one GPU; N = 2 / 4 ranks: 16 / 8 per
     GPU) against the fp32 oracle with the same bounds as B = 1 (imagen_pytorch.py:1470-1671).  These batch sizes are the first to reach
-    the hybrid ResnetBlocks (GroupNorm pass + k_conv3_halo from 8192 pixel rows on), k_conv4_gn_mb with 4 images per workgroup, the own
-    split-K reduction launches of the 4x4 level and the WN = 2 attention-prologue projection; the test asserts the plan contains them, so
-    that a planner change cannot silently move the timed plan off the tested kernels."""
+    the hybrid ResnetBlocks (GroupNorm pass + k_conv3_halo from 8192 pixel rows on), the WN = 2 attention-prologue projection and -- r06, the
+    default -- the 4x4 level on the LDS-tiled kernels with split-K groups and the Upsample convs with the pixel shuffle on the LDS-tiled
+    kernels; "r05" switches the last two off (k_conv4_gn_mb with 4 images per workgroup and its own split-K reduction launches; still what
+    B <= 4 runs, and a fallback).  The test asserts the plan contains the kernels it names, so that a planner change cannot silently move the
+    timed plan off the tested kernels."""
     from sparsefusion_amd import unet as U
     name = "canonical"
     sd = state(name)
     net = _unet(name, sd)
+    if plan == "r05":
+        net.lds_mid_min_rows = net.unfused_min_rows_4 = net.unfused_min_rows_8 = 0
     g = torch.Generator().manual_seed(600 + B)
     x, cond = torch.randn(B, 4, 32, 32, generator=g), torch.randn(B, 256, 32, 32, generator=g)
     ls = unet_ref.log_snr(torch.rand(B, generator=g) * 0.98 + 0.01)
@@ -206,18 +211,26 @@ def test_large_batch_default_plans_match_oracle(B):
         y_ref = unet_ref.unet_forward(sd, x, ls, cond)
     y = net.forward_with_cond_scale(x.to(DEV), ls.to(DEV), cond_images=cond.to(DEV)).cpu()
     ops = net._plan(B, torch.device(DEV)).ops
-    halo = [o for o in ops if o.type == U.OP_CONV and o.i[14] >= 256 and o.i[9] == 3]
+    halo = [o for o in ops if o.type == U.OP_CONV and o.i[14] >= 256 and o.i[9] == 3 and o.i[1] >= 16]
     gn_pass = [o for o in ops if o.type == U.OP_GN_ACT]
     c4 = [o for o in ops if o.type == U.OP_FCONV and o.i[12] == U.FNORM_GN_SELF and o.i[1] == 4 and o.i[8] == 3]
+    l4 = [o for o in ops if o.type == U.OP_CONV and o.i[14] >= 256 and o.i[9] == 3 and o.i[1] == 4]
+    shuf = [o for o in ops if o.type == U.OP_CONV and o.flags & 2]
     attn = [o for o in ops if o.type == U.OP_FCONV and o.i[12] == U.FNORM_ATTN]
     n_red = sum(o.type == U.OP_SPLITK_REDUCE for o in ops)
-    print(f"B={B}: {len(ops)} ops; {len(halo)} LDS-tiled 3x3 convs, {len(gn_pass)} GroupNorm passes, {len(c4)} 4x4 GroupNorm-self convs "
-          f"(slices {sorted({o.i[17] for o in c4})}), {n_red} reductions, attention WN {sorted({o.i[16] for o in attn})}")
+    print(f"B={B} {plan}: {len(ops)} ops; {len(halo)} LDS-tiled 3x3 convs at 32x32 / 16x16, {len(gn_pass)} GroupNorm passes, {len(c4)} fused 4x4 "
+          f"GroupNorm-self convs (slices {sorted({o.i[17] for o in c4})}), {len(l4)} LDS-tiled 4x4 convs (groups {sorted({o.i[13] for o in l4})}), "
+          f"{n_red} reductions, attention WN {sorted({o.i[16] for o in attn})}")
     assert len(halo) >= 8 and len(gn_pass) >= 8                                      # the 32x32 level (B = 8) / + the 16x16 level (B >= 16) left the fused kernels
     if B >= 32:
         assert len(halo) >= 16
-    assert len(c4) == 16 and all(o.i[17] == 4 and o.i[19] == 0 for o in c4)          # k_conv4_gn_mb: 4 slices, images side by side
-    assert n_red >= 8 and attn and all(o.i[16] == 2 for o in attn)                   # own reductions; WN = 2 attention projection
+    if plan == "r05":
+        assert len(c4) == 16 and all(o.i[17] == 4 and o.i[19] == 0 for o in c4)      # k_conv4_gn_mb: 4 slices, images side by side
+        assert n_red >= 8 and all(o.i[14] < 256 for o in shuf)                       # own reductions
+    else:
+        assert (len(c4), len(l4)) == ((16, 1) if B == 8 else (0, 17)) and all(o.i[13] > 1 for o in l4)      # from 256 rows on: k_conv3_halo_sm, split-K groups
+        assert len(shuf) == 3 and all(o.i[14] >= 256 for o in shuf)                  # pixel shuffle on k_conv_lds
+    assert attn and all(o.i[16] == 2 for o in attn)                                  # WN = 2 attention projection
     r, c = rel_err(y, y_ref), cosine(y, y_ref)
     worst = max(rel_err(y[b:b + 1], y_ref[b:b + 1]) for b in range(B))
     print(f"B={B}: rel L2 vs oracle {r:.3e} cosine {c:.6f}; worst image {worst:.3e}")

@@ -279,6 +279,86 @@ def test_conv3_halo_matches_conv_lds(case, sel):
             assert torch.equal(tw.cpu().view(B, H, W, Cout), o_.to(torch.bfloat16))
 
 
+LDS_SPLITK_CASES = [
+    # B, H, Cin, Cout, k, pad, bnf, sel (0: default = k_conv3_halo_sm for a 3x3 on whole 4x4 / 8x8 maps, else k_conv_glds when it can; 1: k_conv_lds;
+    #                                    3 / 4: k_conv_glds ring depth; 8 / 9: k_conv3_halo_sm ring depth), a_f32, groups, resid, deferred
+    (8, 4, 1024, 1024, 3, 1, 4, 4, False, 16, False, False),    # the 4x4 level at B = 8: ONE pixel tile, 16 channel tiles, 16 groups of 9 stages
+    (8, 4, 1024, 1024, 3, 1, 4, 0, False, 8, False, False),     # ... on k_conv3_halo_sm: 8 whole maps per tile, 8 groups of two 64-channel chunks
+    (32, 4, 1024, 1024, 3, 1, 4, 3, False, 4, True, False),     # B = 32: 4 x 16 tiles, 4 groups of 36 stages; residual in the reduction
+    (32, 4, 1024, 1024, 3, 1, 4, 9, False, 4, True, False),     # ... k_conv3_halo_sm, 4 chunks per group
+    (32, 4, 2048, 1024, 3, 1, 8, 4, False, 8, False, True),     # conv1 of an up block on the concat; reduction deferred: the slabs are checked
+    (32, 4, 2048, 1024, 3, 1, 8, 8, False, 8, False, True),     # ... k_conv3_halo_sm, 3-deep ring
+    (11, 4, 1024, 200, 3, 1, 8, 0, False, 3, False, False),     # ragged: 11 maps (the second tile holds 3), Cout = 200, 16 chunks in 3 groups (5 / 5 / 6)
+    (32, 8, 1024, 1024, 3, 1, 8, 0, False, 2, False, False),    # the 8x8 level at B = 32: 2 whole maps per tile, 16 x 8 tiles, 2 groups
+    (5, 8, 512, 512, 3, 1, 4, 9, False, 1, True, False),        # 8x8, no split-K: the epilogue writes the output (bias, residual); 5 maps = 2.5 tiles
+    (9, 4, 1024, 640, 1, 0, 4, 0, False, 3, False, False),      # 1x1, ragged M = 144, 16 stages in 3 groups (5 / 5 / 6)
+    (8, 4, 512, 1024, 3, 1, 8, 1, True, 4, False, False),       # k_conv_lds, fp32 activations
+    (16, 4, 96, 200, 3, 1, 8, 1, False, 3, True, False),        # KS = 27 is odd (padded last stage), ragged Cout
+]
+
+
+@pytest.mark.parametrize("case", LDS_SPLITK_CASES)
+def test_conv_lds_tiled_split_k(case):
+    """r06: split-K groups on the LDS-tiled kernels (the 4x4 level of the B >= 8 plans; k_conv3_halo_sm on whole 4x4 / 8x8 maps, k_conv_glds,
+    k_conv_lds): workspace [group][row][npad] as k_conv_igemm leaves it, reduced by k_splitk_reduce (bias, residual) or left to the consumer
+    (flag 8) -- against conv2d on the same rounded operands."""
+    B, H, Cin, Cout, k, pad, bnf, sel, a_f32, groups, use_res, deferred = case
+    g = torch.Generator().manual_seed(Cin + Cout + k + B)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    wp, cpad = _pack_conv(w)
+    assert cpad == Cin
+    xh = x.permute(0, 2, 3, 1).contiguous()
+    xd = xh.to(DEV) if a_f32 else xh.to(torch.bfloat16).to(DEV)
+    M, npad = B * H * H, (Cout + 15) // 16 * 16
+    out = torch.full((M, Cout), float("nan"), device=DEV)
+    res = torch.randn(M, Cout, generator=g).to(DEV) if use_res else None
+    ws = torch.full((groups, M, npad), float("nan"), device=DEV) if groups > 1 else None
+    _run([_op(1, (1 if a_f32 else 0) | (8 if deferred else 0), p=(xd, wp, bias.to(DEV), out, res, ws),
+              i=(B, H, H, Cin, H, H, Cout, Cout, 0, k, k, 1, pad, groups, 256 + 16 * sel + bnf))])
+    ref = F.conv2d(bf(x), bf(w), None, padding=pad).permute(0, 2, 3, 1).reshape(M, Cout)
+    if groups == 1:
+        ref = ref + bias + (res.cpu() if use_res else 0)
+        assert torch.allclose(out.cpu(), ref, rtol=2e-4, atol=3e-4), (out.cpu() - ref).abs().max()
+        return
+    assert not bool(torch.isnan(ws[:, :, :Cout]).any())
+    assert torch.allclose(ws.cpu()[:, :, :Cout].sum(0), ref, rtol=2e-4, atol=3e-4), (ws.cpu()[:, :, :Cout].sum(0) - ref).abs().max()
+    if deferred:
+        assert bool(torch.isnan(out).all())
+        return
+    ref = ref + bias
+    if use_res:
+        ref = ref + res.cpu()
+    assert torch.allclose(out.cpu(), ref, rtol=2e-4, atol=3e-4), (out.cpu() - ref).abs().max()
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,bnf,sel,a_f32", [
+    (32, 4, 1024, 4096, 8, 1, True),        # ups.0: 4x4 -> 8x8 (k_conv_lds: the UNet hands the Upsample its fp32 residual stream)
+    (8, 8, 1024, 2048, 8, 1, True),         # ups.1 at B = 8
+    (8, 16, 512, 1024, 8, 0, False),        # k_conv_glds (operand-type activations)
+    (3, 4, 128, 72, 4, 0, False),           # ragged M = 48, Cout = 72 (18 output channels)
+])
+def test_conv_lds_tiled_pixel_shuffle(B, H, Cin, Cout, bnf, sel, a_f32):
+    """r06: the SiLU + PixelShuffle(2) epilogue of an Upsample (imagen_pytorch.py:578-606) on the LDS-tiled kernels, into a channel
+    window of a wider tensor (ldc / co_off), against torch pixel_shuffle."""
+    g = torch.Generator().manual_seed(Cin + Cout + B)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    wp, _ = _pack_conv(w)
+    xh = x.permute(0, 2, 3, 1).contiguous()
+    xd = xh.to(DEV) if a_f32 else xh.to(torch.bfloat16).to(DEV)
+    ldc, co_off = Cout // 4 + 8, 4
+    up = torch.full((B, 2 * H, 2 * H, ldc), float("nan"), device=DEV)
+    _run([_op(1, (1 if a_f32 else 0) | 2, p=(xd, wp, bias.to(DEV), up, None, None),
+              i=(B, H, H, Cin, H, H, Cout, ldc, co_off, 1, 1, 1, 0, 1, 256 + 16 * sel + bnf))])
+    ref = F.pixel_shuffle(F.silu(F.conv2d(bf(x), bf(w), bias)), 2).permute(0, 2, 3, 1)
+    got = up.cpu()
+    assert torch.allclose(got[..., co_off:co_off + Cout // 4], ref, rtol=2e-4, atol=3e-4), (got[..., co_off:co_off + Cout // 4] - ref).abs().max()
+    assert bool(torch.isnan(got[..., :co_off]).all()) and bool(torch.isnan(got[..., co_off + Cout // 4:]).all())
+
+
 def test_conv_accumulates_and_pixel_shuffle():
     g = torch.Generator().manual_seed(3)
     B, H, C = 2, 8, 128
@@ -305,7 +385,11 @@ def test_conv_accumulates_and_pixel_shuffle():
 
 
 @pytest.mark.parametrize("B,H,C1,C2,with_ss", [(1, 32, 256, 256, True), (2, 8, 1024, 512, False), (1, 4, 1024, 0, True),
-                                                 (3, 16, 64, 0, True), (1, 32, 512, 0, False)])
+                                                 (3, 16, 64, 0, True), (1, 32, 512, 0, False),
+                                                 # r06: k_gn_one (one launch; <256 | 1024 threads, 2 .. 16 float4 per thread>; the plans take it from B * 8 >= 256 workgroups on, flag 8 forces it)
+                                                 (32, 8, 1024, 0, True),
+                                                 (8, 4, 1024, 0, True), (9, 4, 1024, 1024, False), (8, 8, 1024, 512, True), (8, 16, 512, 256, True),
+                                                 (8, 32, 256, 0, True), (8, 32, 256, 256, False), (16, 16, 512, 0, True)])
 def test_gn_act(B, H, C1, C2, with_ss):
     g = torch.Generator().manual_seed(C1 + C2 + H)
     HW, C = H * H, C1 + C2
@@ -318,7 +402,7 @@ def test_gn_act(B, H, C1, C2, with_ss):
     ssd = ss_all.to(DEV)
     ss_ptr = ssd.data_ptr() + C * 4 if with_ss else 0        # the block's slice starts at column C
     stats = torch.zeros(B * 8 * 2, dtype=torch.float64, device=DEV)
-    _run([_op(2, 0, p=(x1.to(DEV), x2.to(DEV) if C2 else None, gamma.to(DEV), beta.to(DEV), ss_ptr, out, raw, stats),
+    _run([_op(2, 8 if B >= 8 else 0, p=(x1.to(DEV), x2.to(DEV) if C2 else None, gamma.to(DEV), beta.to(DEV), ss_ptr, out, raw, stats),      # flag 8: k_gn_one below its 256-workgroup rule
               i=(B, HW, C1, C2, 3 * C), f=(1e-5, 2 ** -0.5))])
     xc = torch.cat([x1, x2 * 2 ** -0.5], -1) if C2 else x1
     ref = F.group_norm(xc.permute(0, 2, 1).reshape(B, C, H, H), 8, gamma, beta, eps=1e-5)
@@ -378,26 +462,31 @@ def test_gemv(M, N, K, in_silu, act):
         assert torch.equal(y1.cpu()[0, :N], y.cpu()[m, :N]), m
 
 
-@pytest.mark.parametrize("M,N,K,in_silu,act", [(51, 1024, 17, False, 1), (51, 4160, 1024, True, 0), (20, 136, 300, False, 2)])
-def test_gemv_many_rows_on_mfma(M, N, K, in_silu, act):
-    """OP_GEMV with 9..64 rows (a sampler's time table, Unet.time_table) runs on k_gemm_rows (csrc/gemm_rows.h): rows on the MFMA
-    M side, x split into bf16 hi + lo.  Same arithmetic as k_gemv (fp32 x times bf16 w) to ~1e-5, row by row."""
+@pytest.mark.parametrize("first_form", [False, True])
+@pytest.mark.parametrize("M,N,K,in_silu,act", [(51, 1024, 17, False, 1), (51, 4160, 1024, True, 0), (20, 136, 300, False, 2),
+                                               (32, 512, 1024, False, 1), (32, 1024, 512, False, 2), (9, 256, 125, True, 0)])
+def test_gemv_many_rows_on_mfma(M, N, K, in_silu, act, first_form):
+    """OP_GEMV with 9..64 rows (a sampler's time table, Unet.time_table; the GlobalContext MLPs of a large batch) runs on k_gemm_rows /
+    k_gemm_rows_ks (csrc/gemm_rows.h; N <= 4096: the K-sliced form, flag 8 forces the first one): rows on the MFMA M side, x split into
+    bf16 hi + lo.  Same arithmetic as k_gemv (fp32 x times bf16 w) to ~1e-5, row by row.  (float4 staging where the row stride is a
+    multiple of 4 and K of 8.)"""
     g = torch.Generator().manual_seed(N + K)
+    ldx = K if K % 8 == 0 and N <= 4096 else K + 3
     w = torch.randn(N, K, generator=g) / K ** 0.5
     b = torch.randn(N, generator=g)
-    x = torch.randn(M, K + 3, generator=g)
+    x = torch.randn(M, ldx, generator=g)
     Kp = (K + 7) // 8 * 8
     wp = F.pad(w, (0, Kp - K)).to(torch.bfloat16).contiguous().to(DEV)
     y = torch.full((M, N + 2), float("nan"), device=DEV)
-    flags = (1 if in_silu else 0) | (act << 1)
-    _run([_op(4, flags, p=(x.to(DEV), wp, b.to(DEV), y), i=(M, N, K, Kp, K + 3, N + 2))])
+    flags = (1 if in_silu else 0) | (act << 1) | (8 if first_form else 0)
+    _run([_op(4, flags, p=(x.to(DEV), wp, b.to(DEV), y), i=(M, N, K, Kp, ldx, N + 2))])
     xin = x[:, :K]
     ref = F.linear(F.silu(xin) if in_silu else xin, bf(w), b)
     ref = F.silu(ref) if act == 1 else torch.sigmoid(ref) if act == 2 else ref
     assert torch.allclose(y.cpu()[:, :N], ref, rtol=1e-4, atol=1e-4), float((y.cpu()[:, :N] - ref).abs().max())
     assert bool(torch.isnan(y[:, N:]).all())
     y8 = torch.zeros(8, N + 2, device=DEV)                    # the 8-row kernel on the first rows: the two kernels agree
-    _run([_op(4, flags, p=(x[:8].contiguous().to(DEV), wp, b.to(DEV), y8), i=(8, N, K, Kp, K + 3, N + 2))])
+    _run([_op(4, flags, p=(x[:8].contiguous().to(DEV), wp, b.to(DEV), y8), i=(8, N, K, Kp, ldx, N + 2))])
     assert torch.allclose(y8.cpu()[:, :N], y.cpu()[:8, :N], rtol=3e-5, atol=3e-5)
 
 

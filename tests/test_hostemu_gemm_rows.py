@@ -31,8 +31,13 @@ def _lib():
     (51, 200, 320, 320, 264, 1, 0, True),      # batched time_mlps: SiLU in, ragged N (200 = 3 x 64 + 8), ldy > N
     (20, 64, 300, 640, 64, 0, 2, False),       # token k/v: row stride 2 x cond_dim, K crosses the 128-column chunks raggedly, no bias
     (64, 48, 64, 64, 48, 0, 0, True),
+    (32, 512, 1024, 1024, 512, 0, 1, True),    # GlobalContext net.0 of a 1024-channel block at B = 32: 8 chunks, two per wave (float4 staging)
+    (9, 1024, 512, 512, 1024, 0, 2, True),     # net.2 at B = 9: one m-fragment, sigmoid
+    (16, 40, 648, 648, 40, 1, 0, False),       # 6 chunks (waves 0, 1 take two, the last ragged: 8 columns), ragged N
 ])
-def test_gemm_rows_matches_fp32_x_times_bf16_w(M, N, K, ldx, ldy, in_silu, out_act, bias):
+@pytest.mark.parametrize("ks", [False, True])
+def test_gemm_rows_matches_fp32_x_times_bf16_w(M, N, K, ldx, ldy, in_silu, out_act, bias, ks):
+    """ks: k_gemm_rows_ks (r06: N / 16 workgroups, the waves split K by 128-column chunk; the GlobalContext MLPs of the large-batch plans)."""
     lib = _lib()
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, ldx, generator=g)
@@ -43,7 +48,7 @@ def test_gemm_rows_matches_fp32_x_times_bf16_w(M, N, K, ldx, ldy, in_silu, out_a
     b = torch.randn(N, generator=g) if bias else None
     y = torch.full((M, ldy), float("nan"))
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
-    lib.emu_gemm_rows(ptr(x), ptr(wb.view(torch.int16)), ptr(b), ptr(y), M, N, K, Kp, ldx, ldy, in_silu, out_act)
+    (lib.emu_gemm_rows_ks if ks else lib.emu_gemm_rows)(ptr(x), ptr(wb.view(torch.int16)), ptr(b), ptr(y), M, N, K, Kp, ldx, ldy, in_silu, out_act)
     xin = F.silu(x[:, :K]) if in_silu else x[:, :K]
     want = xin.double() @ wb[:, :K].double().t()
     if bias:

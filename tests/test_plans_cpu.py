@@ -41,8 +41,13 @@ def _audit(ops, name, sized=False):
             if groups > 1:
                 assert o.p[5] or not sized, where + ": split-K without workspace"
                 assert not (o.flags & 2), where + ": pixel shuffle cannot be split-K"
-            if tile >= 256:                                                     # k_conv_lds contract
-                assert groups == 1 and not (o.flags & (2 | 8)) and tile - 256 in (4, 8), where
+            if tile >= 256:                                                     # k_conv_lds / k_conv_glds contract (r06: split-K groups, pixel shuffle)
+                assert tile - 256 in (4, 8) and 1 <= groups <= 16, where
+                assert groups == 1 or not (o.flags & 128), where + ": no GroupNorm partials under split-K"
+                if o.flags & 2:
+                    assert groups == 1 and Cout % 4 == 0 and not (o.flags & (4 | 8 | 32 | 64 | 128)) and not o.p[4], where
+                stages = (kh * kw * (Cin // 32) + 1) // 2
+                assert groups <= stages, where + ": more split-K groups than stages"
             else:
                 assert tile // 16 in (1, 2, 4) and tile % 16 in (1, 2, 4), where
             if o.flags & 8:
@@ -371,6 +376,7 @@ def test_4x4_level_rules_for_more_than_one_image():
     from sparsefusion_amd import unet as U
     net = U.Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2), layer_attns=(False, False, False, True),
                  layer_cross_attns=(False,) * 4, cond_images_channels=256, attn_pool_text=False)
+    net.unfused_min_rows_4 = 0                  # (r06: from B = 8 on the default plan takes the 4x4 ResnetBlocks off the fused kernels, see the next test)
 
     def convs4(B):
         ops = U._Plan(net, B, CPU).build().ops
@@ -398,3 +404,34 @@ def test_4x4_level_rules_for_more_than_one_image():
     net.conv4_mb, net.conv4_reduce_min_batch = True, 0
     ops4, c4 = convs4(4)
     assert sum(o.type == U.OP_SPLITK_REDUCE for o in ops4) == n_red1 and sum(o.i[9] == 1 for o in c4) == sum(o.i[9] == 1 for o in c1)
+
+
+def test_large_batch_plans_run_the_4x4_level_on_the_lds_tiled_kernels():
+    """r06: from B = 8 on (lds_mid_min_batch) convs of >= 128 rows that have too few 128-row tiles run on the LDS-tiled kernels with split-K
+    groups, and the Upsample 1x1 convs run the pixel shuffle there; from B = 16 on (unfused_min_rows_4 = 256 rows) the 4x4 ResnetBlocks run
+    GroupNorm as its own pass and their 3x3 convs on k_conv3_halo_sm (operand-type input, groups <= Cin / 128: two 64-channel chunks per
+    group at least, workgroups <= 256 + one tile row); B <= 4 plans hold no such op; the switches restore the r05 plans."""
+    from sparsefusion_amd import unet as U
+    net = U.Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2), layer_attns=(False, False, False, True),
+                 layer_cross_attns=(False,) * 4, cond_images_channels=256, attn_pool_text=False)
+    for B in (1, 2, 4):
+        ops = U._Plan(net, B, CPU).build().ops
+        assert not any(o.type == U.OP_CONV and o.i[14] >= 256 and (o.i[13] > 1 or o.flags & 2) for o in ops), B
+    for B in (8, 16, 32):
+        ops = U._Plan(net, B, CPU).build().ops
+        c4 = [o for o in ops if o.type == U.OP_CONV and o.i[1] == 4 and o.i[9] == 3 and o.i[11] == 1]
+        fused4 = sum(o.type == U.OP_FCONV and o.i[12] == U.FNORM_GN_SELF and o.i[1] == 4 and o.i[8] == 3 for o in ops)
+        assert all(o.i[14] >= 256 and o.i[13] > 1 for o in c4), (B, [(o.i[14], o.i[13]) for o in c4])
+        assert (len(c4), fused4) == ((1, 16) if B == 8 else (17, 0)), (B, len(c4), fused4)
+        for o in c4:
+            bnf, groups = o.i[14] - 256, o.i[13]
+            tiles = ((B * 16 + 127) // 128) * ((o.i[6] // 16 + bnf - 1) // bnf)
+            assert tiles * groups <= 256 + tiles, (B, tiles, groups)
+            if not o.flags & 1:                                      # operand-type input: k_conv3_halo_sm
+                assert o.i[3] % 64 == 0 and groups <= o.i[3] // 128, (B, o.i[3], groups)
+        ps = [o for o in ops if o.type == U.OP_CONV and o.flags & 2]
+        assert len(ps) == 3 and all(o.i[14] >= 256 and o.i[13] == 1 and not o.p[7] for o in ps), B
+    net.lds_mid_min_rows = 0
+    ops = U._Plan(net, 16, CPU).build().ops
+    assert not any(o.type == U.OP_CONV and o.i[14] >= 256 and (o.i[13] > 1 or o.flags & 2) for o in ops)
+    assert sum(o.type == U.OP_FCONV and o.i[12] == U.FNORM_GN_SELF and o.i[1] == 4 and o.i[8] == 3 for o in ops) == 16
