@@ -99,24 +99,36 @@ SF_KERNEL(256) void k_gemm_rows(GemmRowsArgs a) {
 // slice (same-wave DS order, no workgroup barrier inside the K loop), so the dependent chain is 4x shorter and every staging load of a chunk is
 // in flight at once; one LDS reduction over the 4 waves at the end.  Only the rows that exist are staged.  Same arithmetic per product as
 // k_gemm_rows (hi + lo split of x, bf16 weights), another summation order over K (per wave, then over waves).
-#define GRK_WAVE_ELEMS (2 * 64 * GR_LD)                                   // hi + lo slices of one wave, operand-type elements
-#define GRK_LDS_BYTES (4 * GRK_WAVE_ELEMS * 2 + 3 * 16 * 64 * 4)           // + the reduction buffer [3 waves][4 fragments x 4 rows][64 lanes]
+// NW waves per workgroup: 4 (up to 64 rows) or 8 (up to 32 rows: a 1024-column K is then ONE chunk per wave -- no second round trip behind the
+// first chunk's MFMAs; the slices hold 32 rows).  Dynamic LDS: NW hi + lo slices of ROWS rows + the reduction buffer [NW - 1][MFMAX x 4][64].
+template <int NW>
+struct GemmRowsKs {
+  static constexpr int ROWS = NW == 8 ? 32 : 64, MFMAX = ROWS / 16;
+  static constexpr int WAVE_ELEMS = 2 * ROWS * GR_LD;                      // hi + lo slices of one wave, operand-type elements
+  static constexpr int RED = MFMAX * 4 * 64;                               // floats per wave in the reduction buffer
+  static constexpr int LDS_BYTES = NW * WAVE_ELEMS * 2 + (NW - 1) * RED * 4;
+  static_assert(LDS_BYTES <= 163840, "LDS");
+};
 
-SF_KERNEL(256) void k_gemm_rows_ks(GemmRowsArgs a) {
+template <int NW>
+SF_KERNEL(NW * 64) void k_gemm_rows_ks(GemmRowsArgs a) {
+  using Gk = GemmRowsKs<NW>;
+  constexpr int MFMAX = Gk::MFMAX;
   SF_DYN_LDS(lds);
   const int tid = threadIdx.x, lane = tid & 63, wave = sf_uniform(tid >> 6);
-  sf_opnd* hi = reinterpret_cast<sf_opnd*>(lds) + wave * GRK_WAVE_ELEMS;
-  sf_opnd* lo = hi + 64 * GR_LD;
-  float* red = reinterpret_cast<float*>(lds + 4 * GRK_WAVE_ELEMS * 2);
+  sf_opnd* hi = reinterpret_cast<sf_opnd*>(lds) + wave * Gk::WAVE_ELEMS;
+  sf_opnd* lo = hi + Gk::ROWS * GR_LD;
+  float* red = reinterpret_cast<float*>(lds + NW * Gk::WAVE_ELEMS * 2);
   const int n = lane & 15, g = lane >> 4;
   const int ncol = blockIdx.x * 16 + n;
   const sf_opnd* __restrict__ wrow = a.W + (long)min(ncol, a.N - 1) * a.Kp;
   const int MF = (a.M + 15) >> 4;
   const bool vec = (a.ldx & 3) == 0 && (a.K & 7) == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;      // float4 loads of whole 8-column pieces
+  const float bv = (a.bias ? a.bias : reinterpret_cast<const float*>(a.W))[a.bias ? min(ncol, a.N - 1) : 0];      // requested at entry (an unconditional load from a selected address), used by wave 0's epilogue
   f32x4 acc[4];
 #pragma unroll
   for (int mf = 0; mf < 4; ++mf) acc[mf] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int kc = wave * GR_KC; kc < a.K; kc += 4 * GR_KC) {
+  for (int kc = wave * GR_KC; kc < a.K; kc += NW * GR_KC) {
     bf16x8 bw[GR_KC / 32];                          // the chunk's weight fragments, requested before its x rows are staged
 #pragma unroll
     for (int ks = 0; ks < GR_KC / 32; ++ks) {
@@ -128,9 +140,9 @@ SF_KERNEL(256) void k_gemm_rows_ks(GemmRowsArgs a) {
     if (vec && kc + GR_KC <= a.K) {
       // a whole chunk, float4 rows: ALL loads of the chunk first (a rolled loop waits for each pair before the next goes out: 8 L2 round
       // trips per chunk at 32 rows -- measured 11 us per launch), then the hi / lo split
-      f32x4 xv[16][2];
+      f32x4 xv[4 * MFMAX][2];
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
+      for (int it = 0; it < 4 * MFMAX; ++it) {
         const int idx = lane + it * 64;
         if (idx < lim) {
           const int m = idx / (GR_KC / 8), k8 = (idx % (GR_KC / 8)) * 8;
@@ -140,7 +152,7 @@ SF_KERNEL(256) void k_gemm_rows_ks(GemmRowsArgs a) {
         }
       }
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
+      for (int it = 0; it < 4 * MFMAX; ++it) {
         const int idx = lane + it * 64;
         if (idx < lim) {
           const int m = idx / (GR_KC / 8), k8 = (idx % (GR_KC / 8)) * 8;
@@ -191,7 +203,7 @@ SF_KERNEL(256) void k_gemm_rows_ks(GemmRowsArgs a) {
         const bf16x8 b = bw[ks];
         const int col = ks * 32 + 8 * g;
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf) {
+        for (int mf = 0; mf < MFMAX; ++mf) {
           if (mf < MF) {
             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&hi[(mf * 16 + n) * GR_LD + col]);
             const bf16x8 al = *reinterpret_cast<const bf16x8*>(&lo[(mf * 16 + n) * GR_LD + col]);
@@ -205,21 +217,23 @@ SF_KERNEL(256) void k_gemm_rows_ks(GemmRowsArgs a) {
   }
   if (wave > 0) {
 #pragma unroll
-    for (int mf = 0; mf < 4; ++mf)
+    for (int mf = 0; mf < MFMAX; ++mf)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[((wave - 1) * 16 + mf * 4 + r) * 64 + lane] = acc[mf][r];
+      for (int r = 0; r < 4; ++r) red[(wave - 1) * Gk::RED + (mf * 4 + r) * 64 + lane] = acc[mf][r];
   }
   sf_sync();
   if (wave != 0 || ncol >= a.N) return;
-  const float bv = a.bias ? a.bias[ncol] : 0.0f;
 #pragma unroll
-  for (int mf = 0; mf < 4; ++mf)
+  for (int mf = 0; mf < MFMAX; ++mf)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int m = mf * 16 + 4 * g + r;
       if (m < a.M) {
         const int o = (mf * 4 + r) * 64 + lane;
-        float v = acc[mf][r] + red[o] + red[16 * 64 + o] + red[2 * 16 * 64 + o] + bv;
+        float v = acc[mf][r];
+#pragma unroll
+        for (int w = 0; w < NW - 1; ++w) v += red[w * Gk::RED + o];
+        v += a.bias ? bv : 0.0f;
         if (a.out_act == 1) v = sf_silu(v);
         else if (a.out_act == 2) v = sf_sigmoid(v);
         a.y[(long)m * a.ldy + ncol] = v;

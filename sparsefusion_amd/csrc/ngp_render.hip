@@ -318,7 +318,7 @@ static NgpChunks ngp_bwd_plan(uint32_t N) {
     if (ok(N, k)) { equal(k); return c; }
   uint32_t k = NGP_BWD_CHUNKS;
   while (k > 1 && !ok(N, k)) --k;
-  if (k == 1 && N > 8192) {
+  if (N / k > 8192) {                   // (r06, ADVICE r05: also when an equal split exists but is coarser than 8192 rays -- N = 51 712 = 2 x 25 856)
     // r05: a ray count with no equal split (N = 200^2, 65 535, ...) used to fall back to ONE chunk, and the bins -- sized by
     // the largest chunk -- then grew with all rays (7.9 GB at 40 000 rays, 13 GB at 65 535).  Unequal chunks: as many chunks of `per`
     // rays (a multiple of 256, 8192 unless that needs more than 64 chunks) as fit, and the remainder as the last one; the kernels take

@@ -851,15 +851,18 @@ static int run_gemv(const sf_op& op, hipStream_t st) {
                    op.i[5], (int)(op.flags & 1), (int)((op.flags >> 1) & 3)};
     if (a.Kp < 8 || a.Kp % 8) SF_FAIL(SF_ERR_INVALID, "gemv: padded K must be a multiple of 8");
     if (N <= 4096 && !(op.flags & 8)) {                         // r06: the GlobalContext MLPs of a large batch -- N / 16 workgroups, K split over the waves (flag 8: the first form)
+      const bool w8 = M <= 32 && a.K > 4 * GR_KC;                // 8 waves: every wave has ONE chunk of a 1024-column K (the slices hold 32 rows)
       static unsigned mask = 0;
       int dev = 0;
       if (hipGetDevice(&dev) != hipSuccess) SF_FAIL(SF_ERR_LAUNCH, "hipGetDevice failed");
       if (dev >= 32 || !(mask & (1u << dev))) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_rows_ks), hipFuncAttributeMaxDynamicSharedMemorySize, GRK_LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_rows_ks<4>), hipFuncAttributeMaxDynamicSharedMemorySize, GemmRowsKs<4>::LDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_rows_ks<8>), hipFuncAttributeMaxDynamicSharedMemorySize, GemmRowsKs<8>::LDS_BYTES) != hipSuccess)
           SF_FAIL(SF_ERR_LAUNCH, "gemv: cannot raise the dynamic LDS limit of k_gemm_rows_ks");
         if (dev < 32) mask |= 1u << dev;
       }
-      k_gemm_rows_ks<<<sf_div_up(N, 16), 256, GRK_LDS_BYTES, st>>>(a);
+      if (w8) k_gemm_rows_ks<8><<<sf_div_up(N, 16), 512, GemmRowsKs<8>::LDS_BYTES, st>>>(a);
+      else k_gemm_rows_ks<4><<<sf_div_up(N, 16), 256, GemmRowsKs<4>::LDS_BYTES, st>>>(a);
       SF_CHECK_LAUNCH("gemm_rows_ks");
       return SF_OK;
     }

@@ -318,7 +318,7 @@ class _Plan:
     # -------- op emitters
     def conv(self, x, x_f32, H, W, wname, bname, out, ldc, co_off, Cout, k, stride=1, pad=0, resid=None, pixshuf=False,
              defer=False, w_ptr=None, batch=None, out_hw=None, upsampled=False, relu=False, gelu=False, twin=None, want_slots=False,
-             nchw=False):
+             nchw=False, defer_max_groups=8):
         """One implicit-GEMM launch.  `w_ptr` replaces the named weight by a device-packed B operand (attention),
         `batch` overrides the plan batch (per-sample GEMMs), `out_hw` the output size (asymmetric padding),
         `upsampled` makes (H, W) the dims of a nearest-x2 view of the stored [H/2, W/2] input.  `twin`: a dense operand-type
@@ -370,7 +370,7 @@ class _Plan:
             ws = self.ws_ptrs[wi]
         elif twin_ws:
             ws = twin_ws
-        defer = bool(defer and not relu and not gelu and 1 < groups <= 8 and not accum and not pixshuf and co_off == 0 and ldc == Cout == out.C and M == out.rows
+        defer = bool(defer and not relu and not gelu and 1 < groups <= defer_max_groups and not accum and not pixshuf and co_off == 0 and ldc == Cout == out.C and M == out.rows
                      and (self.u.lazy_consumers & 1))
         bias, res = self.wptr(bname) if bname else 0, resid.ptr if resid else 0
         # r04: the SiLU + PixelShuffle epilogue of an Upsample also leaves the (sum, sum of squares) slots of its output for the next
@@ -646,6 +646,16 @@ class _Plan:
         gr = self.fused_geometry(H, cin, cout, FNORM_NONE, 1) if cin != cout else g1
         if g1 is None or g2 is None or gr is None or x.C % 32 or rows % 16:
             return None
+        if (B >= 2 and (getattr(self.u, "rc_small_tiles", 0) & H) and cin != cout and skip is not None and getattr(self.u, "conv3s", True)
+                and getattr(self.u, "pair_res_conv", True)):
+            # r06: a (conv1 on the concat || res_conv) pair of B >= 2 keeps the B = 1 tile where k_conv3s_rc has it: the 32- / 64-pixel tiles of
+            # B >= 2 do not fit that kernel's registers, and the general pair kernel they fall back to is slower than more workgroups of the small one
+            TR0, WM0 = {8: (2, 1), 16: (1, 1), 32: (1, 2)}[H]
+            s1, sr = self._fused_geometry(H, cin, cout, norm, 3, TR0, WM0), self._fused_geometry(H, cin, cout, FNORM_NONE, 1, TR0, WM0)
+            tw = getattr(self.u, f"conv3s_tw{H}", 0) or H
+            if (s1 is not None and sr is not None and s1[1:3] == sr[1:3] and sr[3] == 1
+                    and (H.bit_length() - 1, x.C, skip.C, cout, tw.bit_length() - 1, s1[1], s1[2]) in CONV3S_RC_VARIANTS):
+                g1, gr = s1, sr
         slots = norm == FNORM_GN_SLOTS
         h = self.zf32(rows, cout, HW)
         # conv1 and res_conv read the same input and are independent: one launch (k_conv_fused_pair) when their tiles match
@@ -762,7 +772,8 @@ class _Plan:
         rows = B * HW
         # large batches at the 32x32 / 16x16 levels: GroupNorm as its own pass + the 3x3 convs on k_conv3_halo (csrc/conv_halo.h, 700-950
         # TFLOP/s from 128 tiles on) beat the GroupNorm-fused weight-streaming kernels, which are built for M of a few tiles
-        big = rows >= getattr(self.u, "unfused_min_rows", 1 << 30) and H % 16 == 0 and cin % 64 == 0 and cout % 64 == 0
+        big = (rows >= (getattr(self.u, f"unfused_min_rows_{H}", 0) or getattr(self.u, "unfused_min_rows", 1 << 30)) and H % 16 == 0 and cin % 64 == 0
+               and cout % 64 == 0)                  # (unfused_min_rows_16 / _32: a per-level threshold, 0 = unfused_min_rows)
         # r06: the 4x4 / 8x8 levels of large batches likewise (their 3x3 convs then run on k_conv_glds with split-K groups, conv(): lds_mid_min_rows)
         low = getattr(self.u, f"unfused_min_rows_{H}", 0) if H in (4, 8) else 0
         big = big or bool(low and rows >= low and getattr(self.u, "lds_mid_min_rows", 0) and cin % 64 == 0 and cout % 64 == 0)
@@ -1033,7 +1044,9 @@ class _Plan:
             if lv < n_lv - 1:
                 y = self.zf32(B * (H // 2) ** 2, do, (H // 2) ** 2)
                 # split-K partials stay in the workspace: the consumer (slot pass / 4x4 GroupNorm prologue) reduces them
-                self.conv(x, True, H, H, f"downs.{lv}.4.weight", f"downs.{lv}.4.bias", y, do, 0, do, 4, 2, 1, defer=bool(u.fused))
+                # (into the 4x4 level: k_conv4_gn gathers at most 4 slabs -- more would send its consumer to the general kernel, silently: ADVICE r05)
+                self.conv(x, True, H, H, f"downs.{lv}.4.weight", f"downs.{lv}.4.bias", y, do, 0, do, 4, 2, 1, defer=bool(u.fused),
+                          defer_max_groups=4 if (H // 2 == 4 and getattr(u, "conv4", True)) else 8)
                 H //= 2
             else:
                 y = self.zf32(B * H * H, do, H * H)
@@ -1041,7 +1054,7 @@ class _Plan:
                 # conv whose centre tap carries the 1x1 weights too (merged at pack time, Unet._packed): one launch and one
                 # 18.9 MB weight stream instead of two launches + a split-K reduction; its partials stay lazy for mid_block1
                 self.conv(x, True, H, H, f"downs.{lv}.4.__merged__.weight", f"downs.{lv}.4.__merged__.bias", y, do, 0, do, 3, 1, 1,
-                          defer=bool(u.fused))
+                          defer=bool(u.fused), defer_max_groups=4 if (H == 4 and getattr(u, "conv4", True)) else 8)
             x = y
         mid = x.C
         x = self.resnet("mid_block1", x, None, mid, H, cross=True)
@@ -1181,11 +1194,14 @@ class Unet(nn.Module):
         self.conv_waves_target = 1024       # waves wanted per conv launch (4 per CU) before split-K stops
         self.lds_conv_min_blocks = 96       # use k_conv_lds when a layer has at least this many 128 x 128 output tiles
         self.lds_mid_min_rows = 128      # r06: convs of >= this many rows that have too few 128-row tiles for lds_conv_min_blocks run on the LDS-tiled kernels with split-K groups (_Plan.conv); 0 = off
+        self.rc_small_tiles = 32         # r06: bit mask of map sides (32 | 16 | 8) whose B >= 2 (conv1 || res_conv) pairs keep the B = 1 tile of k_conv3s_rc (32: B = 2 eval 1.155 -> 1.139 ms, B = 4 1.562 -> 1.520; 32 | 16: B = 4 1.580, B = 8 2.451 -> 2.550)
         self.gn_one = True               # r06: GroupNorm passes of B >= 32 plans (B * 8 >= 256 workgroups) in one launch (k_gn_one); False: k_gn_stats + k_gn_apply everywhere
         self.lds_mid_min_batch = 8       # ... in plans of at least this many images (the B = 1 .. 4 plans keep their measured kernels)
         self.unfused_min_rows_4 = 256    # r06: 4x4-level ResnetBlocks with B*16 >= this leave the fused kernels (as unfused_min_rows at 32x32 / 16x16; measured: B = 8 loses 0.12 ms, B = 16 gains 0.22, B = 32 0.49); 0 = never
         self.unfused_min_rows_8 = 1024   # ... 8x8 level (k_conv3_halo_sm; measured: B = 8 loses 0.14 ms, B = 16 gains 0.04, B = 32 0.56)
         self.unfused_lin_min_rows = 256      # r06: attention / feed-forward linears of the 4x4 level with >= this many token rows leave the fused kernels (measured: B = 16 3.683 -> 3.670 ms, B = 32 4.664 -> 4.472)
+        self.unfused_min_rows_16 = 4096  # r06: the 16x16 level's own threshold (0 = unfused_min_rows; measured with k_gemm_rows_ks / the r06 plans: B = 16 3.641 -> 3.313 ms; 2048 rows lose: B = 8 2.454 -> 2.512)
+        self.unfused_min_rows_32 = 0     # ... 32x32 level (4096 rows lose: B = 4 1.575 -> 1.686 ms)
         self.unfused_min_rows = 8192     # ResnetBlocks with B*H*W >= this at the 32x32 / 16x16 levels leave the fused kernels (_Plan.resnet; measured r03: B = 8 eval 3.33 -> 2.96 ms, B = 32 11.5 -> 7.8 ms, B = 4 unchanged)
         self.lazy_consumers = 3             # bit 0: split-K reductions, bit 1: gated residuals are materialised by their first consumer
         # Planner attributes (plain Python attributes since r04 -- the SF_* environment switches of the r01-r03 A/B runs are retired;

@@ -19,5 +19,6 @@ extern "C" void emu_gemm_rows(const float* x, const uint16_t* W, const float* bi
 extern "C" void emu_gemm_rows_ks(const float* x, const uint16_t* W, const float* bias, float* y, int M, int N, int K, int Kp, int ldx,
                                  int ldy, int in_silu, int out_act) {
   GemmRowsArgs a{x, reinterpret_cast<const __bf16*>(W), bias, y, M, N, K, Kp, ldx, ldy, in_silu, out_act};
-  hipemu::launch((unsigned)((N + 15) / 16), 256, GRK_LDS_BYTES, [&] { k_gemm_rows_ks(a); });
+  if (M <= 32 && K > 4 * GR_KC) hipemu::launch((unsigned)((N + 15) / 16), 512, GemmRowsKs<8>::LDS_BYTES, [&] { k_gemm_rows_ks<8>(a); });      // (run_gemv's rule)
+  else hipemu::launch((unsigned)((N + 15) / 16), 256, GemmRowsKs<4>::LDS_BYTES, [&] { k_gemm_rows_ks<4>(a); });
 }

@@ -95,7 +95,7 @@ def test_render_backward_workspace_is_bounded_for_any_ray_count():
     T = 64
     per_sample = 72 * T * 4                                            # composite / field gradients: 72 N T floats
     bins_8192 = 8192 * 2 * T * 4 * 24 * 16                             # 96 sixteen-byte entries per sample of one 8192-ray chunk
-    for N in (16384, 40000, 65535, 10000, 8192 * 3 + 1):
+    for N in (16384, 40000, 65535, 10000, 8192 * 3 + 1, 51712):        # 51 712 = 2^9 x 101: its only equal split is 2 x 25 856 rays (r06)
         wb = lib.sf_ngp_render_workspace_bytes(N, T)
         assert wb <= N * per_sample + bins_8192 + (1 << 24), (N, wb)            # + cursors and per-bucket slack (8.4 MB)
     assert lib.sf_ngp_render_workspace_bytes(256, T) < 256 * per_sample + 256 * 2 * T * 4 * 24 * 16 + (1 << 24)

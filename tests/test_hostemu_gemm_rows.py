@@ -33,7 +33,8 @@ def _lib():
     (64, 48, 64, 64, 48, 0, 0, True),
     (32, 512, 1024, 1024, 512, 0, 1, True),    # GlobalContext net.0 of a 1024-channel block at B = 32: 8 chunks, two per wave (float4 staging)
     (9, 1024, 512, 512, 1024, 0, 2, True),     # net.2 at B = 9: one m-fragment, sigmoid
-    (16, 40, 648, 648, 40, 1, 0, False),       # 6 chunks (waves 0, 1 take two, the last ragged: 8 columns), ragged N
+    (16, 40, 648, 648, 40, 1, 0, False),       # 6 chunks over 8 waves (two idle, the last ragged: 8 columns), ragged N
+    (40, 64, 1024, 1024, 64, 0, 0, True),      # 40 rows: the 4-wave form, two chunks per wave
 ])
 @pytest.mark.parametrize("ks", [False, True])
 def test_gemm_rows_matches_fp32_x_times_bf16_w(M, N, K, ldx, ldy, in_silu, out_act, bias, ks):

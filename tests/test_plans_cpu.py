@@ -435,3 +435,38 @@ def test_large_batch_plans_run_the_4x4_level_on_the_lds_tiled_kernels():
     ops = U._Plan(net, 16, CPU).build().ops
     assert not any(o.type == U.OP_CONV and o.i[14] >= 256 and (o.i[13] > 1 or o.flags & 2) for o in ops)
     assert sum(o.type == U.OP_FCONV and o.i[12] == U.FNORM_GN_SELF and o.i[1] == 4 and o.i[8] == 3 for o in ops) == 16
+
+
+def test_every_forced_4_slice_conv_meets_the_host_predicates_of_k_conv4_gn():
+    """the planner forces S = 4 (and un-pairs the res_conv) for the 4x4 GroupNorm-self convs on ITS assumptions; the host decides
+    later (csrc/fused_host.h: conv4_cs4, conv4_mb_setup) and silently falls back to the general kernel -- 4 slices + a reduce launch, correct
+    but slow -- when a predicate fails.  The predicates, restated on the planned ops (sized plans: real arena offsets): 16-byte aligned
+    affine operands and a float4-aligned scale/shift row stride; a lazy split-K source of at most 4 slabs; a slice of two whole groups in
+    ONE source (C1 % Cs == 0) of 256 | 512 channels; B >= 2: 32-bit element offsets and, for Cs = 512, no split-K source unless B is odd."""
+    from sparsefusion_amd import unet as U
+    net = U.Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2), layer_attns=(False, False, False, True),
+                 layer_cross_attns=(False,) * 4, cond_images_channels=256, attn_pool_text=False)
+    net.unfused_min_rows_4 = 0                                      # keep the 4x4 level on the fused kernels at every B
+    checked = 0
+    for B in (1, 2, 3, 4, 6, 8, 16, 32):
+        s = U._Plan(net, B, CPU).build()
+        plan = U._Plan(net, B, CPU, (s.zero.off, s.misc.off + s.ws_bytes + s.ws2_bytes + 512, s.ws_bytes, s.ws2_bytes)).build()
+        for k, o in enumerate(plan.ops):
+            if not (o.type == U.OP_FCONV and o.i[12] == U.FNORM_GN_SELF and o.i[1] == 4 and o.i[8] == 3 and o.i[17] == 4):
+                continue
+            if o.flags & (16 | 32 | 64 | 128):
+                continue                                            # pairs / pipelined / pooled ops are not k_conv4_gn's
+            where = (B, k)
+            C1, C2, S = o.i[3], o.i[4], o.i[17]
+            C = C1 + C2
+            Cs = C // S
+            assert Cs in (256, 512) and (C // 8) * 2 == Cs, where                        # a slice = two whole groups
+            assert C1 % Cs == 0, where                                                   # ... inside ONE source
+            assert o.p[13] % 16 == 0 and o.p[14] % 16 == 0 and (o.p[15] or 0) % 16 == 0 and o.i[18] % 4 == 0, where      # gamma, beta, scale/shift row
+            assert o.i[14:17] == [4, 1, 1][:3] or tuple(o.i[14:17]) == (4, 1, 1), where  # TR, WM, WN
+            if o.i[9] == 1:
+                assert o.i[10] <= 4, where                                               # lazy split-K source: <= 4 slabs
+            if B >= 2 and not (o.i[19] & 1):
+                assert B * 16 * max(C1, o.i[11]) < (1 << 30), where                      # 32-bit element offsets
+            checked += 1
+    assert checked >= 8 * 12
