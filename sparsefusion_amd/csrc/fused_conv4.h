@@ -20,8 +20,10 @@
 #pragma once
 #include "fused_kernels.h"
 
-// CS4 = float4 chunks per slice (64: Cs = 256, 128: Cs = 512); LAZY = mode of source 1 (FSrc)
-template <int CS4, int LAZY>
+// CS4 = float4 chunks per slice (64: Cs = 256, 128: Cs = 512); LAZY = mode of source 1 (FSrc); NORM = false (r06): the same launch without the
+// GroupNorm -- FNORM_NONE, the operand is the (scaled) source value, SiLU only if the op asks: the merged 3x3 + 1x1 conv of the last Downsample
+// (imagen_pytorch.py:1294-1297), which ran on k_conv_igemm at 13.5 us where its GroupNorm-self neighbours take 7.5
+template <int CS4, int LAZY, bool NORM = true>
 SF_DEV void conv4_gn_body(const FConvArgs& a, const int bid) {
   constexpr int NT = 512, NE = CS4 / 32;              // 16 pixels x CS4 chunks over 512 threads: 2 | 4 elements per thread
   constexpr int CPS = CS4 / 8;                        // 32-channel k-chunks per slice: 8 | 16
@@ -44,17 +46,20 @@ SF_DEV void conv4_gn_body(const FConvArgs& a, const int bid) {
   FGather<LAZY> gq[NE];
 #pragma unroll
   for (int u = 0; u < NE; ++u) gq[u].issue(a, mb + px0 + u * (NT / CS4), c);
-  const float* ssrow = a.ss ? a.ss + (long)b * a.ss_stride : a.gamma;      // any valid address when there is no scale / shift
-  const int shoff = a.ss ? a.C : 0;
-  f32x4 qg = *reinterpret_cast<const f32x4*>(a.gamma + c);
-  f32x4 qb = *reinterpret_cast<const f32x4*>(a.beta + c);
-  const f32x4 qsc = *reinterpret_cast<const f32x4*>(ssrow + c);
-  const f32x4 qsh = *reinterpret_cast<const f32x4*>(ssrow + shoff + c);
+  f32x4 qg = f32x4{1.f, 1.f, 1.f, 1.f}, qb = f32x4{0.f, 0.f, 0.f, 0.f}, qsc = qb, qsh = qb;
+  if constexpr (NORM) {
+    const float* ssrow = a.ss ? a.ss + (long)b * a.ss_stride : a.gamma;      // any valid address when there is no scale / shift
+    const int shoff = a.ss ? a.C : 0;
+    qg = *reinterpret_cast<const f32x4*>(a.gamma + c);
+    qb = *reinterpret_cast<const f32x4*>(a.beta + c);
+    qsc = *reinterpret_cast<const f32x4*>(ssrow + c);
+    qsh = *reinterpret_cast<const f32x4*>(ssrow + shoff + c);
+  }
   const int nf = nt < a.n_frags ? nt : a.n_frags - 1;
   const int n = nf * 16 + (lane & 15);
   // context-logit weight of this output channel (wave 0 uses it): an UNCONDITIONAL load from a selected address, ahead of the weight
   // slice -- a load under `if (a.wk)` behind it would make the compiler drain the whole slice at the merge
-  const float wkq = (a.wk ? a.wk : a.gamma)[a.wk && n < a.Cout ? n : 0];
+  const float wkq = (a.wk ? a.wk : reinterpret_cast<const float*>(a.w))[a.wk && n < a.Cout ? n : 0];
   const float wkv = a.wk ? wkq : 0.0f;
   const bf16x8* wbase = a.w + ((long)nf * a.KS + s * CPS) * 64 + lane;
   bf16x8 fb[KW];
@@ -85,30 +90,32 @@ SF_DEV void conv4_gn_body(const FConvArgs& a, const int bid) {
     sm += (w[0] + w[1]) + (w[2] + w[3]);
     sq = fmaf(w[0], w[0], sq); sq = fmaf(w[1], w[1], sq); sq = fmaf(w[2], w[2], sq); sq = fmaf(w[3], w[3], sq);
   }
-  sm = sf_group_sum(sm, W);
-  sq = sf_group_sum(sq, W);
-  float* misc = reinterpret_cast<float*>(lds + a.misc_off);
-  float* part = misc + 160;                              // [NSEG][2]
-  if ((lane & (W - 1)) == 0) { part[2 * (tid / W)] = sm; part[2 * (tid / W) + 1] = sq; }
-  sf_sync();
-  // ---- (4) (mean, rstd) of this thread's group: its NSEG / 2 partials in segment order (uniform addresses per half-wave: broadcasts)
-  const int gi = c4 / W;                                 // 0 | 1
-  double S = 0.0, Q = 0.0;
+  if constexpr (NORM) {
+    sm = sf_group_sum(sm, W);
+    sq = sf_group_sum(sq, W);
+    float* misc = reinterpret_cast<float*>(lds + a.misc_off);
+    float* part = misc + 160;                              // [NSEG][2]
+    if ((lane & (W - 1)) == 0) { part[2 * (tid / W)] = sm; part[2 * (tid / W) + 1] = sq; }
+    sf_sync();
+    // ---- (4) (mean, rstd) of this thread's group: its NSEG / 2 partials in segment order (uniform addresses per half-wave: broadcasts)
+    const int gi = c4 / W;                                 // 0 | 1
+    double S = 0.0, Q = 0.0;
 #pragma unroll
-  for (int k = 0; k < NSEG / 2; ++k) {
-    S += (double)part[2 * (2 * k + gi)];
-    Q += (double)part[2 * (2 * k + gi) + 1];
-  }
-  const double mean_d = S * a.inv_n;
-  double var = Q * a.inv_n - mean_d * mean_d;
-  if (var < 0.0) var = 0.0;
-  const float mean = (float)mean_d, rstd = sf_rsqrt((float)var + a.eps);
-  // y = x * A + B  ==  ((x - mean) * rstd * gamma + beta) * (scale + 1) + shift   (x = the scaled source value)
+    for (int k = 0; k < NSEG / 2; ++k) {
+      S += (double)part[2 * (2 * k + gi)];
+      Q += (double)part[2 * (2 * k + gi) + 1];
+    }
+    const double mean_d = S * a.inv_n;
+    double var = Q * a.inv_n - mean_d * mean_d;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)mean_d, rstd = sf_rsqrt((float)var + a.eps);
+    // y = x * A + B  ==  ((x - mean) * rstd * gamma + beta) * (scale + 1) + shift   (x = the scaled source value)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float A = rstd * qg[j], scj = a.ss ? qsc[j] + 1.0f : 1.0f, shj = a.ss ? qsh[j] : 0.0f;
-    qg[j] = A * scj;
-    qb[j] = (qb[j] - mean * A) * scj + shj;
+    for (int j = 0; j < 4; ++j) {
+      const float A = rstd * qg[j], scj = a.ss ? qsc[j] + 1.0f : 1.0f, shj = a.ss ? qsh[j] : 0.0f;
+      qg[j] = A * scj;
+      qb[j] = (qb[j] - mean * A) * scj + shj;
+    }
   }
   // ---- (5) normalise, activate, bf16 into the frame; the workgroups of n-tile 0 materialise a lazy first source
 #pragma unroll
@@ -160,10 +167,10 @@ SF_DEV void conv4_gn_body(const FConvArgs& a, const int bid) {
   }
 }
 
-template <int CS4, int LAZY>
+template <int CS4, int LAZY, bool NORM = true>
 SF_KERNEL(512) void k_conv4_gn(FConvArgs a) {
   sf_touch_kernarg<(int)sizeof(FConvArgs)>();
-  conv4_gn_body<CS4, LAZY>(a, (int)blockIdx.x);
+  conv4_gn_body<CS4, LAZY, NORM>(a, (int)blockIdx.x);
 }
 
 // k_conv4_gn_mb: the same op for NB = 2 | 4 images per workgroup (r05, B >= 2).  With one image per workgroup every image's 256 workgroups

@@ -263,10 +263,15 @@ static inline int lin4_c4t(const sf_op& op, const FConvArgs& a, int WM, int WN) 
 
 // k_conv4_gn (fused_conv4.h, r05) takes the op when it is the 4x4 level's GroupNorm-self 3x3 conv in the geometry the kernel is written
 // for; returns CS4 (64 | 128) or 0 = the general kernel.  Op flag 128 (planner attribute Unet.conv4 = False) keeps the general kernel.
+// (r06: also the same geometry WITHOUT a norm -- k_conv4_gn<CS4, 0, false>: one plain source, slices of 256 channels, B = 1)
+static inline bool conv4_nonorm(const FConvArgs& a) {
+  return a.norm == FNORM_NONE && a.B == 1 && a.s1.mode == 0 && a.s2.C == 0 && a.cps == 8 && !a.wk && !a.pre_gelu && ((uintptr_t)a.s1.p & 15) == 0;
+}
 static inline int conv4_cs4(const sf_op& op, const FConvArgs& a, int WM, int WN) {
   if (op.flags & (16 | 32 | 64 | 128)) return 0;
-  if (a.norm != FNORM_GN_SELF || a.H != 4 || a.W != 4 || a.k != 3 || a.TR != 4 || WM != 1 || WN != 1) return 0;
+  if ((a.norm != FNORM_GN_SELF && !conv4_nonorm(a)) || a.H != 4 || a.W != 4 || a.k != 3 || a.TR != 4 || WM != 1 || WN != 1) return 0;
   if (a.S < 2 || !a.ws || a.dbg || a.G != 8 || (a.cps != 8 && a.cps != 16)) return 0;
+  if (a.norm == FNORM_NONE) return a.cps * 8;
   if (((a.C / a.G) / 4) * 2 != a.cps * 8) return 0;                        // a slice = two whole groups
   if (a.s1.mode == 1 && a.s1.groups > 4) return 0;
   if (((uintptr_t)a.gamma | (uintptr_t)a.beta | (uintptr_t)a.ss) & 15 || (a.ss && a.ss_stride % 4)) return 0;      // float4 affine operands
@@ -336,7 +341,7 @@ static inline int conv3s_rc_twl(const sf_op& op1, const FConvArgs& a, const FCon
 // LDS layout (NB frames, a reduction buffer per image) and the grid, or 0 = one image per workgroup.  Op field i[19] bit 0 (planner
 // attribute Unet.conv4_mb = False; FNORM_ATTN ops use i[19] otherwise) keeps k_conv4_gn.
 static inline int conv4_mb_setup(const sf_op& op, FConvArgs& a, int cs4, uint32_t& grid, uint32_t& lds_bytes) {
-  if ((op.i[19] & 1) || a.B < 2) return 0;
+  if ((op.i[19] & 1) || a.B < 2 || a.norm != FNORM_GN_SELF) return 0;
   if (a.s1.C % (cs4 * 4)) return 0;                                         // a slice lies in ONE source: the kernel selects its base pointers per workgroup
   if ((long)a.M * (a.s1.mode == 1 ? a.s1.npad : a.s1.C) >= (1L << 30)) return 0;     // 32-bit element offsets
   int nb = 0;

@@ -25,11 +25,11 @@ static int launch_fconv(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStre
   return SF_OK;
 }
 
-template <int CS4, int LAZY>
+template <int CS4, int LAZY, bool NORM = true>
 static int launch_conv4(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStream_t st) {
   static unsigned mask = 0;
-  if (int rc = allow_big_lds(k_conv4_gn<CS4, LAZY>, lds, mask)) return rc;
-  k_conv4_gn<CS4, LAZY><<<grid, 512, lds, st>>>(a);
+  if (int rc = allow_big_lds(k_conv4_gn<CS4, LAZY, NORM>, lds, mask)) return rc;
+  k_conv4_gn<CS4, LAZY, NORM><<<grid, 512, lds, st>>>(a);
   SF_CHECK_LAUNCH("conv4_gn");
   return SF_OK;
 }
@@ -109,6 +109,7 @@ static int run_fconv(const sf_op& op, hipStream_t st) {
 #undef SF_TRY4M
       SF_FAIL(SF_ERR_INVALID, "fconv: no k_conv4_gn_mb variant for Cs4 %d lazy %d x %d images", cs4, a.s1.mode, nb);
     }
+    if (a.norm == FNORM_NONE) return launch_conv4<64, 0, false>(a, grid, lds, st);      // (conv4_nonorm: Cs = 256, plain source)
 #define SF_TRY4(c4_, lz_) if (cs4 == c4_ && a.s1.mode == lz_) return launch_conv4<c4_, lz_>(a, grid, lds, st);
     SF_TRY4(64, 0) SF_TRY4(64, 1) SF_TRY4(64, 2) SF_TRY4(128, 0) SF_TRY4(128, 1) SF_TRY4(128, 2)
 #undef SF_TRY4

@@ -774,7 +774,7 @@ static int run_gn(const sf_op& op, hipStream_t st) {
   const int c4 = C / 4;
   // r06: one launch for statistics + normalisation when B * G workgroups are a fair share of the chip and a group's slab fits the registers of its
   // workgroup (the large-batch UNet plans: G = 8, B >= 32; flag 4 = the two-launch form, flag 8 = this form at any B, for comparison)
-  if (!(op.flags & (2 | 4)) && (B * G >= 256 || (op.flags & 8)) && chunks <= 1024 * 16) {      // (measured: B = 32 eval 4.81 -> 4.66 ms; at 64 / 128 workgroups the pair wins: B = 8 2.46 vs 2.54 ms, B = 16 3.65 vs 3.68; flag 8 forces k_gn_one)
+  if (!(op.flags & (2 | 4)) && (B * G >= 256 || (B * G >= 64 && (long)B * HW * C <= (1L << 19)) || (op.flags & 8)) && chunks <= 1024 * 16) {      // (... or a tensor of <= 2 MB on >= 64 workgroups: the 4x4 level of B >= 8)      // (measured: B = 32 eval 4.81 -> 4.66 ms; at 64 / 128 workgroups the pair wins: B = 8 2.46 vs 2.54 ms, B = 16 3.65 vs 3.68; flag 8 forces k_gn_one)
     float* s1 = (float*)op.p[0];
     const float *s2 = (const float*)op.p[1], *ga = (const float*)op.p[2], *be = (const float*)op.p[3], *ssp = (const float*)op.p[4];
     sf_opnd *o = (sf_opnd*)op.p[5], *rw = (sf_opnd*)op.p[6];

@@ -1053,8 +1053,16 @@ class _Plan:
                 # Parallel(conv3x3, conv1x1) of the last level (imagen_pytorch.py:1294-1297: the two outputs are summed) = ONE 3x3
                 # conv whose centre tap carries the 1x1 weights too (merged at pack time, Unet._packed): one launch and one
                 # 18.9 MB weight stream instead of two launches + a split-K reduction; its partials stay lazy for mid_block1
-                self.conv(x, True, H, H, f"downs.{lv}.4.__merged__.weight", f"downs.{lv}.4.__merged__.bias", y, do, 0, do, 3, 1, 1,
-                          defer=bool(u.fused), defer_max_groups=4 if (H == 4 and getattr(u, "conv4", True)) else 8)
+                if (B == 1 and u.fused and getattr(u, "conv4", True) and getattr(u, "merged_down_conv4", True) and H == 4 and x.C == do == 1024
+                        and x.rows == 16 and (x.lazy is None or x.lazy[0] != "splitk")):
+                    # r06: ... on k_conv4_gn's un-normalised form (csrc/fused_conv4.h, NORM = false): 4 slices of 256 channels, slabs out
+                    # (13.5 -> ~7 us at B = 1; k_conv_igemm keeps it for B >= 2, where k_conv4_gn_mb has no such form)
+                    self.need(x)
+                    self.fconv(x, None, 4, f"downs.{lv}.4.__merged__.weight", f"downs.{lv}.4.__merged__.bias", y, do, 3, FNORM_NONE, (4, 1, 1, 4),
+                               silu=False)
+                else:
+                    self.conv(x, True, H, H, f"downs.{lv}.4.__merged__.weight", f"downs.{lv}.4.__merged__.bias", y, do, 0, do, 3, 1, 1,
+                              defer=bool(u.fused), defer_max_groups=4 if (H == 4 and getattr(u, "conv4", True)) else 8)
             x = y
         mid = x.C
         x = self.resnet("mid_block1", x, None, mid, H, cross=True)
@@ -1194,6 +1202,7 @@ class Unet(nn.Module):
         self.conv_waves_target = 1024       # waves wanted per conv launch (4 per CU) before split-K stops
         self.lds_conv_min_blocks = 96       # use k_conv_lds when a layer has at least this many 128 x 128 output tiles
         self.lds_mid_min_rows = 128      # r06: convs of >= this many rows that have too few 128-row tiles for lds_conv_min_blocks run on the LDS-tiled kernels with split-K groups (_Plan.conv); 0 = off
+        self.merged_down_conv4 = True     # r06: the merged 3x3 + 1x1 conv of the last Downsample on k_conv4_gn<64, 0, false> at B = 1; False: k_conv_igemm
         self.rc_small_tiles = 32         # r06: bit mask of map sides (32 | 16 | 8) whose B >= 2 (conv1 || res_conv) pairs keep the B = 1 tile of k_conv3s_rc (32: B = 2 eval 1.155 -> 1.139 ms, B = 4 1.562 -> 1.520; 32 | 16: B = 4 1.580, B = 8 2.451 -> 2.550)
         self.gn_one = True               # r06: GroupNorm passes of B >= 32 plans (B * 8 >= 256 workgroups) in one launch (k_gn_one); False: k_gn_stats + k_gn_apply everywhere
         self.lds_mid_min_batch = 8       # ... in plans of at least this many images (the B = 1 .. 4 plans keep their measured kernels)

@@ -411,6 +411,8 @@ CONV_CASES = {
     "conv4_mb_concat_plain_2048_b2": dict(B=2, H=4, W=4, C1=1024, C2=1024, Cout=16, k=3, norm=GN_SELF, WM=1, WN=1, S=4, seed=80, ss=False),
     "conv4_mb_concat_lazy_512_512_b4": dict(B=4, H=4, W=4, C1=512, C2=512, Cout=16, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=1, seed=81),
     "conv4_one_image_per_workgroup_b4": dict(B=4, H=4, W=4, C1=1024, C2=0, Cout=16, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=1, seed=75, one_image=True),
+    # r06: the same geometry without a norm (k_conv4_gn<64, 0, false>): the merged 3x3 + 1x1 conv of the last Downsample at B = 1
+    "conv4_no_norm_plain_1024": dict(B=1, H=4, W=4, C1=1024, C2=0, Cout=32, k=3, norm=NONE, WM=1, WN=1, S=4, silu=False, ss=False, slots=False, seed=145),
     "conv4_geometry_on_the_general_kernel": dict(B=1, H=4, W=4, C1=1024, C2=0, Cout=16, k=3, norm=GN_SELF, WM=1, WN=1, S=4, lazy=1, seed=71, general=True),
     # 8x8 level: 2-row tiles with halo rows from neighbouring tiles, statistics from producer slots, final epilogue + slots
     "gn_slots_concat_8x8": dict(B=1, H=8, W=8, C1=128, C2=128, Cout=32, k=3, norm=GN_SLOTS, WM=1, WN=1, resid=True, seed=2),

@@ -137,6 +137,7 @@ extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
         snprintf(err, errn, "fconv: no k_conv4_gn_mb variant");
         return 1;
       }
+      if (a.norm == FNORM_NONE) { hipemu::launch(grid, 512, lds, [&] { k_conv4_gn<64, 0, false>(a); }); ++g_conv4_launches; return 0; }
 #define SF_TRY4(c4_, lz_) \
       if (cs4 == c4_ && a.s1.mode == lz_) { hipemu::launch(grid, 512, lds, [&] { k_conv4_gn<c4_, lz_>(a); }); ++g_conv4_launches; return 0; }
       SF_TRY4(64, 0) SF_TRY4(64, 1) SF_TRY4(64, 2) SF_TRY4(128, 0) SF_TRY4(128, 1) SF_TRY4(128, 2)

@@ -168,7 +168,7 @@ def test_plan_switches_match_oracle(switch):
     y_def = net.forward_with_cond_scale(x.to(DEV), ls.to(DEV), cond_images=cond.to(DEV)).cpu()
     n_def = [o.type for o in net._plan(B, torch.device(DEV)).ops]
     if switch == "hybrid_rows":
-        net.unfused_min_rows = 512
+        net.unfused_min_rows = net.unfused_min_rows_16 = 512       # (r06: the 16x16 level has a threshold of its own)
     elif switch == "no_big_tiles":
         net.big_tile_min_batch = 999
     else:
@@ -242,6 +242,29 @@ def test_large_batch_default_plans_match_oracle(B, plan):
     # the batch plan and the one-image plan agree per image to the same bf16 bound (other tiles, other summation orders)
     y0 = net.forward_with_cond_scale(x[B - 1:].to(DEV), ls[B - 1:].to(DEV), cond_images=cond[B - 1:].to(DEV)).cpu()
     assert rel_err(y0, y[B - 1:]) < TOL_REL
+
+
+@pytest.mark.parametrize("B", [3, 5, 9, 12, 17, 24])
+def test_ragged_batches_agree_with_the_one_image_plan(B):
+    """The r06 planner rules switch kernels by row counts (128 / 256 / 1024 / 4096 / 8192 rows, 128-row tiles of whole 4x4 / 8x8 maps, split-K
+    groups, k_gemm_rows_ks with 4 | 8 waves, k_gn_one from 256 workgroups): batches that fill their last tile only partly (B = 9: 144 rows at the
+    4x4 level = 1.125 tiles; B = 17: the first batch past the 256-row and 4096-row thresholds with a one-map tail; odd B: no k_conv4_gn_mb) are where
+    a tail bug would live.  Every image of the batch against the SAME image through the one-image plan (itself pinned to the reference golden):
+    same bound as between two plans of one batch, and the batch output is finite everywhere."""
+    name = "canonical"
+    sd = state(name)
+    net = _unet(name, sd)
+    g = torch.Generator().manual_seed(700 + B)
+    x, cond = torch.randn(B, 4, 32, 32, generator=g), torch.randn(B, 256, 32, 32, generator=g)
+    ls = unet_ref.log_snr(torch.rand(B, generator=g) * 0.98 + 0.01)
+    y = net.forward_with_cond_scale(x.to(DEV), ls.to(DEV), cond_images=cond.to(DEV)).cpu()
+    assert torch.isfinite(y).all()
+    worst = 0.0
+    for b in sorted({0, 1, B // 2, B - 2, B - 1}):
+        y1 = net.forward_with_cond_scale(x[b:b + 1].to(DEV), ls[b:b + 1].to(DEV), cond_images=cond[b:b + 1].to(DEV)).cpu()
+        worst = max(worst, rel_err(y[b:b + 1], y1))
+    print(f"B={B}: worst image vs the one-image plan {worst:.3e}")
+    assert worst < TOL_REL
 
 
 def test_plms_batch8_trajectory_matches_oracle_sampler():

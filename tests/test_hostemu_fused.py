@@ -92,6 +92,9 @@ def test_the_4x4_geometry_runs_on_k_conv4_gn():
     fc.run_conv_case("emu", **fc.CONV_CASES["conv4_one_image_per_workgroup_b4"])    # op field i[19] bit 0 keeps k_conv4_gn
     assert m1 == m0 + 2 and fused.lib().emu_conv4_mb_launches() == m1 and fused.lib().emu_conv4_launches() == n1 + 1
     n1 += 1
+    fc.run_conv_case("emu", **fc.CONV_CASES["conv4_no_norm_plain_1024"])        # r06: the un-normalised form of the geometry (k_conv4_gn<64, 0, false>)
+    assert fused.lib().emu_conv4_launches() == n1 + 1
+    n1 += 1
     fc.run_conv_case("emu", **fc.CONV_CASES["lin4_ln_ff1_1024_gelu"])           # k_lin4_ln counts on the same counter
     n2 = fused.lib().emu_conv4_launches()
     fc.run_conv_case("emu", **fc.CONV_CASES["lin4_shape_on_the_general_kernel"])

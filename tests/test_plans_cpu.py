@@ -111,7 +111,7 @@ def _audit(ops, name, sized=False):
         elif o.type == unet.OP_LN:
             assert o.p[0] and o.p[1] and o.p[3] and o.i[1] % 64 == 0 and o.i[1] <= 2048, where
         elif o.type == unet.OP_GEMV:
-            assert o.p[0] and o.p[1] and o.p[3] and 1 <= o.i[0] <= 8 and o.i[3] % 8 == 0, where
+            assert o.p[0] and o.p[1] and o.p[3] and 1 <= o.i[0] <= 64 and o.i[3] % 8 == 0, where      # (<= 8 rows: k_gemv; 9 .. 64: k_gemm_rows / _ks)
     return n_conv
 
 
@@ -470,3 +470,16 @@ def test_every_forced_4_slice_conv_meets_the_host_predicates_of_k_conv4_gn():
                 assert B * 16 * max(C1, o.i[11]) < (1 << 30), where                      # 32-bit element offsets
             checked += 1
     assert checked >= 8 * 12
+
+
+def test_unet_plans_of_every_batch_regime_pass_the_op_audit():
+    """The op audit of test_unet_plan_invariants (operand presence, alignment contracts, split-K workspaces, lazy tensors all consumed) over the
+    batch sizes at which the r06 planner rules switch kernels, ragged ones included (B = 9, 17, 33: a partly filled last tile of whole maps)."""
+    from sparsefusion_amd.unet import Unet, _Plan
+    net = Unet(channels=4, dim=256, dim_mults=(1, 2, 4, 4), num_resnet_blocks=(2, 2, 2, 2), layer_attns=(False, False, False, True),
+               layer_cross_attns=(False,) * 4, cond_images_channels=256, attn_pool_text=False)
+    for B in (2, 3, 5, 8, 9, 12, 16, 17, 24, 32, 33):
+        s = _Plan(net, B, CPU).build()
+        plan = _Plan(net, B, CPU, (s.zero.off, s.misc.off + s.ws_bytes + s.ws2_bytes + 512, s.ws_bytes, s.ws2_bytes)).build()
+        assert _audit(plan.ops, f"unet B={B}", sized=True) >= 91
+        assert plan.ws_owner is None or plan.ws_owner.lazy is None

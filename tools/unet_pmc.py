@@ -26,8 +26,9 @@ FUSED = ("k_conv_fused", "k_gca_pool_rc", "k_conv4_gn", "k_lin4_ln", "k_conv3s")
 def kclass(name):
     n = name.replace("void ", "").split("(")[0]
     for key in ("k_conv3s", "k_conv_fused_pipe_rc", "k_conv_fused_pipe_pair", "k_conv_fused_pipe", "k_conv_fused_pair", "k_conv4_gn_mb", "k_conv4_gn", "k_lin4_ln",
-                "k_gca_pool_rc", "k_conv_fused", "k_gca_net0", "k_gca_gate", "k_gca_pool", "k_conv_igemm", "k_conv_lds", "k_conv3_halo", "k_layernorm",
-                "k_splitk_reduce", "k_slots", "k_init_x", "k_gn_"):
+                "k_gca_pool_rc", "k_conv_fused", "k_gca_net0", "k_gca_gate", "k_gca_pool", "k_gca_logits", "k_conv_igemm", "k_conv_lds", "k_conv_glds",
+                "k_conv3_halo_sm", "k_conv3_halo", "k_gemm_rows_ks", "k_gemm_rows", "k_gemv", "k_attn16", "k_layernorm",
+                "k_splitk_reduce", "k_slots", "k_init_x", "k_gn_one", "k_gn_"):      # (r06: the kernels of the large-batch plans)
         if key in n:
             return key
     return "other"
