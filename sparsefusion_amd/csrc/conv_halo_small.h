@@ -63,9 +63,22 @@ SF_DEV void conv_halo_sm_body(const ConvArgs& a) {
   const int tiles = a.m_tiles * a.n_tiles;
   const int grp = a.groups > 1 ? sf_uniform((int)blockIdx.x / tiles) : 0;
   const int bid = (int)blockIdx.x - grp * tiles;
-  int t = bid;
-  if (tiles % 8 == 0) t = (bid & 7) * (tiles >> 3) + (bid >> 3);
-  const int nt = t % a.n_tiles, mt = t / a.n_tiles;
+  // Tile order.  Workgroups are dealt round-robin over the 8 XCDs (XCD = bid & 7), each with its own L2.  These layers are weight-heavy (19-38 MB
+  // of weights against 1-4 MB of operand-type activations): XCD x owns the channel tiles [x n_tiles / 8, (x + 1) n_tiles / 8) of ALL pixel tiles, so
+  // its L2 streams 1/8 of the weights -- 2.4 MB of a 1024 -> 1024 layer, resident across the pixel tiles -- instead of all of them (the pixel-major
+  // order of k_conv3_halo, right for the activation-heavy 32x32 / 16x16 layers, made every XCD fetch every weight: 103 MB of HBM fetch per
+  // dispatch at B = 32, profiles/r06_unet_eval_b32_pmc.json).  The activations are then read by all 8 L2s, which is the cheaper side here.
+  int nt, mt;
+  if (a.n_tiles % 8 == 0) {
+    const int npx = a.n_tiles >> 3, j = bid >> 3;
+    nt = (bid & 7) * npx + j % npx;
+    mt = j / npx;
+  } else {
+    int t = bid;
+    if (tiles % 8 == 0) t = (bid & 7) * (tiles >> 3) + (bid >> 3);
+    nt = t % a.n_tiles;
+    mt = t / a.n_tiles;
+  }
   const int P = a.cchunks >> 1;                                                                  // 64-channel chunks
   const int h_lo = a.groups > 1 ? (int)((long)grp * P / a.groups) : 0;
   const int h_hi = a.groups > 1 ? (int)((long)(grp + 1) * P / a.groups) : P;

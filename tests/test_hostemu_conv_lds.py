@@ -374,6 +374,7 @@ HALO_SM_CASES = [
     (16, 4, 256, 128, 4, 9, 4, False),     # ONE chunk per group (no second frame to stage)
     (2, 8, 128, 128, 8, 9, 1, False),      # one tile of 2 whole 8x8 maps
     (5, 8, 192, 64, 4, 8, 3, True),        # 8x8, ragged: 5 maps (the third tile holds one), 3 chunks in 3 groups
+    (17, 4, 128, 512, 4, 9, 2, False),     # 8 channel tiles: the weight-major XCD order (XCD x owns channel tile x of all 3 pixel tiles), ragged third tile
 ]
 
 
