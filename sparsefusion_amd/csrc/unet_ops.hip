@@ -846,7 +846,9 @@ static int run_ln(const sf_op& op, hipStream_t st) {
 static int run_gemv(const sf_op& op, hipStream_t st) {
   const int M = op.i[0], N = op.i[1];
   if (M > 64) SF_FAIL(SF_ERR_INVALID, "gemv: at most 64 rows");
-  if (M > 8) {                                                  // many rows (a sampler's time table): rows on the MFMA M side, weights read once
+  // (r06: from 8 rows on -- the GlobalContext MLPs of a B = 8 hybrid block ran on k_gemv at 12.9 us per launch, 18 launches per eval -- the
+  // K-sliced MFMA form takes the op when N <= 4096; flag 8 keeps k_gemv (<= 8 rows) / k_gemm_rows (more))
+  if (M > 8 || (M == 8 && N <= 4096 && !(op.flags & 8))) {     // many rows (a sampler's time table): rows on the MFMA M side, weights read once
     GemmRowsArgs a{(const float*)op.p[0], (const sf_opnd*)op.p[1], (const float*)op.p[2], (float*)op.p[3], M, N, op.i[2], op.i[3], op.i[4],
                    op.i[5], (int)(op.flags & 1), (int)((op.flags >> 1) & 3)};
     if (a.Kp < 8 || a.Kp % 8) SF_FAIL(SF_ERR_INVALID, "gemv: padded K must be a multiple of 8");

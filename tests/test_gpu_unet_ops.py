@@ -450,7 +450,7 @@ def test_gemv(M, N, K, in_silu, act):
     Kp = (K + 7) // 8 * 8
     wp = F.pad(w, (0, Kp - K)).to(torch.bfloat16).contiguous().to(DEV)
     y = torch.zeros(M, N + 2, device=DEV)
-    _run([_op(4, (1 if in_silu else 0) | (act << 1), p=(x.to(DEV), wp, b.to(DEV), y), i=(M, N, K, Kp, K + 3, N + 2))])
+    _run([_op(4, (1 if in_silu else 0) | (act << 1) | 8, p=(x.to(DEV), wp, b.to(DEV), y), i=(M, N, K, Kp, K + 3, N + 2))])      # flag 8: k_gemv also at 8 rows (r06: k_gemm_rows_ks takes those)
     xin = x[:, :K]
     ref = F.linear(F.silu(xin) if in_silu else xin, bf(w), b)
     ref = F.silu(ref) if act == 1 else torch.sigmoid(ref) if act == 2 else ref
@@ -464,7 +464,8 @@ def test_gemv(M, N, K, in_silu, act):
 
 @pytest.mark.parametrize("first_form", [False, True])
 @pytest.mark.parametrize("M,N,K,in_silu,act", [(51, 1024, 17, False, 1), (51, 4160, 1024, True, 0), (20, 136, 300, False, 2),
-                                               (32, 512, 1024, False, 1), (32, 1024, 512, False, 2), (9, 256, 125, True, 0)])
+                                               (32, 512, 1024, False, 1), (32, 1024, 512, False, 2), (9, 256, 125, True, 0),
+                                               (8, 512, 1024, False, 1), (8, 1024, 512, False, 2)])      # 8 rows: the GlobalContext MLPs of a B = 8 hybrid block
 def test_gemv_many_rows_on_mfma(M, N, K, in_silu, act, first_form):
     """OP_GEMV with 9..64 rows (a sampler's time table, Unet.time_table; the GlobalContext MLPs of a large batch) runs on k_gemm_rows /
     k_gemm_rows_ks (csrc/gemm_rows.h; N <= 4096: the K-sliced form, flag 8 forces the first one): rows on the MFMA M side, x split into
