@@ -132,7 +132,7 @@ class _LpipsFn(torch.autograd.Function):
         V = pred.shape[0]
         fwd, bwd = mod._plans_for(V, pred.shape[-1], pred.device)
         fwd.x_view.copy_(torch.cat([pred, target], 0).reshape(2 * V, -1))
-        _lib.check(_lib.lib().sf_plan_run(fwd.op_array, len(fwd.ops), _lib.stream_ptr()), "lpips forward plan")
+        _lib.check(mod.clib.sf_plan_run(fwd.op_array, len(fwd.ops), _lib.stream_ptr()), "lpips forward plan", mod.clib)
         ctx.mod, ctx.bwd, ctx.shape = mod, bwd, pred.shape
         ctx.serial = mod._serial = mod._serial + 1
         return fwd.dist_view.clone().view(V, 1, 1, 1)
@@ -142,9 +142,17 @@ class _LpipsFn(torch.autograd.Function):
         if ctx.serial != ctx.mod._serial:
             raise RuntimeError("PerceptualLoss: backward after another forward -- the feature maps live in one static arena")
         bwd = ctx.bwd
-        bwd.gscale_view.copy_(g.reshape(-1, 1).float())
-        _lib.check(_lib.lib().sf_plan_run(bwd.op_array, len(bwd.ops), _lib.stream_ptr()), "lpips backward plan")
-        return None, bwd.out_view.clone().view(ctx.shape), None
+        mod = ctx.mod
+        sc = mod.grad_scale
+        g = g.reshape(-1, 1).float()
+        if sc == 1.0:
+            bwd.gscale_view.copy_(g)
+        else:                      # the backward is linear in the upstream gradient: run it at max |g| = sc (device-side, no sync), undo at the end
+            gmax = g.abs().max().clamp_min(1e-30)
+            bwd.gscale_view.copy_(g * (sc / gmax))
+        _lib.check(mod.clib.sf_plan_run(bwd.op_array, len(bwd.ops), _lib.stream_ptr()), "lpips backward plan", mod.clib)
+        out = bwd.out_view.clone() if sc == 1.0 else bwd.out_view * (gmax / sc)
+        return None, out.view(ctx.shape), None
 
 
 class LPIPS(nn.Module):
@@ -169,6 +177,16 @@ class LPIPS(nn.Module):
         self.lds_conv_min_blocks = 96
         self.conv_twin = True             # conv -> conv links of a VGG slice in operand type (r03); False = fp32 reads
         self._pack_cache, self._plans, self._serial = None, {}, 0
+        # r06: MFMA operand type of THIS module (None = the process default, bf16; "f16" = IEEE half: 3 more mantissa bits through the 26 conv
+        # layers of a forward + backward) and the power of two the upstream gradient is multiplied by on its way in (and the image gradient divided
+        # by on its way out): half has 5 exponent bits, LPIPS gradients of a 256^2 image sit around 1e-7 .. 1e-5 per element
+        self.operand, self.grad_scale = None, 1.0
+        # Measured against the fp32 oracle at 256^2 (tools/exp/lpips_operand_probe.py, profiles/r06_lpips_operand_probe.log): set_operand("f16")
+        # (upstream gradient normalised to max |g| = 4096) brings the gradient's relative L2 from 5.0e-2 (bf16) to 1.7e-2 and the distance from
+        # 1.5e-4 to 3.0e-5 at the same speed -- WITHOUT the scale the half gradients (1e-7 .. 1e-6 per element) underflow to 100 % error.  It is
+        # NOT the default: in the K-step distillation test the field trained with bf16 LPIPS gradients agrees with the oracle-trained field to
+        # 103 / 108 dB, the one trained with the half gradients to 71 / 74 dB (profiles/r06_e2e_lpips_operand_ab.log; both 0.0000 dB from the
+        # target): bf16's rounding error is larger but unbiased over 8 exponent bits, and Adam normalises away the magnitude that half preserves.
         # the `lpips` package ships pretrained VGG16 + learned lin heads; this module starts from a seeded random init and has
         # no network access: until load_state_dict() brings real weights the distance is NOT the LPIPS metric
         self._weights_loaded = False
@@ -177,6 +195,20 @@ class LPIPS(nn.Module):
 
     def invalidate(self):
         self._pack_cache, self._plans = None, {}
+
+    def set_operand(self, operand, grad_scale=None):
+        """operand: None | "bf16" | "f16" (the IEEE-half build of the library, libsparsefusion_hip_f16.so); grad_scale: see __init__
+        (default 4096 for "f16", 1 otherwise; != 1: the upstream gradient is normalised to max |g| = grad_scale first)."""
+        if operand not in (None, "bf16", "f16"):
+            raise ValueError("operand must be None, 'bf16' or 'f16'")
+        self.operand = operand
+        self.grad_scale = float(grad_scale if grad_scale is not None else (4096.0 if operand == "f16" else 1.0))
+        self.invalidate()
+        return self
+
+    @property
+    def clib(self):
+        return _lib.lib(self.operand)
 
     def load_state_dict(self, sd, strict=True):
         # the package also registers the lin layers a second time under `lins.{k}.*` and the scaling buffers
@@ -200,7 +232,7 @@ class LPIPS(nn.Module):
     def _packed(self, device):
         if self._pack_cache is not None and self._pack_cache[0] == str(device):
             return self._pack_cache[1]
-        lib = _lib.lib()
+        lib = self.clib
         packed = {"__scaling__": torch.tensor(SHIFT + SCALE, dtype=torch.float32, device=device)}
 
         def pack(w4):

@@ -1,6 +1,8 @@
 """LPIPS(net='vgg') on the HIP plan vs the torch-fp32 restatement of the published algorithm (oracle/lpips_ref.py).
 The `lpips` package and the pretrained VGG16 are not available (parity unpinned, see the oracle header): both sides use
-the same seeded synthetic weights.  bf16 MFMA operands / fp32 accumulate: distance within 1e-2 relative (measured
+the same seeded synthetic weights.  r06 option set_operand("f16"): IEEE-half MFMA operands / fp32 accumulate with a normalised upstream
+gradient: distance within 2e-3 (measured 3e-5), gradient within 3e-2 / cosine > 0.9995 (measured 1.7e-2 / 0.99985).  bf16 operands (the
+default): distance within 1e-2 relative (measured
 3e-4), gradient w.r.t. the rendered image within 8e-2 relative L2 and cosine > 0.997 (measured 5e-2 / 0.9988: 13 conv
 layers forward and 13 backward in bf16, plus ReLU masks that flip for pre-activations within bf16 rounding of zero; r04: the
 error is localised per feature tap and attributed to operand rounding by the last test of this file)."""
@@ -17,8 +19,11 @@ def _cos(a, b):
     return torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0).item()
 
 
+@pytest.mark.parametrize("operand", ["f16", "bf16"])
 @pytest.mark.parametrize("B,R", [(1, 64), (2, 32), (1, 256)])
-def test_lpips_distance_and_gradient(B, R):
+def test_lpips_distance_and_gradient(B, R, operand):
+    """r06: set_operand("f16") = the IEEE-half operand build with the upstream gradient normalised to max |g| = 4096 (gradient within 3e-2 of
+    the fp32 oracle, measured 1.5-1.7e-2; distance 2-6e-5); "bf16" = the default (8e-2, measured 5e-2)."""
     from sparsefusion_amd.lpips import LPIPS, lpips_param_spec
     assert [k for k, _ in lpips_param_spec()] == [k for k, _ in lpips_ref.lpips_param_spec()]
     sd = lpips_ref.init_state(seed=0)
@@ -26,13 +31,17 @@ def test_lpips_distance_and_gradient(B, R):
     missing = net.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     net = net.to(DEV)
+    assert net.operand is None and net.grad_scale == 1.0                       # the default stays bf16 (see LPIPS.__init__ for the measurement)
+    if operand == "f16":
+        net.set_operand("f16")
+        assert net.grad_scale == 4096.0
     g = torch.Generator().manual_seed(R + B)
     base = torch.rand(B, 3, R, R, generator=g)
     pred = (base + 0.15 * torch.randn(B, 3, R, R, generator=g)).clamp(0, 1)
     target = base
     p_ref = pred.clone().requires_grad_(True)
     d_ref = lpips_ref.lpips(sd, p_ref, target, normalize=True)
-    w = torch.rand(B, 1, 1, 1, generator=g) + 0.5
+    w = (torch.rand(B, 1, 1, 1, generator=g) + 0.5) * (0.1 / B)                  # the loop's weighting: 0.1 * mean (distillation.py:312-314)
     (d_ref * w).sum().backward()
     p = pred.to(DEV).requires_grad_(True)
     d = net(p, target.to(DEV), normalize=True)
@@ -43,8 +52,8 @@ def test_lpips_distance_and_gradient(B, R):
     print(f"B={B} R={R}: d={d.flatten().tolist()} ref={d_ref.flatten().tolist()} rel {rel_d:.2e}; grad rel L2 {rel_g:.2e} "
           f"cos {_cos(p.grad.cpu(), p_ref.grad):.5f}")
     assert float(d_ref.detach().min()) > 1e-3                                   # a non-trivial distance
-    assert rel_d < 1e-2
-    assert rel_g < 8e-2 and _cos(p.grad.cpu(), p_ref.grad) > 0.997
+    assert rel_d < (2e-3 if operand == "f16" else 1e-2)
+    assert (rel_g < 3e-2 and _cos(p.grad.cpu(), p_ref.grad) > 0.9995) if operand == "f16" else (rel_g < 8e-2 and _cos(p.grad.cpu(), p_ref.grad) > 0.997)
     # identical images: zero distance (and a finite, ~zero gradient)
     q = target.to(DEV).requires_grad_(True)
     z = net(q, target.to(DEV), normalize=True)
