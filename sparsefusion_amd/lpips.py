@@ -187,6 +187,7 @@ class LPIPS(nn.Module):
         # NOT the default: in the K-step distillation test the field trained with bf16 LPIPS gradients agrees with the oracle-trained field to
         # 103 / 108 dB, the one trained with the half gradients to 71 / 74 dB (profiles/r06_e2e_lpips_operand_ab.log; both 0.0000 dB from the
         # target): bf16's rounding error is larger but unbiased over 8 exponent bits, and Adam normalises away the magnitude that half preserves.
+        # (And half can overflow where bf16 cannot: the backward of the unit-normalisation amplifies by 1 / |feature|, unbounded on real weights.)
         # the `lpips` package ships pretrained VGG16 + learned lin heads; this module starts from a seeded random init and has
         # no network access: until load_state_dict() brings real weights the distance is NOT the LPIPS metric
         self._weights_loaded = False
