@@ -544,3 +544,213 @@ SF_KERNEL(512) void k_lin4_ln(FConvArgs a) {
   sf_touch_kernarg<(int)sizeof(FConvArgs)>();
   lin4_ln_body<C4T, WN>(a, (int)blockIdx.x);
 }
+
+// k_lin4_attn (r06): the attention core in the prologue of its output projection (FNORM_ATTN: 8 heads x 64 = 512 inner channels, the 16 query
+// tokens of one image, <= 24 keys; external/imagen_pytorch.py:480-566, :731-805) on k_lin4_ln's skeleton -- the same op, operands and LDS layout
+// as k_conv_fused<1, WN, ., FNORM_ATTN, 0, 8>, whose prologue text this is, with what the general kernel keeps generic made static: 512
+// channels = 16 k-steps = TWO per wave, so the wave's whole weight share (2 x WN fragments) is requested right behind the q / k / v loads
+// (no ring), bias and residual rows of the finalising waves at entry, ONE barrier between the frame and the MFMAs.
+template <int WN>
+SF_DEV void lin4_attn_body(const FConvArgs& a, const int bid) {
+  constexpr int KW = 2, F = WN, NW = 8;
+  SF_DYN_LDS(lds);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int MT = a.B;
+  int mt, nt;
+  fconv_tile_of(a, bid, MT, mt, nt);
+  const long m0 = (long)mt * 16;
+  const int b = mt;
+  const bf16x8* wbase[WN];
+#pragma unroll
+  for (int ni = 0; ni < WN; ++ni) {
+    int nf = nt * WN + ni;
+    if (nf > a.n_frags - 1) nf = a.n_frags - 1;
+    wbase[ni] = a.w + (long)nf * a.KS * 64 + lane;
+  }
+  bf16x8 fb[KW][WN];
+  const int my_nf = nt * WN + wave;                    // wave f < F finalises fragment f
+  const bool fin = wave < F && my_nf < a.n_frags;
+  const int n = (my_nf < a.n_frags ? my_nf : a.n_frags - 1) * 16 + (lane & 15);
+  const int nc = n < a.Cout ? n : a.Cout - 1;
+  const long mrow = m0 + (lane >> 4) * 4;
+  float bv = 0.0f, rv[4] = {0.f, 0.f, 0.f, 0.f};
+#define LIN4_ATTN_WEIGHTS() do { \
+    _Pragma("unroll") for (int i = 0; i < KW; ++i) \
+      _Pragma("unroll") for (int ni = 0; ni < WN; ++ni) fb[i][ni] = __builtin_nontemporal_load(&wbase[ni][(long)(wave * KW + i) * 64]); \
+    const float bvq = (a.bias ? a.bias : reinterpret_cast<const float*>(a.w))[a.bias ? nc : 0]; \
+    bv = a.bias ? bvq : 0.0f; \
+    const float* rp = a.resid ? a.resid : a.out; \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) { const float q_ = rp[(mrow + r) * a.ldc + a.co_off + nc]; rv[r] = a.resid ? q_ : 0.0f; } \
+    if (a.accum) { _Pragma("unroll") for (int r = 0; r < 4; ++r) rv[r] += a.out[(mrow + r) * a.ldc + a.co_off + nc]; } \
+  } while (0)
+  // ---- (b1'') the attention core: wave = head (8 waves x 64 lanes = the 512 inner channels), the tile's 16 pixels = the 16
+  // query tokens.  Keys / values are staged once in LDS (fp32), scores and P . V run on the matrix cores, the softmax on the D
+  // fragments by shuffles; the result goes straight into the frame as the conv's A operand.
+  const FAttn& at = a.attn;
+  float* sp = reinterpret_cast<float*>(lds + a.attn_off);                 // [8 heads][16 queries][SF_ATTN_PSTRIDE]
+  float* skv = sp + 8 * 16 * SF_ATTN_PSTRIDE;                             // keys [regions][J][KSTRIDE], then values
+  const int J = at.J, nreg = at.per_head ? 8 : 1;
+  // query A fragments straight from global memory: row (lane & 15), dims 32 ks + 8 (lane >> 4) .. + 7 of head `wave`
+  const float* qp = at.q + ((long)b * 16 + (lane & 15)) * at.ldq + wave * 64 + 8 * (lane >> 4);
+  f32x4 q[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const f32x4*>(qp + 32 * (u >> 1) + 4 * (u & 1));
+  // key / value rows: per-head segments -> this wave stages the J rows of ITS head; shared head -> the 8 waves split the rows
+  // (all of a wave's <= 4 rows are loaded before the first LDS store, from clamped addresses: a load inside the row loop was one
+  // cold round trip per row -- the rows were written by the previous kernel on other XCDs -- 7.7 us of prologue instead of ~2)
+  {
+    const int j0 = at.per_head ? 0 : wave, jst = at.per_head ? 1 : NW;
+    const int reg = at.per_head ? wave : 0;
+    const int r0 = at.seg[0].rows, r1 = at.seg[1].rows;
+    constexpr int NR = 4;                                            // per head: J <= 4; shared: ceil(24 / 8) = 3
+    float kq[NR], vq[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const int j = j0 + u * jst < J ? j0 + u * jst : J - 1;
+      const int si = j < r0 ? 0 : (j < r0 + r1 ? 1 : 2);
+      const int r = j - (si == 0 ? 0 : (si == 1 ? r0 : r0 + r1));
+      const float* kp = si == 0 ? at.seg[0].k : (si == 1 ? at.seg[1].k : at.seg[2].k);
+      const int voff = si == 0 ? at.seg[0].v_off : (si == 1 ? at.seg[1].v_off : at.seg[2].v_off);
+      const int rs = si == 0 ? at.seg[0].row_stride : (si == 1 ? at.seg[1].row_stride : at.seg[2].row_stride);
+      const int bs = si == 0 ? at.seg[0].batch_stride : (si == 1 ? at.seg[1].batch_stride : at.seg[2].batch_stride);
+      const int hs = si == 0 ? at.seg[0].head_stride : (si == 1 ? at.seg[1].head_stride : at.seg[2].head_stride);
+      const long off = (long)b * bs + (long)r * rs + (long)wave * (at.per_head ? hs : 0) + lane;
+      kq[u] = kp[off];
+      vq[u] = kp[off + voff];
+    }
+    LIN4_ATTN_WEIGHTS();    // the weight share goes out BEHIND the q / k / v loads: loads return in order, and the first wait below is for k / v
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const int j = j0 + u * jst;
+      if (j < J) {
+        skv[(reg * J + j) * SF_ATTN_KSTRIDE + lane] = kq[u];
+        skv[((nreg + reg) * J + j) * SF_ATTN_KSTRIDE + lane] = vq[u];
+      }
+    }
+  }
+  sf_sync();
+  const float* kb = skv + (at.per_head ? wave : 0) * J * SF_ATTN_KSTRIDE;
+  const float* vb = skv + (nreg + (at.per_head ? wave : 0)) * J * SF_ATTN_KSTRIDE;
+  // Matrix-core form (the first r04 version ran scores and P.V on the vector units out of broadcast LDS reads: 3 us of LDS time
+  // per workgroup).  fp32 operands are split into operand-type hi + lo parts and the lo x lo product is dropped (relative 2^-16):
+  // S = Q K^T as 2 key blocks x 2 k-steps x 3 MFMAs, O = P V as 4 dim blocks x 3 MFMAs.  Fragment conventions (sf_dev.h):
+  // A[m = lane & 15][k = 8 (lane >> 4) + j], B[k = 8 (lane >> 4) + j][n = lane & 15], D[m = 4 (lane >> 4) + r][n = lane & 15].
+  auto split = [](const f32x4& a, const f32x4& c, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi[e] = (sf_opnd)a[e]; lo[e] = (sf_opnd)(a[e] - (float)hi[e]);
+      hi[4 + e] = (sf_opnd)c[e]; lo[4 + e] = (sf_opnd)(c[e] - (float)hi[4 + e]);
+    }
+  };
+  const int g = lane >> 4, n16 = lane & 15;
+  bf16x8 qh[2], ql[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) split(q[2 * ks], q[2 * ks + 1], qh[ks], ql[ks]);
+  f32x4 sacc[2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int j = 16 * cb + n16;
+    const float* kr = kb + (j < J ? j : J - 1) * SF_ATTN_KSTRIDE + 8 * g;
+    sacc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 kh, kl;
+      split(*reinterpret_cast<const f32x4*>(kr + 32 * ks), *reinterpret_cast<const f32x4*>(kr + 32 * ks + 4), kh, kl);
+      sacc[cb] = sf_mfma16(qh[ks], kh, sacc[cb]);
+      sacc[cb] = sf_mfma16(qh[ks], kl, sacc[cb]);
+      sacc[cb] = sf_mfma16(ql[ks], kh, sacc[cb]);
+    }
+  }
+  // softmax of row i = 4 g + r over the keys: this lane holds columns n16 and 16 + n16; the other columns sit in the 16 lanes of its group
+  float* prow = sp + wave * 16 * SF_ATTN_PSTRIDE;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float s0 = n16 < J ? sacc[0][r] * at.scale : -INFINITY;
+    const float s1 = 16 + n16 < J ? sacc[1][r] * at.scale : -INFINITY;
+    float mx = fmaxf(s0, s1);
+    mx = fmaxf(mx, sf_shfl_xor(mx, 1)); mx = fmaxf(mx, sf_shfl_xor(mx, 2)); mx = fmaxf(mx, sf_shfl_xor(mx, 4)); mx = fmaxf(mx, sf_shfl_xor(mx, 8));
+    const float e0 = n16 < J ? expf(s0 - mx) : 0.0f, e1 = 16 + n16 < J ? expf(s1 - mx) : 0.0f;
+    float den = e0 + e1;
+    den += sf_shfl_xor(den, 1); den += sf_shfl_xor(den, 2); den += sf_shfl_xor(den, 4); den += sf_shfl_xor(den, 8);
+    const float inv = 1.0f / den;
+    prow[(4 * g + r) * SF_ATTN_PSTRIDE + n16] = e0 * inv;               // zeros beyond the last key
+    prow[(4 * g + r) * SF_ATTN_PSTRIDE + 16 + n16] = e1 * inv;
+  }
+  sf_wave_sync();
+  bf16x8 ph, pl;
+  {
+    const float* pr = prow + n16 * SF_ATTN_PSTRIDE + 8 * g;             // A fragment: row n16, keys 8 g .. 8 g + 7
+    split(*reinterpret_cast<const f32x4*>(pr), *reinterpret_cast<const f32x4*>(pr + 4), ph, pl);
+  }
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    f32x4 va, vc;                                                       // B fragment: keys 8 g + t (clamped: their P is 0), dim 16 db + n16
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int j0 = 8 * g + t, j1 = 8 * g + 4 + t;
+      va[t] = vb[(j0 < J ? j0 : J - 1) * SF_ATTN_KSTRIDE + 16 * db + n16];
+      vc[t] = vb[(j1 < J ? j1 : J - 1) * SF_ATTN_KSTRIDE + 16 * db + n16];
+    }
+    bf16x8 vh, vl;
+    split(va, vc, vh, vl);
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+    o = sf_mfma16(ph, vh, o);
+    o = sf_mfma16(ph, vl, o);
+    o = sf_mfma16(pl, vh, o);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<sf_opnd*>(lds + (long)(4 * g + r) * a.pix_stride + (wave * 64 + 16 * db + n16) * 2) = (sf_opnd)o[r];
+  }
+
+#undef LIN4_ATTN_WEIGHTS
+  sf_sync();
+  // ---- this wave's two k-steps on the frame [token][channel]
+  f32x4 acc[WN];
+#pragma unroll
+  for (int ni = 0; ni < WN; ++ni) acc[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const char* abase = lds + (long)(lane & 15) * a.pix_stride + (lane >> 4) * 16;
+#pragma unroll
+  for (int i = 0; i < KW; ++i) {
+    const bf16x8 fa = *reinterpret_cast<const bf16x8*>(abase + (wave * KW + i) * 64);
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) acc[ni] = sf_mfma16(fa, fb[i][ni], acc[ni]);
+  }
+  // ---- the 8 K-slices meet in LDS; wave f finalises fragment f: bias, residual, output, statistics slots
+  float* red = reinterpret_cast<float*>(lds + a.red_off);         // [wave][frag][r][lane]
+#pragma unroll
+  for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[((wave * F + ni) * 4 + r) * 64 + lane] = acc[ni][r];
+  sf_sync();
+  if (fin) {
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float sacc = 0.0f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) sacc += red[((w * F + wave) * 4 + r) * 64 + lane];
+      if (n < a.Cout) {
+        float y = sacc + bv + rv[r];
+        if (a.out_gelu) y = sf_gelu(y);
+        a.out[(mrow + r) * a.ldc + a.co_off + n] = y;
+        s1 += y;
+        s2 = fmaf(y, y, s2);
+      }
+    }
+    if (a.slots_out) {
+      s1 = sf_wave_sum(s1);
+      s2 = sf_wave_sum(s2);
+      if (lane == 0) {
+        float* slo = a.slots_out + ((m0 >> 4) * (long)(a.ldc >> 4) + (a.co_off >> 4) + my_nf) * 2;
+        slo[0] = s1;
+        slo[1] = s2;
+      }
+    }
+  }
+}
+
+template <int WN>
+SF_KERNEL(512) void k_lin4_attn(FConvArgs a) {
+  sf_touch_kernarg<(int)sizeof(FConvArgs)>();
+  lin4_attn_body<WN>(a, (int)blockIdx.x);
+}

@@ -261,6 +261,15 @@ static inline int lin4_c4t(const sf_op& op, const FConvArgs& a, int WM, int WN) 
   return a.C / 128;
 }
 
+// k_lin4_attn (fused_conv4.h, r06): the attention-prologue output projection of the 16-token map (8 heads x 64 inner channels) on k_lin4_ln's
+// skeleton; returns WN (1 | 2) or 0 = the general kernel.  Op flag 128 (planner attribute Unet.conv4 = False) keeps the general kernel.
+static inline int lin4_attn_wn(const sf_op& op, const FConvArgs& a, int WM, int WN) {
+  if (op.flags & (1 | 2 | 16 | 32 | 64 | 128)) return 0;
+  if (a.norm != FNORM_ATTN || a.H != 4 || a.W != 4 || a.k != 1 || a.TR != 4 || WM != 1 || (WN != 1 && WN != 2)) return 0;
+  if (a.S != 1 || a.C != 512 || a.s2.C || a.s1.mode || a.dbg || a.logit_part) return 0;
+  return WN;
+}
+
 // k_conv4_gn (fused_conv4.h, r05) takes the op when it is the 4x4 level's GroupNorm-self 3x3 conv in the geometry the kernel is written
 // for; returns CS4 (64 | 128) or 0 = the general kernel.  Op flag 128 (planner attribute Unet.conv4 = False) keeps the general kernel.
 // (r06: also the same geometry WITHOUT a norm -- k_conv4_gn<CS4, 0, false>: one plain source, slices of 256 channels, B = 1)

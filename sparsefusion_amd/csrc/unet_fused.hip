@@ -52,6 +52,15 @@ static int launch_lin4(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStrea
   return SF_OK;
 }
 
+template <int WN>
+static int launch_lin4_attn(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStream_t st) {
+  static unsigned mask = 0;
+  if (int rc = allow_big_lds(k_lin4_attn<WN>, lds, mask)) return rc;
+  k_lin4_attn<WN><<<grid, 512, lds, st>>>(a);
+  SF_CHECK_LAUNCH("lin4_attn");
+  return SF_OK;
+}
+
 template <int WM, int WN, int EPT, bool POOL>
 static int launch_fconv_pipe(const FConvArgs& a, uint32_t grid, uint32_t lds, hipStream_t st) {
   static unsigned mask = 0;
@@ -119,6 +128,8 @@ static int run_fconv(const sf_op& op, hipStream_t st) {
     SF_TRYL(8, 1) SF_TRYL(8, 2) SF_TRYL(16, 1) SF_TRYL(16, 2)
 #undef SF_TRYL
   }
+  if (const int wn = lin4_attn_wn(op, a, WM, WN))       // r06: the attention-prologue projection of the 16-token map on its own kernel
+    return wn == 1 ? launch_lin4_attn<1>(a, grid, lds, st) : launch_lin4_attn<2>(a, grid, lds, st);
 #define SF_TRY(wm, wn, d, nm_, lz_) \
   if (WM == wm && WN == wn && a.norm == nm_ && a.s1.mode == lz_) return launch_fconv<wm, wn, d, nm_, lz_>(a, grid, lds, st);
   SF_FCONV_VARIANTS(SF_TRY)

@@ -292,7 +292,7 @@ def run_gca_case(backend, B, H, C, lazy=False, seed=0, epilogue_chunks=False, rc
         assert torch.allclose(h2_d.cpu(), h2, atol=1e-5)
 
 
-def run_attn_case(backend, B=2, cross=False, context=True, Cout=48, seed=0, tol=4e-3, dbg=None, reps=1, WN=1):
+def run_attn_case(backend, B=2, cross=False, context=True, Cout=48, seed=0, tol=4e-3, dbg=None, reps=1, WN=1, general=False):
     """k_conv_fused<.., FNORM_ATTN>: the 16-token attention core (8 heads x 64, keys = [context tokens,] null k/v, the tokens' one
     shared k/v head -- or, cross-attention, null + 2 per-head time tokens; imagen_pytorch.py:480-566, :731-805) as the prologue of
     its output projection, against softmax(q k^T scale) v -> bf16 -> linear in torch."""
@@ -349,7 +349,7 @@ def run_attn_case(backend, B=2, cross=False, context=True, Cout=48, seed=0, tol=
     out = torch.full((B * 16, Cout), float("nan")).to(dev)
     wp, bias_d, res_d = fused.pack_conv_weights(w).to(dev), bias.to(dev), res.to(dev)
     segs = segs + [(0, 0, 0, 0, 0, 0)] * (3 - len(segs))
-    op = fused.mkop(OP_FCONV, 0,
+    op = fused.mkop(OP_FCONV, 128 if general else 0,      # 128: keep the general kernel (r06: k_lin4_attn takes the op otherwise)
                     p=(qkv_d, None, None, None, None, None, None, wp, bias_d, out, res_d, None, None, None, None, None, dbg, None, None) + tuple(sg[0] for sg in segs),
                     i=(B, 4, 4, inner, 0, Cout, Cout, 0, 1, 0, 0, 0, ATTN, 8, 4, 1, WN, 1, 0, nq) + tuple(x for sg in segs for x in sg[2:]),
                     f=(1e-5, 1.0, 1.0) + tuple((sg[1] - sg[0]) // 4 for sg in segs) + (scale,))
@@ -366,7 +366,11 @@ def run_attn_case(backend, B=2, cross=False, context=True, Cout=48, seed=0, tol=
 
 ATTN_CASES = {"self_context": dict(B=2, cross=False, context=True, seed=61), "self_plain": dict(B=1, cross=False, context=False, seed=62),
               "cross_time_tokens": dict(B=2, cross=True, seed=63, Cout=64),
-              "self_context_wn2": dict(B=2, cross=False, context=True, seed=68, Cout=64, WN=2)}      # the B >= 8 tile of the output projection
+              "self_context_wn2": dict(B=2, cross=False, context=True, seed=68, Cout=64, WN=2),      # the B >= 8 tile of the output projection
+              # r06: the cases above run on k_lin4_attn (csrc/fused_conv4.h); op flag 128 keeps k_conv_fused<.., FNORM_ATTN>
+              "self_context_on_the_general_kernel": dict(B=2, cross=False, context=True, seed=61, general=True),
+              "cross_time_tokens_on_the_general_kernel": dict(B=2, cross=True, seed=63, Cout=64, general=True),
+              "self_plain_ragged_cout": dict(B=3, cross=False, context=False, seed=69, Cout=40)}
 
 GCA_CASES = {"4x4_lazy": dict(B=2, H=4, C=128, lazy=True),
              "4x4_lazy_res_conv_beside_pool": dict(B=2, H=4, C=128, lazy=True, seed=21, rc=(96, 64)),

@@ -143,6 +143,11 @@ extern "C" int emu_run_op(const sf_op* op, char* err, int errn) {
       SF_TRY4(64, 0) SF_TRY4(64, 1) SF_TRY4(64, 2) SF_TRY4(128, 0) SF_TRY4(128, 1) SF_TRY4(128, 2)
 #undef SF_TRY4
     }
+    if (const int wn = lin4_attn_wn(*op, a, WM, WN)) {       // r06: k_lin4_attn
+      if (wn == 1) hipemu::launch(grid, 512, lds, [&] { k_lin4_attn<1>(a); }); else hipemu::launch(grid, 512, lds, [&] { k_lin4_attn<2>(a); });
+      ++g_conv4_launches;
+      return 0;
+    }
     if (const int c4t = lin4_c4t(*op, a, WM, WN)) {
 #define SF_TRYL(c_, wn_) \
       if (c4t == c_ && WN == wn_) { hipemu::launch(grid, 512, lds, [&] { k_lin4_ln<c_, wn_>(a); }); ++g_conv4_launches; return 0; }

@@ -100,6 +100,10 @@ def test_the_4x4_geometry_runs_on_k_conv4_gn():
     fc.run_conv_case("emu", **fc.CONV_CASES["lin4_shape_on_the_general_kernel"])
     fc.run_conv_case("emu", **fc.CONV_CASES["layernorm_linear"])
     assert n2 == n1 + 1 and fused.lib().emu_conv4_launches() == n2
+    fc.run_attn_case("emu", **fc.ATTN_CASES["self_plain"])                       # r06: k_lin4_attn counts on the same counter
+    n3 = fused.lib().emu_conv4_launches()
+    fc.run_attn_case("emu", **fc.ATTN_CASES["self_context_on_the_general_kernel"])
+    assert n3 == n2 + 1 and fused.lib().emu_conv4_launches() == n3
 
 
 CONV3S_ON_CPU = sorted(n for n in fc.CONV_CASES_FULL if n.startswith("conv3s_"))
