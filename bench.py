@@ -324,7 +324,7 @@ def unet_roofline(hp, B=1):
     all_conv_bytes = int(sum(_op_weight_bytes(o) for o in ops if o.type in (OP_CONV, OP_FCONV)))
     achieved = fconv_bytes / (fconv_ms * 1e-3) / 1e9
     tflops = fconv_flops / (fconv_ms * 1e-3) / 1e12
-    return {"bound": "hbm", "kernel": "k_conv3s / k_conv_fused / k_conv_fused_pipe / _pair / _rc / k_gca_pool_rc / k_conv4_gn / k_lin4_ln (GroupNorm | LayerNorm + conv in one launch)",
+    return {"bound": "hbm", "kernel": "k_conv3s / k_conv_fused / k_conv_fused_pipe / _pair / _rc / k_gca_pool_rc / k_conv4_gn / k_lin4_ln / k_lin4_attn (GroupNorm | LayerNorm | attention core + conv in one launch)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None,
             "traffic_note": "not collected in this run (--no-traffic, B > 1 or a multi-rank run): see profiles/r06_unet_eval_b1_pmc.json",
@@ -352,7 +352,7 @@ def measure_fconv_counters(timeout_s=300):
         d = unet_pmc.summarise(acc, 3, pred=lambda k: any(s_ in k for s_ in unet_pmc.FUSED)).get("selected")
         if not d or d.get("fetch_bytes_per_dispatch") is None:
             return None, "the counter passes recorded no fused-conv dispatch"
-        return d, ("per-dispatch means over the fused-conv dispatches (k_conv_fused* / k_conv3s / k_conv4_gn / k_lin4_ln / k_gca_pool_rc) of a child process "
+        return d, ("per-dispatch means over the fused-conv dispatches (k_conv_fused* / k_conv3s / k_conv4_gn / k_lin4_ln / k_lin4_attn / k_gca_pool_rc) of a child process "
                    "(3 evals, B = 1, plain launches) under rocprofv3 --kernel-trace --pmc, one counter group per pass; FETCH_SIZE KiB x 1024 x 2 (gfx950)")
     except Exception as e:                                            # noqa: BLE001 -- a bench line without counters is still a bench line
         return None, "counter passes failed: %r" % (e,)

@@ -20,12 +20,12 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GROUPS = (("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"))
-FUSED = ("k_conv_fused", "k_gca_pool_rc", "k_conv4_gn", "k_lin4_ln", "k_conv3s")      # the fused [norm +] conv launches: bench.py's `roofline` family
+FUSED = ("k_conv_fused", "k_gca_pool_rc", "k_conv4_gn", "k_lin4_ln", "k_lin4_attn", "k_conv3s")      # the fused [norm +] conv launches: bench.py's `roofline` family
 
 
 def kclass(name):
     n = name.replace("void ", "").split("(")[0]
-    for key in ("k_conv3s", "k_conv_fused_pipe_rc", "k_conv_fused_pipe_pair", "k_conv_fused_pipe", "k_conv_fused_pair", "k_conv4_gn_mb", "k_conv4_gn", "k_lin4_ln",
+    for key in ("k_conv3s", "k_conv_fused_pipe_rc", "k_conv_fused_pipe_pair", "k_conv_fused_pipe", "k_conv_fused_pair", "k_conv4_gn_mb", "k_conv4_gn", "k_lin4_ln", "k_lin4_attn",
                 "k_gca_pool_rc", "k_conv_fused", "k_gca_net0", "k_gca_gate", "k_gca_pool", "k_gca_logits", "k_conv_igemm", "k_conv_lds", "k_conv_glds",
                 "k_conv3_halo_sm", "k_conv3_halo", "k_gemm_rows_ks", "k_gemm_rows", "k_gemv", "k_attn16", "k_layernorm",
                 "k_splitk_reduce", "k_slots", "k_init_x", "k_gn_one", "k_gn_"):      # (r06: the kernels of the large-batch plans)
